@@ -1,0 +1,146 @@
+/*
+ * oracle/kat_grid.c — TEST INFRASTRUCTURE ONLY.
+ *
+ * Restates the PROCEDURE of the reference's two grid integration tests so the
+ * oracle can be pinned by them (the loops are the reference tests' own; the
+ * functions under test are the oracle's):
+ *   tests/src/long_term_planner_tests.cc:264-323  gridTestOneJoint
+ *   tests/src/long_term_planner_tests.cc:325-407  GridTimeScalingTest
+ * Each returns the number of failed expectations and reports the number of
+ * expectations checked plus the worst goal error seen.
+ */
+#include <math.h>
+#include <stdlib.h>
+
+typedef struct {
+    int dof;
+    double t_sample;
+    const double *q_min, *q_max, *v_max, *a_max, *j_max;
+} ltpo_planner;
+
+int ltpo_opt_switch_times(const ltpo_planner *, int, double, double, double, double, double, double *, double *, char *);
+int ltpo_time_scaling_ex(const ltpo_planner *, int, double, double, double, double, double, double, double *, double *, char *, int *);
+int ltpo_traj_len(const ltpo_planner *, const double *);
+void ltpo_get_trajectory(const ltpo_planner *, const double *, const double *, const char *, const double *, const double *,
+                         const double *, const double *, int, double *, double *, double *, double *);
+
+static double dmin(double a, double b) { return b < a ? b : a; }
+static double dmax(double a, double b) { return a < b ? b : a; }
+
+/* final (q, v, a) of the sampled 1-DoF trajectory */
+static int final_state(const ltpo_planner *P, const double *t, double dir, char mod, double q_0, double v_0, double a_0,
+                       double v_drive, double *qe, double *ve, double *ae)
+{
+    int len = ltpo_traj_len(P, t);
+    double *buf;
+    if (len <= 0) return 0;
+    buf = (double *)malloc(sizeof(double) * 4 * (size_t)len);
+    ltpo_get_trajectory(P, t, &dir, &mod, &q_0, &v_0, &a_0, &v_drive, len, buf, buf + len, buf + 2 * len, buf + 3 * len);
+    *qe = buf[len - 1];
+    *ve = buf[2 * len - 1];
+    *ae = buf[3 * len - 1];
+    free(buf);
+    return len;
+}
+
+long ltpo_kat_grid_one_joint(long *n_checks, double *worst_err)
+{
+    const double eps = 1e-6, tol = 0.02, step = 0.1;
+    const double q_min[1] = {-3.1}, q_max[1] = {3.1}, v_max[1] = {1.0}, a_max[1] = {2.0}, j_max[1] = {15.0};
+    const double q_0 = 0.5;
+    ltpo_planner P = {1, 0.004, q_min, q_max, v_max, a_max, j_max};
+    long fails = 0;
+    int i, j, k;
+    *n_checks = 0;
+    *worst_err = 0;
+    for (i = (int)q_min[0] / step; i <= (int)q_max[0] / step; i++) {
+        double q_goal = i * step;
+        for (j = (int)-v_max[0] / step; j < (int)v_max[0] / step; j++) {
+            double v_0 = j * step;
+            double a_lb, a_ub;
+            if (v_0 >= 0) {
+                a_lb = -(a_max[0] - eps);
+                a_ub = dmin(a_max[0] - eps, sqrt(2 * j_max[0] * (v_max[0] - v_0)));
+            } else {
+                a_lb = dmax(-(a_max[0] - eps), -sqrt(2 * j_max[0] * (v_max[0] - fabs(v_0))));
+                a_ub = a_max[0];
+            }
+            for (k = (int)a_lb / step; k < (int)a_ub / step; k++) {
+                double a_0 = k * step - eps;
+                double t[7] = {0, 0, 0, 0, 0, 0, 0}, dir, qe = 0, ve, ae, err;
+                char mod;
+                int ok = ltpo_opt_switch_times(&P, 0, q_goal, q_0, v_0, a_0, v_max[0], t, &dir, &mod);
+                (*n_checks)++;
+                if (!ok) { fails++; }
+                if (!final_state(&P, t, dir, mod, q_0, v_0, a_0, v_max[0], &qe, &ve, &ae)) { fails++; continue; }
+                err = fabs(qe - q_goal);
+                (*n_checks)++;
+                if (!(err <= tol)) fails++;
+                if (err > *worst_err) *worst_err = err;
+            }
+        }
+    }
+    return fails;
+}
+
+/* case_hist[0..8]: how often timeScaling ended in "none" (0) or case 1..8 */
+long ltpo_kat_grid_time_scaling(long *n_checks, double *worst_err, long *case_hist)
+{
+    const double eps = 1e-6, tol_q = 0.02, tol_t = 0.1, step = 0.1;
+    const double q_min[1] = {-6}, q_max[1] = {7}, v_max[1] = {1.0}, a_max[1] = {2.0}, j_max[1] = {15.0};
+    const double q_0 = 0.5;
+    const double incr[6] = {0.05, 0.1, 0.2, 0.5, 1.0, 2.0};
+    ltpo_planner P = {1, 0.004, q_min, q_max, v_max, a_max, j_max};
+    long fails = 0;
+    int i, j, k, l, c;
+    *n_checks = 0;
+    *worst_err = 0;
+    for (c = 0; c < 9; c++) case_hist[c] = 0;
+    for (i = (int)q_min[0] / step; i <= (int)q_max[0] / step; i++) {
+        double q_goal = i * step;
+        for (j = (int)-v_max[0] / step; j < (int)v_max[0] / step; j++) {
+            double v_0 = j * step;
+            double a_lb, a_ub, a_range;
+            int n_steps;
+            v_0 = (j > 0) ? v_0 - eps : v_0 + eps;
+            if (v_0 >= 0) {
+                a_lb = -(a_max[0] - eps);
+                a_ub = dmin(a_max[0] - eps, sqrt(2 * j_max[0] * (v_max[0] - v_0)));
+            } else {
+                a_lb = dmax(-(a_max[0] - eps), -sqrt(2 * j_max[0] * (v_max[0] - fabs(v_0))));
+                a_ub = a_max[0];
+            }
+            a_range = a_ub - a_lb;
+            n_steps = (int)floor(a_range / step);
+            for (k = 0; k < n_steps; k++) {
+                double a_0 = a_lb + k * step;
+                double t_ltp[7] = {0, 0, 0, 0, 0, 0, 0}, dir;
+                char mod;
+                int ok = ltpo_opt_switch_times(&P, 0, q_goal, q_0, v_0, a_0, v_max[0], t_ltp, &dir, &mod);
+                (*n_checks)++;
+                if (!ok) { fails++; continue; }
+                for (l = 0; l < 6; l++) {
+                    double t_scaled[7] = {0, 0, 0, 0, 0, 0, 0}, v_drive, qe = 0, ve = 0, ae = 0, err;
+                    char mod2 = 0;
+                    int okts, cs = 0, m;
+                    if (t_ltp[6] < tol_q) break;
+                    okts = ltpo_time_scaling_ex(&P, 0, q_goal, q_0, v_0, a_0, dir, t_ltp[6] + incr[l], t_scaled, &v_drive, &mod2, &cs);
+                    case_hist[cs]++;
+                    if (!okts) for (m = 0; m < 7; m++) t_scaled[m] = t_ltp[m];
+                    if (!final_state(&P, t_scaled, dir, mod2, q_0, v_0, a_0, v_drive, &qe, &ve, &ae)) { fails++; continue; }
+                    err = fabs(qe - q_goal);
+                    (*n_checks)++;
+                    if (!(err <= tol_q)) fails++;
+                    if (err > *worst_err) *worst_err = err;
+                    if (fabs(t_ltp[6] + incr[l] - t_scaled[6]) > tol_t) {
+                        (*n_checks) += 3;
+                        if (!(fabs(ve) <= tol_q)) fails++;
+                        if (!(fabs(ae) <= tol_q)) fails++;
+                        if (!(fabs(t_scaled[2] - t_scaled[6]) <= eps)) fails++;
+                    }
+                }
+            }
+        }
+    }
+    return fails;
+}

@@ -1,0 +1,154 @@
+"""Pins the CPU oracle to every known-answer table the reference's own tests hold.
+
+Expected values and tolerances come from tests/golden/reference_kat.json, a data
+transcription of /root/reference/tests/src/long_term_planner_tests.cc and
+tests/src/roots_tests.cc (cited per table in the JSON).
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+
+def _oracle_1dof(oracle_mod, kat, i=None, tab=None, t_sample=None):
+    f = kat["fixture_1dof"]
+    lim = {k: f[k] for k in ("q_min", "q_max", "v_max", "a_max", "j_max")}
+    if tab is not None:
+        for k in lim:
+            if k in tab:
+                lim[k] = [tab[k][i]]
+    return oracle_mod.Oracle(1, t_sample or f["t_sample"], **lim)
+
+
+def test_roots_f32_eigen_order(oracle_mod, kat):
+    # roots_tests.cc:9-32 — float, degree 6, eigenvalues in Eigen's output order
+    k = kat["roots_f32_deg6"]
+    re, im, st = oracle_mod.roots_f32(k["poly"])
+    assert st == 0
+    for i in range(6):
+        assert abs(float(re[i]) - k["re"][i]) <= k["tol"], (i, re)
+        tol_im = k["tol_imag_real_roots"] if k["im"][i] == 0.0 else k["tol"]
+        assert abs(float(im[i]) - k["im"][i]) <= tol_im, (i, im)
+    # the four real roots have an exactly-zero imaginary part (roots.h:47 relies on it)
+    assert all(float(im[i]) == 0.0 for i in range(4))
+
+
+def test_roots_f64_against_lapack(oracle_mod):
+    # independent cross-check of the restated QR against numpy.roots (LAPACK)
+    rng = np.random.default_rng(7)
+    for deg in (4, 5, 6):
+        for _ in range(300):
+            p = rng.normal(size=deg + 1) * 10.0 ** rng.integers(-2, 3, size=deg + 1)
+            re, im, st = oracle_mod.roots_f64(p)
+            assert st == 0
+            mine = np.sort_complex(re + 1j * im)
+            ref = np.sort_complex(np.roots(p))
+            assert np.allclose(mine, ref, rtol=1e-7, atol=1e-9), (p, mine, ref)
+
+
+def test_smallest_root_selection(oracle_mod):
+    # (x-1)(x-2)(x^2+1): smallest positive exactly-real root is 1
+    p = np.poly([1.0, 2.0, 1j, -1j]).real
+    assert abs(oracle_mod.smallest_root(p) - 1.0) < 1e-12
+    # x^4 + 1: no real root -> +inf (roots.h:45-49)
+    assert oracle_mod.smallest_root([1, 0, 0, 0, 1]) == float("inf")
+    # leading zero coefficient -> defined as "no admissible root"
+    assert oracle_mod.smallest_root([0, 1, 0, 0, -1]) == float("inf")
+    # roots <= 1e-7 are rejected
+    p = np.poly([1e-8, 3.0, -1.0, -2.0])
+    assert abs(oracle_mod.smallest_root(p) - 3.0) < 1e-9
+
+
+def test_opt_braking_kat(oracle_mod, kat):
+    k = kat["opt_braking"]
+    for i in range(len(k["v_0"])):
+        o = _oracle_1dof(oracle_mod, kat, i, k)
+        for sgn in ((1, -1) if i >= k["mirror_from"] else (1,)):
+            q, t, d = o.opt_braking(0, sgn * k["v_0"][i], sgn * k["a_0"][i])
+            assert np.all(np.abs(t[:3] - np.array(k["t_rel"][i])) <= k["eps"]), (i, sgn, t)
+            assert abs(q - sgn * k["q"][i]) <= k["eps"], (i, sgn, q)
+
+
+def test_opt_switch_times_kat(oracle_mod, kat):
+    k = kat["opt_switch_times"]
+    for i in range(len(k["q_goal"])):
+        o = _oracle_1dof(oracle_mod, kat, i, k)
+        for sgn in ((1, -1) if i >= k["mirror_from"] else (1,)):
+            ok, t, d, m = o.opt_switch_times(0, sgn * k["q_goal"][i], sgn * k["q_0"][i], sgn * k["v_0"][i], sgn * k["a_0"][i], k["v_max"][i])
+            assert ok
+            assert np.all(np.abs(t[:3] - np.array(k["t"][i][:3])) <= k["eps"]), (i, sgn, t)
+            # the full table holds too (table inputs are rounded to 4 digits)
+            assert np.all(np.abs(t - np.array(k["t"][i])) <= k["full_table_tol"]), (i, sgn, t)
+            assert np.all(np.abs(np.diff(np.concatenate([[0.0], t])) - np.array(k["t_rel"][i])) <= k["full_table_tol"])
+
+
+@pytest.mark.parametrize("name", ["trajectory_v0", "trajectory_v1", "trajectory_v2"])
+def test_plan_trajectory_endpoint_kat(oracle_mod, kat, name):
+    k = kat[name]
+    for i in range(len(k["q_goal"])):
+        o = _oracle_1dof(oracle_mod, kat, i, k)
+        r = o.plan_trajectory([k["q_goal"][i]], [k["q_0"][i]], [k["v_0"][i]], [k["a_0"][i]])
+        assert r["status"] == 1, (name, i)
+        assert abs(r["q"][0, r["length"] - 1] - k["q_goal"][i]) <= k["tol_q_end"], (name, i)
+
+
+def test_time_scaling_kat(oracle_mod, kat):
+    k = kat["time_scaling"]
+    cases = set()
+    for i in range(len(k["q_goal"])):
+        o = _oracle_1dof(oracle_mod, kat, i, k)
+        for sgn in ((1, -1) if i >= k["mirror_from"] else (1,)):
+            ok, t, vd, m, case = o.time_scaling(0, sgn * k["q_goal"][i], sgn * k["q_0"][i], sgn * k["v_0"][i], sgn * k["a_0"][i],
+                                                sgn * k["dir"][i], k["t_required"][i])
+            assert ok, (i, sgn)
+            cases.add(case)
+            assert np.all(np.abs(t[:3] - np.array(k["t"][i][:3])) <= k["eps"]), (i, sgn, t)
+            assert np.all(np.abs(t - np.array(k["t"][i])) <= k["full_table_tol"]), (i, sgn, t)
+    # the unit table reaches the closed-form cases and the modified-profile polynomial cases
+    assert {1, 2, 6, 8} <= cases, cases
+
+
+def test_grid_one_joint(oracle_mod):
+    # long_term_planner_tests.cc:264-323 (procedure restated in oracle/kat_grid.c)
+    L = oracle_mod.lib()
+    L.ltpo_kat_grid_one_joint.restype = C.c_long
+    n = C.c_long(); worst = C.c_double()
+    fails = L.ltpo_kat_grid_one_joint(C.byref(n), C.byref(worst))
+    assert fails == 0 and n.value > 50000 and worst.value < 0.02
+
+
+def test_grid_time_scaling(oracle_mod):
+    # long_term_planner_tests.cc:325-407; 594 984 timeScaling calls, as SURVEY.md App. B counted
+    L = oracle_mod.lib()
+    L.ltpo_kat_grid_time_scaling.restype = C.c_long
+    n = C.c_long(); worst = C.c_double(); hist = (C.c_long * 9)()
+    fails = L.ltpo_kat_grid_time_scaling(C.byref(n), C.byref(worst), hist)
+    h = list(hist)
+    assert fails == 0 and worst.value < 0.02
+    assert sum(h) == 594984
+    # accepted-case histogram of the compiled reference TU: c3 422, c4 60, c5 13, c6 0, c7 4, c8 0, none 351
+    assert h[3:] == [422, 60, 13, 0, 4, 0] and h[0] == 351 and h[1] + h[2] == 594134
+
+
+def test_check_inputs(oracle_mod, kat):
+    f = kat["fixture_1dof"]
+    o = oracle_mod.Oracle(1, f["t_sample"], f["q_min"], f["q_max"], [1.0], [2.0], [15.0])
+    assert o.check_inputs([0.0], [0.5], [0.5])
+    assert not o.check_inputs([3.2], [0.0], [0.0])
+    assert not o.check_inputs([0.0], [1.1], [0.0])
+    assert not o.check_inputs([0.0], [0.0], [-2.1])
+    assert not o.check_inputs([0.0], [0.99], [1.9])  # v + a|a|/(2j) > v_max
+
+
+def test_sampler_oob_and_zero_plan(oracle_mod, kat):
+    # all-zero plan has traj_len 1 and the reference writes j[1]; defined as dropped.
+    f = kat["fixture_1dof"]
+    o = oracle_mod.Oracle(1, 0.001, f["q_min"], f["q_max"], [2.0], [2.0], [4.0])
+    r = o.plan_trajectory([1.0], [1.0], [0.0], [0.0])
+    assert r["status"] == 1 and r["length"] == 1
+    assert r["q"][0, 0] == 1.0 and r["v"][0, 0] == 0.0 and r["a"][0, 0] == 0.0
+    # rest-to-rest 1 rad with Ts = 0.25: t6/Ts is an exact integer
+    o = oracle_mod.Oracle(1, 0.25, f["q_min"], f["q_max"], [2.0], [2.0], [4.0])
+    r = o.plan_trajectory([1.0], [0.0], [0.0], [0.0])
+    assert r["status"] == 1 and r["length"] >= 2
+    assert np.all(np.isfinite(r["q"]))
