@@ -1,0 +1,147 @@
+/*
+ * ltp_hip.h — C ABI of libltp_hip.so, the MI355X (gfx950) batched planner.
+ *
+ * This is the drop-in boundary for the reference's hot path
+ * LongTermPlanner::planTrajectory and the member functions under it. The
+ * reference has no FFI layer of its own (it is one C++ class:
+ * /root/reference/include/long_term_planner/long_term_planner.h:61-308), so each
+ * entry point below names the reference member it replaces; the drop-in C++
+ * class in include/long_term_planner/long_term_planner.h forwards to exactly
+ * these symbols and INTEGRATION.md shows the binding.
+ *
+ * Conventions: plain C, opaque handle, caller-owned buffers, `int` return
+ * (0 = LTP_OK, otherwise an ltp_error and ltp_last_error() has the text), no
+ * exceptions cross the boundary. `stream` is a hipStream_t (NULL = the default
+ * stream). Functions ending in _batch take DEVICE pointers and only enqueue
+ * work; functions ending in _host take host pointers and are synchronous.
+ * All arithmetic is IEEE binary64, as in the reference.
+ */
+#ifndef LTP_HIP_H
+#define LTP_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ltp_planner ltp_planner;
+
+typedef enum {
+    LTP_OK = 0,
+    LTP_ERR_INVALID_ARGUMENT = 1,
+    LTP_ERR_NO_DEVICE = 2,      /* no HIP device / HIP runtime error: the product has no CPU fallback */
+    LTP_ERR_OUT_OF_MEMORY = 3,
+    LTP_ERR_HIP = 4
+} ltp_error;
+
+/* per-query status bits; LongTermPlanner::planTrajectory's bool is (status == 0) */
+#define LTP_STATUS_INVALID_INPUT 1  /* checkInputs false            (src/long_term_planner.cc:14-15, 68-77) */
+#define LTP_STATUS_OPT_FAILED    2  /* optSwitchTimes false         (cc:29)                               */
+#define LTP_STATUS_NO_SLOWEST    4  /* slowest_joint == -1          (cc:39)                               */
+#define LTP_STATUS_END_LIMIT     8  /* last q outside [q_min,q_max] (cc:59-61); trajectory IS filled      */
+#define LTP_STATUS_NONFINITE    16  /* defined here: non-finite switching times, traj_len = 0 (ref.: UB)  */
+#define LTP_STATUS_OVERFLOW     32  /* trajectory did not fit the output tile passed to ltp_sample_batch  */
+
+/* Queries: element (query p, joint j) of each array is ptr[p*query_stride + j*joint_stride].
+ * Row-major [n][dof] (the reference's vector-per-query view): query_stride = dof, joint_stride = 1.
+ * Joint-major SoA [dof][n]: query_stride = 1, joint_stride = n. */
+typedef struct {
+    const double* q_goal;
+    const double* q_0;
+    const double* v_0;
+    const double* a_0;
+    long long query_stride;
+    long long joint_stride;
+} ltp_queries;
+
+/* Switching-time records, query-major (what planTrajectory holds in locals, cc:18-24, 31-32, 42). */
+typedef struct {
+    double* t_opt;        /* [n][dof][7] optimal switch times  (cc:18, 27-30)            */
+    double* t_scaled;     /* [n][dof][7] synchronised times after the fallback (cc:20, 43-55) */
+    double* dir;          /* [n][dof]    direction of motion   (cc:22)                    */
+    double* v_drive;      /* [n][dof]    cruise velocity       (cc:42)                    */
+    signed char* mod;     /* [n][dof]    modified-jerk-profile flag (cc:24)               */
+    double* t_required;   /* [n]         slowest joint's end time (cc:31)                 */
+    int* slowest;         /* [n]         slowest joint, -1 if none (cc:32)                */
+    int* traj_len;        /* [n]         Trajectory::length (cc:716-719), 0 if not sampled */
+    int* status;          /* [n]         LTP_STATUS_* bits                                 */
+} ltp_records;
+
+/* ---- lifetime / configuration -------------------------------------------------------------- */
+
+/* LongTermPlanner::LongTermPlanner(dof, t_sample, q_min, q_max, v_max, a_max, j_max)
+ * (long_term_planner.h:118-131). The five arrays hold `dof` doubles. device = HIP ordinal. */
+int ltp_create(int dof, double t_sample, const double* q_min, const double* q_max, const double* v_max,
+               const double* a_max, const double* j_max, int device, ltp_planner** out);
+void ltp_destroy(ltp_planner* p);
+/* LongTermPlanner::setLimits (long_term_planner.h:176-187); n_limits = entries per array */
+int ltp_set_limits(ltp_planner* p, int n_limits, const double* q_min, const double* q_max, const double* v_max,
+                   const double* a_max, const double* j_max);
+/* LongTermPlanner::setSampleTime (long_term_planner.h:194-196) */
+int ltp_set_sample_time(ltp_planner* p, double t_sample);
+/* LongTermPlanner::setDoF (long_term_planner.h:203-205) */
+int ltp_set_dof(ltp_planner* p, int dof);
+int ltp_get_dof(const ltp_planner* p);
+double ltp_get_sample_time(const ltp_planner* p);
+const char* ltp_last_error(const ltp_planner* p);
+/* rows of the packed trajectory layout are padded to this many doubles */
+int ltp_row_stride(int traj_len);
+
+/* ---- batched hot path (device pointers, asynchronous on `stream`) -------------------------- */
+
+/* planTrajectory stages 1-3 for n queries (cc:14-55): checkInputs, optSwitchTimes per joint,
+ * slowest-joint reduction, timeScaling per other joint, fallback copy; then traj_len (cc:716-719).
+ * offsets (device, [n+1], may be NULL) receives the exclusive scan of the packed trajectory sizes
+ * in doubles: plan p occupies [offsets[p], offsets[p+1]) of a packed buffer, laid out
+ * [q,v,a,j][joint][ltp_row_stride(traj_len[p])]. */
+int ltp_plan_switch_times_batch(ltp_planner* p, long long n, const ltp_queries* in, const ltp_records* out,
+                                unsigned long long* offsets, void* stream);
+
+/* getTrajectory (cc:706-841) + the end-limit check (cc:59-61) for plans [first, first+count):
+ * plan p is written at out + (offsets[p] - offsets[first]); plans that would end beyond
+ * `capacity` doubles get LTP_STATUS_OVERFLOW and are skipped. flags bit 0: use non-temporal stores. */
+int ltp_sample_batch(ltp_planner* p, long long first, long long count, const ltp_queries* in, const ltp_records* rec,
+                     const unsigned long long* offsets, double* out, unsigned long long capacity, int flags, void* stream);
+
+/* Synthetic queries of SURVEY.md §8(d) (distribution of tests/randomConfiguration.m:14-34 with per-joint
+ * limits), counter-based: query index first_query+p, so shards of one batch can be generated anywhere. */
+int ltp_generate_queries_batch(ltp_planner* p, long long n, unsigned long long seed, long long first_query,
+                               double* q_goal, double* q_0, double* v_0, double* a_0,
+                               long long query_stride, long long joint_stride, void* stream);
+
+/* ---- host-pointer convenience (synchronous) ------------------------------------------------- */
+
+/* Full planTrajectory (cc:7-63) for n row-major [n][dof] host queries. Any record pointer may be NULL.
+ * If packed != NULL, *packed receives a malloc'ed buffer of offsets[n] doubles (free with ltp_free_host)
+ * and offsets ([n+1], host) must be non-NULL. */
+int ltp_plan_batch_host(ltp_planner* p, long long n, const double* q_goal, const double* q_0, const double* v_0,
+                        const double* a_0, const ltp_records* host_records, unsigned long long* offsets,
+                        double** packed);
+
+/* LongTermPlanner::getTrajectory (cc:706-841) for n host records ([n][dof][7] times etc.). */
+int ltp_get_trajectory_host(ltp_planner* p, long long n, const double* t, const double* dir, const signed char* mod,
+                            const double* q_0, const double* v_0, const double* a_0, const double* v_drive,
+                            int* traj_len, int* status, unsigned long long* offsets, double** packed);
+void ltp_free_host(void* ptr);
+
+/* LongTermPlanner::checkInputs (cc:68-77) */
+int ltp_check_inputs_host(ltp_planner* p, const double* q_0, const double* v_0, const double* a_0, int* ok);
+/* LongTermPlanner::optBraking (cc:650-701); t_rel[7] is in/out (only [0..2] are written) */
+int ltp_opt_braking_host(ltp_planner* p, int joint, double v_0, double a_0, double* q, double* t_rel, double* dir);
+/* LongTermPlanner::optSwitchTimes (cc:82-353); t[7] is in/out (written only where the reference writes it) */
+int ltp_opt_switch_times_host(ltp_planner* p, int joint, double q_goal, double q_0, double v_0, double a_0, double v_drive,
+                              double* t, double* dir, char* mod, int* ok);
+/* LongTermPlanner::timeScaling (cc:358-645); accepted_case (may be NULL): 1..8, 0 = none */
+int ltp_time_scaling_host(ltp_planner* p, int joint, double q_goal, double q_0, double v_0, double a_0, double dir,
+                          double t_required, double* scaled_t, double* v_drive, char* mod, int* ok, int* accepted_case);
+
+/* ---- diagnostics used by the parity tests ---------------------------------------------------- */
+/* out[i*8 + {0..7}] = x/y, sqrt|x|, x^3, x^4, x^6, floor(x/y), ceil(x/y), x*y+x computed on the device */
+int ltp_debug_math_probe_host(ltp_planner* p, long long n, const double* x, const double* y, double* out);
+/* root[i] = smallest positive exactly-real root of the degree-`degree` polynomial coef[i*7 .. i*7+degree]
+ * (roots.h:22-50 semantics) */
+int ltp_debug_roots_probe_host(ltp_planner* p, long long n, int degree, const double* coef, double* root);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LTP_HIP_H */

@@ -1,0 +1,113 @@
+"""ctypes binding of libltp_hip.so (C ABI declared in include/ltp_hip.h).
+
+The library is built in-tree by ``longtermplanner_amd/csrc/Makefile`` (hipcc, gfx950) and must be
+present: there is no CPU or PyTorch fallback behind this module. A missing library, or a machine
+without a HIP device, raises.
+"""
+import ctypes as C
+import os
+import subprocess
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libltp_hip.so")
+CSRC = os.path.join(_PKG, "csrc")
+
+LTP_OK = 0
+STATUS_INVALID_INPUT = 1
+STATUS_OPT_FAILED = 2
+STATUS_NO_SLOWEST = 4
+STATUS_END_LIMIT = 8
+STATUS_NONFINITE = 16
+STATUS_OVERFLOW = 32
+
+ERROR_NAMES = {1: "LTP_ERR_INVALID_ARGUMENT", 2: "LTP_ERR_NO_DEVICE", 3: "LTP_ERR_OUT_OF_MEMORY", 4: "LTP_ERR_HIP"}
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int)
+_bp = C.POINTER(C.c_byte)
+_up = C.POINTER(C.c_ulonglong)
+
+
+class LtpError(RuntimeError):
+    def __init__(self, code, text=""):
+        super().__init__(f"{ERROR_NAMES.get(code, code)}: {text}")
+        self.code = code
+
+
+class Queries(C.Structure):
+    _fields_ = [("q_goal", C.c_void_p), ("q_0", C.c_void_p), ("v_0", C.c_void_p), ("a_0", C.c_void_p),
+                ("query_stride", C.c_longlong), ("joint_stride", C.c_longlong)]
+
+
+class Records(C.Structure):
+    _fields_ = [("t_opt", C.c_void_p), ("t_scaled", C.c_void_p), ("dir", C.c_void_p), ("v_drive", C.c_void_p),
+                ("mod", C.c_void_p), ("t_required", C.c_void_p), ("slowest", C.c_void_p), ("traj_len", C.c_void_p),
+                ("status", C.c_void_p)]
+
+
+def build(force=False):
+    """Compile libltp_hip.so for gfx950 (hipcc cross-compiles without a GPU)."""
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".hpp", "Makefile"))]
+    srcs.append(os.path.join(os.path.dirname(_PKG), "include", "ltp_hip.h"))
+    newest = max(os.path.getmtime(s) for s in srcs)
+    if force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < newest:
+        subprocess.check_call(["make", "-C", CSRC, "-s", "all"])
+    return LIB_PATH
+
+
+_SIGNATURES = {
+    "ltp_create": (C.c_int, [C.c_int, C.c_double, _dp, _dp, _dp, _dp, _dp, C.c_int, C.POINTER(C.c_void_p)]),
+    "ltp_destroy": (None, [C.c_void_p]),
+    "ltp_set_limits": (C.c_int, [C.c_void_p, C.c_int, _dp, _dp, _dp, _dp, _dp]),
+    "ltp_set_sample_time": (C.c_int, [C.c_void_p, C.c_double]),
+    "ltp_set_dof": (C.c_int, [C.c_void_p, C.c_int]),
+    "ltp_get_dof": (C.c_int, [C.c_void_p]),
+    "ltp_get_sample_time": (C.c_double, [C.c_void_p]),
+    "ltp_last_error": (C.c_char_p, [C.c_void_p]),
+    "ltp_row_stride": (C.c_int, [C.c_int]),
+    "ltp_plan_switch_times_batch": (C.c_int, [C.c_void_p, C.c_longlong, C.POINTER(Queries), C.POINTER(Records), C.c_void_p, C.c_void_p]),
+    "ltp_sample_batch": (C.c_int, [C.c_void_p, C.c_longlong, C.c_longlong, C.POINTER(Queries), C.POINTER(Records), C.c_void_p,
+                                   C.c_void_p, C.c_ulonglong, C.c_int, C.c_void_p]),
+    "ltp_generate_queries_batch": (C.c_int, [C.c_void_p, C.c_longlong, C.c_ulonglong, C.c_longlong, C.c_void_p, C.c_void_p,
+                                             C.c_void_p, C.c_void_p, C.c_longlong, C.c_longlong, C.c_void_p]),
+    "ltp_plan_batch_host": (C.c_int, [C.c_void_p, C.c_longlong, _dp, _dp, _dp, _dp, C.POINTER(Records), _up, C.POINTER(_dp)]),
+    "ltp_get_trajectory_host": (C.c_int, [C.c_void_p, C.c_longlong, _dp, _dp, _bp, _dp, _dp, _dp, _dp, _ip, _ip, _up, C.POINTER(_dp)]),
+    "ltp_free_host": (None, [C.c_void_p]),
+    "ltp_check_inputs_host": (C.c_int, [C.c_void_p, _dp, _dp, _dp, _ip]),
+    "ltp_opt_braking_host": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_double, _dp, _dp, _dp]),
+    "ltp_opt_switch_times_host": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double,
+                                            _dp, _dp, C.c_char_p, _ip]),
+    "ltp_time_scaling_host": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double,
+                                        C.c_double, _dp, _dp, C.c_char_p, _ip, _ip]),
+    "ltp_debug_math_probe_host": (C.c_int, [C.c_void_p, C.c_longlong, _dp, _dp, _dp]),
+    "ltp_debug_roots_probe_host": (C.c_int, [C.c_void_p, C.c_longlong, C.c_int, _dp, _dp]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load libltp_hip.so; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "(the planner has no CPU fallback)")
+        # One HIP runtime per process: PyTorch-ROCm wheels bundle their own libamdhip64.so.7. If torch is
+        # going to be used in this process (streams, device tensors, torch.distributed) it has to be loaded
+        # first so that libltp_hip.so binds to the same runtime; two runtimes cannot both open the GPU.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(L, name)   # AttributeError if the library does not export a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def exported_symbols():
+    return sorted(_SIGNATURES)

@@ -1,0 +1,546 @@
+// ltp_capi.hip — the C ABI of libltp_hip.so (include/ltp_hip.h): handle, workspace, launches.
+// Host-side only; every computation is a kernel in ltp_kernels.hip. There is deliberately no CPU
+// implementation behind these entry points: without a HIP device they fail with LTP_ERR_NO_DEVICE.
+#include "../../include/ltp_hip.h"
+#include "ltp_kernels.hpp"
+
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+struct ltp_planner {
+    int dof = 0;
+    double t_sample = 0.001;
+    int device = 0;
+    std::vector<double> h_lim[5];          // q_min, q_max, v_max, a_max, j_max as given (any length)
+    double* d_lim = nullptr;               // 5 * lim_cap doubles
+    int lim_cap = 0;
+    unsigned long long* d_queue = nullptr; // compaction queue of (query*dof + joint)
+    unsigned long long* d_queue_count = nullptr;
+    unsigned long long* d_block_sums = nullptr;
+    unsigned long long* d_offsets_scratch = nullptr;
+    long long ws_items = 0;                // capacity in (query, joint) items
+    long long ws_queries = 0;
+    double* d_small = nullptr;             // 16 doubles for the one-lane entry points
+    std::mutex mu;
+    std::string err;
+};
+
+namespace {
+
+int fail(ltp_planner* p, int code, const std::string& msg)
+{
+    if (p) p->err = msg;
+    return code;
+}
+
+int hip_fail(ltp_planner* p, hipError_t e, const char* what)
+{
+    const int code = (e == hipErrorNoDevice || e == hipErrorInvalidDevice || e == hipErrorInsufficientDriver)
+                         ? LTP_ERR_NO_DEVICE
+                         : (e == hipErrorOutOfMemory ? LTP_ERR_OUT_OF_MEMORY : LTP_ERR_HIP);
+    return fail(p, code, std::string(what) + ": " + hipGetErrorString(e));
+}
+
+#define LTP_HIP_TRY(p, expr)                                   \
+    do {                                                       \
+        hipError_t e_ = (expr);                                \
+        if (e_ != hipSuccess) return hip_fail((p), e_, #expr); \
+    } while (0)
+
+int upload_limits(ltp_planner* p)
+{
+    int n = 0;
+    for (int k = 0; k < 5; ++k) n = (int)p->h_lim[k].size() > n ? (int)p->h_lim[k].size() : n;
+    if (n < 1) n = 1;
+    LTP_HIP_TRY(p, hipSetDevice(p->device));
+    if (n > p->lim_cap) {
+        if (p->d_lim) LTP_HIP_TRY(p, hipFree(p->d_lim));
+        p->d_lim = nullptr;
+        LTP_HIP_TRY(p, hipMalloc((void**)&p->d_lim, sizeof(double) * 5 * n));
+        p->lim_cap = n;
+    }
+    std::vector<double> flat(5 * (size_t)p->lim_cap, 0.0);
+    for (int k = 0; k < 5; ++k)
+        for (size_t i = 0; i < p->h_lim[k].size(); ++i) flat[(size_t)k * p->lim_cap + i] = p->h_lim[k][i];
+    LTP_HIP_TRY(p, hipMemcpy(p->d_lim, flat.data(), sizeof(double) * flat.size(), hipMemcpyHostToDevice));
+    return LTP_OK;
+}
+
+ltp::Limits dev_limits(const ltp_planner* p)
+{
+    ltp::Limits L;
+    L.q_min = p->d_lim;
+    L.q_max = p->d_lim + p->lim_cap;
+    L.v_max = p->d_lim + 2 * (size_t)p->lim_cap;
+    L.a_max = p->d_lim + 3 * (size_t)p->lim_cap;
+    L.j_max = p->d_lim + 4 * (size_t)p->lim_cap;
+    return L;
+}
+
+// the reference indexes its limit vectors unchecked (UB when short); here it is an error
+int check_config(ltp_planner* p)
+{
+    if (p->dof < 0) return fail(p, LTP_ERR_INVALID_ARGUMENT, "dof < 0");
+    for (int k = 0; k < 5; ++k)
+        if ((int)p->h_lim[k].size() < p->dof) return fail(p, LTP_ERR_INVALID_ARGUMENT, "a limit vector has fewer than dof entries");
+    if (!(p->t_sample > 0.0)) return fail(p, LTP_ERR_INVALID_ARGUMENT, "t_sample must be > 0");
+    return LTP_OK;
+}
+
+int reserve(ltp_planner* p, long long n)
+{
+    const long long items = n * (long long)(p->dof > 0 ? p->dof : 1);
+    LTP_HIP_TRY(p, hipSetDevice(p->device));
+    if (!p->d_queue_count) LTP_HIP_TRY(p, hipMalloc((void**)&p->d_queue_count, sizeof(unsigned long long)));
+    if (!p->d_small) LTP_HIP_TRY(p, hipMalloc((void**)&p->d_small, sizeof(double) * 16));
+    if (items > p->ws_items) {
+        if (p->d_queue) LTP_HIP_TRY(p, hipFree(p->d_queue));
+        p->d_queue = nullptr;
+        LTP_HIP_TRY(p, hipMalloc((void**)&p->d_queue, sizeof(unsigned long long) * (size_t)items));
+        p->ws_items = items;
+    }
+    if (n > p->ws_queries) {
+        if (p->d_block_sums) LTP_HIP_TRY(p, hipFree(p->d_block_sums));
+        if (p->d_offsets_scratch) LTP_HIP_TRY(p, hipFree(p->d_offsets_scratch));
+        p->d_block_sums = p->d_offsets_scratch = nullptr;
+        const long long nb = (n + ltp::kScanBlock - 1) / ltp::kScanBlock;
+        LTP_HIP_TRY(p, hipMalloc((void**)&p->d_block_sums, sizeof(unsigned long long) * (size_t)(nb + 1)));
+        LTP_HIP_TRY(p, hipMalloc((void**)&p->d_offsets_scratch, sizeof(unsigned long long) * (size_t)(n + 1)));
+        p->ws_queries = n;
+    }
+    return LTP_OK;
+}
+
+ltp::Queries to_dev(const ltp_queries* in)
+{
+    ltp::Queries q;
+    q.q_goal = in->q_goal; q.q_0 = in->q_0; q.v_0 = in->v_0; q.a_0 = in->a_0;
+    q.sq = in->query_stride; q.sj = in->joint_stride;
+    return q;
+}
+
+ltp::Records to_dev(const ltp_records* r)
+{
+    ltp::Records o;
+    o.t_opt = r->t_opt; o.t_scaled = r->t_scaled; o.dir = r->dir; o.v_drive = r->v_drive; o.mod = r->mod;
+    o.t_required = r->t_required; o.slowest = r->slowest; o.traj_len = r->traj_len; o.status = r->status;
+    return o;
+}
+
+bool records_complete(const ltp_records* r)
+{
+    return r && r->t_opt && r->t_scaled && r->dir && r->v_drive && r->mod && r->t_required && r->slowest && r->traj_len && r->status;
+}
+
+// device-side record arrays owned for the duration of a *_host call
+struct DevRecords {
+    ltp_records r{};
+    std::vector<void*> owned;
+    ~DevRecords() { for (void* q : owned) (void)hipFree(q); }
+    template <class T> hipError_t alloc(T** out, size_t count)
+    {
+        void* ptr = nullptr;
+        hipError_t e = hipMalloc(&ptr, sizeof(T) * (count ? count : 1));
+        if (e == hipSuccess) { owned.push_back(ptr); *out = (T*)ptr; }
+        return e;
+    }
+    hipError_t alloc_all(long long n, int dof)
+    {
+        const size_t nd = (size_t)n * dof;
+        hipError_t e;
+        if ((e = alloc(&r.t_opt, nd * 7)) != hipSuccess) return e;
+        if ((e = alloc(&r.t_scaled, nd * 7)) != hipSuccess) return e;
+        if ((e = alloc(&r.dir, nd)) != hipSuccess) return e;
+        if ((e = alloc(&r.v_drive, nd)) != hipSuccess) return e;
+        if ((e = alloc(&r.mod, nd)) != hipSuccess) return e;
+        if ((e = alloc(&r.t_required, (size_t)n)) != hipSuccess) return e;
+        if ((e = alloc(&r.slowest, (size_t)n)) != hipSuccess) return e;
+        if ((e = alloc(&r.traj_len, (size_t)n)) != hipSuccess) return e;
+        return alloc(&r.status, (size_t)n);
+    }
+};
+
+}  // namespace
+
+extern "C" {
+
+int ltp_create(int dof, double t_sample, const double* q_min, const double* q_max, const double* v_max,
+               const double* a_max, const double* j_max, int device, ltp_planner** out)
+{
+    if (!out) return LTP_ERR_INVALID_ARGUMENT;
+    *out = nullptr;
+    if (dof < 0 || (dof > 0 && (!q_min || !q_max || !v_max || !a_max || !j_max))) return LTP_ERR_INVALID_ARGUMENT;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) return LTP_ERR_NO_DEVICE;
+    if (device < 0 || device >= count) return LTP_ERR_NO_DEVICE;
+    ltp_planner* p = new ltp_planner();
+    p->dof = dof;
+    p->t_sample = t_sample;
+    p->device = device;
+    const double* src[5] = {q_min, q_max, v_max, a_max, j_max};
+    for (int k = 0; k < 5; ++k) p->h_lim[k].assign(src[k], src[k] + dof);
+    int rc = upload_limits(p);
+    if (rc == LTP_OK) rc = reserve(p, 1);
+    if (rc != LTP_OK) { ltp_destroy(p); return rc; }
+    *out = p;
+    return LTP_OK;
+}
+
+void ltp_destroy(ltp_planner* p)
+{
+    if (!p) return;
+    (void)hipSetDevice(p->device);
+    if (p->d_lim) (void)hipFree(p->d_lim);
+    if (p->d_queue) (void)hipFree(p->d_queue);
+    if (p->d_queue_count) (void)hipFree(p->d_queue_count);
+    if (p->d_block_sums) (void)hipFree(p->d_block_sums);
+    if (p->d_offsets_scratch) (void)hipFree(p->d_offsets_scratch);
+    if (p->d_small) (void)hipFree(p->d_small);
+    delete p;
+}
+
+int ltp_set_limits(ltp_planner* p, int n_limits, const double* q_min, const double* q_max, const double* v_max,
+                   const double* a_max, const double* j_max)
+{
+    if (!p || n_limits < 0 || (n_limits > 0 && (!q_min || !q_max || !v_max || !a_max || !j_max))) return fail(p, LTP_ERR_INVALID_ARGUMENT, "bad limits");
+    std::lock_guard<std::mutex> g(p->mu);
+    const double* src[5] = {q_min, q_max, v_max, a_max, j_max};
+    for (int k = 0; k < 5; ++k) p->h_lim[k].assign(src[k], src[k] + n_limits);
+    LTP_HIP_TRY(p, hipSetDevice(p->device));
+    LTP_HIP_TRY(p, hipDeviceSynchronize());   // limits are read by in-flight kernels
+    return upload_limits(p);
+}
+
+int ltp_set_sample_time(ltp_planner* p, double t_sample)
+{
+    if (!p) return LTP_ERR_INVALID_ARGUMENT;
+    std::lock_guard<std::mutex> g(p->mu);
+    p->t_sample = t_sample;
+    return LTP_OK;
+}
+
+int ltp_set_dof(ltp_planner* p, int dof)
+{
+    if (!p || dof < 0) return fail(p, LTP_ERR_INVALID_ARGUMENT, "dof < 0");
+    std::lock_guard<std::mutex> g(p->mu);
+    p->dof = dof;
+    return LTP_OK;
+}
+
+int ltp_get_dof(const ltp_planner* p) { return p ? p->dof : -1; }
+double ltp_get_sample_time(const ltp_planner* p) { return p ? p->t_sample : 0.0; }
+const char* ltp_last_error(const ltp_planner* p) { return p ? p->err.c_str() : "null planner"; }
+int ltp_row_stride(int traj_len)
+{
+    if (traj_len <= 0) return 0;
+    return (traj_len + ltp::kRowAlign - 1) / ltp::kRowAlign * ltp::kRowAlign;
+}
+
+int ltp_plan_switch_times_batch(ltp_planner* p, long long n, const ltp_queries* in, const ltp_records* out,
+                                unsigned long long* offsets, void* stream)
+{
+    if (!p || n < 0 || !in || !records_complete(out)) return fail(p, LTP_ERR_INVALID_ARGUMENT, "null argument");
+    std::lock_guard<std::mutex> g(p->mu);
+    int rc = check_config(p);
+    if (rc != LTP_OK) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    LTP_HIP_TRY(p, hipSetDevice(p->device));
+    if (n == 0 || p->dof == 0) {
+        // dof == 0: every query fails with slowest_joint == -1 (cc:39); nothing to launch per joint
+        if (offsets) LTP_HIP_TRY(p, hipMemsetAsync(offsets, 0, sizeof(unsigned long long) * (size_t)(n + 1), s));
+        if (n > 0) {
+            std::vector<int> st((size_t)n, LTP_STATUS_NO_SLOWEST), neg((size_t)n, -1);
+            std::vector<double> tr((size_t)n, -1.0);
+            LTP_HIP_TRY(p, hipMemcpyAsync(out->status, st.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice, s));
+            LTP_HIP_TRY(p, hipMemcpyAsync(out->slowest, neg.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice, s));
+            LTP_HIP_TRY(p, hipMemcpyAsync(out->t_required, tr.data(), sizeof(double) * (size_t)n, hipMemcpyHostToDevice, s));
+            LTP_HIP_TRY(p, hipMemsetAsync(out->traj_len, 0, sizeof(int) * (size_t)n, s));
+            LTP_HIP_TRY(p, hipStreamSynchronize(s));
+        }
+        return LTP_OK;
+    }
+    rc = reserve(p, n);
+    if (rc != LTP_OK) return rc;
+    const ltp::Limits L = dev_limits(p);
+    const ltp::Queries q = to_dev(in);
+    const ltp::Records r = to_dev(out);
+    LTP_HIP_TRY(p, hipMemsetAsync(p->d_queue_count, 0, sizeof(unsigned long long), s));
+    ltp::launch_switch_times(s, n, p->dof, p->t_sample, L, q, r, p->d_queue, p->d_queue_count);
+    ltp::launch_scaling_slow(s, n, p->dof, p->t_sample, L, q, r, p->d_queue, p->d_queue_count);
+    ltp::launch_offsets(s, n, p->dof, p->t_sample, r, p->d_block_sums, offsets ? offsets : p->d_offsets_scratch);
+    LTP_HIP_TRY(p, hipGetLastError());
+    return LTP_OK;
+}
+
+int ltp_sample_batch(ltp_planner* p, long long first, long long count, const ltp_queries* in, const ltp_records* rec,
+                     const unsigned long long* offsets, double* out, unsigned long long capacity, int flags, void* stream)
+{
+    if (!p || first < 0 || count < 0 || !in || !records_complete(rec) || !offsets || (!out && capacity > 0))
+        return fail(p, LTP_ERR_INVALID_ARGUMENT, "null argument");
+    if (((uintptr_t)out & 15u) != 0) return fail(p, LTP_ERR_INVALID_ARGUMENT, "trajectory buffer must be 16-byte aligned");
+    std::lock_guard<std::mutex> g(p->mu);
+    int rc = check_config(p);
+    if (rc != LTP_OK) return rc;
+    if (count == 0 || p->dof == 0) return LTP_OK;
+    LTP_HIP_TRY(p, hipSetDevice(p->device));
+    ltp::launch_sample((hipStream_t)stream, first, count, p->dof, p->t_sample, dev_limits(p), to_dev(in), to_dev(rec), offsets,
+                       out, capacity, flags & 1);
+    LTP_HIP_TRY(p, hipGetLastError());
+    return LTP_OK;
+}
+
+int ltp_generate_queries_batch(ltp_planner* p, long long n, unsigned long long seed, long long first_query,
+                               double* q_goal, double* q_0, double* v_0, double* a_0,
+                               long long query_stride, long long joint_stride, void* stream)
+{
+    if (!p || n < 0 || !q_goal || !q_0 || !v_0 || !a_0) return fail(p, LTP_ERR_INVALID_ARGUMENT, "null argument");
+    std::lock_guard<std::mutex> g(p->mu);
+    int rc = check_config(p);
+    if (rc != LTP_OK) return rc;
+    if (p->dof > 64) return fail(p, LTP_ERR_INVALID_ARGUMENT, "generator supports dof <= 64");
+    LTP_HIP_TRY(p, hipSetDevice(p->device));
+    ltp::launch_generate((hipStream_t)stream, n, p->dof, dev_limits(p), seed, first_query, q_goal, q_0, v_0, a_0, query_stride,
+                         joint_stride);
+    LTP_HIP_TRY(p, hipGetLastError());
+    return LTP_OK;
+}
+
+// ---- host-pointer convenience ------------------------------------------------------------------
+
+static int run_sample_to_host(ltp_planner* p, long long n, const ltp_queries& dq, const ltp_records& dr,
+                              unsigned long long* d_offsets, unsigned long long* offsets, double** packed)
+{
+    LTP_HIP_TRY(p, hipMemcpy(offsets, d_offsets, sizeof(unsigned long long) * (size_t)(n + 1), hipMemcpyDeviceToHost));
+    const unsigned long long total = offsets[n];
+    double* d_out = nullptr;
+    LTP_HIP_TRY(p, hipMalloc((void**)&d_out, sizeof(double) * (size_t)(total ? total : 2)));
+    // padding between rows is never written by the sampler: make the host copy deterministic
+    hipError_t e = hipMemset(d_out, 0, sizeof(double) * (size_t)(total ? total : 2));
+    int rc = LTP_OK;
+    if (e != hipSuccess) rc = hip_fail(p, e, "hipMemset");
+    if (rc == LTP_OK) rc = ltp_sample_batch(p, 0, n, &dq, &dr, d_offsets, d_out, total, 0, nullptr);
+    if (rc == LTP_OK) {
+        e = hipDeviceSynchronize();
+        if (e != hipSuccess) rc = hip_fail(p, e, "hipDeviceSynchronize");
+    }
+    if (rc == LTP_OK) {
+        double* h = (double*)malloc(sizeof(double) * (size_t)(total ? total : 1));
+        if (!h) rc = fail(p, LTP_ERR_OUT_OF_MEMORY, "malloc");
+        else {
+            e = hipMemcpy(h, d_out, sizeof(double) * (size_t)total, hipMemcpyDeviceToHost);
+            if (e != hipSuccess) { free(h); rc = hip_fail(p, e, "hipMemcpy"); }
+            else *packed = h;
+        }
+    }
+    (void)hipFree(d_out);
+    return rc;
+}
+
+static int download_records(ltp_planner* p, long long n, int dof, const ltp_records& d, const ltp_records* h)
+{
+    if (!h) return LTP_OK;
+    const size_t nd = (size_t)n * dof;
+    if (h->t_opt) LTP_HIP_TRY(p, hipMemcpy(h->t_opt, d.t_opt, sizeof(double) * nd * 7, hipMemcpyDeviceToHost));
+    if (h->t_scaled) LTP_HIP_TRY(p, hipMemcpy(h->t_scaled, d.t_scaled, sizeof(double) * nd * 7, hipMemcpyDeviceToHost));
+    if (h->dir) LTP_HIP_TRY(p, hipMemcpy(h->dir, d.dir, sizeof(double) * nd, hipMemcpyDeviceToHost));
+    if (h->v_drive) LTP_HIP_TRY(p, hipMemcpy(h->v_drive, d.v_drive, sizeof(double) * nd, hipMemcpyDeviceToHost));
+    if (h->mod) LTP_HIP_TRY(p, hipMemcpy(h->mod, d.mod, nd, hipMemcpyDeviceToHost));
+    if (h->t_required) LTP_HIP_TRY(p, hipMemcpy(h->t_required, d.t_required, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost));
+    if (h->slowest) LTP_HIP_TRY(p, hipMemcpy(h->slowest, d.slowest, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost));
+    if (h->traj_len) LTP_HIP_TRY(p, hipMemcpy(h->traj_len, d.traj_len, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost));
+    if (h->status) LTP_HIP_TRY(p, hipMemcpy(h->status, d.status, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost));
+    return LTP_OK;
+}
+
+int ltp_plan_batch_host(ltp_planner* p, long long n, const double* q_goal, const double* q_0, const double* v_0,
+                        const double* a_0, const ltp_records* host_records, unsigned long long* offsets, double** packed)
+{
+    if (!p || n < 0 || (n > 0 && (!q_goal || !q_0 || !v_0 || !a_0)) || (packed && !offsets)) return fail(p, LTP_ERR_INVALID_ARGUMENT, "null argument");
+    if (packed) *packed = nullptr;
+    int rc;
+    { std::lock_guard<std::mutex> g(p->mu); rc = check_config(p); }
+    if (rc != LTP_OK) return rc;
+    LTP_HIP_TRY(p, hipSetDevice(p->device));
+    const int dof = p->dof;
+    const size_t nd = (size_t)n * dof;
+    DevRecords dr;
+    LTP_HIP_TRY(p, dr.alloc_all(n, dof));
+    double* d_in[4] = {nullptr, nullptr, nullptr, nullptr};
+    const double* h_in[4] = {q_goal, q_0, v_0, a_0};
+    for (int k = 0; k < 4; ++k) {
+        LTP_HIP_TRY(p, dr.alloc(&d_in[k], nd));
+        if (nd) LTP_HIP_TRY(p, hipMemcpy(d_in[k], h_in[k], sizeof(double) * nd, hipMemcpyHostToDevice));
+    }
+    unsigned long long* d_off = nullptr;
+    LTP_HIP_TRY(p, dr.alloc(&d_off, (size_t)n + 1));
+    ltp_queries dq{d_in[0], d_in[1], d_in[2], d_in[3], dof, 1};
+    rc = ltp_plan_switch_times_batch(p, n, &dq, &dr.r, d_off, nullptr);
+    if (rc != LTP_OK) return rc;
+    LTP_HIP_TRY(p, hipDeviceSynchronize());
+    if (packed) {
+        rc = run_sample_to_host(p, n, dq, dr.r, d_off, offsets, packed);
+        if (rc != LTP_OK) return rc;
+    } else if (offsets) {
+        LTP_HIP_TRY(p, hipMemcpy(offsets, d_off, sizeof(unsigned long long) * (size_t)(n + 1), hipMemcpyDeviceToHost));
+    }
+    return download_records(p, n, dof, dr.r, host_records);   // after sampling: status carries END_LIMIT
+}
+
+int ltp_get_trajectory_host(ltp_planner* p, long long n, const double* t, const double* dir, const signed char* mod,
+                            const double* q_0, const double* v_0, const double* a_0, const double* v_drive,
+                            int* traj_len, int* status, unsigned long long* offsets, double** packed)
+{
+    if (!p || n < 0 || !offsets || !packed || (n > 0 && (!t || !dir || !mod || !q_0 || !v_0 || !a_0 || !v_drive)))
+        return fail(p, LTP_ERR_INVALID_ARGUMENT, "null argument");
+    *packed = nullptr;
+    int rc;
+    { std::lock_guard<std::mutex> g(p->mu); rc = check_config(p); if (rc == LTP_OK) rc = reserve(p, n > 0 ? n : 1); }
+    if (rc != LTP_OK) return rc;
+    LTP_HIP_TRY(p, hipSetDevice(p->device));
+    const int dof = p->dof;
+    const size_t nd = (size_t)n * dof;
+    DevRecords dr;
+    LTP_HIP_TRY(p, dr.alloc_all(n, dof));
+    if (nd) {
+        LTP_HIP_TRY(p, hipMemcpy(dr.r.t_scaled, t, sizeof(double) * nd * 7, hipMemcpyHostToDevice));
+        LTP_HIP_TRY(p, hipMemcpy(dr.r.dir, dir, sizeof(double) * nd, hipMemcpyHostToDevice));
+        LTP_HIP_TRY(p, hipMemcpy(dr.r.mod, mod, nd, hipMemcpyHostToDevice));
+        LTP_HIP_TRY(p, hipMemcpy(dr.r.v_drive, v_drive, sizeof(double) * nd, hipMemcpyHostToDevice));
+    }
+    if (n) LTP_HIP_TRY(p, hipMemset(dr.r.status, 0, sizeof(int) * (size_t)n));
+    double* d_in[3] = {nullptr, nullptr, nullptr};
+    const double* h_in[3] = {q_0, v_0, a_0};
+    for (int k = 0; k < 3; ++k) {
+        LTP_HIP_TRY(p, dr.alloc(&d_in[k], nd));
+        if (nd) LTP_HIP_TRY(p, hipMemcpy(d_in[k], h_in[k], sizeof(double) * nd, hipMemcpyHostToDevice));
+    }
+    unsigned long long* d_off = nullptr;
+    LTP_HIP_TRY(p, dr.alloc(&d_off, (size_t)n + 1));
+    LTP_HIP_TRY(p, hipMemset(d_off, 0, sizeof(unsigned long long) * ((size_t)n + 1)));
+    ltp_queries dq{d_in[0], d_in[0], d_in[1], d_in[2], dof, 1};   // q_goal is not used by the sampler
+    if (n > 0 && dof > 0) {
+        std::lock_guard<std::mutex> g(p->mu);
+        ltp::launch_offsets(nullptr, n, dof, p->t_sample, to_dev(&dr.r), p->d_block_sums, d_off);
+        LTP_HIP_TRY(p, hipGetLastError());
+    }
+    LTP_HIP_TRY(p, hipDeviceSynchronize());
+    rc = run_sample_to_host(p, n, dq, dr.r, d_off, offsets, packed);
+    if (rc != LTP_OK) return rc;
+    if (traj_len) LTP_HIP_TRY(p, hipMemcpy(traj_len, dr.r.traj_len, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost));
+    if (status) LTP_HIP_TRY(p, hipMemcpy(status, dr.r.status, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost));
+    return LTP_OK;
+}
+
+void ltp_free_host(void* ptr) { free(ptr); }
+
+int ltp_check_inputs_host(ltp_planner* p, const double* q_0, const double* v_0, const double* a_0, int* ok)
+{
+    if (!p || !ok) return fail(p, LTP_ERR_INVALID_ARGUMENT, "null argument");
+    // checkInputs is stage 0 of the batched kernel: run one query through it with q_goal = q_0
+    const int dof = p->dof;
+    std::vector<double> topt((size_t)dof * 7 + 1), tsc((size_t)dof * 7 + 1), dir((size_t)dof + 1), vd((size_t)dof + 1);
+    std::vector<signed char> mod((size_t)dof + 1);
+    double tr; int slow, len, st;
+    ltp_records r{topt.data(), tsc.data(), dir.data(), vd.data(), mod.data(), &tr, &slow, &len, &st};
+    const int rc = ltp_plan_batch_host(p, 1, q_0, q_0, v_0, a_0, &r, nullptr, nullptr);
+    if (rc != LTP_OK) return rc;
+    *ok = (st & LTP_STATUS_INVALID_INPUT) ? 0 : 1;
+    return LTP_OK;
+}
+
+int ltp_opt_braking_host(ltp_planner* p, int joint, double v_0, double a_0, double* q, double* t_rel, double* dir)
+{
+    if (!p || !q || !t_rel || !dir) return fail(p, LTP_ERR_INVALID_ARGUMENT, "null argument");
+    std::lock_guard<std::mutex> g(p->mu);
+    if (joint < 0 || joint >= p->lim_cap) return fail(p, LTP_ERR_INVALID_ARGUMENT, "joint out of range");
+    LTP_HIP_TRY(p, hipSetDevice(p->device));
+    double buf[16] = {0};
+    memcpy(buf, t_rel, sizeof(double) * 7);
+    LTP_HIP_TRY(p, hipMemcpy(p->d_small, buf, sizeof(buf), hipMemcpyHostToDevice));
+    ltp::launch_single_opt_braking(nullptr, joint, p->t_sample, dev_limits(p), v_0, a_0, p->d_small);
+    LTP_HIP_TRY(p, hipGetLastError());
+    LTP_HIP_TRY(p, hipMemcpy(buf, p->d_small, sizeof(buf), hipMemcpyDeviceToHost));
+    memcpy(t_rel, buf, sizeof(double) * 7);
+    *q = buf[7];
+    *dir = buf[8];
+    return LTP_OK;
+}
+
+int ltp_opt_switch_times_host(ltp_planner* p, int joint, double q_goal, double q_0, double v_0, double a_0, double v_drive,
+                              double* t, double* dir, char* mod, int* ok)
+{
+    if (!p || !t || !dir || !mod || !ok) return fail(p, LTP_ERR_INVALID_ARGUMENT, "null argument");
+    std::lock_guard<std::mutex> g(p->mu);
+    if (joint < 0 || joint >= p->lim_cap) return fail(p, LTP_ERR_INVALID_ARGUMENT, "joint out of range");
+    LTP_HIP_TRY(p, hipSetDevice(p->device));
+    double buf[16] = {0};
+    memcpy(buf, t, sizeof(double) * 7);
+    LTP_HIP_TRY(p, hipMemcpy(p->d_small, buf, sizeof(buf), hipMemcpyHostToDevice));
+    ltp::launch_single_opt_switch(nullptr, joint, p->t_sample, dev_limits(p), q_goal, q_0, v_0, a_0, v_drive, p->d_small);
+    LTP_HIP_TRY(p, hipGetLastError());
+    LTP_HIP_TRY(p, hipMemcpy(buf, p->d_small, sizeof(buf), hipMemcpyDeviceToHost));
+    memcpy(t, buf, sizeof(double) * 7);
+    *dir = buf[7];
+    *mod = (char)(int)buf[8];
+    *ok = (int)buf[9];
+    return LTP_OK;
+}
+
+int ltp_time_scaling_host(ltp_planner* p, int joint, double q_goal, double q_0, double v_0, double a_0, double dir,
+                          double t_required, double* scaled_t, double* v_drive, char* mod, int* ok, int* accepted_case)
+{
+    if (!p || !scaled_t || !v_drive || !mod || !ok) return fail(p, LTP_ERR_INVALID_ARGUMENT, "null argument");
+    std::lock_guard<std::mutex> g(p->mu);
+    if (joint < 0 || joint >= p->lim_cap) return fail(p, LTP_ERR_INVALID_ARGUMENT, "joint out of range");
+    LTP_HIP_TRY(p, hipSetDevice(p->device));
+    double buf[16] = {0};
+    memcpy(buf, scaled_t, sizeof(double) * 7);
+    LTP_HIP_TRY(p, hipMemcpy(p->d_small, buf, sizeof(buf), hipMemcpyHostToDevice));
+    ltp::launch_single_time_scaling(nullptr, joint, p->t_sample, dev_limits(p), q_goal, q_0, v_0, a_0, dir, t_required, p->d_small);
+    LTP_HIP_TRY(p, hipGetLastError());
+    LTP_HIP_TRY(p, hipMemcpy(buf, p->d_small, sizeof(buf), hipMemcpyDeviceToHost));
+    memcpy(scaled_t, buf, sizeof(double) * 7);
+    *v_drive = buf[7];
+    *mod = (char)(int)buf[8];
+    *ok = (int)buf[9];
+    if (accepted_case) *accepted_case = (int)buf[10];
+    return LTP_OK;
+}
+
+int ltp_debug_math_probe_host(ltp_planner* p, long long n, const double* x, const double* y, double* out)
+{
+    if (!p || n < 0 || !x || !y || !out) return fail(p, LTP_ERR_INVALID_ARGUMENT, "null argument");
+    LTP_HIP_TRY(p, hipSetDevice(p->device));
+    double *dx = nullptr, *dy = nullptr, *dout = nullptr;
+    DevRecords holder;
+    LTP_HIP_TRY(p, holder.alloc(&dx, (size_t)n));
+    LTP_HIP_TRY(p, holder.alloc(&dy, (size_t)n));
+    LTP_HIP_TRY(p, holder.alloc(&dout, (size_t)n * 8));
+    LTP_HIP_TRY(p, hipMemcpy(dx, x, sizeof(double) * (size_t)n, hipMemcpyHostToDevice));
+    LTP_HIP_TRY(p, hipMemcpy(dy, y, sizeof(double) * (size_t)n, hipMemcpyHostToDevice));
+    ltp::launch_math_probe(nullptr, n, dx, dy, dout);
+    LTP_HIP_TRY(p, hipGetLastError());
+    LTP_HIP_TRY(p, hipMemcpy(out, dout, sizeof(double) * (size_t)n * 8, hipMemcpyDeviceToHost));
+    return LTP_OK;
+}
+
+int ltp_debug_roots_probe_host(ltp_planner* p, long long n, int degree, const double* coef, double* root)
+{
+    if (!p || n < 0 || !coef || !root || degree < 4 || degree > 6) return fail(p, LTP_ERR_INVALID_ARGUMENT, "bad argument");
+    LTP_HIP_TRY(p, hipSetDevice(p->device));
+    double *dc = nullptr, *dr = nullptr;
+    DevRecords holder;
+    LTP_HIP_TRY(p, holder.alloc(&dc, (size_t)n * 7));
+    LTP_HIP_TRY(p, holder.alloc(&dr, (size_t)n));
+    LTP_HIP_TRY(p, hipMemcpy(dc, coef, sizeof(double) * (size_t)n * 7, hipMemcpyHostToDevice));
+    ltp::launch_roots_probe(nullptr, n, degree, dc, dr);
+    LTP_HIP_TRY(p, hipGetLastError());
+    LTP_HIP_TRY(p, hipMemcpy(root, dr, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost));
+    return LTP_OK;
+}
+
+}  // extern "C"

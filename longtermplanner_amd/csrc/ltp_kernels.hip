@@ -1,0 +1,764 @@
+// ltp_kernels.hip — hand-written CDNA4 (gfx950) kernels for the batched planner.
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (see Makefile). No fast-math:
+// the inf/NaN flow of the reference is part of the contract.
+#include "ltp_kernels.hpp"
+#include "ltp_profile.hpp"
+
+namespace ltp {
+
+typedef double double2_t __attribute__((ext_vector_type(2)));
+
+LTP_DEV JointLimits load_limits(const Limits& lim, int j)
+{
+    JointLimits L;
+    L.q_min = lim.q_min[j];
+    L.q_max = lim.q_max[j];
+    L.v_max = lim.v_max[j];
+    L.a_max = lim.a_max[j];
+    L.j_max = lim.j_max[j];
+    return L;
+}
+
+// ---------------------------------------------------------------------------------------
+// Stage 1 + reduction + closed-form scaling.
+// Block = 64 queries x JB joint slots; wave y handles joints y, y+JB, ... of 64 consecutive
+// queries, so joint limits are wave-uniform (SGPRs) and query-major/joint-major inputs are
+// both read with one address stride per lane. The per-query slowest-joint reduction
+// (reference cc:31-39: strict '>', first index wins, NaN never wins, init -1) goes through
+// LDS across the JB waves.
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kQueriesPerBlock* kMaxJointSlots)
+k_switch_times(long long n, int dof, double t_sample, Limits lim, Queries in, Records out,
+               unsigned long long* __restrict__ queue, unsigned long long* __restrict__ queue_count)
+{
+    __shared__ double s_t[kMaxJointSlots][kQueriesPerBlock];
+    __shared__ int s_j[kMaxJointSlots][kQueriesPerBlock];
+    __shared__ int s_f[kMaxJointSlots][kQueriesPerBlock];
+
+    const int x = threadIdx.x, y = threadIdx.y, JB = blockDim.y;
+    const long long q = (long long)blockIdx.x * kQueriesPerBlock + x;
+    const bool live = q < n;
+
+    double best_t = -1.0;
+    int best_j = -1, flags = 0;
+    for (int j = y; j < dof; j += JB) {
+        const JointLimits L = load_limits(lim, j);
+        if (live) {
+            const long long ix = q * in.sq + (long long)j * in.sj;
+            const double qg = in.q_goal[ix], q0 = in.q_0[ix], v0 = in.v_0[ix], a0 = in.a_0[ix];
+            if (!check_inputs_joint(L, q0, v0, a0)) flags |= kStatusInvalidInput;
+            double t[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+            double dir = 0.0;
+            int mod = 0;
+            const bool ok = opt_switch_times(L.a_max, L.j_max, t_sample, qg, q0, v0, a0, L.v_max, t, dir, mod);
+            if (!ok) flags |= kStatusOptFailed;
+            const long long rj = q * dof + j;
+#pragma unroll
+            for (int k = 0; k < 7; ++k) out.t_opt[rj * 7 + k] = t[k];
+            out.dir[rj] = dir;
+            out.mod[rj] = (signed char)mod;
+            if (t[6] > best_t) { best_t = t[6]; best_j = j; }
+        }
+    }
+    s_t[y][x] = best_t;
+    s_j[y][x] = best_j;
+    s_f[y][x] = flags;
+    __syncthreads();
+    double t_required = -1.0;
+    int slowest = -1;
+    flags = 0;
+    for (int yy = 0; yy < JB; ++yy) {
+        const double bt = s_t[yy][x];
+        const int bj = s_j[yy][x];
+        flags |= s_f[yy][x];
+        if (bj >= 0 && (bt > t_required || (bt == t_required && bj < slowest))) { t_required = bt; slowest = bj; }
+    }
+    if (slowest < 0) flags |= kStatusNoSlowest;
+    if (live && y == 0) {
+        out.t_required[q] = t_required;
+        out.slowest[q] = slowest;
+        out.status[q] = flags;
+    }
+
+    // Stage 3, closed-form cases c1, c2 (reference cc:378-446); others go to the queue.
+    for (int j = y; j < dof; j += JB) {
+        const JointLimits L = load_limits(lim, j);
+        bool need_slow = false;
+        const long long rj = q * dof + j;
+        if (live) {
+            double ts[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+            double vd = L.v_max;
+            int mod;
+            bool write = true;
+            if (flags != 0) {
+                mod = 0;   // failed query: zero record, never sampled
+            } else {
+                double topt[7];
+#pragma unroll
+                for (int k = 0; k < 7; ++k) topt[k] = out.t_opt[rj * 7 + k];
+                mod = out.mod[rj];
+                if (j != slowest) {
+                    const long long ix = q * in.sq + (long long)j * in.sj;
+                    const double qg = in.q_goal[ix], q0 = in.q_0[ix];
+                    double v0 = in.v_0[ix], a0 = in.a_0[ix];
+                    const double dir = out.dir[rj];
+                    if (dir < 0.0) { v0 = -v0; a0 = -a0; }
+                    vd = v_drive_candidate<1>(L.a_max, L.j_max, qg, q0, v0, a0, dir, t_required);
+                    bool acc = try_v_drive(L.a_max, L.j_max, t_sample, qg, q0, v0, a0, dir, t_required, vd, ts, mod);
+                    if (!acc) {
+                        vd = v_drive_candidate<2>(L.a_max, L.j_max, qg, q0, v0, a0, dir, t_required);
+                        acc = try_v_drive(L.a_max, L.j_max, t_sample, qg, q0, v0, a0, dir, t_required, vd, ts, mod);
+                    }
+                    if (!acc) { need_slow = true; write = false; }
+                }
+                if (write) {
+                    // cc:50-55: no scaled solution (or the slowest joint) -> optimal times
+                    double mx = ts[0];
+#pragma unroll
+                    for (int k = 1; k < 7; ++k) if (mx < ts[k]) mx = ts[k];
+                    if (mx <= 0.0) {
+#pragma unroll
+                        for (int k = 0; k < 7; ++k) ts[k] = topt[k];
+                    }
+                }
+            }
+            if (write) {
+#pragma unroll
+                for (int k = 0; k < 7; ++k) out.t_scaled[rj * 7 + k] = ts[k];
+                out.v_drive[rj] = vd;
+                out.mod[rj] = (signed char)mod;
+            }
+        }
+        // wave-level compaction of the rare polynomial cases: one atomic per wave
+        const unsigned long long mask = __ballot(need_slow);
+        if (mask != 0ull) {
+            const int leader = __ffsll((long long)mask) - 1;
+            unsigned long long base = 0ull;
+            if (x == leader) base = atomicAdd(queue_count, (unsigned long long)__popcll(mask));
+            base = __shfl(base, leader);
+            if (need_slow) {
+                const int rank = __popcll(mask & ((1ull << x) - 1ull));
+                queue[base + rank] = (unsigned long long)rj;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// Stage 3, polynomial cases c3..c8 (reference cc:449-638) and the reset (cc:640-644) +
+// fallback (cc:50-55), one lane per queued (query, joint): the divergent rare path runs
+// with full waves instead of dragging 64-lane waves of the main kernel through it.
+// ---------------------------------------------------------------------------------------
+template <int C>
+LTP_DEV bool scaling_case(const JointLimits& L, double t_sample, double qg, double q0, double v0, double a0, double dir,
+                          double tr, double& vd, double (&ts)[7], int& mod)
+{
+    vd = v_drive_candidate<C>(L.a_max, L.j_max, qg, q0, v0, a0, dir, tr);
+    return try_v_drive(L.a_max, L.j_max, t_sample, qg, q0, v0, a0, dir, tr, vd, ts, mod);
+}
+
+__global__ void __launch_bounds__(64)
+k_scaling_slow(int dof, double t_sample, Limits lim, Queries in, Records out,
+               const unsigned long long* __restrict__ queue, const unsigned long long* __restrict__ queue_count)
+{
+    const unsigned long long count = *queue_count;
+    for (unsigned long long it = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; it < count;
+         it += (unsigned long long)gridDim.x * blockDim.x) {
+        const long long rj = (long long)queue[it];
+        const long long q = rj / dof;
+        const int j = (int)(rj - q * dof);
+        const JointLimits L = load_limits(lim, j);
+        const long long ix = q * in.sq + (long long)j * in.sj;
+        const double qg = in.q_goal[ix], q0 = in.q_0[ix];
+        double v0 = in.v_0[ix], a0 = in.a_0[ix];
+        const double dir = out.dir[rj];
+        const double tr = out.t_required[q];
+        if (dir < 0.0) { v0 = -v0; a0 = -a0; }
+        double ts[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        double vd;
+        int mod = 0;
+        bool acc = scaling_case<3>(L, t_sample, qg, q0, v0, a0, dir, tr, vd, ts, mod);
+        if (!acc) acc = scaling_case<4>(L, t_sample, qg, q0, v0, a0, dir, tr, vd, ts, mod);
+        if (!acc) acc = scaling_case<5>(L, t_sample, qg, q0, v0, a0, dir, tr, vd, ts, mod);
+        if (!acc) acc = scaling_case<6>(L, t_sample, qg, q0, v0, a0, dir, tr, vd, ts, mod);
+        if (!acc) acc = scaling_case<7>(L, t_sample, qg, q0, v0, a0, dir, tr, vd, ts, mod);
+        if (!acc) acc = scaling_case<8>(L, t_sample, qg, q0, v0, a0, dir, tr, vd, ts, mod);
+        if (!acc) {
+            mod = 0;
+            zero7(ts);
+            vd = L.v_max;
+        }
+        double mx = ts[0];
+#pragma unroll
+        for (int k = 1; k < 7; ++k) if (mx < ts[k]) mx = ts[k];
+        if (mx <= 0.0) {
+#pragma unroll
+            for (int k = 0; k < 7; ++k) ts[k] = out.t_opt[rj * 7 + k];
+        }
+#pragma unroll
+        for (int k = 0; k < 7; ++k) out.t_scaled[rj * 7 + k] = ts[k];
+        out.v_drive[rj] = vd;
+        out.mod[rj] = (signed char)mod;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// traj_len (cc:716-719), per-plan packed size and the exclusive scan of sizes.
+// Packed layout of plan p at out + offsets[p]: [array q,v,a,j][joint][row_stride] doubles,
+// row_stride = round_up(traj_len, 16) so that every row starts 128-B aligned.
+// ---------------------------------------------------------------------------------------
+LTP_DEV unsigned long long plan_size(int len, int dof)
+{
+    if (len <= 0) return 0ull;
+    const unsigned long long stride = ((unsigned long long)len + (kRowAlign - 1)) / kRowAlign * kRowAlign;
+    return 4ull * (unsigned long long)dof * stride;
+}
+
+__global__ void __launch_bounds__(256)
+k_finalize(long long n, int dof, double t_sample, Records rec, unsigned long long* __restrict__ block_sums)
+{
+    __shared__ unsigned long long s_part[256];
+    const long long base = (long long)blockIdx.x * kScanBlock;
+    unsigned long long local = 0ull;
+    for (int e = 0; e < kScanBlock / 256; ++e) {
+        const long long q = base + e * 256 + threadIdx.x;
+        if (q < n) {
+            int len = 0, st = rec.status[q];
+            if (st == 0) {
+                bool finite = true;
+                for (int j = 0; j < dof; ++j) {
+                    const double* t = rec.t_scaled + (q * dof + j) * 7;
+#pragma unroll
+                    for (int k = 0; k < 7; ++k) finite = finite && dfinite(t[k]);
+                    const int l = (int)dceil(t[6] / t_sample) + 1;
+                    len = l > len ? l : len;
+                }
+                if (!finite) { len = 0; st |= kStatusNonFinite; rec.status[q] = st; }
+            }
+            rec.traj_len[q] = len;
+            local += plan_size(len, dof);
+        }
+    }
+    s_part[threadIdx.x] = local;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) s_part[threadIdx.x] += s_part[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = s_part[0];
+}
+
+// exclusive scan of block_sums in place, single block
+__global__ void __launch_bounds__(1024)
+k_scan_top(long long nb, unsigned long long* __restrict__ block_sums)
+{
+    __shared__ unsigned long long s[1024];
+    __shared__ unsigned long long carry;
+    if (threadIdx.x == 0) carry = 0ull;
+    __syncthreads();
+    for (long long base = 0; base < nb; base += 1024) {
+        const long long i = base + threadIdx.x;
+        const unsigned long long v = i < nb ? block_sums[i] : 0ull;
+        s[threadIdx.x] = v;
+        __syncthreads();
+        for (int d = 1; d < 1024; d <<= 1) {
+            const unsigned long long add = (int)threadIdx.x >= d ? s[threadIdx.x - d] : 0ull;
+            __syncthreads();
+            s[threadIdx.x] += add;
+            __syncthreads();
+        }
+        if (i < nb) block_sums[i] = carry + s[threadIdx.x] - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry += s[1023];
+        __syncthreads();
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_scan_apply(long long n, int dof, const int* __restrict__ traj_len, const unsigned long long* __restrict__ block_sums,
+             unsigned long long* __restrict__ offsets)
+{
+    __shared__ unsigned long long s[256];
+    const long long base = (long long)blockIdx.x * kScanBlock;
+    constexpr int E = kScanBlock / 256;
+    // thread owns E consecutive plans
+    unsigned long long sz[E], local = 0ull;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const long long q = base + (long long)threadIdx.x * E + e;
+        sz[e] = q < n ? plan_size(traj_len[q], dof) : 0ull;
+        local += sz[e];
+    }
+    s[threadIdx.x] = local;
+    __syncthreads();
+    for (int d = 1; d < 256; d <<= 1) {
+        const unsigned long long add = (int)threadIdx.x >= d ? s[threadIdx.x - d] : 0ull;
+        __syncthreads();
+        s[threadIdx.x] += add;
+        __syncthreads();
+    }
+    unsigned long long run = block_sums[blockIdx.x] + s[threadIdx.x] - local;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const long long q = base + (long long)threadIdx.x * E + e;
+        if (q < n) {
+            offsets[q] = run;
+            run += sz[e];
+            if (q == n - 1) offsets[n] = run;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// The sampler: reference getTrajectory (cc:706-841).
+//
+// The reference integrates a piecewise-constant jerk sample by sample. Here the jerk array of
+// one joint (seven range fills cc:759-766, then up to eight "+=" fractional corrections
+// cc:768-807) is cut at every index where it, or one of the three snap rules (cc:815-829),
+// can change: at most kMaxSegments runs of constant jerk and constant mode. One lane per joint
+// walks those runs once and leaves, per run, the state before its first sample in LDS. After
+// that every sample is independent: within a run that starts after state (a_s, v_s, q_s),
+//     a[m] = a_s + m*Ts*J
+//     v[m] = v_s + Ts*(m*a_s + Ts*J*m(m+1)/2)
+//     q[m] = q_s + Ts*(m*v_s + Ts*(a_s*m(m+1)/2 + Ts*J*m(m+1)(m+2)/6))
+// are exactly the sums the recurrence forms (up to the order of rounding, ~1e-13), so all 256
+// lanes stream q/v/a/j rows to HBM as 16-byte stores, 1 KiB contiguous per wave instruction.
+// ---------------------------------------------------------------------------------------
+constexpr int kModeTail = 1;    // i > s6: a = 0, v = 0 (cc:815-829)
+constexpr int kModeVSnap = 2;   // phase 4 interior: v = v_drive*dir (cc:822-823)
+
+struct SegTable {
+    int start[kSampleJointGroup][kMaxSegments + 1];
+    int mode[kSampleJointGroup][kMaxSegments];
+    double J[kSampleJointGroup][kMaxSegments];
+    double a[kSampleJointGroup][kMaxSegments];
+    double v[kSampleJointGroup][kMaxSegments];
+    double q[kSampleJointGroup][kMaxSegments];
+    double vsnap[kSampleJointGroup];
+    int nseg[kSampleJointGroup];
+};
+
+struct JerkPlan {   // everything jerk_at() needs, per joint (registers of the prep lane)
+    int s[7];
+    double Jp[7];
+    double c_s0p1, c_s1, c_s2p1, c_s1_merged, c_s3, c_s4p1, c_s4_merged, c_s5, c_s6p1;
+};
+
+// value of the reference's j_traj[joint][i] after fills and corrections
+LTP_DEV double jerk_at(const JerkPlan& P, int i)
+{
+    const int* s = P.s;
+    double val = 0.0;
+    if (s[0] > 0 && i < s[0]) val = P.Jp[0];
+#pragma unroll
+    for (int k = 1; k < 7; ++k)
+        if (s[k] - s[k - 1] > 0 && i >= s[k - 1] && i < s[k]) val = P.Jp[k];
+    if (s[2] >= s[1]) {
+        if (i == s[0] + 1) val = val + P.c_s0p1;
+        if (s[1] > 0 && i == s[1]) val = val + P.c_s1;
+        if (i == s[2] + 1) val = val + P.c_s2p1;
+    } else {
+        if (s[1] > 0 && i == s[1]) val = val + P.c_s1_merged;
+    }
+    if (s[3] > 0 && i == s[3]) val = val + P.c_s3;
+    if (s[2] - s[0] > 0) {
+        if (i == s[4] + 1) val = val + P.c_s4p1;
+    } else {
+        if (s[4] > 0 && i == s[4]) val = val + P.c_s4_merged;
+    }
+    if (s[5] > 0 && i == s[5]) val = val + P.c_s5;
+    if (i == s[6] + 1) val = val + P.c_s6p1;
+    return val;
+}
+
+// state after the m-th sample (m >= 1) of a run that starts after (a_s, v_s, q_s)
+LTP_DEV void run_eval(int mode, double J, double a_s, double v_s, double q_s, double vsnap, double Ts, int m,
+                      double& a, double& v, double& q)
+{
+    const double md = (double)m;
+    const double tj = Ts * J;
+    const long long ml = m;
+    const double s1 = (double)(ml * (ml + 1) / 2);
+    a = (mode & kModeTail) ? 0.0 : a_s + md * tj;
+    if (mode & kModeVSnap) {
+        v = vsnap;
+        q = q_s + md * (Ts * vsnap);
+    } else if (mode & kModeTail) {
+        v = 0.0;
+        q = q_s;
+    } else {
+        const double s2 = (double)(ml * (ml + 1) * (ml + 2) / 6);
+        v = v_s + Ts * (md * a_s + tj * s1);
+        q = q_s + Ts * (md * v_s + Ts * (s1 * a_s + tj * s2));
+    }
+}
+
+__global__ void __launch_bounds__(kSampleThreads)
+k_sample(long long first, long long count, int dof, double t_sample, Limits lim, Queries in, Records rec,
+         const unsigned long long* __restrict__ offsets, double* __restrict__ out, unsigned long long capacity,
+         int streaming_stores)
+{
+    __shared__ SegTable tab;
+    const long long p = first + blockIdx.x;
+    if (blockIdx.x >= count) return;
+    const int len = rec.traj_len[p];
+    if (len <= 0) return;   // failed / non-finite query: nothing to sample (uniform per block)
+    const unsigned long long off0 = offsets[first];
+    const unsigned long long rel = offsets[p] - off0;
+    const unsigned long long stride = ((unsigned long long)len + (kRowAlign - 1)) / kRowAlign * kRowAlign;
+    if (rel + 4ull * dof * stride > capacity) {
+        if (threadIdx.x == 0 && blockIdx.y == 0) atomicOr(&rec.status[p], kStatusOverflow);
+        return;
+    }
+    const int j0 = blockIdx.y * kSampleJointGroup;
+    const int nj = (dof - j0) < kSampleJointGroup ? (dof - j0) : kSampleJointGroup;
+    const double Ts = t_sample;
+
+    if ((int)threadIdx.x < nj) {
+        const int jl = threadIdx.x, j = j0 + jl;
+        const long long rj = p * dof + j;
+        const long long ix = p * in.sq + (long long)j * in.sj;
+        const double* t = rec.t_scaled + rj * 7;
+        const double dir = rec.dir[rj];
+        const int mod = rec.mod[rj];
+        const double jm = lim.j_max[j];
+        JerkPlan P;
+        double fr[7];
+        {
+            const double dj = dir * jm;
+            // cc:735-744: profile {1,0,-1,0,-1,0,1}, or {-1,0,1,0,-1,0,1} for the modified profile
+            P.Jp[0] = dj * (mod == 1 ? -1.0 : 1.0);
+            P.Jp[1] = dj * 0.0;
+            P.Jp[2] = dj * (mod == 1 ? 1.0 : -1.0);
+            P.Jp[3] = dj * 0.0;
+            P.Jp[4] = dj * -1.0;
+            P.Jp[5] = dj * 0.0;
+            P.Jp[6] = dj * 1.0;
+        }
+#pragma unroll
+        for (int k = 0; k < 7; ++k) {
+            const double tk = t[k];
+            fr[k] = tk - Ts * dfloor(tk / Ts);                                   // cc:747
+            P.s[k] = (k & 1) ? (int)dceil(tk / Ts) : (int)dfloor(tk / Ts);       // cc:751-757
+        }
+        // the nine possible correction terms (cc:771-807)
+        P.c_s0p1 = fr[0] / Ts * P.Jp[0];
+        P.c_s1 = (1 - fr[1] / Ts) * P.Jp[2];
+        P.c_s2p1 = fr[2] / Ts * P.Jp[2];
+        P.c_s1_merged = fr[0] / Ts * P.Jp[0] + (fr[2] - fr[0]) / Ts * P.Jp[2];
+        P.c_s3 = (1 - fr[3] / Ts) * P.Jp[4];
+        P.c_s4p1 = fr[4] / Ts * P.Jp[4];
+        P.c_s4_merged = fr[4] / Ts * P.Jp[4] + fr[0] / Ts * P.Jp[0] + (fr[2] - fr[0]) / Ts * P.Jp[2];
+        P.c_s5 = (1 - fr[5] / Ts) * P.Jp[6];
+        P.c_s6p1 = fr[6] / Ts * P.Jp[6];
+
+        const int* s = P.s;
+        const bool phase4 = s[3] - s[2] > 2;                                     // cc:813
+        // candidate cut points: every index where the jerk or a snap rule can change
+        const int cand[19] = {s[0], s[0] + 1, s[0] + 2, s[1], s[1] + 1, s[2], s[2] + 1, s[2] + 2, s[3] - 1, s[3],
+                              s[3] + 1, s[4], s[4] + 1, s[4] + 2, s[5], s[5] + 1, s[6], s[6] + 1, s[6] + 2};
+        int* st = tab.start[jl];
+        int ns = 1;
+        st[0] = 0;
+#pragma unroll
+        for (int c = 0; c < 19; ++c) {
+            const int b = cand[c];
+            if (b > 0 && b < len) {
+                // sorted insert without duplicates (the list is nearly sorted already)
+                int pos = ns;
+                while (pos > 0 && st[pos - 1] > b) --pos;
+                if (!(pos > 0 && st[pos - 1] == b) && ns < kMaxSegments) {
+                    for (int m = ns; m > pos; --m) st[m] = st[m - 1];
+                    st[pos] = b;
+                    ++ns;
+                }
+            }
+        }
+        st[ns] = len;
+        tab.nseg[jl] = ns;
+        const double vsnap = rec.v_drive[rj] * dir;                              // cc:823
+        tab.vsnap[jl] = vsnap;
+        double a = in.a_0[ix], v = in.v_0[ix], q = in.q_0[ix];                   // state "before sample 0" (cc:810-812)
+        for (int k = 0; k < ns; ++k) {
+            const int b = st[k], e = st[k + 1];
+            int mode = 0;
+            if (b > s[6]) mode |= kModeTail;
+            if (phase4 && b >= s[2] + 1 && b < s[3] - 1) mode |= kModeVSnap;
+            const double J = jerk_at(P, b);
+            tab.mode[jl][k] = mode;
+            tab.J[jl][k] = J;
+            tab.a[jl][k] = a;
+            tab.v[jl][k] = v;
+            tab.q[jl][k] = q;
+            double an, vn, qn;
+            run_eval(mode, J, a, v, q, vsnap, Ts, e - b, an, vn, qn);
+            a = an; v = vn; q = qn;
+        }
+    }
+    __syncthreads();
+
+    double* const plan_base = out + rel;
+    const unsigned long long arr_stride = (unsigned long long)dof * stride;   // distance between q, v, a, j blocks
+    const int npairs = (len + 1) >> 1;
+    for (int jl = 0; jl < nj; ++jl) {
+        const int j = j0 + jl;
+        double* const row = plan_base + (unsigned long long)j * stride;
+        const int* st = tab.start[jl];
+        const int ns = tab.nseg[jl];
+        const double vsnap = tab.vsnap[jl];
+        int k = 0;
+        for (int pr = threadIdx.x; pr < npairs; pr += kSampleThreads) {
+            const int i0 = 2 * pr;
+            double2_t oq, ov, oa, oj;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int i = i0 + h;
+                double a = 0.0, v = 0.0, q = 0.0, J = 0.0;
+                if (i < len) {
+                    while (k + 1 < ns && st[k + 1] <= i) ++k;
+                    J = tab.J[jl][k];
+                    run_eval(tab.mode[jl][k], J, tab.a[jl][k], tab.v[jl][k], tab.q[jl][k], vsnap, Ts, i - st[k] + 1, a, v, q);
+                    if (i == len - 1) {
+                        // cc:59-61: last sample outside the position limits -> planTrajectory returns false
+                        if (q < lim.q_min[j] || q > lim.q_max[j]) atomicOr(&rec.status[p], kStatusEndLimit);
+                    }
+                }
+                oq[h] = q; ov[h] = v; oa[h] = a; oj[h] = J;
+            }
+            double2_t* dq = reinterpret_cast<double2_t*>(row + i0);
+            double2_t* dv = reinterpret_cast<double2_t*>(row + arr_stride + i0);
+            double2_t* da = reinterpret_cast<double2_t*>(row + 2 * arr_stride + i0);
+            double2_t* dj = reinterpret_cast<double2_t*>(row + 3 * arr_stride + i0);
+            if (streaming_stores) {
+                __builtin_nontemporal_store(oq, dq);
+                __builtin_nontemporal_store(ov, dv);
+                __builtin_nontemporal_store(oa, da);
+                __builtin_nontemporal_store(oj, dj);
+            } else {
+                *dq = oq; *dv = ov; *da = oa; *dj = oj;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// Synthetic queries (distribution of reference tests/randomConfiguration.m:14-34
+// generalised to per-joint limits). Counter-based: value = f(seed, query, joint, field), so any
+// shard of any batch can be generated independently and the host reproduces it bit for bit.
+// ---------------------------------------------------------------------------------------
+LTP_DEV double unit_random(unsigned long long seed, unsigned long long query, unsigned int joint, unsigned int field)
+{
+    unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (((query * 64ull + joint) * 4ull + field) + 1ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z = z ^ (z >> 31);
+    return (double)(z >> 11) * 0x1.0p-53;
+}
+
+__global__ void __launch_bounds__(256)
+k_generate(long long n, int dof, Limits lim, unsigned long long seed, long long first_query,
+           double* __restrict__ q_goal, double* __restrict__ q_0, double* __restrict__ v_0, double* __restrict__ a_0,
+           long long sq, long long sj)
+{
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n * dof) return;
+    const long long q = idx / dof;
+    const int j = (int)(idx - q * dof);
+    const JointLimits L = load_limits(lim, j);
+    const unsigned long long gq = (unsigned long long)(first_query + q);
+    const double eps = 1e-6;
+    const double u0 = unit_random(seed, gq, j, 0), u1 = unit_random(seed, gq, j, 1);
+    const double u2 = unit_random(seed, gq, j, 2), u3 = unit_random(seed, gq, j, 3);
+    const double q0 = L.q_min + u0 * (L.q_max - L.q_min);
+    const double qg = L.q_min + u1 * (L.q_max - L.q_min);
+    const double vm = L.v_max - eps;
+    const double v0 = -vm + u2 * (2.0 * vm);
+    double a_lb, a_ub;
+    if (v0 >= 0.0) {
+        a_lb = -(L.a_max - eps);
+        a_ub = dmin(L.a_max - eps, dsqrt(2.0 * L.j_max * (L.v_max - v0)));
+    } else {
+        a_lb = dmax(-(L.a_max - eps), -dsqrt(2.0 * L.j_max * (L.v_max - dabs(v0))));
+        a_ub = L.a_max;
+    }
+    const double a0 = a_lb + u3 * (a_ub - a_lb);
+    const long long ix = q * sq + (long long)j * sj;
+    q_goal[ix] = qg;
+    q_0[ix] = q0;
+    v_0[ix] = v0;
+    a_0[ix] = a0;
+}
+
+// ---------------------------------------------------------------------------------------
+// One-lane mirrors of the protected member functions (for the reference's KAT-style tests).
+// ---------------------------------------------------------------------------------------
+__global__ void k_single_opt_braking(int joint, double t_sample, Limits lim, double v_0, double a_0, double* out)
+{
+    const JointLimits L = load_limits(lim, joint);
+    double r[7] = {out[0], out[1], out[2], out[3], out[4], out[5], out[6]};
+    double q, dir;
+    opt_braking(L.a_max, L.j_max, t_sample, v_0, a_0, q, r, dir);
+#pragma unroll
+    for (int k = 0; k < 7; ++k) out[k] = r[k];
+    out[7] = q;
+    out[8] = dir;
+}
+
+__global__ void k_single_opt_switch(int joint, double t_sample, Limits lim, double q_goal, double q_0, double v_0, double a_0,
+                                    double v_drive, double* io)
+{
+    const JointLimits L = load_limits(lim, joint);
+    double t[7] = {io[0], io[1], io[2], io[3], io[4], io[5], io[6]};
+    double dir = 0.0;
+    int mod = 0;
+    const bool ok = opt_switch_times(L.a_max, L.j_max, t_sample, q_goal, q_0, v_0, a_0, v_drive, t, dir, mod);
+#pragma unroll
+    for (int k = 0; k < 7; ++k) io[k] = t[k];
+    io[7] = dir;
+    io[8] = (double)mod;
+    io[9] = ok ? 1.0 : 0.0;
+}
+
+__global__ void k_single_time_scaling(int joint, double t_sample, Limits lim, double q_goal, double q_0, double v_0, double a_0,
+                                      double dir, double tr, double* io)
+{
+    const JointLimits L = load_limits(lim, joint);
+    if (dir < 0.0) { v_0 = -v_0; a_0 = -a_0; }
+    double ts[7] = {io[0], io[1], io[2], io[3], io[4], io[5], io[6]};
+    double vd;
+    int mod = 0, which = 0;
+    bool acc = scaling_case<1>(L, t_sample, q_goal, q_0, v_0, a_0, dir, tr, vd, ts, mod);
+    if (acc) which = 1;
+    if (!acc) { acc = scaling_case<2>(L, t_sample, q_goal, q_0, v_0, a_0, dir, tr, vd, ts, mod); if (acc) which = 2; }
+    if (!acc) { acc = scaling_case<3>(L, t_sample, q_goal, q_0, v_0, a_0, dir, tr, vd, ts, mod); if (acc) which = 3; }
+    if (!acc) { acc = scaling_case<4>(L, t_sample, q_goal, q_0, v_0, a_0, dir, tr, vd, ts, mod); if (acc) which = 4; }
+    if (!acc) { acc = scaling_case<5>(L, t_sample, q_goal, q_0, v_0, a_0, dir, tr, vd, ts, mod); if (acc) which = 5; }
+    if (!acc) { acc = scaling_case<6>(L, t_sample, q_goal, q_0, v_0, a_0, dir, tr, vd, ts, mod); if (acc) which = 6; }
+    if (!acc) { acc = scaling_case<7>(L, t_sample, q_goal, q_0, v_0, a_0, dir, tr, vd, ts, mod); if (acc) which = 7; }
+    if (!acc) { acc = scaling_case<8>(L, t_sample, q_goal, q_0, v_0, a_0, dir, tr, vd, ts, mod); if (acc) which = 8; }
+    if (!acc) { mod = 0; zero7(ts); vd = L.v_max; }
+#pragma unroll
+    for (int k = 0; k < 7; ++k) io[k] = ts[k];
+    io[7] = vd;
+    io[8] = (double)mod;
+    io[9] = acc ? 1.0 : 0.0;
+    io[10] = (double)which;
+}
+
+// device arithmetic probes: tests compare these with the host's libm bit for bit
+__global__ void k_math_probe(long long n, const double* x, const double* y, double* out)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double a = x[i], b = y[i];
+    double* o = out + i * 8;
+    o[0] = a / b;
+    o[1] = dsqrt(dabs(a));
+    o[2] = pw3(a);
+    o[3] = pw4(a);
+    o[4] = pw6(a);
+    o[5] = dfloor(a / b);
+    o[6] = dceil(a / b);
+    o[7] = a * b + a;
+}
+
+template <int N>
+LTP_DEV double probe_root(const double* c)
+{
+    double p[N + 1];
+#pragma unroll
+    for (int i = 0; i <= N; ++i) p[i] = c[i];
+    return smallest_positive_real_root<N>(p);
+}
+
+__global__ void k_roots_probe(long long n, int degree, const double* coef, double* root)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double* c = coef + i * 7;
+    double r;
+    if (degree == 4) r = probe_root<4>(c);
+    else if (degree == 5) r = probe_root<5>(c);
+    else r = probe_root<6>(c);
+    root[i] = r;
+}
+
+// ---------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------
+void launch_switch_times(hipStream_t s, long long n, int dof, double t_sample, Limits lim, Queries in, Records out,
+                         unsigned long long* queue, unsigned long long* queue_count)
+{
+    if (n <= 0) return;
+    const int jb = dof < kMaxJointSlots ? dof : kMaxJointSlots;
+    const dim3 block(kQueriesPerBlock, jb);
+    const dim3 grid((unsigned)((n + kQueriesPerBlock - 1) / kQueriesPerBlock));
+    hipLaunchKernelGGL(k_switch_times, grid, block, 0, s, n, dof, t_sample, lim, in, out, queue, queue_count);
+}
+
+void launch_scaling_slow(hipStream_t s, long long n, int dof, double t_sample, Limits lim, Queries in, Records out,
+                         const unsigned long long* queue, const unsigned long long* queue_count)
+{
+    if (n <= 0) return;
+    // the queue length is only known on the device: fixed grid, grid-stride over the queue
+    long long blocks = (n * dof + 63) / 64;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_scaling_slow, dim3((unsigned)blocks), dim3(64), 0, s, dof, t_sample, lim, in, out, queue, queue_count);
+}
+
+void launch_offsets(hipStream_t s, long long n, int dof, double t_sample, Records rec,
+                    unsigned long long* block_sums, unsigned long long* offsets)
+{
+    if (n <= 0) return;
+    const long long nb = (n + kScanBlock - 1) / kScanBlock;
+    hipLaunchKernelGGL(k_finalize, dim3((unsigned)nb), dim3(256), 0, s, n, dof, t_sample, rec, block_sums);
+    hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, s, nb, block_sums);
+    hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nb), dim3(256), 0, s, n, dof, rec.traj_len, block_sums, offsets);
+}
+
+void launch_sample(hipStream_t s, long long first, long long count, int dof, double t_sample, Limits lim, Queries in,
+                   Records rec, const unsigned long long* offsets, double* out, unsigned long long capacity,
+                   int streaming_stores)
+{
+    if (count <= 0) return;
+    const dim3 grid((unsigned)count, (unsigned)((dof + kSampleJointGroup - 1) / kSampleJointGroup));
+    hipLaunchKernelGGL(k_sample, grid, dim3(kSampleThreads), 0, s, first, count, dof, t_sample, lim, in, rec, offsets, out,
+                       capacity, streaming_stores);
+}
+
+void launch_generate(hipStream_t s, long long n, int dof, Limits lim, unsigned long long seed, long long first_query,
+                     double* q_goal, double* q_0, double* v_0, double* a_0, long long sq, long long sj)
+{
+    if (n <= 0) return;
+    const long long total = n * dof;
+    hipLaunchKernelGGL(k_generate, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, n, dof, lim, seed, first_query,
+                       q_goal, q_0, v_0, a_0, sq, sj);
+}
+
+void launch_single_opt_braking(hipStream_t s, int joint, double t_sample, Limits lim, double v_0, double a_0, double* out10)
+{
+    hipLaunchKernelGGL(k_single_opt_braking, dim3(1), dim3(1), 0, s, joint, t_sample, lim, v_0, a_0, out10);
+}
+void launch_single_opt_switch(hipStream_t s, int joint, double t_sample, Limits lim, double q_goal, double q_0, double v_0,
+                              double a_0, double v_drive, double* io10)
+{
+    hipLaunchKernelGGL(k_single_opt_switch, dim3(1), dim3(1), 0, s, joint, t_sample, lim, q_goal, q_0, v_0, a_0, v_drive, io10);
+}
+void launch_single_time_scaling(hipStream_t s, int joint, double t_sample, Limits lim, double q_goal, double q_0, double v_0,
+                                double a_0, double dir, double t_required, double* out11)
+{
+    hipLaunchKernelGGL(k_single_time_scaling, dim3(1), dim3(1), 0, s, joint, t_sample, lim, q_goal, q_0, v_0, a_0, dir,
+                       t_required, out11);
+}
+void launch_math_probe(hipStream_t s, long long n, const double* x, const double* y, double* out)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_math_probe, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, x, y, out);
+}
+void launch_roots_probe(hipStream_t s, long long n, int degree, const double* coef, double* root)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_roots_probe, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, n, degree, coef, root);
+}
+
+}  // namespace ltp

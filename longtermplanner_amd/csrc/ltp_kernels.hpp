@@ -1,0 +1,85 @@
+// ltp_kernels.hpp — gfx950 kernels of the batched planner (declarations + shared structs).
+//
+// Pipeline for one batch (reference src/long_term_planner.cc:7-63, one query = one call):
+//   k_switch_times   stage 1 (checkInputs + optSwitchTimes per (query, joint)), the
+//                    slowest-joint reduction in LDS, and the two closed-form timeScaling
+//                    cases; lanes that need the polynomial cases are compacted into a queue
+//   k_scaling_slow   timeScaling cases 3..8 + reset, run densely over the queue
+//   k_finalize       traj_len (cc:716-719), padded row stride, per-plan output size,
+//                    block sums for the offsets scan
+//   k_scan_top / k_scan_apply   exclusive scan -> packed trajectory offsets
+//   k_sample         getTrajectory (cc:706-841) + end-limit check (cc:59-61), HBM-write bound
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ltp {
+
+// status bits (planTrajectory's bool == (status == 0))
+enum : int {
+    kStatusInvalidInput = 1,   // checkInputs false (cc:14-15)
+    kStatusOptFailed = 2,      // optSwitchTimes false for a joint (cc:29)
+    kStatusNoSlowest = 4,      // slowest_joint == -1 (cc:39)
+    kStatusEndLimit = 8,       // last q sample outside [q_min,q_max] (cc:59-61); trajectory is filled
+    kStatusNonFinite = 16,     // DEFINED: non-finite switching times -> traj_len 0 (reference: UB)
+    kStatusOverflow = 32,      // trajectory does not fit the caller's output tile; not sampled
+};
+
+constexpr int kQueriesPerBlock = 64;   // one wave = 64 queries of one joint
+constexpr int kMaxJointSlots = 8;      // blockDim.y of k_switch_times
+constexpr int kRowAlign = 16;          // trajectory rows padded to 16 doubles (128 B)
+constexpr int kSampleJointGroup = 8;   // joints handled by one k_sample block
+constexpr int kMaxSegments = 24;       // piecewise-constant jerk segments per joint
+constexpr int kSampleThreads = 256;
+constexpr int kScanBlock = 1024;       // plans per finalize/scan block
+
+struct Limits {            // device pointers, [dof] each
+    const double* q_min;
+    const double* q_max;
+    const double* v_max;
+    const double* a_max;
+    const double* j_max;
+};
+
+struct Queries {           // element (query p, joint j) at ptr[p * sq + j * sj]
+    const double* q_goal;
+    const double* q_0;
+    const double* v_0;
+    const double* a_0;
+    long long sq, sj;
+};
+
+struct Records {           // query-major outputs of stages 1-3
+    double* t_opt;         // [n][dof][7]
+    double* t_scaled;      // [n][dof][7]
+    double* dir;           // [n][dof]
+    double* v_drive;       // [n][dof]
+    signed char* mod;      // [n][dof]
+    double* t_required;    // [n]
+    int* slowest;          // [n]
+    int* traj_len;         // [n]
+    int* status;           // [n]
+};
+
+void launch_switch_times(hipStream_t s, long long n, int dof, double t_sample, Limits lim, Queries in, Records out,
+                         unsigned long long* queue, unsigned long long* queue_count);
+void launch_scaling_slow(hipStream_t s, long long n, int dof, double t_sample, Limits lim, Queries in, Records out,
+                         const unsigned long long* queue, const unsigned long long* queue_count);
+void launch_offsets(hipStream_t s, long long n, int dof, double t_sample, Records rec,
+                    unsigned long long* block_sums, unsigned long long* offsets);
+void launch_sample(hipStream_t s, long long first, long long count, int dof, double t_sample, Limits lim, Queries in,
+                   Records rec, const unsigned long long* offsets, double* out, unsigned long long capacity,
+                   int streaming_stores);
+void launch_generate(hipStream_t s, long long n, int dof, Limits lim, unsigned long long seed, long long first_query,
+                     double* q_goal, double* q_0, double* v_0, double* a_0, long long sq, long long sj);
+
+// single-joint mirrors of the protected methods (one lane)
+void launch_single_opt_braking(hipStream_t s, int joint, double t_sample, Limits lim, double v_0, double a_0, double* out10);
+void launch_single_opt_switch(hipStream_t s, int joint, double t_sample, Limits lim, double q_goal, double q_0, double v_0,
+                              double a_0, double v_drive, double* io10);
+void launch_single_time_scaling(hipStream_t s, int joint, double t_sample, Limits lim, double q_goal, double q_0, double v_0,
+                                double a_0, double dir, double t_required, double* out11);
+void launch_math_probe(hipStream_t s, long long n, const double* x, const double* y, double* out);
+void launch_roots_probe(hipStream_t s, long long n, int degree, const double* coef, double* root);
+
+}  // namespace ltp

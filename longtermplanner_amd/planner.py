@@ -1,0 +1,251 @@
+"""Host-side mirror of the reference's ``LongTermPlanner`` class on top of the C ABI.
+
+Same names, argument meaning and return conventions as
+/root/reference/include/long_term_planner/long_term_planner.h:61-308 (constructor, planTrajectory,
+checkInputs, setLimits, setSampleTime, setDoF and the four protected methods), plus the batched
+calls that are the reason this package exists. Every method runs on the GPU through
+libltp_hip.so; nothing here computes planner arithmetic on the host.
+"""
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import List, Optional
+
+import numpy as np
+
+from . import _abi
+
+_dp = C.POINTER(C.c_double)
+
+
+def _vec(x):
+    return np.ascontiguousarray(np.asarray(x, dtype=np.float64).reshape(-1))
+
+
+def _ptr(a):
+    return a.ctypes.data_as(_dp)
+
+
+@dataclass
+class Trajectory:
+    """reference struct Trajectory (long_term_planner.h:37-45): q/v/a/j are [joint][sample]."""
+    dof: int = 0
+    t_sample: float = 0.0
+    length: int = 0
+    q: List = field(default_factory=list)
+    v: List = field(default_factory=list)
+    a: List = field(default_factory=list)
+    j: List = field(default_factory=list)
+
+
+def unpack_trajectory(packed, offset, dof, length):
+    """Views [dof][length] of q, v, a, j inside a packed buffer (layout: include/ltp_hip.h)."""
+    stride = _abi.lib().ltp_row_stride(int(length))
+    blk = packed[offset: offset + 4 * dof * stride].reshape(4, dof, stride)
+    return blk[0, :, :length], blk[1, :, :length], blk[2, :, :length], blk[3, :, :length]
+
+
+class DeviceBatch:
+    """Device-resident records of one ltp_plan_switch_times_batch call (torch tensors)."""
+
+    def __init__(self, n, dof, device):
+        import torch
+        f64 = dict(dtype=torch.float64, device=device)
+        self.n, self.dof = n, dof
+        self.t_opt = torch.empty((n, dof, 7), **f64)
+        self.t_scaled = torch.empty((n, dof, 7), **f64)
+        self.dir = torch.empty((n, dof), **f64)
+        self.v_drive = torch.empty((n, dof), **f64)
+        self.mod = torch.empty((n, dof), dtype=torch.int8, device=device)
+        self.t_required = torch.empty((n,), **f64)
+        self.slowest = torch.empty((n,), dtype=torch.int32, device=device)
+        self.traj_len = torch.empty((n,), dtype=torch.int32, device=device)
+        self.status = torch.empty((n,), dtype=torch.int32, device=device)
+        self.offsets = torch.empty((n + 1,), dtype=torch.int64, device=device)   # uint64 on the device side
+
+    def c_records(self):
+        return _abi.Records(self.t_opt.data_ptr(), self.t_scaled.data_ptr(), self.dir.data_ptr(), self.v_drive.data_ptr(),
+                            self.mod.data_ptr(), self.t_required.data_ptr(), self.slowest.data_ptr(),
+                            self.traj_len.data_ptr(), self.status.data_ptr())
+
+
+class LongTermPlanner:
+    def __init__(self, dof=0, t_sample=0.001, q_min=(), q_max=(), v_max=(), a_max=(), j_max=(), device=0):
+        # default arguments reproduce the reference's dummy constructor (long_term_planner.h:103-105)
+        self._lib = _abi.lib()
+        self._h = C.c_void_p()
+        arrs = [_vec(x) for x in (q_min, q_max, v_max, a_max, j_max)]
+        for a in arrs:
+            if a.size < dof:
+                raise ValueError("limit vectors need at least dof entries")
+        rc = self._lib.ltp_create(int(dof), float(t_sample), *[_ptr(a) for a in arrs], int(device), C.byref(self._h))
+        if rc != _abi.LTP_OK:
+            raise _abi.LtpError(rc, "ltp_create failed (no HIP device? the planner has no CPU fallback)")
+        self.device = int(device)
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            self._lib.ltp_destroy(h)
+            self._h = None
+
+    def _check(self, rc):
+        if rc != _abi.LTP_OK:
+            raise _abi.LtpError(rc, (self._lib.ltp_last_error(self._h) or b"").decode())
+
+    # ---- configuration (long_term_planner.h:176-205) ----
+    def setLimits(self, q_min, q_max, v_max, a_max, j_max):
+        arrs = [_vec(x) for x in (q_min, q_max, v_max, a_max, j_max)]
+        n = min(a.size for a in arrs)
+        self._check(self._lib.ltp_set_limits(self._h, n, *[_ptr(a) for a in arrs]))
+
+    def setSampleTime(self, t_sample):
+        self._check(self._lib.ltp_set_sample_time(self._h, float(t_sample)))
+
+    def setDoF(self, dof):
+        self._check(self._lib.ltp_set_dof(self._h, int(dof)))
+
+    @property
+    def dof(self):
+        return self._lib.ltp_get_dof(self._h)
+
+    @property
+    def t_sample(self):
+        return self._lib.ltp_get_sample_time(self._h)
+
+    # ---- the reference's public calls ----
+    def checkInputs(self, q_0, v_0, a_0):
+        ok = C.c_int()
+        self._check(self._lib.ltp_check_inputs_host(self._h, _ptr(_vec(q_0)), _ptr(_vec(v_0)), _ptr(_vec(a_0)), C.byref(ok)))
+        return bool(ok.value)
+
+    def planTrajectory(self, q_goal, q_0, v_0, a_0, traj: Trajectory):
+        """long_term_planner.h:144-150 / src/long_term_planner.cc:7-63. `traj` is overwritten only if the
+        reference would have overwritten it (status has none of the pre-sampling failure bits)."""
+        r = self.planBatchHost(q_goal, q_0, v_0, a_0, sample=True)
+        st = int(r["status"][0])
+        if st & (_abi.STATUS_INVALID_INPUT | _abi.STATUS_OPT_FAILED | _abi.STATUS_NO_SLOWEST | _abi.STATUS_NONFINITE):
+            return False
+        n = int(r["traj_len"][0])
+        q, v, a, j = unpack_trajectory(r["packed"], int(r["offsets"][0]), self.dof, n)
+        traj.dof, traj.t_sample, traj.length = self.dof, self.t_sample, n
+        traj.q, traj.v, traj.a, traj.j = q.copy(), v.copy(), a.copy(), j.copy()
+        return st == 0
+
+    # ---- the reference's protected methods (exposed to tests through a subclass there) ----
+    def optBraking(self, joint, v_0, a_0, t_rel=None):
+        t = np.zeros(7) if t_rel is None else np.array(t_rel, dtype=np.float64)
+        q = C.c_double(); d = C.c_double()
+        self._check(self._lib.ltp_opt_braking_host(self._h, int(joint), float(v_0), float(a_0), C.byref(q), _ptr(t), C.byref(d)))
+        return True, q.value, t, d.value
+
+    def optSwitchTimes(self, joint, q_goal, q_0, v_0, a_0, v_drive, t=None):
+        tt = np.zeros(7) if t is None else np.array(t, dtype=np.float64)
+        d = C.c_double(); m = C.create_string_buffer(1); ok = C.c_int()
+        self._check(self._lib.ltp_opt_switch_times_host(self._h, int(joint), float(q_goal), float(q_0), float(v_0), float(a_0),
+                                                        float(v_drive), _ptr(tt), C.byref(d), m, C.byref(ok)))
+        return bool(ok.value), tt, d.value, m.raw[0]
+
+    def timeScaling(self, joint, q_goal, q_0, v_0, a_0, dir_, t_required, scaled_t=None):
+        tt = np.zeros(7) if scaled_t is None else np.array(scaled_t, dtype=np.float64)
+        vd = C.c_double(); m = C.create_string_buffer(1); ok = C.c_int(); case = C.c_int()
+        self._check(self._lib.ltp_time_scaling_host(self._h, int(joint), float(q_goal), float(q_0), float(v_0), float(a_0),
+                                                    float(dir_), float(t_required), _ptr(tt), C.byref(vd), m, C.byref(ok),
+                                                    C.byref(case)))
+        return bool(ok.value), tt, vd.value, m.raw[0], case.value
+
+    def getTrajectory(self, t, dir_, mod_jerk_profile, q_0, v_0, a_0, v_drive):
+        r = self.getTrajectoryBatchHost(np.asarray(t, dtype=np.float64).reshape(1, self.dof, 7), dir_, mod_jerk_profile, q_0, v_0, a_0, v_drive)
+        n = int(r["traj_len"][0])
+        q, v, a, j = unpack_trajectory(r["packed"], 0, self.dof, n)
+        return Trajectory(self.dof, self.t_sample, n, q.copy(), v.copy(), a.copy(), j.copy())
+
+    # ---- batched host-pointer calls (numpy in, numpy out; synchronous) ----
+    def planBatchHost(self, q_goal, q_0, v_0, a_0, sample=True):
+        D = self.dof
+        ins = [np.ascontiguousarray(np.asarray(x, dtype=np.float64).reshape(-1, D) if D else np.zeros((1, 0))) for x in (q_goal, q_0, v_0, a_0)]
+        n = ins[0].shape[0]
+        r = dict(t_opt=np.zeros((n, D, 7)), t_scaled=np.zeros((n, D, 7)), dir=np.zeros((n, D)), v_drive=np.zeros((n, D)),
+                 mod=np.zeros((n, D), dtype=np.int8), t_required=np.zeros(n), slowest=np.zeros(n, dtype=np.int32),
+                 traj_len=np.zeros(n, dtype=np.int32), status=np.zeros(n, dtype=np.int32))
+        rec = _abi.Records(*[r[k].ctypes.data for k in ("t_opt", "t_scaled", "dir", "v_drive", "mod", "t_required", "slowest", "traj_len", "status")])
+        offsets = np.zeros(n + 1, dtype=np.uint64)
+        packed = _dp()
+        self._check(self._lib.ltp_plan_batch_host(self._h, n, *[_ptr(x) for x in ins], C.byref(rec),
+                                                  offsets.ctypes.data_as(C.POINTER(C.c_ulonglong)),
+                                                  C.byref(packed) if sample else None))
+        r["offsets"] = offsets
+        if sample:
+            total = int(offsets[n])
+            r["packed"] = np.ctypeslib.as_array(packed, shape=(max(total, 1),))[:total].copy()
+            self._lib.ltp_free_host(packed)
+        return r
+
+    def getTrajectoryBatchHost(self, t, dir_, mod, q_0, v_0, a_0, v_drive):
+        D = self.dof
+        t = np.ascontiguousarray(np.asarray(t, dtype=np.float64).reshape(-1, D, 7))
+        n = t.shape[0]
+        f = [np.ascontiguousarray(np.asarray(x, dtype=np.float64).reshape(n, D)) for x in (dir_, q_0, v_0, a_0, v_drive)]
+        modb = np.ascontiguousarray(np.asarray(mod, dtype=np.int8).reshape(n, D))
+        traj_len = np.zeros(n, dtype=np.int32); status = np.zeros(n, dtype=np.int32)
+        offsets = np.zeros(n + 1, dtype=np.uint64)
+        packed = _dp()
+        self._check(self._lib.ltp_get_trajectory_host(self._h, n, _ptr(t), _ptr(f[0]), modb.ctypes.data_as(C.POINTER(C.c_byte)),
+                                                      _ptr(f[1]), _ptr(f[2]), _ptr(f[3]), _ptr(f[4]),
+                                                      traj_len.ctypes.data_as(C.POINTER(C.c_int)), status.ctypes.data_as(C.POINTER(C.c_int)),
+                                                      offsets.ctypes.data_as(C.POINTER(C.c_ulonglong)), C.byref(packed)))
+        total = int(offsets[n])
+        out = np.ctypeslib.as_array(packed, shape=(max(total, 1),))[:total].copy()
+        self._lib.ltp_free_host(packed)
+        return dict(traj_len=traj_len, status=status, offsets=offsets, packed=out)
+
+    # ---- batched device calls (torch CUDA tensors, asynchronous on torch's current stream) ----
+    def _stream(self):
+        import torch
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    @staticmethod
+    def _queries(q_goal, q_0, v_0, a_0, layout):
+        n, D = (q_0.shape if layout == "query_major" else q_0.shape[::-1])
+        sq, sj = (D, 1) if layout == "query_major" else (1, n)
+        for x in (q_goal, q_0, v_0, a_0):
+            assert x.is_cuda and x.is_contiguous() and x.dtype.is_floating_point and x.element_size() == 8
+        return n, _abi.Queries(q_goal.data_ptr(), q_0.data_ptr(), v_0.data_ptr(), a_0.data_ptr(), sq, sj)
+
+    def generateQueries(self, n, seed=12345, first_query=0, layout="query_major"):
+        """Synthetic batch on the device (ltp_generate_queries_batch); returns q_goal, q_0, v_0, a_0."""
+        import torch
+        D = self.dof
+        shape = (n, D) if layout == "query_major" else (D, n)
+        sq, sj = (D, 1) if layout == "query_major" else (1, n)
+        out = [torch.empty(shape, dtype=torch.float64, device=f"cuda:{self.device}") for _ in range(4)]
+        self._check(self._lib.ltp_generate_queries_batch(self._h, n, seed, first_query, *[x.data_ptr() for x in out], sq, sj, self._stream()))
+        return out
+
+    def planSwitchTimesBatch(self, q_goal, q_0, v_0, a_0, layout="query_major", batch: Optional[DeviceBatch] = None):
+        """Stages 1-3 + traj_len + packed offsets for a device batch (ltp_plan_switch_times_batch)."""
+        n, q = self._queries(q_goal, q_0, v_0, a_0, layout)
+        if batch is None or batch.n != n or batch.dof != self.dof:
+            batch = DeviceBatch(n, self.dof, q_0.device)
+        batch.queries = q
+        rec = batch.c_records()
+        self._check(self._lib.ltp_plan_switch_times_batch(self._h, n, C.byref(q), C.byref(rec), batch.offsets.data_ptr(), self._stream()))
+        return batch
+
+    def sampleBatch(self, batch: DeviceBatch, first, count, out, streaming=True):
+        """getTrajectory for plans [first, first+count) into the float64 CUDA tensor `out` (ltp_sample_batch)."""
+        rec = batch.c_records()
+        self._check(self._lib.ltp_sample_batch(self._h, first, count, C.byref(batch.queries), C.byref(rec), batch.offsets.data_ptr(),
+                                               out.data_ptr(), out.numel(), 1 if streaming else 0, self._stream()))
+
+    # ---- diagnostics for the parity tests ----
+    def debugMathProbe(self, x, y):
+        x, y = _vec(x), _vec(y)
+        out = np.zeros((x.size, 8))
+        self._check(self._lib.ltp_debug_math_probe_host(self._h, x.size, _ptr(x), _ptr(y), _ptr(out)))
+        return out
+
+    def debugRootsProbe(self, degree, coef):
+        coef = np.ascontiguousarray(np.asarray(coef, dtype=np.float64).reshape(-1, 7))
+        out = np.zeros(coef.shape[0])
+        self._check(self._lib.ltp_debug_roots_probe_host(self._h, coef.shape[0], int(degree), _ptr(coef), _ptr(out)))
+        return out

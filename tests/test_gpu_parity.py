@@ -1,0 +1,128 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle on identical inputs.
+
+Bar (BASELINE.json north_star): switching times and q/v/a/j samples within 1e-9 of the reference
+arithmetic; integer outputs (slowest joint, traj_len, mod flag, status) exact.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-9
+
+
+@pytest.fixture(scope="module")
+def amd():
+    import longtermplanner_amd as m
+    return m
+
+
+def _mk(amd, oracle_mod, name, ts=0.001, dof=None):
+    D, lim = amd.limit_set(name, dof)
+    return D, lim, amd.LongTermPlanner(D, ts, device=0, **lim), oracle_mod.Oracle(D, ts, **lim)
+
+
+def test_device_arithmetic_is_ieee(amd, oracle_mod):
+    # division, sqrt, floor/ceil bit-exact vs the host; x^3, x^4, x^6 within 1 ulp of libm pow
+    D, lim, ltp, _ = _mk(amd, oracle_mod, "panda")
+    rng = np.random.default_rng(1)
+    x = rng.normal(size=200000) * 10.0 ** rng.integers(-3, 4, size=200000)
+    y = rng.normal(size=200000) * 10.0 ** rng.integers(-3, 4, size=200000)
+    out = ltp.debugMathProbe(x, y)
+    assert np.array_equal(out[:, 0], x / y)
+    assert np.array_equal(out[:, 1], np.sqrt(np.abs(x)))
+    assert np.array_equal(out[:, 5], np.floor(x / y))
+    assert np.array_equal(out[:, 6], np.ceil(x / y))
+    assert np.array_equal(out[:, 7], x * y + x), "a*b+c was contracted into an fma on the device"
+    for col, e in ((2, 3), (3, 4), (4, 6)):
+        ref = np.power(x, e)
+        ulp = np.abs(out[:, col] - ref) / np.spacing(np.abs(ref))
+        assert ulp.max() <= 1.0, (e, ulp.max())
+        assert (ulp == 0).mean() > 0.9
+
+
+@pytest.mark.parametrize("degree", [4, 5, 6])
+def test_device_root_finder_matches_oracle(amd, oracle_mod, degree):
+    D, lim, ltp, _ = _mk(amd, oracle_mod, "panda")
+    rng = np.random.default_rng(degree)
+    n = 20000
+    coef = np.zeros((n, 7))
+    coef[:, :degree + 1] = rng.normal(size=(n, degree + 1)) * 10.0 ** rng.integers(-2, 3, size=(n, degree + 1))
+    # sprinkle structured cases: real roots by construction, zero leading coefficient
+    for i in range(0, n, 10):
+        coef[i, :degree + 1] = np.poly(rng.uniform(-3, 3, size=degree))
+    coef[7, 0] = 0.0
+    got = ltp.debugRootsProbe(degree, coef)
+    ref = np.array([oracle_mod.smallest_root(coef[i, :degree + 1]) for i in range(n)])
+    both_inf = np.isinf(got) & np.isinf(ref)
+    assert np.array_equal(np.isinf(got), np.isinf(ref)), "real/complex classification differs"
+    rel = np.abs(got[~both_inf] - ref[~both_inf]) / np.maximum(1.0, np.abs(ref[~both_inf]))
+    assert rel.max() < 1e-12, rel.max()
+
+
+@pytest.mark.parametrize("name,dof,n", [("panda", None, 20000), ("ref", None, 20000), ("ref30", None, 3000), ("ref", 1, 5000), ("ref", 6, 5000)])
+def test_switch_times_parity(amd, oracle_mod, name, dof, n):
+    D, lim, ltp, orc = _mk(amd, oracle_mod, name, dof=dof)
+    qg, q0, v0, a0 = amd.generate_queries(n, lim, seed=12345)
+    r = ltp.planBatchHost(qg, q0, v0, a0, sample=False)
+    o = orc.plan_batch(qg, q0, v0, a0, sample=False)
+    ok = o["status"] != 0
+    assert np.array_equal((r["status"] & 7) == 0, ok)
+    assert ok.mean() > 0.99
+    assert np.array_equal(r["slowest"][ok], o["slowest"][ok])
+    assert np.array_equal(r["mod"][ok], o["mod"][ok])
+    assert np.array_equal(r["dir"][ok], o["dir"][ok])
+    assert np.array_equal(r["traj_len"][ok], o["traj_len"][ok])
+    for k in ("t_opt", "t_scaled", "v_drive", "t_required"):
+        d = np.abs(r[k][ok] - o[k][ok])
+        assert np.nanmax(d) <= TOL, (k, np.nanmax(d))
+        assert np.array_equal(np.isnan(r[k][ok]), np.isnan(o[k][ok]))
+
+
+@pytest.mark.parametrize("name,ts,n", [("panda", 0.001, 300), ("ref", 0.001, 120), ("ref", 0.004, 300), ("ref30", 0.004, 60)])
+def test_dense_trajectory_parity(amd, oracle_mod, name, ts, n):
+    D, lim, ltp, orc = _mk(amd, oracle_mod, name, ts=ts)
+    qg, q0, v0, a0 = amd.generate_queries(n, lim, seed=777)
+    r = ltp.planBatchHost(qg, q0, v0, a0, sample=True)
+    o = orc.plan_batch(qg, q0, v0, a0, sample=True)
+    assert np.array_equal(r["traj_len"], o["traj_len"])
+    # planTrajectory's bool: oracle status 1 <-> device status 0; 2 <-> END_LIMIT
+    assert np.array_equal(r["status"] == 0, o["status"] == 1)
+    assert np.array_equal((r["status"] & amd.STATUS_END_LIMIT) != 0, o["status"] == 2)
+    worst = 0.0
+    for p in range(n):
+        if o["status"][p] == 0:
+            continue
+        L, q, v, a, j = orc.get_trajectory(o["t_scaled"][p], o["dir"][p], o["mod"][p], q0[p], v0[p], a0[p], o["v_drive"][p])
+        g = amd.unpack_trajectory(r["packed"], int(r["offsets"][p]), D, L)
+        for got, ref in zip(g, (q, v, a, j)):
+            worst = max(worst, float(np.max(np.abs(got - ref))))
+    assert worst <= TOL, worst
+
+
+def test_get_trajectory_from_oracle_records(amd, oracle_mod):
+    # the sampler alone, fed the ORACLE's switching times: isolates K4 from K1-K3
+    D, lim, ltp, orc = _mk(amd, oracle_mod, "ref", ts=0.004)
+    qg, q0, v0, a0 = amd.generate_queries(400, lim, seed=31)
+    o = orc.plan_batch(qg, q0, v0, a0, sample=False)
+    r = ltp.getTrajectoryBatchHost(o["t_scaled"], o["dir"], o["mod"], q0, v0, a0, o["v_drive"])
+    assert np.array_equal(r["traj_len"], o["traj_len"])
+    worst = 0.0
+    for p in range(400):
+        L, q, v, a, j = orc.get_trajectory(o["t_scaled"][p], o["dir"][p], o["mod"][p], q0[p], v0[p], a0[p], o["v_drive"][p])
+        g = amd.unpack_trajectory(r["packed"], int(r["offsets"][p]), D, L)
+        for got, ref in zip(g, (q, v, a, j)):
+            worst = max(worst, float(np.max(np.abs(got - ref))))
+    assert worst <= TOL, worst
+
+
+def test_device_generator_matches_host(amd, oracle_mod):
+    import torch
+    D, lim, ltp, _ = _mk(amd, oracle_mod, "panda")
+    host = amd.generate_queries(5000, lim, seed=99, first_query=1234)
+    for layout in ("query_major", "joint_major"):
+        dev = ltp.generateQueries(5000, seed=99, first_query=1234, layout=layout)
+        torch.cuda.synchronize()
+        for h, d in zip(host, dev):
+            d = d.cpu().numpy()
+            assert np.array_equal(h, d if layout == "query_major" else d.T)
