@@ -45,7 +45,7 @@ def cpu_baseline(dof, lim, t_sample, seed, sample_switch_only):
     from longtermplanner_amd import generate_queries
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     cores = max(1, min(cores, 16))   # a one-GPU box's CPU share
-    per_thread = 12288 if not sample_switch_only else 400000
+    per_thread = 49152 if not sample_switch_only else 1000000
     n = per_thread * cores
     qg, q0, v0, a0 = generate_queries(n, lim, seed=seed)
     orc = oracle.Oracle(dof, t_sample, **lim)
@@ -72,11 +72,14 @@ def main():
     ap.add_argument("--batch", type=int, default=1_000_000, help="queries per GPU per step")
     ap.add_argument("--limits", default="panda", choices=["panda", "ref", "ref30"])
     ap.add_argument("--t-sample", type=float, default=0.001)
-    ap.add_argument("--tile-gib", type=float, default=32.0, help="size of the reused trajectory output tile")
+    ap.add_argument("--tile-gib", type=float, default=192.0, help="size of the reused trajectory output tile")
     ap.add_argument("--seed", type=int, default=12345)
     ap.add_argument("--switch-only", action="store_true", help="config[1]: stages 1-3 only, no sampling")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--plain-stores", action="store_true", help="sampler uses plain instead of non-temporal stores")
+    ap.add_argument("--window-gib", type=float, default=0.0, help="DIAGNOSTIC: chunk capacity; chunks rotate through windows of the tile")
+    ap.add_argument("--spread", type=int, default=0, help="sampler block->plan interleave factor (0 = library default 64, 1 = plan order)")
+    ap.add_argument("--dry-sampler", action="store_true", help="DIAGNOSTIC ONLY: sampler stores without arithmetic (invalid as a result)")
     ap.add_argument("--gather", action="store_true", help="also all_gather t_required over RCCL each step (optional path)")
     args = ap.parse_args()
 
@@ -118,13 +121,16 @@ def main():
             return
         offsets_pinned.copy_(batch.offsets, non_blocking=True)
         torch.cuda.current_stream().synchronize()       # chunk boundaries depend on this batch's trajectory lengths
-        bounds = chunk_bounds(offsets_pinned.numpy().view(np.uint64), tile.numel())
+        win = int(args.window_gib * (1 << 30)) // 8 if args.window_gib > 0 else tile.numel()
+        nwin = max(1, tile.numel() // win)
+        bounds = chunk_bounds(offsets_pinned.numpy().view(np.uint64), win)
         n_chunks = len(bounds)
-        for first, end in bounds:
+        for ci, (first, end) in enumerate(bounds):
+            view = tile[(ci % nwin) * win:(ci % nwin + 1) * win]
             if timed:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-            ltp.sampleBatch(batch, first, end - first, tile, streaming=not args.plain_stores)
+            ltp.sampleBatch(batch, first, end - first, view, streaming=not args.plain_stores, dry=args.dry_sampler, spread=args.spread)
             if timed:
                 e1.record()
                 ev_pairs.append((e0, e1))
@@ -185,7 +191,7 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f64",
-            "data": "synthetic",
+            "data": "synthetic" if not args.dry_sampler else "DIAGNOSTIC dry sampler: NOT a valid result",
             "config": {
                 "workload": (f"{n} x {dof}-DoF queries per GPU per step, limits '{args.limits}', Tsample {args.t_sample} s, "
                              + ("switching times only (stages 1-3)" if args.switch_only else

@@ -98,7 +98,10 @@ int ltp_plan_switch_times_batch(ltp_planner* p, long long n, const ltp_queries* 
 
 /* getTrajectory (cc:706-841) + the end-limit check (cc:59-61) for plans [first, first+count):
  * plan p is written at out + (offsets[p] - offsets[first]); plans that would end beyond
- * `capacity` doubles get LTP_STATUS_OVERFLOW and are skipped. flags bit 0: use non-temporal stores. */
+ * `capacity` doubles get LTP_STATUS_OVERFLOW and are skipped.
+ * flags: bit 0 = non-temporal stores (recommended); bit 1 = diagnostic dry run (stores without arithmetic);
+ * bits 8..23 = block interleave factor (0 = default 64, 1 = blocks in plan order). Large tiles (>= 64 GiB)
+ * written with the default interleave reach the HBM fill ceiling; see DESIGN.md. */
 int ltp_sample_batch(ltp_planner* p, long long first, long long count, const ltp_queries* in, const ltp_records* rec,
                      const unsigned long long* offsets, double* out, unsigned long long capacity, int flags, void* stream);
 
@@ -135,6 +138,8 @@ int ltp_time_scaling_host(ltp_planner* p, int joint, double q_goal, double q_0, 
                           double t_required, double* scaled_t, double* v_drive, char* mod, int* ok, int* accepted_case);
 
 /* ---- diagnostics used by the parity tests ---------------------------------------------------- */
+/* device_buffer (2 x count u64, or NULL to switch off): k_sample block start/end on the 100 MHz wall clock */
+int ltp_debug_set_sample_stamps(ltp_planner* p, unsigned long long* device_buffer);
 /* out[i*8 + {0..7}] = x/y, sqrt|x|, x^3, x^4, x^6, floor(x/y), ceil(x/y), x*y+x computed on the device */
 int ltp_debug_math_probe_host(ltp_planner* p, long long n, const double* x, const double* y, double* out);
 /* root[i] = smallest positive exactly-real root of the degree-`degree` polynomial coef[i*7 .. i*7+degree]

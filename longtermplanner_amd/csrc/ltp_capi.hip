@@ -24,6 +24,7 @@ struct ltp_planner {
     long long ws_items = 0;                // capacity in (query, joint) items
     long long ws_queries = 0;
     double* d_small = nullptr;             // 16 doubles for the one-lane entry points
+    unsigned long long* dbg_stamps = nullptr; // diagnostic: per-block start/end stamps of k_sample (caller-owned)
     std::mutex mu;
     std::string err;
 };
@@ -288,7 +289,7 @@ int ltp_sample_batch(ltp_planner* p, long long first, long long count, const ltp
     if (count == 0 || p->dof == 0) return LTP_OK;
     LTP_HIP_TRY(p, hipSetDevice(p->device));
     ltp::launch_sample((hipStream_t)stream, first, count, p->dof, p->t_sample, dev_limits(p), to_dev(in), to_dev(rec), offsets,
-                       out, capacity, flags & 1);
+                       out, capacity, flags, p->dbg_stamps);
     LTP_HIP_TRY(p, hipGetLastError());
     return LTP_OK;
 }
@@ -508,6 +509,14 @@ int ltp_time_scaling_host(ltp_planner* p, int joint, double q_goal, double q_0, 
     *mod = (char)(int)buf[8];
     *ok = (int)buf[9];
     if (accepted_case) *accepted_case = (int)buf[10];
+    return LTP_OK;
+}
+
+int ltp_debug_set_sample_stamps(ltp_planner* p, unsigned long long* device_buffer)
+{
+    if (!p) return LTP_ERR_INVALID_ARGUMENT;
+    std::lock_guard<std::mutex> g(p->mu);
+    p->dbg_stamps = device_buffer;
     return LTP_OK;
 }
 

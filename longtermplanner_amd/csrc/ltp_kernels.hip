@@ -327,14 +327,17 @@ k_scan_apply(long long n, int dof, const int* __restrict__ traj_len, const unsig
 constexpr int kModeTail = 1;    // i > s6: a = 0, v = 0 (cc:815-829)
 constexpr int kModeVSnap = 2;   // phase 4 interior: v = v_drive*dir (cc:822-823)
 
+// Inside one run, with m = 1-based position in the run, S1 = m(m+1)/2 and S2 = m(m+1)(m+2)/6, every
+// output row is  x(m) = c0 + (c1*m + (c2*S1 + c3*S2)):
+//   q: {q_s, Ts*v_s, Ts*Ts*a_s, Ts*Ts*Ts*J}   v: {v_s, Ts*a_s, Ts*Ts*J, 0}   a: {a_s, Ts*J, 0, 0}   j: {J, 0, 0, 0}
+// and the three snap rules of cc:815-829 only change coefficients, so the streaming loop is branch-free.
+struct RunCoef {
+    double c[4][4];   // [q, v, a, j][c0..c3]
+};
+
 struct SegTable {
     int start[kSampleJointGroup][kMaxSegments + 1];
-    int mode[kSampleJointGroup][kMaxSegments];
-    double J[kSampleJointGroup][kMaxSegments];
-    double a[kSampleJointGroup][kMaxSegments];
-    double v[kSampleJointGroup][kMaxSegments];
-    double q[kSampleJointGroup][kMaxSegments];
-    double vsnap[kSampleJointGroup];
+    double c[kSampleJointGroup][kMaxSegments][4][4];
     int nseg[kSampleJointGroup];
 };
 
@@ -371,36 +374,65 @@ LTP_DEV double jerk_at(const JerkPlan& P, int i)
     return val;
 }
 
-// state after the m-th sample (m >= 1) of a run that starts after (a_s, v_s, q_s)
-LTP_DEV void run_eval(int mode, double J, double a_s, double v_s, double q_s, double vsnap, double Ts, int m,
-                      double& a, double& v, double& q)
+// coefficients of a run that starts after state (a_s, v_s, q_s)
+LTP_DEV RunCoef run_coef(int mode, double J, double a_s, double v_s, double q_s, double vsnap, double Ts)
 {
-    const double md = (double)m;
+    RunCoef r;
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int y = 0; y < 4; ++y) r.c[x][y] = 0.0;
     const double tj = Ts * J;
-    const long long ml = m;
-    const double s1 = (double)(ml * (ml + 1) / 2);
-    a = (mode & kModeTail) ? 0.0 : a_s + md * tj;
+    r.c[3][0] = J;
+    if (!(mode & kModeTail)) { r.c[2][0] = a_s; r.c[2][1] = tj; }
+    r.c[0][0] = q_s;
     if (mode & kModeVSnap) {
-        v = vsnap;
-        q = q_s + md * (Ts * vsnap);
-    } else if (mode & kModeTail) {
-        v = 0.0;
-        q = q_s;
-    } else {
-        const double s2 = (double)(ml * (ml + 1) * (ml + 2) / 6);
-        v = v_s + Ts * (md * a_s + tj * s1);
-        q = q_s + Ts * (md * v_s + Ts * (s1 * a_s + tj * s2));
+        r.c[1][0] = vsnap;
+        r.c[0][1] = Ts * vsnap;
+    } else if (!(mode & kModeTail)) {
+        r.c[1][0] = v_s; r.c[1][1] = Ts * a_s; r.c[1][2] = Ts * tj;
+        r.c[0][1] = Ts * v_s; r.c[0][2] = Ts * (Ts * a_s); r.c[0][3] = Ts * (Ts * tj);
     }
+    return r;
 }
 
+LTP_DEV double run_eval(const double (&c)[4], int m)
+{
+    const double md = (double)m;
+    const double s1 = 0.5 * (md * (md + 1.0));
+    const double s2 = s1 * (md + 2.0) * (1.0 / 3.0);
+    return c[0] + (c[1] * md + (c[2] * s1 + c[3] * s2));
+}
+
+template <bool STREAMING>
+LTP_DEV void store2(double2_t* dst, double2_t val)
+{
+    if constexpr (STREAMING) __builtin_nontemporal_store(val, dst);
+    else *dst = val;
+}
+
+// One block = one plan (x one group of <= 8 joints): lanes 0..nj-1 build the run tables of their joints in LDS,
+// then all 256 lanes stream the rows. Blocks are dealt to plans `count/spread` apart (spread = 64 by default):
+// on MI355X a narrow moving write front only reaches ~5.2 TB/s, while blocks that write all over a >= 64 GiB
+// tile at the same time reach the fill-kernel ceiling (~6.6 TB/s) — see DESIGN.md, "What bounds the sampler".
+template <bool STREAMING, bool DRY>
 __global__ void __launch_bounds__(kSampleThreads)
 k_sample(long long first, long long count, int dof, double t_sample, Limits lim, Queries in, Records rec,
          const unsigned long long* __restrict__ offsets, double* __restrict__ out, unsigned long long capacity,
-         int streaming_stores)
+         unsigned long long* __restrict__ stamps, int spread)
 {
     __shared__ SegTable tab;
-    const long long p = first + blockIdx.x;
-    if (blockIdx.x >= count) return;
+    // Block -> plan map. spread > 1 deals consecutive blocks to plans count/spread apart, so the blocks that are
+    // resident at the same time write all over the output tile instead of one narrow moving front.
+    long long local = blockIdx.x;
+    if (spread > 1) {
+        const long long per = (count + spread - 1) / spread;
+        local = (long long)(blockIdx.x % spread) * per + blockIdx.x / spread;
+    }
+    if (local >= count) return;
+    const long long p = first + local;
+    // diagnostic only (stamps == nullptr in every product call): block start/end on the 100 MHz wall clock
+    if (stamps && threadIdx.x == 0 && blockIdx.y == 0) stamps[2 * local] = wall_clock64();
     const int len = rec.traj_len[p];
     if (len <= 0) return;   // failed / non-finite query: nothing to sample (uniform per block)
     const unsigned long long off0 = offsets[first];
@@ -477,67 +509,63 @@ k_sample(long long first, long long count, int dof, double t_sample, Limits lim,
         st[ns] = len;
         tab.nseg[jl] = ns;
         const double vsnap = rec.v_drive[rj] * dir;                              // cc:823
-        tab.vsnap[jl] = vsnap;
         double a = in.a_0[ix], v = in.v_0[ix], q = in.q_0[ix];                   // state "before sample 0" (cc:810-812)
         for (int k = 0; k < ns; ++k) {
             const int b = st[k], e = st[k + 1];
             int mode = 0;
             if (b > s[6]) mode |= kModeTail;
             if (phase4 && b >= s[2] + 1 && b < s[3] - 1) mode |= kModeVSnap;
-            const double J = jerk_at(P, b);
-            tab.mode[jl][k] = mode;
-            tab.J[jl][k] = J;
-            tab.a[jl][k] = a;
-            tab.v[jl][k] = v;
-            tab.q[jl][k] = q;
-            double an, vn, qn;
-            run_eval(mode, J, a, v, q, vsnap, Ts, e - b, an, vn, qn);
-            a = an; v = vn; q = qn;
+            const RunCoef rc = run_coef(mode, jerk_at(P, b), a, v, q, vsnap, Ts);
+#pragma unroll
+            for (int x = 0; x < 4; ++x)
+#pragma unroll
+                for (int y = 0; y < 4; ++y) tab.c[jl][k][x][y] = rc.c[x][y];
+            // state at the run's last sample = what the streaming loop will store there
+            q = run_eval(rc.c[0], e - b);
+            v = run_eval(rc.c[1], e - b);
+            a = run_eval(rc.c[2], e - b);
         }
+        // cc:59-61: q now holds sample len-1
+        if (q < lim.q_min[j] || q > lim.q_max[j]) atomicOr(&rec.status[p], kStatusEndLimit);
     }
     __syncthreads();
 
+    // Streaming: per joint, every lane produces q, v, a and j of two consecutive samples and issues four 16-B
+    // stores, i.e. four 1 KiB wave stores into the four rows of that joint. (Measured on MI355X: this runs at
+    // the same rate as the identical store pattern without any arithmetic; deeper unrolling or writing the rows
+    // one after the other is slower.)
     double* const plan_base = out + rel;
     const unsigned long long arr_stride = (unsigned long long)dof * stride;   // distance between q, v, a, j blocks
     const int npairs = (len + 1) >> 1;
     for (int jl = 0; jl < nj; ++jl) {
-        const int j = j0 + jl;
-        double* const row = plan_base + (unsigned long long)j * stride;
+        double* const row = plan_base + (unsigned long long)(j0 + jl) * stride;
         const int* st = tab.start[jl];
         const int ns = tab.nseg[jl];
-        const double vsnap = tab.vsnap[jl];
         int k = 0;
         for (int pr = threadIdx.x; pr < npairs; pr += kSampleThreads) {
-            const int i0 = 2 * pr;
-            double2_t oq, ov, oa, oj;
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int i = i0 + h;
-                double a = 0.0, v = 0.0, q = 0.0, J = 0.0;
-                if (i < len) {
-                    while (k + 1 < ns && st[k + 1] <= i) ++k;
-                    J = tab.J[jl][k];
-                    run_eval(tab.mode[jl][k], J, tab.a[jl][k], tab.v[jl][k], tab.q[jl][k], vsnap, Ts, i - st[k] + 1, a, v, q);
-                    if (i == len - 1) {
-                        // cc:59-61: last sample outside the position limits -> planTrajectory returns false
-                        if (q < lim.q_min[j] || q > lim.q_max[j]) atomicOr(&rec.status[p], kStatusEndLimit);
-                    }
-                }
-                oq[h] = q; ov[h] = v; oa[h] = a; oj[h] = J;
-            }
-            double2_t* dq = reinterpret_cast<double2_t*>(row + i0);
-            double2_t* dv = reinterpret_cast<double2_t*>(row + arr_stride + i0);
-            double2_t* da = reinterpret_cast<double2_t*>(row + 2 * arr_stride + i0);
-            double2_t* dj = reinterpret_cast<double2_t*>(row + 3 * arr_stride + i0);
-            if (streaming_stores) {
-                __builtin_nontemporal_store(oq, dq);
-                __builtin_nontemporal_store(ov, dv);
-                __builtin_nontemporal_store(oa, da);
-                __builtin_nontemporal_store(oj, dj);
+            const int i0 = 2 * pr, i1 = i0 + 1;
+            double2_t o[4];
+            if constexpr (DRY) {
+                o[0] = o[1] = o[2] = o[3] = double2_t{(double)i0, (double)i1};
             } else {
-                *dq = oq; *dv = ov; *da = oa; *dj = oj;
+                while (k + 1 < ns && st[k + 1] <= i0) ++k;
+                const int k1 = (k + 1 < ns && st[k + 1] <= i1) ? k + 1 : k;
+                const int m0 = i0 - st[k] + 1, m1 = i1 - st[k1] + 1;
+                const bool pad = i1 >= len;   // odd length: second half of the last slot is row padding
+#pragma unroll
+                for (int x = 0; x < 4; ++x) {
+                    const double x0 = run_eval(tab.c[jl][k][x], m0);
+                    const double x1 = run_eval(tab.c[jl][k1][x], m1);
+                    o[x] = double2_t{x0, pad ? 0.0 : x1};
+                }
             }
+#pragma unroll
+            for (int x = 0; x < 4; ++x) store2<STREAMING>(reinterpret_cast<double2_t*>(row + x * arr_stride + i0), o[x]);
         }
+    }
+    if (stamps) {
+        __syncthreads();
+        if (threadIdx.x == 0 && blockIdx.y == 0) stamps[2 * local + 1] = wall_clock64();
     }
 }
 
@@ -718,12 +746,26 @@ void launch_offsets(hipStream_t s, long long n, int dof, double t_sample, Record
 
 void launch_sample(hipStream_t s, long long first, long long count, int dof, double t_sample, Limits lim, Queries in,
                    Records rec, const unsigned long long* offsets, double* out, unsigned long long capacity,
-                   int streaming_stores)
+                   int flags, unsigned long long* stamps)
 {
     if (count <= 0) return;
-    const dim3 grid((unsigned)count, (unsigned)((dof + kSampleJointGroup - 1) / kSampleJointGroup));
-    hipLaunchKernelGGL(k_sample, grid, dim3(kSampleThreads), 0, s, first, count, dof, t_sample, lim, in, rec, offsets, out,
-                       capacity, streaming_stores);
+    int spread = (flags >> 8) & 0xFFFF;
+    if (spread == 0) spread = kSampleSpread;
+    if ((long long)spread > count) spread = (int)count;
+    long long gx = count;
+    if (spread > 1) gx = ((count + spread - 1) / spread) * spread;
+    const dim3 grid((unsigned)gx, (unsigned)((dof + kSampleJointGroup - 1) / kSampleJointGroup));
+    const dim3 block(kSampleThreads);
+    // flags bit 0: non-temporal stores; bit 1 (diagnostic): skip the arithmetic and store sample indices, which
+    // measures the ceiling of this store pattern; bits 8..23: block interleave factor (0 = default 64, 1 = plan order)
+#define LTP_SAMPLE_CASE(ST, DR) hipLaunchKernelGGL((k_sample<ST, DR>), grid, block, 0, s, first, count, dof, t_sample, lim, in, rec, offsets, out, capacity, stamps, spread)
+    switch (flags & 3) {
+    case 0: LTP_SAMPLE_CASE(false, false); break;
+    case 1: LTP_SAMPLE_CASE(true, false); break;
+    case 2: LTP_SAMPLE_CASE(false, true); break;
+    default: LTP_SAMPLE_CASE(true, true); break;
+    }
+#undef LTP_SAMPLE_CASE
 }
 
 void launch_generate(hipStream_t s, long long n, int dof, Limits lim, unsigned long long seed, long long first_query,

@@ -31,6 +31,7 @@ constexpr int kRowAlign = 16;          // trajectory rows padded to 16 doubles (
 constexpr int kSampleJointGroup = 8;   // joints handled by one k_sample block
 constexpr int kMaxSegments = 24;       // piecewise-constant jerk segments per joint
 constexpr int kSampleThreads = 256;
+constexpr int kSampleSpread = 64;      // default block->plan interleave of k_sample
 constexpr int kScanBlock = 1024;       // plans per finalize/scan block
 
 struct Limits {            // device pointers, [dof] each
@@ -69,7 +70,7 @@ void launch_offsets(hipStream_t s, long long n, int dof, double t_sample, Record
                     unsigned long long* block_sums, unsigned long long* offsets);
 void launch_sample(hipStream_t s, long long first, long long count, int dof, double t_sample, Limits lim, Queries in,
                    Records rec, const unsigned long long* offsets, double* out, unsigned long long capacity,
-                   int streaming_stores);
+                   int flags, unsigned long long* stamps = nullptr);
 void launch_generate(hipStream_t s, long long n, int dof, Limits lim, unsigned long long seed, long long first_query,
                      double* q_goal, double* q_0, double* v_0, double* a_0, long long sq, long long sj);
 

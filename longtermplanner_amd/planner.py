@@ -231,11 +231,12 @@ class LongTermPlanner:
         self._check(self._lib.ltp_plan_switch_times_batch(self._h, n, C.byref(q), C.byref(rec), batch.offsets.data_ptr(), self._stream()))
         return batch
 
-    def sampleBatch(self, batch: DeviceBatch, first, count, out, streaming=True):
-        """getTrajectory for plans [first, first+count) into the float64 CUDA tensor `out` (ltp_sample_batch)."""
+    def sampleBatch(self, batch: DeviceBatch, first, count, out, streaming=True, dry=False, spread=0):
+        """getTrajectory for plans [first, first+count) into the float64 CUDA tensor `out` (ltp_sample_batch).
+        dry=True is a diagnostic: same stores, no arithmetic (ceiling of the store pattern)."""
         rec = batch.c_records()
         self._check(self._lib.ltp_sample_batch(self._h, first, count, C.byref(batch.queries), C.byref(rec), batch.offsets.data_ptr(),
-                                               out.data_ptr(), out.numel(), 1 if streaming else 0, self._stream()))
+                                               out.data_ptr(), out.numel(), (1 if streaming else 0) | (2 if dry else 0) | (int(spread) << 8), self._stream()))
 
     # ---- diagnostics for the parity tests ----
     def debugMathProbe(self, x, y):
