@@ -1,0 +1,269 @@
+// long_term_planner/long_term_planner.h — drop-in for the reference header of the same path.
+//
+// Same namespace, struct, class, constructor and method signatures as
+// /root/reference/include/long_term_planner/long_term_planner.h (Trajectory :37-45, sign :54-56,
+// LongTermPlanner :61-308; implementation src/long_term_planner.cc). Every method forwards to the
+// MI355X library through the C ABI of include/ltp_hip.h — there is no host implementation of the
+// planner arithmetic in this header or behind it, and no <Eigen/Dense> dependency (the reference
+// header pulls Eigen in publicly; the root finder now lives on the device).
+//
+// Differences a user can observe:
+//   * a HIP device is required; a missing device / HIP error throws std::runtime_error (the reference
+//     has no error channel besides `bool`, and silently computing on the CPU is not offered);
+//   * the reference's std::cerr diagnostic at cc:343 is not printed;
+//   * corners the reference leaves undefined (out-of-range writes of the sampler,
+//     non-finite switching times) are defined: dropped writes / `false`;
+//   * NEW: planTrajectoryBatch(), the batched overload this library exists for.
+#ifndef long_term_planner_H
+#define long_term_planner_H
+
+#include <algorithm>
+#include <array>
+#include <cmath>
+#include <cstddef>
+#include <functional>
+#include <math.h>
+#include <numeric>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "ltp_hip.h"
+
+namespace long_term_planner {
+
+/** @brief Trajectory structure (reference long_term_planner.h:37-45). q/v/a/j are [joint][sample]. */
+struct Trajectory {
+  int dof;
+  double t_sample;
+  int length;
+  std::vector<std::vector<double>> q;
+  std::vector<std::vector<double>> v;
+  std::vector<std::vector<double>> a;
+  std::vector<std::vector<double>> j;
+};
+
+/** @brief -1 / 0 / +1 (reference long_term_planner.h:54-56). */
+template <typename T> int sign(T val) {
+  return (T(0) < val) - (val < T(0));
+}
+
+/** @brief Result of the batched overload: switching-time records plus packed dense trajectories. */
+struct BatchTrajectory {
+  long long n = 0;
+  int dof = 0;
+  double t_sample = 0.0;
+  std::vector<double> t_opt;        ///< [n][dof][7]
+  std::vector<double> t_scaled;     ///< [n][dof][7]
+  std::vector<double> dir;          ///< [n][dof]
+  std::vector<double> v_drive;      ///< [n][dof]
+  std::vector<signed char> mod;     ///< [n][dof]
+  std::vector<double> t_required;   ///< [n]
+  std::vector<int> slowest;         ///< [n]
+  std::vector<int> length;          ///< [n] Trajectory::length, 0 if the plan failed before sampling
+  std::vector<int> status;          ///< [n] LTP_STATUS_* bits; planTrajectory's bool is (status == 0)
+  std::vector<unsigned long long> offsets;  ///< [n+1] plan p occupies packed[offsets[p], offsets[p+1])
+  std::vector<double> packed;       ///< per plan: [q,v,a,j][joint][ltp_row_stride(length)]
+  /// pointer to sample 0 of array `arr` (0=q,1=v,2=a,3=j) of joint `joint` of plan `p`
+  const double* row(long long p, int arr, int joint) const {
+    return packed.data() + offsets[p] + (static_cast<std::size_t>(arr) * dof + joint) * ltp_row_stride(length[p]);
+  }
+  /// copy plan p out as a reference-style Trajectory
+  Trajectory trajectory(long long p) const {
+    Trajectory t;
+    t.dof = dof; t.t_sample = t_sample; t.length = length[p];
+    std::vector<std::vector<double>>* dst[4] = {&t.q, &t.v, &t.a, &t.j};
+    for (int arr = 0; arr < 4; ++arr) {
+      dst[arr]->resize(dof);
+      for (int i = 0; i < dof; ++i) (*dst[arr])[i].assign(row(p, arr, i), row(p, arr, i) + length[p]);
+    }
+    return t;
+  }
+};
+
+/** @brief Plans a trajectory for multiple joints (reference long_term_planner.h:61-308). */
+class LongTermPlanner {
+ private:
+  int dof_;
+  double t_sample_;
+  std::vector<double> q_min_;
+  std::vector<double> q_max_;
+  std::vector<double> v_max_;
+  std::vector<double> a_max_;
+  std::vector<double> j_max_;
+
+  // device-side twin of the members above; created lazily, never shared between copies
+  mutable ltp_planner* handle_ = nullptr;
+  mutable bool dirty_ = true;
+  int device_ = 0;
+
+  static void raise(const ltp_planner* h, int rc, const char* what) {
+    throw std::runtime_error(std::string("long_term_planner (MI355X): ") + what + " failed with code " + std::to_string(rc) +
+                             (h ? std::string(": ") + ltp_last_error(h) : std::string(" (no HIP device? there is no CPU fallback)")));
+  }
+
+  ltp_planner* handle() const {
+    const int n = static_cast<int>(std::min({q_min_.size(), q_max_.size(), v_max_.size(), a_max_.size(), j_max_.size()}));
+    if (!handle_) {
+      const int rc = ltp_create(0, t_sample_, nullptr, nullptr, nullptr, nullptr, nullptr, device_, &handle_);
+      if (rc != LTP_OK) raise(nullptr, rc, "ltp_create");
+      dirty_ = true;
+    }
+    if (dirty_) {
+      int rc = ltp_set_limits(handle_, n, q_min_.data(), q_max_.data(), v_max_.data(), a_max_.data(), j_max_.data());
+      if (rc != LTP_OK) raise(handle_, rc, "ltp_set_limits");
+      if ((rc = ltp_set_sample_time(handle_, t_sample_)) != LTP_OK) raise(handle_, rc, "ltp_set_sample_time");
+      if ((rc = ltp_set_dof(handle_, dof_)) != LTP_OK) raise(handle_, rc, "ltp_set_dof");
+      dirty_ = false;
+    }
+    return handle_;
+  }
+
+  void release() {
+    if (handle_) ltp_destroy(handle_);
+    handle_ = nullptr;
+  }
+
+ public:
+  /** @brief Dummy planner (reference long_term_planner.h:103-105). */
+  LongTermPlanner() : dof_(0), t_sample_(0.001) {}
+
+  /** @brief reference long_term_planner.h:118-131 */
+  LongTermPlanner(int dof, double t_sample, std::vector<double> q_min, std::vector<double> q_max, std::vector<double> v_max,
+                  std::vector<double> a_max, std::vector<double> j_max)
+      : dof_(dof), t_sample_(t_sample), q_min_(q_min), q_max_(q_max), v_max_(v_max), a_max_(a_max), j_max_(j_max) {}
+
+  LongTermPlanner(const LongTermPlanner& o)
+      : dof_(o.dof_), t_sample_(o.t_sample_), q_min_(o.q_min_), q_max_(o.q_max_), v_max_(o.v_max_), a_max_(o.a_max_),
+        j_max_(o.j_max_), device_(o.device_) {}
+  LongTermPlanner& operator=(const LongTermPlanner& o) {
+    if (this != &o) {
+      dof_ = o.dof_; t_sample_ = o.t_sample_; q_min_ = o.q_min_; q_max_ = o.q_max_; v_max_ = o.v_max_; a_max_ = o.a_max_;
+      j_max_ = o.j_max_; device_ = o.device_; dirty_ = true;
+    }
+    return *this;
+  }
+  ~LongTermPlanner() { release(); }
+
+  /** @brief reference long_term_planner.h:144-150, src/long_term_planner.cc:7-63 */
+  bool planTrajectory(const std::vector<double>& q_goal, const std::vector<double>& q_0, const std::vector<double>& v_0,
+                      const std::vector<double>& a_0, Trajectory& traj) {
+    BatchTrajectory b;
+    planTrajectoryBatch(1, q_goal.data(), q_0.data(), v_0.data(), a_0.data(), b);
+    const int st = b.status[0];
+    // the reference leaves `traj` untouched when it returns false before sampling (cc:14-39)
+    if (st & (LTP_STATUS_INVALID_INPUT | LTP_STATUS_OPT_FAILED | LTP_STATUS_NO_SLOWEST | LTP_STATUS_NONFINITE)) return false;
+    traj = b.trajectory(0);
+    return st == 0;   // LTP_STATUS_END_LIMIT: false with the trajectory filled (cc:59-61)
+  }
+
+  /**
+   * @brief NEW batched overload: n independent queries, row-major [n][dof] host arrays.
+   * @return number of queries for which planTrajectory would have returned true.
+   */
+  long long planTrajectoryBatch(long long n, const double* q_goal, const double* q_0, const double* v_0, const double* a_0,
+                                BatchTrajectory& out, bool sample = true) {
+    ltp_planner* h = handle();
+    const std::size_t nd = static_cast<std::size_t>(n) * dof_;
+    out.n = n; out.dof = dof_; out.t_sample = t_sample_;
+    out.t_opt.assign(nd * 7, 0.0); out.t_scaled.assign(nd * 7, 0.0); out.dir.assign(nd, 0.0); out.v_drive.assign(nd, 0.0);
+    out.mod.assign(nd, 0); out.t_required.assign(n, 0.0); out.slowest.assign(n, -1); out.length.assign(n, 0);
+    out.status.assign(n, 0); out.offsets.assign(n + 1, 0ull); out.packed.clear();
+    // zero-sized vectors have a null data(); the C ABI wants non-null record pointers
+    double dummy_d = 0; signed char dummy_c = 0;
+    ltp_records rec{nd ? out.t_opt.data() : &dummy_d, nd ? out.t_scaled.data() : &dummy_d, nd ? out.dir.data() : &dummy_d,
+                    nd ? out.v_drive.data() : &dummy_d, nd ? out.mod.data() : &dummy_c, out.t_required.data(),
+                    out.slowest.data(), out.length.data(), out.status.data()};
+    double* packed = nullptr;
+    const int rc = ltp_plan_batch_host(h, n, q_goal, q_0, v_0, a_0, &rec, out.offsets.data(), sample ? &packed : nullptr);
+    if (rc != LTP_OK) raise(h, rc, "ltp_plan_batch_host");
+    if (packed) {
+      out.packed.assign(packed, packed + out.offsets[n]);
+      ltp_free_host(packed);
+    }
+    long long ok = 0;
+    for (long long p = 0; p < n; ++p) ok += out.status[p] == 0;
+    return ok;
+  }
+
+  /** @brief reference long_term_planner.h:161-165, cc:68-77 */
+  bool checkInputs(const std::vector<double>& q_0, const std::vector<double>& v_0, const std::vector<double>& a_0) {
+    int ok = 0;
+    ltp_planner* h = handle();
+    const int rc = ltp_check_inputs_host(h, q_0.data(), v_0.data(), a_0.data(), &ok);
+    if (rc != LTP_OK) raise(h, rc, "ltp_check_inputs_host");
+    return ok != 0;
+  }
+
+  /** @brief reference long_term_planner.h:176-187 */
+  inline void setLimits(std::vector<double> q_min, std::vector<double> q_max, std::vector<double> v_max,
+                        std::vector<double> a_max, std::vector<double> j_max) {
+    q_min_ = q_min; q_max_ = q_max; v_max_ = v_max; a_max_ = a_max; j_max_ = j_max;
+    dirty_ = true;
+  }
+
+  /** @brief reference long_term_planner.h:194-196 */
+  inline void setSampleTime(double t_sample) { t_sample_ = t_sample; dirty_ = true; }
+
+  /** @brief reference long_term_planner.h:203-205 (takes a double there as well) */
+  inline void setDoF(double dof) { dof_ = dof; dirty_ = true; }
+
+  /** @brief NEW: HIP device ordinal used by this planner (default 0). */
+  inline void setDevice(int device) { if (device != device_) { release(); device_ = device; dirty_ = true; } }
+
+  /** @brief NEW: the C-ABI handle, for callers that drive the device-pointer entry points of ltp_hip.h directly. */
+  ltp_planner* nativeHandle() { return handle(); }
+
+ protected:
+  /** @brief reference long_term_planner.h:223-231, cc:82-353 */
+  bool optSwitchTimes(int joint, double q_goal, double q_0, double v_0, double a_0, double v_drive, std::array<double, 7>& t,
+                      double& dir, char& mod_jerk_profile) {
+    int ok = 0;
+    ltp_planner* h = handle();
+    const int rc = ltp_opt_switch_times_host(h, joint, q_goal, q_0, v_0, a_0, v_drive, t.data(), &dir, &mod_jerk_profile, &ok);
+    if (rc != LTP_OK) raise(h, rc, "ltp_opt_switch_times_host");
+    return ok != 0;
+  }
+
+  /** @brief reference long_term_planner.h:249-259, cc:358-645 */
+  bool timeScaling(int joint, double q_goal, double q_0, double v_0, double a_0, double dir, double t_required,
+                   std::array<double, 7>& scaled_t, double& v_drive, char& mod_jerk_profile) {
+    int ok = 0;
+    ltp_planner* h = handle();
+    const int rc = ltp_time_scaling_host(h, joint, q_goal, q_0, v_0, a_0, dir, t_required, scaled_t.data(), &v_drive,
+                                         &mod_jerk_profile, &ok, nullptr);
+    if (rc != LTP_OK) raise(h, rc, "ltp_time_scaling_host");
+    return ok != 0;
+  }
+
+  /** @brief reference long_term_planner.h:279-285, cc:650-701 (writes t_rel[0..2] only) */
+  bool optBraking(int joint, double v_0, double a_0, double& q, std::array<double, 7>& t_rel, double& dir) {
+    ltp_planner* h = handle();
+    const int rc = ltp_opt_braking_host(h, joint, v_0, a_0, &q, t_rel.data(), &dir);
+    if (rc != LTP_OK) raise(h, rc, "ltp_opt_braking_host");
+    return true;
+  }
+
+  /** @brief reference long_term_planner.h:299-307, cc:706-841 */
+  Trajectory getTrajectory(const std::vector<std::array<double, 7>>& t, const std::vector<double>& dir,
+                           const std::vector<char>& mod_jerk_profile, const std::vector<double>& q_0,
+                           const std::vector<double>& v_0, const std::vector<double>& a_0, const std::vector<double>& v_drive) {
+    ltp_planner* h = handle();
+    BatchTrajectory b;
+    b.n = 1; b.dof = dof_; b.t_sample = t_sample_;
+    b.length.assign(1, 0); b.status.assign(1, 0); b.offsets.assign(2, 0ull);
+    std::vector<signed char> mod(mod_jerk_profile.begin(), mod_jerk_profile.end());
+    double* packed = nullptr;
+    const int rc = ltp_get_trajectory_host(h, 1, t.empty() ? nullptr : t[0].data(), dir.data(), mod.data(), q_0.data(), v_0.data(),
+                                           a_0.data(), v_drive.data(), b.length.data(), b.status.data(), b.offsets.data(), &packed);
+    if (rc != LTP_OK) raise(h, rc, "ltp_get_trajectory_host");
+    if (packed) {
+      b.packed.assign(packed, packed + b.offsets[1]);
+      ltp_free_host(packed);
+    }
+    return b.trajectory(0);
+  }
+};
+}  // namespace long_term_planner
+
+#endif  // long_term_planner_H

@@ -360,7 +360,8 @@ static int download_records(ltp_planner* p, long long n, int dof, const ltp_reco
 int ltp_plan_batch_host(ltp_planner* p, long long n, const double* q_goal, const double* q_0, const double* v_0,
                         const double* a_0, const ltp_records* host_records, unsigned long long* offsets, double** packed)
 {
-    if (!p || n < 0 || (n > 0 && (!q_goal || !q_0 || !v_0 || !a_0)) || (packed && !offsets)) return fail(p, LTP_ERR_INVALID_ARGUMENT, "null argument");
+    if (!p || n < 0 || (packed && !offsets)) return fail(p, LTP_ERR_INVALID_ARGUMENT, "null argument");
+    if (n > 0 && p->dof > 0 && (!q_goal || !q_0 || !v_0 || !a_0)) return fail(p, LTP_ERR_INVALID_ARGUMENT, "null query array");
     if (packed) *packed = nullptr;
     int rc;
     { std::lock_guard<std::mutex> g(p->mu); rc = check_config(p); }

@@ -1,0 +1,209 @@
+// tests/cpp/dropin_tests.cc — exercises the drop-in C++ class the way the reference's own gtests do.
+//
+// The scenarios, tables and tolerances are those of /root/reference/tests/src/long_term_planner_tests.cc
+// (OptBrakingTest :12-50, OptSwitchTimesTest :52-109, TrajectoryTestV0/V1/V2 :111-196, TimeScalingTest
+// :198-262, gridTestOneJoint :264-323 on a coarser grid) and reach the protected methods through a
+// `using`-exporting subclass exactly as tests/include/long_term_planner_fixture.h:34-39 does, so this file
+// also proves that the protected signatures are source-compatible. Runs on the GPU (no CPU path exists).
+#include <cmath>
+#include <cstdio>
+#include <iostream>
+#include <vector>
+
+#include "long_term_planner/long_term_planner.h"
+
+namespace ltpn = long_term_planner;
+
+class LongTermPlannerExposed : public ltpn::LongTermPlanner {
+ public:
+  using LongTermPlanner::getTrajectory;
+  using LongTermPlanner::optBraking;
+  using LongTermPlanner::optSwitchTimes;
+  using LongTermPlanner::timeScaling;
+  LongTermPlannerExposed() {}
+  explicit LongTermPlannerExposed(int dof, double t_sample, std::vector<double> q_min, std::vector<double> q_max,
+                                  std::vector<double> v_max, std::vector<double> a_max, std::vector<double> j_max)
+      : LongTermPlanner(dof, t_sample, q_min, q_max, v_max, a_max, j_max) {}
+};
+
+static int g_checks = 0, g_fails = 0;
+#define EXPECT_TRUE(c) do { ++g_checks; if (!(c)) { ++g_fails; std::printf("FAIL %s:%d  %s\n", __FILE__, __LINE__, #c); } } while (0)
+#define EXPECT_NEAR(a, b, tol) do { ++g_checks; const double a_ = (a), b_ = (b); if (!(std::fabs(a_ - b_) <= (tol))) { ++g_fails; std::printf("FAIL %s:%d  |%s - %s| = |%.12g - %.12g| > %g\n", __FILE__, __LINE__, #a, #b, a_, b_, (double)(tol)); } } while (0)
+
+static LongTermPlannerExposed fixture1dof()
+{
+  // tests/include/long_term_planner_fixture.h:72-81
+  return LongTermPlannerExposed(1, 0.001, {-3.1}, {3.1}, {10}, {2}, {4});
+}
+
+static void testOptBraking()
+{
+  LongTermPlannerExposed ltp = fixture1dof();
+  const double eps = 0.01;
+  std::vector<double> v_0 = {0, -1.875, -1.875, -0.875, -0.875, 0.5};
+  std::vector<double> a_0 = {0, 1, -1, 1, -1, -2};
+  std::vector<double> a_max = {2, 2, 2, 4, 4, 4}, j_max = {4, 4, 4, 4, 4, 2};
+  std::vector<double> q_goal = {0, -1.0104, -1.9896, -0.2604, -0.7396, -0.4167};
+  std::vector<std::vector<double>> t_rel = {{0, 0, 0}, {0.25, 0.5, 0.5}, {0.75, 0.5, 0.5}, {0.25, 0, 0.5}, {0.75, 0, 0.5}, {1.5, 0, 0.5}};
+  for (int i = 0; i < 6; i++) {
+    ltp.setLimits({-3.1}, {3.1}, {10}, {a_max[i]}, {j_max[i]});
+    double q_ltp, dir;
+    std::array<double, 7> t_ltp{};
+    EXPECT_TRUE(ltp.optBraking(0, v_0[i], a_0[i], q_ltp, t_ltp, dir));
+    for (int j = 0; j < 3; j++) EXPECT_NEAR(t_ltp[j], t_rel[i][j], eps);
+    EXPECT_NEAR(q_ltp, q_goal[i], eps);
+    if (i == 0) continue;
+    EXPECT_TRUE(ltp.optBraking(0, -v_0[i], -a_0[i], q_ltp, t_ltp, dir));
+    for (int j = 0; j < 3; j++) EXPECT_NEAR(t_ltp[j], t_rel[i][j], eps);
+    EXPECT_NEAR(q_ltp, -q_goal[i], eps);
+  }
+}
+
+static void testOptSwitchTimes()
+{
+  LongTermPlannerExposed ltp = fixture1dof();
+  const double eps = 0.001;
+  std::vector<double> v_max = {2, 2, 2, 1, 1, 8, 8, 8, 8};
+  std::vector<double> q_goal = {-1.0, 2.927, 2.8854, 0.2396, 0.6354, 1.927, 1.8854, -0.2604, 0.1354};
+  std::vector<double> v_0 = {0.0, 0.625, 1.875, -0.875, 0.875, 0.625, 1.875, -0.875, 0.875};
+  std::vector<double> a_0 = {0.0, 1.0, -1.0, 1.0, -1.0, 1.0, -1.0, 1.0, -1.0};
+  std::vector<std::vector<double>> t = {{0, 0, 0, 0, 0, 0, 0}, {0.25, 0.5, 1.0, 1.5, 2.0, 2.5, 3.0}, {0.5, 0.5, 0.75, 1.25, 1.75, 2.25, 2.75},
+      {0.25, 0.75, 1.25, 1.75, 2.25, 2.25, 2.75}, {0.5, 0.5, 0.75, 1.25, 1.75, 1.75, 2.25}, {0.25, 0.5, 1.0, 1.0, 1.5, 2.0, 2.5},
+      {0.5, 0.5, 0.5, 0.5, 1.25, 1.75, 2.25}, {0.25, 0.75, 1.25, 1.25, 1.75, 1.75, 2.25}, {0.5, 0.5, 0.5, 0.5, 1.25, 1.25, 1.75}};
+  for (int i = 0; i < 9; i++) {
+    ltp.setLimits({-3.1}, {3.1}, {v_max[i]}, {2}, {4});
+    std::array<double, 7> t_ltp{};
+    double dir;
+    char mod;
+    EXPECT_TRUE(ltp.optSwitchTimes(0, q_goal[i], -1.0, v_0[i], a_0[i], v_max[i], t_ltp, dir, mod));
+    for (int j = 0; j < 3; j++) EXPECT_NEAR(t_ltp[j], t[i][j], eps);
+    if (i == 0) continue;
+    EXPECT_TRUE(ltp.optSwitchTimes(0, -q_goal[i], 1.0, -v_0[i], -a_0[i], v_max[i], t_ltp, dir, mod));
+    for (int j = 0; j < 3; j++) EXPECT_NEAR(t_ltp[j], t[i][j], eps);
+  }
+}
+
+static void testTrajectories()
+{
+  LongTermPlannerExposed ltp = fixture1dof();
+  std::vector<double> v_max = {2, 2, 2, 1, 1, 8, 8, 8, 8};
+  std::vector<std::vector<double>> goals = {{1.1, 1.01, 1.05, 1.1, 1.15, 1.2, 1.25, 1.3, 1.5}, {1.0, 1.01, 1.05, 1.1, 1.15, 1.2, 1.25, 1.3, 1.5},
+                                            {1.1, 1.1, 1.1, 1.1, 1.1, 1.1, 1.1, 1.1, 1.1}};
+  std::vector<std::vector<double>> a0s = {{1e-8, -1e-8, -1e-8, -1e-8, -1e-8, -1e-8, -1e-8, -1e-8, -1e-8},
+                                          {1e-8, 1e-8, 1e-8, 1e-8, 1e-8, 1e-8, 1e-8, 1e-8, 1e-8},
+                                          {1e-1, 1e-2, 1e-3, 1e-4, 1e-5, 1e-6, 1e-7, 1e-8, 1e-9}};
+  for (int v = 0; v < 3; v++)
+    for (int i = 0; i < 9; i++) {
+      ltp.setLimits({-3.1}, {3.1}, {v_max[i]}, {2}, {4});
+      ltpn::Trajectory traj;
+      const bool success = ltp.planTrajectory({goals[v][i]}, {1.0}, {0.0}, {a0s[v][i]}, traj);
+      EXPECT_TRUE(success);
+      if (!success) continue;
+      EXPECT_TRUE(traj.dof == 1 && traj.length >= 1 && (int)traj.q[0].size() == traj.length);
+      EXPECT_NEAR(traj.q[0][traj.length - 1], goals[v][i], 1e-2);
+    }
+}
+
+static void testTimeScaling()
+{
+  LongTermPlannerExposed ltp = fixture1dof();
+  const double eps = 0.1;
+  std::vector<double> a_max = {2, 2, 2, 2, 2, 2, 2, 2, 2, 4, 4, 4}, j_max = {4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 2};
+  std::vector<double> q_goal = {-1.0, 2.927, 2.8854, 0.2396, 0.6354, -7.0104, -8.9896, -3.896, -7.9433, -5.1746, -6.6538, -8.4167};
+  std::vector<double> v_0 = {0.0, 0.625, 1.875, -0.875, 0.875, -3.875, -3.875, -1.875, -1.875, -2.875, -2.875, -1.5};
+  std::vector<double> a_0 = {0.0, 1, -1, 1, -1, 1, -1, 1, -2, 1, -1, -2};
+  std::vector<double> dir = {1.0, 1, 1, 1, 1, -1, -1, -1, -1, -1, -1, -1};
+  std::vector<std::vector<double>> t = {{0, 0, 0}, {0.25, 0.5, 1}, {0.5, 0.5, 0.75}, {0.25, 0.75, 1.25}, {0.5, 0.5, 0.75}, {0.25, 0.75, 1.25},
+      {0.75, 1.25, 1.75}, {0.25, 0.5, 1}, {0.75, 0.75, 1}, {0.25, 0.25, 0.75}, {0.75, 0.75, 1.25}, {1.5, 1.5, 2}};
+  std::vector<double> t_required = {0, 3, 2.75, 2.75, 2.25, 3.25, 3.75, 5, 3.9997, 2.6642, 3.1642, 4.5};
+  for (int i = 0; i < 12; i++) {
+    ltp.setLimits({-3.1}, {3.1}, {4}, {a_max[i]}, {j_max[i]});
+    std::array<double, 7> t_ltp{};
+    double v_drive;
+    char mod;
+    EXPECT_TRUE(ltp.timeScaling(0, q_goal[i], -1.0, v_0[i], a_0[i], dir[i], t_required[i], t_ltp, v_drive, mod));
+    for (int j = 0; j < 3; j++) EXPECT_NEAR(t_ltp[j], t[i][j], eps);
+    if (i == 0) continue;
+    EXPECT_TRUE(ltp.timeScaling(0, -q_goal[i], 1.0, -v_0[i], -a_0[i], -dir[i], t_required[i], t_ltp, v_drive, mod));
+    for (int j = 0; j < 3; j++) EXPECT_NEAR(t_ltp[j], t[i][j], eps);
+  }
+}
+
+static void testGridOneJointCoarse()
+{
+  // gridTestOneJoint (:264-323) with every 5th grid point (one call = several GPU round trips)
+  LongTermPlannerExposed ltp = fixture1dof();
+  const double eps = 1e-6, tol = 0.02, step = 0.1, q_0 = 0.5;
+  std::vector<double> v_max = {1.0};
+  ltp.setSampleTime(0.004);
+  ltp.setLimits({-3.1}, {3.1}, v_max, {2.0}, {15.0});
+  for (int i = -30; i <= 30; i += 5)
+    for (int j = -10; j < 10; j += 5) {
+      const double q_goal = i * step, v_0 = j * step;
+      for (int k = -10; k < 10; k += 5) {
+        const double a_0 = k * step - eps;
+        std::array<double, 7> t_ltp{};
+        double dir;
+        char mod;
+        EXPECT_TRUE(ltp.optSwitchTimes(0, q_goal, q_0, v_0, a_0, v_max[0], t_ltp, dir, mod));
+        ltpn::Trajectory traj = ltp.getTrajectory({t_ltp}, {dir}, {mod}, {q_0}, {v_0}, {a_0}, v_max);
+        EXPECT_TRUE(traj.length >= 1);
+        if (traj.length >= 1) EXPECT_NEAR(traj.q[0][traj.length - 1], q_goal, tol);
+      }
+    }
+}
+
+static void testApiSurface()
+{
+  // default-constructed planner: dof 0 -> planTrajectory false (slowest_joint == -1, cc:39), traj untouched
+  ltpn::LongTermPlanner dummy;
+  ltpn::Trajectory traj;
+  traj.length = -7;
+  EXPECT_TRUE(!dummy.planTrajectory({}, {}, {}, {}, traj));
+  EXPECT_TRUE(traj.length == -7);
+  // checkInputs (cc:68-77), setDoF(double), copy semantics, 6-DoF fixture (fixture.h:97-109)
+  LongTermPlannerExposed six(6, 0.001, std::vector<double>(6, -3.1), std::vector<double>(6, 3.1), std::vector<double>(6, 10.0),
+                             {2, 2, 2, 4, 4, 4}, {4, 4, 4, 4, 4, 2});
+  EXPECT_TRUE(six.checkInputs(std::vector<double>(6, 0.0), std::vector<double>(6, 1.0), std::vector<double>(6, 1.0)));
+  EXPECT_TRUE(!six.checkInputs(std::vector<double>(6, 3.2), std::vector<double>(6, 0.0), std::vector<double>(6, 0.0)));
+  LongTermPlannerExposed copy = six;
+  ltpn::Trajectory t6;
+  const bool ok = copy.planTrajectory({1, -1, 0.5, 2, -2, 0}, {0, 0, 0, 0, 0, 0}, {0.1, 0, -0.1, 0, 0.2, 0}, {0, 0.1, 0, -0.1, 0, 0}, t6);
+  EXPECT_TRUE(ok);
+  EXPECT_TRUE(t6.dof == 6 && (int)t6.q.size() == 6 && (int)t6.j[5].size() == t6.length);
+  const double goals[6] = {1, -1, 0.5, 2, -2, 0};
+  for (int i = 0; i < 6 && ok; i++) {
+    EXPECT_NEAR(t6.q[i][t6.length - 1], goals[i], 0.02);
+    EXPECT_NEAR(t6.v[i][t6.length - 1], 0.0, 1e-12);
+    EXPECT_NEAR(t6.a[i][t6.length - 1], 0.0, 1e-12);
+  }
+  // invalid start state: false, trajectory untouched (cc:14-15)
+  ltpn::Trajectory keep;
+  keep.length = 123;
+  EXPECT_TRUE(!six.planTrajectory({1, -1, 0.5, 2, -2, 0}, {9, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0}, keep));
+  EXPECT_TRUE(keep.length == 123);
+  // batched overload
+  ltpn::BatchTrajectory b;
+  std::vector<double> qg = {1, -1, 0.5, 2, -2, 0, 0.3, 0.2, 0.1, 0, -0.1, -0.2}, z(12, 0.0);
+  const long long n_ok = six.planTrajectoryBatch(2, qg.data(), z.data(), z.data(), z.data(), b);
+  EXPECT_TRUE(n_ok == 2 && b.length[0] > 1 && b.length[1] > 1);
+  EXPECT_NEAR(b.row(1, 0, 0)[b.length[1] - 1], 0.3, 0.02);
+  EXPECT_TRUE(b.trajectory(0).length == b.length[0]);
+}
+
+int main()
+{
+  try {
+    testOptBraking();
+    testOptSwitchTimes();
+    testTrajectories();
+    testTimeScaling();
+    testGridOneJointCoarse();
+    testApiSurface();
+  } catch (const std::exception& e) {
+    std::printf("EXCEPTION: %s\n", e.what());
+    return 2;
+  }
+  std::printf("%d checks, %d failures\n", g_checks, g_fails);
+  return g_fails ? 1 : 0;
+}

@@ -1,0 +1,78 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads, exports every declared symbol, and the
+product fails loudly (never falls back to a CPU path) when no HIP device is present."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def abi():
+    from longtermplanner_amd import _abi
+    _abi.build()
+    return _abi
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "ltp_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(ltp_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol(abi):
+    names = _declared_symbols()
+    assert len(names) >= 20
+    lib = C.CDLL(abi.LIB_PATH)
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/ltp_hip.h but not exported"
+    # and the Python binding binds exactly the declared set
+    assert sorted(abi.exported_symbols()) == names
+
+
+def test_row_stride(abi):
+    lib = abi.lib()
+    assert lib.ltp_row_stride(0) == 0 and lib.ltp_row_stride(-3) == 0
+    assert lib.ltp_row_stride(1) == 16 and lib.ltp_row_stride(16) == 16 and lib.ltp_row_stride(17) == 32
+    assert lib.ltp_row_stride(1718) == 1728
+
+
+def _has_gpu():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+@pytest.mark.skipif(_has_gpu(), reason="checks the no-device behaviour")
+def test_no_device_fails_loudly(abi):
+    import longtermplanner_amd as m
+    with pytest.raises(m.LtpError) as e:
+        m.LongTermPlanner(1, 0.001, [-1], [1], [1], [1], [1])
+    assert e.value.code == 2  # LTP_ERR_NO_DEVICE
+
+
+def test_product_never_touches_the_oracle():
+    # the oracle is test infrastructure: nothing under the package, include/ or the C-ABI sources may reference it
+    bad = []
+    for base in ("longtermplanner_amd", "include"):
+        for dirpath, _, files in os.walk(os.path.join(ROOT, base)):
+            for f in files:
+                if f.endswith((".py", ".h", ".hpp", ".hip", ".cc", "Makefile")):
+                    txt = open(os.path.join(dirpath, f), errors="ignore").read()
+                    if re.search(r"\boracle\b|ltpo_|libltp_oracle", txt):
+                        bad.append(os.path.join(dirpath, f))
+    assert not bad, bad
+
+
+def test_cpp_dropin_builds_with_plain_gxx_and_fails_loudly_without_gpu(abi):
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "cpp"), "-s", "all"])
+    exe = os.path.join(ROOT, "tests", "cpp", "dropin_tests")
+    assert os.path.exists(exe)
+    if not _has_gpu():
+        r = subprocess.run([exe], capture_output=True, text=True)
+        assert r.returncode == 2 and "no CPU fallback" in r.stdout

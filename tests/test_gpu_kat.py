@@ -1,0 +1,158 @@
+"""The reference's own test scenarios, run through the C ABI on the GPU (and against the oracle at 1e-9)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TOL = 1e-9
+
+
+@pytest.fixture(scope="module")
+def amd():
+    import longtermplanner_amd as m
+    return m
+
+
+def _pair(amd, oracle_mod, kat, i=None, tab=None, t_sample=None):
+    f = kat["fixture_1dof"]
+    lim = {k: list(f[k]) for k in ("q_min", "q_max", "v_max", "a_max", "j_max")}
+    if tab is not None:
+        for k in lim:
+            if k in tab:
+                lim[k] = [tab[k][i]]
+    ts = t_sample or f["t_sample"]
+    return amd.LongTermPlanner(1, ts, device=0, **lim), oracle_mod.Oracle(1, ts, **lim)
+
+
+def test_opt_braking_kat(amd, oracle_mod, kat):
+    k = kat["opt_braking"]
+    for i in range(len(k["v_0"])):
+        ltp, orc = _pair(amd, oracle_mod, kat, i, k)
+        for sgn in ((1, -1) if i >= k["mirror_from"] else (1,)):
+            _, q, t, d = ltp.optBraking(0, sgn * k["v_0"][i], sgn * k["a_0"][i])
+            assert np.all(np.abs(t[:3] - np.array(k["t_rel"][i])) <= k["eps"])
+            assert abs(q - sgn * k["q"][i]) <= k["eps"]
+            oq, ot, od = orc.opt_braking(0, sgn * k["v_0"][i], sgn * k["a_0"][i])
+            assert abs(q - oq) <= TOL and np.max(np.abs(t - ot)) <= TOL and d == od
+
+
+def test_opt_switch_times_kat(amd, oracle_mod, kat):
+    k = kat["opt_switch_times"]
+    for i in range(len(k["q_goal"])):
+        ltp, orc = _pair(amd, oracle_mod, kat, i, k)
+        for sgn in ((1, -1) if i >= k["mirror_from"] else (1,)):
+            args = (0, sgn * k["q_goal"][i], sgn * k["q_0"][i], sgn * k["v_0"][i], sgn * k["a_0"][i], k["v_max"][i])
+            ok, t, d, m = ltp.optSwitchTimes(*args)
+            assert ok and np.all(np.abs(t[:3] - np.array(k["t"][i][:3])) <= k["eps"])
+            ook, ot, od, om = orc.opt_switch_times(*args)
+            assert ok == ook and d == od and m == om and np.max(np.abs(t - ot)) <= TOL
+
+
+def test_time_scaling_kat(amd, oracle_mod, kat):
+    k = kat["time_scaling"]
+    for i in range(len(k["q_goal"])):
+        ltp, orc = _pair(amd, oracle_mod, kat, i, k)
+        for sgn in ((1, -1) if i >= k["mirror_from"] else (1,)):
+            args = (0, sgn * k["q_goal"][i], sgn * k["q_0"][i], sgn * k["v_0"][i], sgn * k["a_0"][i], sgn * k["dir"][i], k["t_required"][i])
+            ok, t, vd, m, case = ltp.timeScaling(*args)
+            assert ok and np.all(np.abs(t[:3] - np.array(k["t"][i][:3])) <= k["eps"])
+            ook, ot, ovd, om, ocase = orc.time_scaling(*args)
+            assert (ok, m, case) == (ook, om, ocase)
+            # scenario 0 (t_required = 0) is accepted with v_drive = inf in the reference as well
+            assert np.max(np.abs(t - ot)) <= TOL and (vd == ovd or abs(vd - ovd) <= TOL)
+
+
+@pytest.mark.parametrize("name", ["trajectory_v0", "trajectory_v1", "trajectory_v2"])
+def test_plan_trajectory_endpoint_kat(amd, oracle_mod, kat, name):
+    k = kat[name]
+    for i in range(len(k["q_goal"])):
+        ltp, orc = _pair(amd, oracle_mod, kat, i, k)
+        traj = amd.Trajectory()
+        ok = ltp.planTrajectory([k["q_goal"][i]], [k["q_0"][i]], [k["v_0"][i]], [k["a_0"][i]], traj)
+        assert ok and traj.dof == 1
+        assert abs(traj.q[0][traj.length - 1] - k["q_goal"][i]) <= k["tol_q_end"]
+        o = orc.plan_trajectory([k["q_goal"][i]], [k["q_0"][i]], [k["v_0"][i]], [k["a_0"][i]])
+        assert o["status"] == 1 and o["length"] == traj.length
+        for got, ref in ((traj.q, o["q"]), (traj.v, o["v"]), (traj.a, o["a"]), (traj.j, o["j"])):
+            assert np.max(np.abs(np.asarray(got) - ref)) <= TOL
+
+
+def _grid_inputs(kat_grid):
+    """The (q_goal, v_0, a_0) grid of gridTestOneJoint (long_term_planner_tests.cc:279-298)."""
+    g = kat_grid
+    eps, step = g["eps"], g["step"]
+    v_max, a_max, j_max = g["v_max"][0], g["a_max"][0], g["j_max"][0]
+    rows = []
+    for i in range(int(int(g["q_min"][0]) / step), int(int(g["q_max"][0]) / step) + 1):
+        for j in range(int(int(-v_max) / step), int(int(v_max) / step)):
+            v_0 = j * step
+            if v_0 >= 0:
+                a_lb, a_ub = -(a_max - eps), min(a_max - eps, np.sqrt(2 * j_max * (v_max - v_0)))
+            else:
+                a_lb, a_ub = max(-(a_max - eps), -np.sqrt(2 * j_max * (v_max - abs(v_0)))), a_max
+            for kk in range(int(int(a_lb) / step), int(int(a_ub) / step)):
+                rows.append((i * step, v_0, kk * step - eps))
+    return np.array(rows)
+
+
+def test_grid_one_joint_as_a_batch(amd, oracle_mod, kat):
+    # gridTestOneJoint: optSwitchTimes(v_max) + getTrajectory per grid point == a 1-DoF planTrajectory, so the
+    # whole grid runs as ONE batch through the batched ABI. Final position within the reference's 0.02.
+    g = kat["grid_one_joint"]
+    grid = _grid_inputs(g)
+    assert len(grid) > 20000
+    lim = {k: g[k] for k in ("q_min", "q_max", "v_max", "a_max", "j_max")}
+    ltp = amd.LongTermPlanner(1, g["t_sample"], device=0, **lim)
+    orc = oracle_mod.Oracle(1, g["t_sample"], **lim)
+    q0 = np.full(len(grid), g["q_0"])
+    r = ltp.planBatchHost(grid[:, 0], q0, grid[:, 1], grid[:, 2], sample=True)
+    o = orc.plan_batch(grid[:, 0], q0, grid[:, 1], grid[:, 2], sample=False)
+    ran = (r["status"] & 7) == 0
+    assert np.array_equal(ran, o["status"] != 0)
+    assert np.nanmax(np.abs(r["t_opt"][ran] - o["t_opt"][ran])) <= TOL
+    q_end = np.array([amd.unpack_trajectory(r["packed"], int(r["offsets"][p]), 1, int(r["traj_len"][p]))[0][0, -1] for p in np.nonzero(ran)[0]])
+    assert np.max(np.abs(q_end - grid[ran, 0])) <= g["tol"]
+
+
+def test_grid_time_scaling_sample(amd, oracle_mod, kat):
+    # GridTimeScalingTest (:325-407) on a random subsample of its grid: timeScaling vs the oracle, case by case
+    g = kat["grid_time_scaling"]
+    lim = {k: g[k] for k in ("q_min", "q_max", "v_max", "a_max", "j_max")}
+    ltp = amd.LongTermPlanner(1, g["t_sample"], device=0, **lim)
+    orc = oracle_mod.Oracle(1, g["t_sample"], **lim)
+    rng = np.random.default_rng(3)
+    cases = set()
+    for _ in range(1500):
+        q_goal = rng.integers(-60, 71) * 0.1
+        j = rng.integers(-10, 10)
+        v_0 = j * 0.1 + (-1e-6 if j > 0 else 1e-6)
+        if v_0 >= 0:
+            a_lb, a_ub = -(2.0 - 1e-6), min(2.0 - 1e-6, np.sqrt(30 * (1.0 - v_0)))
+        else:
+            a_lb, a_ub = max(-(2.0 - 1e-6), -np.sqrt(30 * (1.0 - abs(v_0)))), 2.0
+        n_steps = int(np.floor((a_ub - a_lb) / 0.1))
+        if n_steps <= 0:
+            continue
+        a_0 = a_lb + rng.integers(0, n_steps) * 0.1
+        ok, t, d, m = orc.opt_switch_times(0, q_goal, g["q_0"], v_0, a_0, 1.0)
+        if not ok or t[6] < g["tol_q"]:
+            continue
+        t_req = t[6] + g["time_increments"][rng.integers(0, 6)]
+        got = ltp.timeScaling(0, q_goal, g["q_0"], v_0, a_0, d, t_req)
+        ref = orc.time_scaling(0, q_goal, g["q_0"], v_0, a_0, d, t_req)
+        assert (got[0], got[3], got[4]) == (ref[0], ref[3], ref[4])
+        assert np.max(np.abs(got[1] - ref[1])) <= TOL and abs(got[2] - ref[2]) <= TOL
+        cases.add(ref[4])
+    assert {1, 2} <= cases
+
+
+def test_cpp_dropin_class_runs_reference_scenarios():
+    exe = os.path.join(ROOT, "tests", "cpp", "dropin_tests")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "cpp"), "-s", "all"])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "0 failures" in r.stdout

@@ -1,0 +1,69 @@
+"""Host-side logic that needs no GPU: synthetic batches, sharding, chunking, packed layout."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_generator_is_counter_based_and_valid(oracle_mod):
+    from longtermplanner_amd import generate_queries, limit_set
+    for name in ("panda", "ref", "ref30"):
+        D, lim = limit_set(name)
+        full = generate_queries(3000, lim, seed=5)
+        # any shard reproduces its slice of the full batch bit for bit
+        part = generate_queries(1000, lim, seed=5, first_query=1500)
+        for f, p in zip(full, part):
+            assert np.array_equal(f[1500:2500], p)
+        other = generate_queries(3000, lim, seed=6)
+        assert not np.array_equal(full[0], other[0])
+        # every query passes the reference's checkInputs (cc:68-77), as tests/randomConfiguration.m intends
+        orc = oracle_mod.Oracle(D, 0.001, **lim)
+        qg, q0, v0, a0 = full
+        assert all(orc.check_inputs(q0[i], v0[i], a0[i]) for i in range(0, 3000, 7))
+        for arr, lo, hi in ((q0, lim["q_min"], lim["q_max"]), (qg, lim["q_min"], lim["q_max"])):
+            assert np.all(arr >= np.array(lo)) and np.all(arr <= np.array(hi))
+
+
+def test_shard_ranges_partition_the_batch():
+    from longtermplanner_amd.parallel import shard_counts, shard_range
+    for n in (0, 1, 7, 1000, 10_000_000):
+        for world in (1, 2, 3, 8):
+            cover = []
+            for r in range(world):
+                first, count = shard_range(n, r, world)
+                cover.append((first, count))
+            assert cover[0][0] == 0 and sum(c for _, c in cover) == n
+            for (f0, c0), (f1, _) in zip(cover, cover[1:]):
+                assert f0 + c0 == f1
+            assert max(shard_counts(n, world)) - min(shard_counts(n, world)) <= 1
+    with pytest.raises(ValueError):
+        shard_range(10, 2, 2)
+
+
+def test_chunk_bounds_cover_every_plan_once():
+    sys.path.insert(0, ROOT)
+    import bench
+    rng = np.random.default_rng(0)
+    sizes = rng.integers(1, 50, size=1000).astype(np.uint64) * 16
+    offsets = np.concatenate([[0], np.cumsum(sizes)]).astype(np.uint64)
+    for cap in (800, 5000, int(offsets[-1])):
+        bounds = bench.chunk_bounds(offsets, cap)
+        assert bounds[0][0] == 0 and bounds[-1][1] == 1000
+        for (f0, e0), (f1, _) in zip(bounds, bounds[1:]):
+            assert e0 == f1
+        assert all(offsets[e] - offsets[f] <= cap for f, e in bounds)
+    with pytest.raises(RuntimeError):
+        bench.chunk_bounds(offsets, 8)
+
+
+def test_unpack_trajectory_layout():
+    from longtermplanner_amd import unpack_trajectory
+    dof, length, stride = 3, 20, 32
+    packed = np.arange(1000, dtype=np.float64)
+    q, v, a, j = unpack_trajectory(packed, 100, dof, length)
+    assert q.shape == (dof, length)
+    assert q[0, 0] == 100 and q[1, 0] == 100 + stride and v[0, 0] == 100 + dof * stride
+    assert j[2, 19] == 100 + (3 * dof + 2) * stride + 19
