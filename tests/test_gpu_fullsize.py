@@ -1,0 +1,122 @@
+"""BASELINE.json's full size (1M x 7-DoF, 1 ms, full sampling) checked through size-independent properties.
+
+The oracle cannot sample 386 GB in test time, so at this size the sampler is checked by what must hold for ANY
+correct output of getTrajectory (cc:706-841): the Euler recurrences between the stored arrays, exact zero end
+velocity/acceleration, goal reached within the reference's own tolerance, a chunking-independent checksum of every
+byte, and record invariants of stages 1-3; a strided subsample is compared with the oracle directly.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+N = 1_000_000
+
+
+def _chunks(off, cap):
+    first, n = 0, off.size - 1
+    while first < n:
+        end = int(np.searchsorted(off, off[first] + np.uint64(cap), side="right")) - 1
+        assert end > first
+        yield first, min(end, n)
+        first = min(end, n)
+
+
+def test_one_million_plans(oracle_mod):
+    import torch
+    import longtermplanner_amd as amd
+    D, lim = amd.limit_set("panda")
+    Ts = 0.001
+    ltp = amd.LongTermPlanner(D, Ts, device=0, **lim)
+    qg, q0, v0, a0 = ltp.generateQueries(N, seed=12345)
+    b = ltp.planSwitchTimesBatch(qg, q0, v0, a0)
+    torch.cuda.synchronize()
+
+    # ---- record invariants (stages 1-3) ----
+    ran = (b.status & 7) == 0
+    assert ran.float().mean().item() > 0.999
+    ts = b.t_scaled[ran]
+    # ordered up to the reference's own slack: optBraking keeps a phase-2 duration in (-t_sample, 0) unclamped (cc:685)
+    assert torch.all(ts >= -Ts) and torch.all(ts[..., 1:] >= ts[..., :-1] - Ts), "switch times must be ordered (up to t_sample)"
+    idx = torch.arange(N, device="cuda")[ran]
+    slow = b.slowest[ran].long()
+    assert torch.equal(b.t_required[ran], b.t_opt[idx, slow, 6]), "t_required is the slowest joint's optimal end time"
+    assert torch.equal(b.t_scaled[idx, slow], b.t_opt[idx, slow]), "the slowest joint keeps its optimal times"
+    assert torch.all(b.t_opt[ran][..., 6] <= b.t_required[ran][:, None]), "no joint is slower than the slowest"
+    lag = b.t_required[ran][:, None] - ts[..., 6]
+    assert torch.all(lag > -0.01 - 1e-12), "timeScaling's window: never more than tol/10 late"
+    assert (lag < 0.1).float().mean().item() > 0.995, "all but the rare fallback joints are synchronised within tol"
+    want_len = torch.ceil(ts[..., 6] / Ts).max(dim=1).values.int() + 1
+    assert torch.equal(b.traj_len[ran], want_len)
+    assert torch.all(b.traj_len[~ran] == 0)
+    stride = (b.traj_len.long() + 15) // 16 * 16
+    off = b.offsets.cpu().numpy().view(np.uint64)
+    assert np.array_equal(np.diff(off.astype(np.int64)), (4 * D * stride).cpu().numpy())
+
+    # ---- a strided subsample against the oracle, bit for bit on the integers, 1e-9 on the times ----
+    sub = np.arange(0, N, 997)
+    host = [x.cpu().numpy()[sub] for x in (qg, q0, v0, a0)]
+    o = oracle_mod.Oracle(D, Ts, **lim).plan_batch(*host, sample=False)
+    assert np.array_equal(b.traj_len.cpu().numpy()[sub], o["traj_len"])
+    assert np.array_equal(b.slowest.cpu().numpy()[sub], o["slowest"])
+    assert np.array_equal(b.mod.cpu().numpy()[sub], o["mod"])
+    assert np.nanmax(np.abs(b.t_scaled.cpu().numpy()[sub] - o["t_scaled"])) <= 1e-9
+
+    # ---- the sampler, twice with different chunking / block order / store flavour ----
+    lens = b.traj_len.long()
+    checks = []
+    for cap_gib, spread, streaming in ((40, 0, True), (24, 1, False)):
+        tile = torch.empty(cap_gib * (1 << 30) // 8, dtype=torch.float64, device="cuda")
+        checksum = torch.zeros((), dtype=torch.int64, device="cuda")
+        goal_err = torch.zeros(N, dtype=torch.float64, device="cuda")      # per plan: max over joints of |q_end - q_goal|
+        q_end = torch.zeros((N, D), dtype=torch.float64, device="cuda")
+        n_plans = 0
+        for first, end in _chunks(off, tile.numel()):
+            used = int(off[end] - off[first])
+            tile[:used].zero_()                      # padding is never written: zero it so the checksum sees only samples
+            ltp.sampleBatch(b, first, end - first, tile, streaming=streaming, spread=spread)
+            checksum += tile[:used].view(torch.int64).sum()    # exact, order-independent (mod 2^64)
+            sel = torch.arange(first, end, device="cuda")[lens[first:end] > 0]
+            base = torch.from_numpy((off[first:end] - off[first]).astype(np.int64)).cuda()[lens[first:end] > 0]
+            L, S = lens[sel], stride[sel]
+            rows = base[:, None] + torch.arange(D, device="cuda")[None, :] * S[:, None]          # q rows
+            last = rows + (L - 1)[:, None]
+            q_last, v_last, a_last = tile[last], tile[last + (D * S)[:, None]], tile[last + (2 * D * S)[:, None]]
+            assert torch.all(v_last == 0.0) and torch.all(a_last == 0.0), "final velocity/acceleration are set to exactly 0"
+            goal_err[sel] = (q_last - qg[sel]).abs().max(dim=1).values
+            q_end[sel] = q_last
+            n_plans += sel.numel()
+            # sample 0 is the state after one Euler step from (q_0, v_0, a_0) (cc:810-812)
+            j_first, a_first = tile[rows + (3 * D * S)[:, None]], tile[rows + (2 * D * S)[:, None]]
+            v_first, q_first = tile[rows + (D * S)[:, None]], tile[rows]
+            assert torch.allclose(a_first, a0[sel] + Ts * j_first, rtol=0, atol=1e-12)
+            assert torch.allclose(v_first, v0[sel] + Ts * a_first, rtol=0, atol=1e-12)
+            assert torch.allclose(q_first, q0[sel] + Ts * v_first, rtol=0, atol=1e-12)
+            # q[i] = q[i-1] + Ts*v[i] holds at EVERY sample (snaps only ever touch v and a), cc:830
+            for p in sel[:: max(1, sel.numel() // 40)].tolist():
+                o0 = int(off[p] - off[first])
+                Lp, Sp = int(lens[p]), int(stride[p])
+                blk = tile[o0:o0 + 4 * D * Sp].view(4, D, Sp)[:, :, :Lp]
+                assert (blk[0, :, 1:] - (blk[0, :, :-1] + Ts * blk[1, :, 1:])).abs().max().item() < 1e-12
+                # a[i] = a[i-1] + Ts*j[i] up to the last switch, then exactly 0 (cc:815-820)
+                da = (blk[2, :, 1:] - (blk[2, :, :-1] + Ts * blk[3, :, 1:])).abs()
+                assert torch.all((da < 1e-11) | (blk[2, :, 1:] == 0.0))
+        checks.append(int(checksum.item()))
+        assert n_plans == int(ran.sum().item())
+        # Goal reached: the reference's integration tests allow 0.02 on its own (soft) limit set; with the stiff panda
+        # limits SURVEY.md App. B measured mean 9.1e-4 / max 4.2e-2 over 2 000 plans of the reference itself. The
+        # bulk must be that good here; the worst plans of the million are the ALGORITHM's outliers, which is shown
+        # by reproducing their end positions with the oracle to 1e-9.
+        ge = goal_err[ran]
+        assert ge.mean().item() < 4e-3 and torch.quantile(ge[:: 16], 0.999).item() < 0.03   # per plan: max over 7 joints
+        worst = torch.topk(goal_err, 8).indices.cpu().numpy()
+        orc = oracle_mod.Oracle(D, Ts, **lim)
+        for p in worst:
+            r = orc.plan_trajectory(*[x[p].cpu().numpy() for x in (qg, q0, v0, a0)])
+            assert r["status"] in (1, 2) and r["length"] == int(lens[p])
+            assert np.max(np.abs(r["q"][:, -1] - q_end[p].cpu().numpy())) <= 1e-9
+        del tile
+        torch.cuda.empty_cache()
+    assert checks[0] == checks[1], "every byte of every trajectory must be independent of chunking, block order and store flavour"
+    end_limit = ((b.status & amd.STATUS_END_LIMIT) != 0).float().mean().item()
+    assert end_limit < 0.01
