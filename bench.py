@@ -80,6 +80,9 @@ def main():
     ap.add_argument("--window-gib", type=float, default=0.0, help="DIAGNOSTIC: chunk capacity; chunks rotate through windows of the tile")
     ap.add_argument("--spread", type=int, default=0, help="sampler block->plan interleave factor (0 = library default 64, 1 = plan order)")
     ap.add_argument("--dry-sampler", action="store_true", help="DIAGNOSTIC ONLY: sampler stores without arithmetic (invalid as a result)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend for the barrier / timing reduction (gloo: rehearsal of N ranks on one GPU)")
+    ap.add_argument("--device", type=int, default=None, help="HIP device ordinal for every rank (default: LOCAL_RANK)")
     ap.add_argument("--gather", action="store_true", help="also all_gather t_required over RCCL each step (optional path)")
     args = ap.parse_args()
 
@@ -90,13 +93,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.device is not None:
+        local_rank = args.device
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        if args.backend == "nccl":      # "nccl" is RCCL on ROCm
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        else:
+            dist.init_process_group("gloo")
     if world != args.gpus and rank == 0:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
     torch.cuda.set_device(local_rank)
     dev = torch.device(f"cuda:{local_rank}")
+    cdev = dev if args.backend == "nccl" else torch.device("cpu")     # where collective tensors live
 
     dof, lim = limit_set(args.limits)
     ltp = LongTermPlanner(dof, args.t_sample, device=local_rank, **lim)
@@ -108,7 +117,7 @@ def main():
         tile = torch.empty(int(args.tile_gib * (1 << 30)) // 8, dtype=torch.float64, device=dev)
     offsets_pinned = torch.empty(n + 1, dtype=torch.int64, pin_memory=True)
     batch = None
-    gather_buf = [torch.empty(n, dtype=torch.float64, device=dev) for _ in range(world)] if (args.gather and world > 1) else None
+    gather_buf = [torch.empty(n, dtype=torch.float64, device=cdev) for _ in range(world)] if (args.gather and world > 1) else None
     ev_pairs = []
     n_chunks = 0
 
@@ -116,7 +125,7 @@ def main():
         nonlocal batch, n_chunks
         batch = ltp.planSwitchTimesBatch(qg, q0, v0, a0, batch=batch)
         if gather_buf is not None:
-            dist.all_gather(gather_buf, batch.t_required)
+            dist.all_gather(gather_buf, batch.t_required.to(cdev))
         if args.switch_only:
             return
         offsets_pinned.copy_(batch.offsets, non_blocking=True)
@@ -150,7 +159,7 @@ def main():
         step(True)
     sync_all()
     elapsed = time.perf_counter() - t0
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
