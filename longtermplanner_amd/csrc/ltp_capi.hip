@@ -17,8 +17,9 @@ struct ltp_planner {
     std::vector<double> h_lim[5];          // q_min, q_max, v_max, a_max, j_max as given (any length)
     double* d_lim = nullptr;               // 5 * lim_cap doubles
     int lim_cap = 0;
-    unsigned long long* d_queue = nullptr; // compaction queue of (query*dof + joint)
-    unsigned long long* d_queue_count = nullptr;
+    unsigned long long* d_queue = nullptr; // two compaction queues of (query*dof + joint), ws_items entries each
+    unsigned long long* d_queue_count = nullptr;   // [2]
+    signed char* d_lane_flags = nullptr;   // per (query, joint) status bits of stage 1
     unsigned long long* d_block_sums = nullptr;
     unsigned long long* d_offsets_scratch = nullptr;
     long long ws_items = 0;                // capacity in (query, joint) items
@@ -95,12 +96,16 @@ int reserve(ltp_planner* p, long long n)
 {
     const long long items = n * (long long)(p->dof > 0 ? p->dof : 1);
     LTP_HIP_TRY(p, hipSetDevice(p->device));
-    if (!p->d_queue_count) LTP_HIP_TRY(p, hipMalloc((void**)&p->d_queue_count, sizeof(unsigned long long)));
+    if (!p->d_queue_count) LTP_HIP_TRY(p, hipMalloc((void**)&p->d_queue_count, 2 * sizeof(unsigned long long)));
     if (!p->d_small) LTP_HIP_TRY(p, hipMalloc((void**)&p->d_small, sizeof(double) * 16));
     if (items > p->ws_items) {
         if (p->d_queue) LTP_HIP_TRY(p, hipFree(p->d_queue));
+        if (p->d_lane_flags) LTP_HIP_TRY(p, hipFree(p->d_lane_flags));
         p->d_queue = nullptr;
-        LTP_HIP_TRY(p, hipMalloc((void**)&p->d_queue, sizeof(unsigned long long) * (size_t)items));
+        p->d_lane_flags = nullptr;
+        p->ws_items = 0;
+        LTP_HIP_TRY(p, hipMalloc((void**)&p->d_queue, sizeof(unsigned long long) * 2 * (size_t)items));
+        LTP_HIP_TRY(p, hipMalloc((void**)&p->d_lane_flags, (size_t)items));
         p->ws_items = items;
     }
     if (n > p->ws_queries) {
@@ -197,6 +202,7 @@ void ltp_destroy(ltp_planner* p)
     (void)hipSetDevice(p->device);
     if (p->d_lim) (void)hipFree(p->d_lim);
     if (p->d_queue) (void)hipFree(p->d_queue);
+    if (p->d_lane_flags) (void)hipFree(p->d_lane_flags);
     if (p->d_queue_count) (void)hipFree(p->d_queue_count);
     if (p->d_block_sums) (void)hipFree(p->d_block_sums);
     if (p->d_offsets_scratch) (void)hipFree(p->d_offsets_scratch);
@@ -269,9 +275,9 @@ int ltp_plan_switch_times_batch(ltp_planner* p, long long n, const ltp_queries* 
     const ltp::Limits L = dev_limits(p);
     const ltp::Queries q = to_dev(in);
     const ltp::Records r = to_dev(out);
-    LTP_HIP_TRY(p, hipMemsetAsync(p->d_queue_count, 0, sizeof(unsigned long long), s));
-    ltp::launch_switch_times(s, n, p->dof, p->t_sample, L, q, r, p->d_queue, p->d_queue_count);
-    ltp::launch_scaling_slow(s, n, p->dof, p->t_sample, L, q, r, p->d_queue, p->d_queue_count);
+    LTP_HIP_TRY(p, hipMemsetAsync(p->d_queue_count, 0, 2 * sizeof(unsigned long long), s));
+    ltp::launch_switch_times(s, n, p->dof, p->t_sample, L, q, r, p->d_lane_flags, p->d_queue, p->d_queue + p->ws_items,
+                             p->d_queue_count);
     ltp::launch_offsets(s, n, p->dof, p->t_sample, r, p->d_block_sums, offsets ? offsets : p->d_offsets_scratch);
     LTP_HIP_TRY(p, hipGetLastError());
     return LTP_OK;

@@ -20,15 +20,102 @@ LTP_DEV JointLimits load_limits(const Limits& lim, int j)
 }
 
 // ---------------------------------------------------------------------------------------
-// Stage 1 + reduction + closed-form scaling.
-// Block = 64 queries x JB joint slots; wave y handles joints y, y+JB, ... of 64 consecutive
-// queries, so joint limits are wave-uniform (SGPRs) and query-major/joint-major inputs are
-// both read with one address stride per lane. The per-query slowest-joint reduction
-// (reference cc:31-39: strict '>', first index wins, NaN never wins, init -1) goes through
-// LDS across the JB waves.
+// Stages 1-3 of planTrajectory (cc:14-55) as four kernels:
+//   k_opt_fast      every (query, joint) lane: checkInputs + optSwitchTimes(v_max) WITHOUT the quartic sites;
+//                   lanes that reach them are compacted into queue A
+//   k_opt_slow      queue A, densely: optSwitchTimes with the root finder
+//   k_reduce_scale  per query: slowest-joint reduction through LDS (cc:31-39), then timeScaling cases c1/c2
+//                   (closed form) per lane; lanes that need c3..c8 or hit a quartic site go to queue B
+//   k_scaling_slow  queue B, densely: all eight cases in order + reset + fallback
+// The two "fast" kernels carry no polynomial solver (fewer registers, small code); the rare, expensive and
+// divergent paths run with full waves instead of dragging 64-lane waves of the main kernels through them.
+//
+// Block = 64 queries x JB joint slots; wave y handles joints y, y+JB, ... of 64 consecutive queries, so the
+// joint limits are wave-uniform (SGPRs) and both input layouts are read with one stride per lane.
 // ---------------------------------------------------------------------------------------
+constexpr int kLaneDeferred = 64;   // lane_flags bit: optSwitchTimes of this lane is still pending in queue A
+
+// wave-level compaction: one atomicAdd per wave, lanes take consecutive slots
+LTP_DEV void wave_push(bool want, unsigned long long item, unsigned long long* __restrict__ queue,
+                       unsigned long long* __restrict__ queue_count)
+{
+    const unsigned long long mask = __ballot(want);
+    if (mask == 0ull) return;
+    const int lane = threadIdx.x & 63;
+    const int leader = __ffsll((long long)mask) - 1;
+    unsigned long long base = 0ull;
+    if (lane == leader) base = atomicAdd(queue_count, (unsigned long long)__popcll(mask));
+    base = __shfl(base, leader);
+    if (want) queue[base + __popcll(mask & ((1ull << lane) - 1ull))] = item;
+}
+
+LTP_DEV void store_opt_record(const Records& out, long long rj, const double (&t)[7], double dir, int mod)
+{
+#pragma unroll
+    for (int k = 0; k < 7; ++k) out.t_opt[rj * 7 + k] = t[k];
+    out.dir[rj] = dir;
+    out.mod[rj] = (signed char)mod;
+}
+
 __global__ void __launch_bounds__(kQueriesPerBlock* kMaxJointSlots)
-k_switch_times(long long n, int dof, double t_sample, Limits lim, Queries in, Records out,
+k_opt_fast(long long n, int dof, double t_sample, Limits lim, Queries in, Records out, signed char* __restrict__ lane_flags,
+           unsigned long long* __restrict__ queue, unsigned long long* __restrict__ queue_count)
+{
+    const int x = threadIdx.x, y = threadIdx.y, JB = blockDim.y;
+    const long long q = (long long)blockIdx.x * kQueriesPerBlock + x;
+    const bool live = q < n;
+    for (int j = y; j < dof; j += JB) {
+        const JointLimits L = load_limits(lim, j);
+        const long long rj = q * dof + j;
+        bool defer = false;
+        if (live) {
+            const long long ix = q * in.sq + (long long)j * in.sj;
+            const double qg = in.q_goal[ix], q0 = in.q_0[ix], v0 = in.v_0[ix], a0 = in.a_0[ix];
+            int flags = check_inputs_joint(L, q0, v0, a0) ? 0 : kStatusInvalidInput;
+            double t[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+            double dir = 0.0;
+            int mod = 0;
+            const int rc = opt_switch_times<false>(L.a_max, L.j_max, t_sample, qg, q0, v0, a0, L.v_max, t, dir, mod);
+            if (rc == kOptDefer) {
+                defer = true;
+                flags |= kLaneDeferred;
+            } else {
+                if (rc == kOptFalse) flags |= kStatusOptFailed;
+                store_opt_record(out, rj, t, dir, mod);
+            }
+            lane_flags[rj] = (signed char)flags;
+        }
+        wave_push(defer, (unsigned long long)rj, queue, queue_count);
+    }
+}
+
+__global__ void __launch_bounds__(64)
+k_opt_slow(int dof, double t_sample, Limits lim, Queries in, Records out, signed char* __restrict__ lane_flags,
+           const unsigned long long* __restrict__ queue, const unsigned long long* __restrict__ queue_count)
+{
+    const unsigned long long count = *queue_count;
+    for (unsigned long long it = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; it < count;
+         it += (unsigned long long)gridDim.x * blockDim.x) {
+        const long long rj = (long long)queue[it];
+        const long long q = rj / dof;
+        const int j = (int)(rj - q * dof);
+        const JointLimits L = load_limits(lim, j);
+        const long long ix = q * in.sq + (long long)j * in.sj;
+        double t[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        double dir = 0.0;
+        int mod = 0;
+        const int rc = opt_switch_times<true>(L.a_max, L.j_max, t_sample, in.q_goal[ix], in.q_0[ix], in.v_0[ix], in.a_0[ix],
+                                              L.v_max, t, dir, mod);
+        store_opt_record(out, rj, t, dir, mod);
+        int flags = lane_flags[rj] & ~kLaneDeferred;
+        if (rc == kOptFalse) flags |= kStatusOptFailed;
+        lane_flags[rj] = (signed char)flags;
+    }
+}
+
+__global__ void __launch_bounds__(kQueriesPerBlock* kMaxJointSlots)
+k_reduce_scale(long long n, int dof, double t_sample, Limits lim, Queries in, Records out,
+               const signed char* __restrict__ lane_flags,
                unsigned long long* __restrict__ queue, unsigned long long* __restrict__ queue_count)
 {
     __shared__ double s_t[kMaxJointSlots][kQueriesPerBlock];
@@ -39,25 +126,15 @@ k_switch_times(long long n, int dof, double t_sample, Limits lim, Queries in, Re
     const long long q = (long long)blockIdx.x * kQueriesPerBlock + x;
     const bool live = q < n;
 
+    // cc:31-39: strict '>', first index wins, NaN never wins, init -1
     double best_t = -1.0;
     int best_j = -1, flags = 0;
-    for (int j = y; j < dof; j += JB) {
-        const JointLimits L = load_limits(lim, j);
-        if (live) {
-            const long long ix = q * in.sq + (long long)j * in.sj;
-            const double qg = in.q_goal[ix], q0 = in.q_0[ix], v0 = in.v_0[ix], a0 = in.a_0[ix];
-            if (!check_inputs_joint(L, q0, v0, a0)) flags |= kStatusInvalidInput;
-            double t[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-            double dir = 0.0;
-            int mod = 0;
-            const bool ok = opt_switch_times(L.a_max, L.j_max, t_sample, qg, q0, v0, a0, L.v_max, t, dir, mod);
-            if (!ok) flags |= kStatusOptFailed;
+    if (live) {
+        for (int j = y; j < dof; j += JB) {
             const long long rj = q * dof + j;
-#pragma unroll
-            for (int k = 0; k < 7; ++k) out.t_opt[rj * 7 + k] = t[k];
-            out.dir[rj] = dir;
-            out.mod[rj] = (signed char)mod;
-            if (t[6] > best_t) { best_t = t[6]; best_j = j; }
+            const double t6 = out.t_opt[rj * 7 + 6];
+            flags |= lane_flags[rj];
+            if (t6 > best_t) { best_t = t6; best_j = j; }
         }
     }
     s_t[y][x] = best_t;
@@ -80,7 +157,7 @@ k_switch_times(long long n, int dof, double t_sample, Limits lim, Queries in, Re
         out.status[q] = flags;
     }
 
-    // Stage 3, closed-form cases c1, c2 (reference cc:378-446); others go to the queue.
+    // cc:43-55 with the closed-form candidates c1, c2 (cc:378-446)
     for (int j = y; j < dof; j += JB) {
         const JointLimits L = load_limits(lim, j);
         bool need_slow = false;
@@ -88,14 +165,8 @@ k_switch_times(long long n, int dof, double t_sample, Limits lim, Queries in, Re
         if (live) {
             double ts[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
             double vd = L.v_max;
-            int mod;
-            bool write = true;
-            if (flags != 0) {
-                mod = 0;   // failed query: zero record, never sampled
-            } else {
-                double topt[7];
-#pragma unroll
-                for (int k = 0; k < 7; ++k) topt[k] = out.t_opt[rj * 7 + k];
+            int mod = 0;   // failed query: zero record, never sampled
+            if (flags == 0) {
                 mod = out.mod[rj];
                 if (j != slowest) {
                     const long long ix = q * in.sq + (long long)j * in.sj;
@@ -104,57 +175,69 @@ k_switch_times(long long n, int dof, double t_sample, Limits lim, Queries in, Re
                     const double dir = out.dir[rj];
                     if (dir < 0.0) { v0 = -v0; a0 = -a0; }
                     vd = v_drive_candidate<1>(L.a_max, L.j_max, qg, q0, v0, a0, dir, t_required);
-                    bool acc = try_v_drive(L.a_max, L.j_max, t_sample, qg, q0, v0, a0, dir, t_required, vd, ts, mod);
-                    if (!acc) {
+                    int acc = try_v_drive<false>(L.a_max, L.j_max, t_sample, qg, q0, v0, a0, dir, t_required, vd, ts, mod);
+                    if (acc == kOptFalse) {
                         vd = v_drive_candidate<2>(L.a_max, L.j_max, qg, q0, v0, a0, dir, t_required);
-                        acc = try_v_drive(L.a_max, L.j_max, t_sample, qg, q0, v0, a0, dir, t_required, vd, ts, mod);
+                        acc = try_v_drive<false>(L.a_max, L.j_max, t_sample, qg, q0, v0, a0, dir, t_required, vd, ts, mod);
                     }
-                    if (!acc) { need_slow = true; write = false; }
+                    need_slow = (acc != kOptTrue);
                 }
-                if (write) {
+                if (!need_slow) {
                     // cc:50-55: no scaled solution (or the slowest joint) -> optimal times
                     double mx = ts[0];
 #pragma unroll
                     for (int k = 1; k < 7; ++k) if (mx < ts[k]) mx = ts[k];
                     if (mx <= 0.0) {
 #pragma unroll
-                        for (int k = 0; k < 7; ++k) ts[k] = topt[k];
+                        for (int k = 0; k < 7; ++k) ts[k] = out.t_opt[rj * 7 + k];
                     }
                 }
             }
-            if (write) {
+            if (!need_slow) {
 #pragma unroll
                 for (int k = 0; k < 7; ++k) out.t_scaled[rj * 7 + k] = ts[k];
                 out.v_drive[rj] = vd;
                 out.mod[rj] = (signed char)mod;
             }
         }
-        // wave-level compaction of the rare polynomial cases: one atomic per wave
-        const unsigned long long mask = __ballot(need_slow);
-        if (mask != 0ull) {
-            const int leader = __ffsll((long long)mask) - 1;
-            unsigned long long base = 0ull;
-            if (x == leader) base = atomicAdd(queue_count, (unsigned long long)__popcll(mask));
-            base = __shfl(base, leader);
-            if (need_slow) {
-                const int rank = __popcll(mask & ((1ull << x) - 1ull));
-                queue[base + rank] = (unsigned long long)rj;
-            }
-        }
+        wave_push(need_slow, (unsigned long long)rj, queue, queue_count);
     }
 }
 
-// ---------------------------------------------------------------------------------------
-// Stage 3, polynomial cases c3..c8 (reference cc:449-638) and the reset (cc:640-644) +
-// fallback (cc:50-55), one lane per queued (query, joint): the divergent rare path runs
-// with full waves instead of dragging 64-lane waves of the main kernel through it.
-// ---------------------------------------------------------------------------------------
 template <int C>
 LTP_DEV bool scaling_case(const JointLimits& L, double t_sample, double qg, double q0, double v0, double a0, double dir,
                           double tr, double& vd, double (&ts)[7], int& mod)
 {
     vd = v_drive_candidate<C>(L.a_max, L.j_max, qg, q0, v0, a0, dir, tr);
-    return try_v_drive(L.a_max, L.j_max, t_sample, qg, q0, v0, a0, dir, tr, vd, ts, mod);
+    return try_v_drive<true>(L.a_max, L.j_max, t_sample, qg, q0, v0, a0, dir, tr, vd, ts, mod) == kOptTrue;
+}
+
+// cc:358-645 for one (query, joint): the eight candidates in the reference's order, then the reset
+LTP_DEV bool time_scaling_full(const JointLimits& L, double t_sample, double qg, double q0, double v0, double a0, double dir,
+                               double tr, double& vd, double (&ts)[7], int& mod, int& which)
+{
+    if (dir < 0.0) { v0 = -v0; a0 = -a0; }   // cc:372-375
+    which = 1;
+    if (scaling_case<1>(L, t_sample, qg, q0, v0, a0, dir, tr, vd, ts, mod)) return true;
+    which = 2;
+    if (scaling_case<2>(L, t_sample, qg, q0, v0, a0, dir, tr, vd, ts, mod)) return true;
+    which = 3;
+    if (scaling_case<3>(L, t_sample, qg, q0, v0, a0, dir, tr, vd, ts, mod)) return true;
+    which = 4;
+    if (scaling_case<4>(L, t_sample, qg, q0, v0, a0, dir, tr, vd, ts, mod)) return true;
+    which = 5;
+    if (scaling_case<5>(L, t_sample, qg, q0, v0, a0, dir, tr, vd, ts, mod)) return true;
+    which = 6;
+    if (scaling_case<6>(L, t_sample, qg, q0, v0, a0, dir, tr, vd, ts, mod)) return true;
+    which = 7;
+    if (scaling_case<7>(L, t_sample, qg, q0, v0, a0, dir, tr, vd, ts, mod)) return true;
+    which = 8;
+    if (scaling_case<8>(L, t_sample, qg, q0, v0, a0, dir, tr, vd, ts, mod)) return true;
+    which = 0;   // cc:640-644
+    mod = 0;
+    zero7(ts);
+    vd = L.v_max;
+    return false;
 }
 
 __global__ void __launch_bounds__(64)
@@ -169,25 +252,11 @@ k_scaling_slow(int dof, double t_sample, Limits lim, Queries in, Records out,
         const int j = (int)(rj - q * dof);
         const JointLimits L = load_limits(lim, j);
         const long long ix = q * in.sq + (long long)j * in.sj;
-        const double qg = in.q_goal[ix], q0 = in.q_0[ix];
-        double v0 = in.v_0[ix], a0 = in.a_0[ix];
-        const double dir = out.dir[rj];
-        const double tr = out.t_required[q];
-        if (dir < 0.0) { v0 = -v0; a0 = -a0; }
         double ts[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
         double vd;
-        int mod = 0;
-        bool acc = scaling_case<3>(L, t_sample, qg, q0, v0, a0, dir, tr, vd, ts, mod);
-        if (!acc) acc = scaling_case<4>(L, t_sample, qg, q0, v0, a0, dir, tr, vd, ts, mod);
-        if (!acc) acc = scaling_case<5>(L, t_sample, qg, q0, v0, a0, dir, tr, vd, ts, mod);
-        if (!acc) acc = scaling_case<6>(L, t_sample, qg, q0, v0, a0, dir, tr, vd, ts, mod);
-        if (!acc) acc = scaling_case<7>(L, t_sample, qg, q0, v0, a0, dir, tr, vd, ts, mod);
-        if (!acc) acc = scaling_case<8>(L, t_sample, qg, q0, v0, a0, dir, tr, vd, ts, mod);
-        if (!acc) {
-            mod = 0;
-            zero7(ts);
-            vd = L.v_max;
-        }
+        int mod = 0, which;
+        time_scaling_full(L, t_sample, in.q_goal[ix], in.q_0[ix], in.v_0[ix], in.a_0[ix], out.dir[rj], out.t_required[q], vd, ts,
+                          mod, which);
         double mx = ts[0];
 #pragma unroll
         for (int k = 1; k < 7; ++k) if (mx < ts[k]) mx = ts[k];
@@ -639,7 +708,7 @@ __global__ void k_single_opt_switch(int joint, double t_sample, Limits lim, doub
     double t[7] = {io[0], io[1], io[2], io[3], io[4], io[5], io[6]};
     double dir = 0.0;
     int mod = 0;
-    const bool ok = opt_switch_times(L.a_max, L.j_max, t_sample, q_goal, q_0, v_0, a_0, v_drive, t, dir, mod);
+    const bool ok = opt_switch_times<true>(L.a_max, L.j_max, t_sample, q_goal, q_0, v_0, a_0, v_drive, t, dir, mod) == kOptTrue;
 #pragma unroll
     for (int k = 0; k < 7; ++k) io[k] = t[k];
     io[7] = dir;
@@ -651,20 +720,10 @@ __global__ void k_single_time_scaling(int joint, double t_sample, Limits lim, do
                                       double dir, double tr, double* io)
 {
     const JointLimits L = load_limits(lim, joint);
-    if (dir < 0.0) { v_0 = -v_0; a_0 = -a_0; }
     double ts[7] = {io[0], io[1], io[2], io[3], io[4], io[5], io[6]};
     double vd;
     int mod = 0, which = 0;
-    bool acc = scaling_case<1>(L, t_sample, q_goal, q_0, v_0, a_0, dir, tr, vd, ts, mod);
-    if (acc) which = 1;
-    if (!acc) { acc = scaling_case<2>(L, t_sample, q_goal, q_0, v_0, a_0, dir, tr, vd, ts, mod); if (acc) which = 2; }
-    if (!acc) { acc = scaling_case<3>(L, t_sample, q_goal, q_0, v_0, a_0, dir, tr, vd, ts, mod); if (acc) which = 3; }
-    if (!acc) { acc = scaling_case<4>(L, t_sample, q_goal, q_0, v_0, a_0, dir, tr, vd, ts, mod); if (acc) which = 4; }
-    if (!acc) { acc = scaling_case<5>(L, t_sample, q_goal, q_0, v_0, a_0, dir, tr, vd, ts, mod); if (acc) which = 5; }
-    if (!acc) { acc = scaling_case<6>(L, t_sample, q_goal, q_0, v_0, a_0, dir, tr, vd, ts, mod); if (acc) which = 6; }
-    if (!acc) { acc = scaling_case<7>(L, t_sample, q_goal, q_0, v_0, a_0, dir, tr, vd, ts, mod); if (acc) which = 7; }
-    if (!acc) { acc = scaling_case<8>(L, t_sample, q_goal, q_0, v_0, a_0, dir, tr, vd, ts, mod); if (acc) which = 8; }
-    if (!acc) { mod = 0; zero7(ts); vd = L.v_max; }
+    const bool acc = time_scaling_full(L, t_sample, q_goal, q_0, v_0, a_0, dir, tr, vd, ts, mod, which);
 #pragma unroll
     for (int k = 0; k < 7; ++k) io[k] = ts[k];
     io[7] = vd;
@@ -715,23 +774,20 @@ __global__ void k_roots_probe(long long n, int degree, const double* coef, doubl
 // launchers
 // ---------------------------------------------------------------------------------------
 void launch_switch_times(hipStream_t s, long long n, int dof, double t_sample, Limits lim, Queries in, Records out,
-                         unsigned long long* queue, unsigned long long* queue_count)
+                         signed char* lane_flags, unsigned long long* queue_a, unsigned long long* queue_b,
+                         unsigned long long* counts /* [2], zeroed by the caller on the same stream */)
 {
     if (n <= 0) return;
     const int jb = dof < kMaxJointSlots ? dof : kMaxJointSlots;
     const dim3 block(kQueriesPerBlock, jb);
     const dim3 grid((unsigned)((n + kQueriesPerBlock - 1) / kQueriesPerBlock));
-    hipLaunchKernelGGL(k_switch_times, grid, block, 0, s, n, dof, t_sample, lim, in, out, queue, queue_count);
-}
-
-void launch_scaling_slow(hipStream_t s, long long n, int dof, double t_sample, Limits lim, Queries in, Records out,
-                         const unsigned long long* queue, const unsigned long long* queue_count)
-{
-    if (n <= 0) return;
-    // the queue length is only known on the device: fixed grid, grid-stride over the queue
-    long long blocks = (n * dof + 63) / 64;
-    if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(k_scaling_slow, dim3((unsigned)blocks), dim3(64), 0, s, dof, t_sample, lim, in, out, queue, queue_count);
+    // queue lengths are only known on the device: fixed grids, grid-stride over the queues
+    long long slow_blocks = (n * dof + 63) / 64;
+    if (slow_blocks > 4096) slow_blocks = 4096;
+    hipLaunchKernelGGL(k_opt_fast, grid, block, 0, s, n, dof, t_sample, lim, in, out, lane_flags, queue_a, counts);
+    hipLaunchKernelGGL(k_opt_slow, dim3((unsigned)slow_blocks), dim3(64), 0, s, dof, t_sample, lim, in, out, lane_flags, queue_a, counts);
+    hipLaunchKernelGGL(k_reduce_scale, grid, block, 0, s, n, dof, t_sample, lim, in, out, lane_flags, queue_b, counts + 1);
+    hipLaunchKernelGGL(k_scaling_slow, dim3((unsigned)slow_blocks), dim3(64), 0, s, dof, t_sample, lim, in, out, queue_b, counts + 1);
 }
 
 void launch_offsets(hipStream_t s, long long n, int dof, double t_sample, Records rec,

@@ -1,10 +1,12 @@
 // ltp_kernels.hpp — gfx950 kernels of the batched planner (declarations + shared structs).
 //
 // Pipeline for one batch (reference src/long_term_planner.cc:7-63, one query = one call):
-//   k_switch_times   stage 1 (checkInputs + optSwitchTimes per (query, joint)), the
-//                    slowest-joint reduction in LDS, and the two closed-form timeScaling
-//                    cases; lanes that need the polynomial cases are compacted into a queue
-//   k_scaling_slow   timeScaling cases 3..8 + reset, run densely over the queue
+//   k_opt_fast       stage 1 (checkInputs + optSwitchTimes per (query, joint)) without the quartic
+//                    sites; lanes that reach them are compacted into queue A
+//   k_opt_slow       queue A, densely, with the root finder
+//   k_reduce_scale   slowest-joint reduction in LDS + the two closed-form timeScaling cases;
+//                    lanes that need the polynomial cases are compacted into queue B
+//   k_scaling_slow   queue B, densely: all eight timeScaling cases + reset
 //   k_finalize       traj_len (cc:716-719), padded row stride, per-plan output size,
 //                    block sums for the offsets scan
 //   k_scan_top / k_scan_apply   exclusive scan -> packed trajectory offsets
@@ -63,9 +65,8 @@ struct Records {           // query-major outputs of stages 1-3
 };
 
 void launch_switch_times(hipStream_t s, long long n, int dof, double t_sample, Limits lim, Queries in, Records out,
-                         unsigned long long* queue, unsigned long long* queue_count);
-void launch_scaling_slow(hipStream_t s, long long n, int dof, double t_sample, Limits lim, Queries in, Records out,
-                         const unsigned long long* queue, const unsigned long long* queue_count);
+                         signed char* lane_flags, unsigned long long* queue_a, unsigned long long* queue_b,
+                         unsigned long long* counts);
 void launch_offsets(hipStream_t s, long long n, int dof, double t_sample, Records rec,
                     unsigned long long* block_sums, unsigned long long* offsets);
 void launch_sample(hipStream_t s, long long first, long long count, int dof, double t_sample, Limits lim, Queries in,

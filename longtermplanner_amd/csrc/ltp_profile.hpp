@@ -76,10 +76,17 @@ LTP_DEV void zero7(double (&t)[7])
     for (int i = 0; i < 7; ++i) t[i] = 0.0;
 }
 
-// cc:82-353. Returns the reference's bool; t is written exactly where the reference writes it.
-__device__ inline bool opt_switch_times(double am, double jm, double t_sample,
-                                        double q_goal, double q_0, double v_0, double a_0, double v_drive,
-                                        double (&t)[7], double& dir, int& mod)
+// cc:82-353. Returns the reference's bool (kOptFalse / kOptTrue); t is written exactly where the reference
+// writes it. With FULL == false the function contains no polynomial solver: a lane that reaches the quartic
+// sites (cc:245-337, a few percent of lanes at most) returns kOptDefer having written nothing, and the caller
+// re-runs it in a kernel built with FULL == true. That keeps the root finder's registers and code out of the
+// kernels every lane runs.
+constexpr int kOptFalse = 0, kOptTrue = 1, kOptDefer = 2;
+
+template <bool FULL>
+__device__ inline int opt_switch_times(double am, double jm, double t_sample,
+                                       double q_goal, double q_0, double v_0, double a_0, double v_drive,
+                                       double (&t)[7], double& dir, int& mod)
 {
     double r[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
     mod = 0;
@@ -88,7 +95,7 @@ __device__ inline bool opt_switch_times(double am, double jm, double t_sample,
     const double q_diff = q_goal - (q_0 + q_stop);
     if (dabs(q_diff) < kEps) {
         cumsum7(r, t);
-        return true;
+        return kOptTrue;
     }
     dir = sgn(q_diff);
     if (dir < 0.0) {
@@ -113,7 +120,7 @@ __device__ inline bool opt_switch_times(double am, double jm, double t_sample,
                 r[1] = 0.0;
             } else {
                 zero7(t);
-                return true;
+                return kOptTrue;
             }
         }
     }
@@ -128,7 +135,7 @@ __device__ inline bool opt_switch_times(double am, double jm, double t_sample,
             r[5] = 0.0;
         } else {
             zero7(t);
-            return true;
+            return kOptTrue;
         }
     }
     double q_part1;
@@ -156,7 +163,7 @@ __device__ inline bool opt_switch_times(double am, double jm, double t_sample,
     if (r[3] < -kEps) {
         if (mod == 1) {
             zero7(t);
-            return false;
+            return kOptFalse;
         }
         const double a2 = pw2(a_0), am2 = pw2(am);
         const double r0_2 = pw2(r[0]), r0_3 = pw3(r[0]), r2_2 = pw2(r[2]), r2_3 = pw3(r[2]);
@@ -198,10 +205,11 @@ __device__ inline bool opt_switch_times(double am, double jm, double t_sample,
             r[3] = 0.0;
         } else {
             zero7(t);
-            return true;
+            return kOptTrue;
         }
 
         if (r[5] < -kEps || r[1] < -kEps) {
+            if constexpr (!FULL) return kOptDefer;
             // quartic site A (cc:246-261)
             {
                 const double c[5] = {
@@ -290,9 +298,9 @@ __device__ inline bool opt_switch_times(double am, double jm, double t_sample,
         if (r[i] < -kEps) bad = true;
         else if (r[i] < 0.0 && r[i] >= -kEps) r[i] = 0.0;
     }
-    if (bad) return false;
+    if (bad) return kOptFalse;
     cumsum7(r, t);
-    return true;
+    return kOptTrue;
 }
 
 // The eight v_drive candidates of timeScaling, cc:378-396 (c=1), 408-436 (2), 449-473 (3),
@@ -455,15 +463,18 @@ __device__ inline double v_drive_candidate(double am, double jm, double q_goal, 
 
 // "if (!isnan(v_drive) && v_drive > 0) { optSwitchTimes(...); window test }" — e.g. cc:398-405.
 // v_0/a_0 are the direction-mapped values; the reference passes dir*v_0, dir*a_0 on.
-__device__ inline bool try_v_drive(double am, double jm, double t_sample, double q_goal, double q_0, double v_0, double a_0,
-                                   double dir, double tr, double v_drive, double (&scaled_t)[7], int& mod)
+// Returns kOptTrue (accepted), kOptFalse (rejected) or, only with FULL == false, kOptDefer.
+template <bool FULL>
+__device__ inline int try_v_drive(double am, double jm, double t_sample, double q_goal, double q_0, double v_0, double a_0,
+                                  double dir, double tr, double v_drive, double (&scaled_t)[7], int& mod)
 {
     if (!disnan(v_drive) && v_drive > 0.0) {
         double trash;
-        const bool ok = opt_switch_times(am, jm, t_sample, q_goal, q_0, dir * v_0, dir * a_0, v_drive, scaled_t, trash, mod);
-        if (ok && tr - scaled_t[6] < kTol && tr - scaled_t[6] > -kTol / 10) return true;
+        const int ok = opt_switch_times<FULL>(am, jm, t_sample, q_goal, q_0, dir * v_0, dir * a_0, v_drive, scaled_t, trash, mod);
+        if (ok == kOptDefer) return kOptDefer;
+        if (ok == kOptTrue && tr - scaled_t[6] < kTol && tr - scaled_t[6] > -kTol / 10) return kOptTrue;
     }
-    return false;
+    return kOptFalse;
 }
 
 }  // namespace ltp
