@@ -278,7 +278,7 @@ int ltp_plan_switch_times_batch(ltp_planner* p, long long n, const ltp_queries* 
     LTP_HIP_TRY(p, hipMemsetAsync(p->d_queue_count, 0, 2 * sizeof(unsigned long long), s));
     ltp::launch_switch_times(s, n, p->dof, p->t_sample, L, q, r, p->d_lane_flags, p->d_queue, p->d_queue + p->ws_items,
                              p->d_queue_count);
-    ltp::launch_offsets(s, n, p->dof, p->t_sample, r, p->d_block_sums, offsets ? offsets : p->d_offsets_scratch);
+    ltp::launch_offsets(s, n, p->dof, p->t_sample, r, p->d_block_sums, offsets ? offsets : p->d_offsets_scratch, true);
     LTP_HIP_TRY(p, hipGetLastError());
     return LTP_OK;
 }
@@ -432,7 +432,7 @@ int ltp_get_trajectory_host(ltp_planner* p, long long n, const double* t, const 
     ltp_queries dq{d_in[0], d_in[0], d_in[1], d_in[2], dof, 1};   // q_goal is not used by the sampler
     if (n > 0 && dof > 0) {
         std::lock_guard<std::mutex> g(p->mu);
-        ltp::launch_offsets(nullptr, n, dof, p->t_sample, to_dev(&dr.r), p->d_block_sums, d_off);
+        ltp::launch_offsets(nullptr, n, dof, p->t_sample, to_dev(&dr.r), p->d_block_sums, d_off, false);
         LTP_HIP_TRY(p, hipGetLastError());
     }
     LTP_HIP_TRY(p, hipDeviceSynchronize());

@@ -33,6 +33,15 @@ LTP_DEV JointLimits load_limits(const Limits& lim, int j)
 // Block = 64 queries x JB joint slots; wave y handles joints y, y+JB, ... of 64 consecutive queries, so the
 // joint limits are wave-uniform (SGPRs) and both input layouts are read with one stride per lane.
 // ---------------------------------------------------------------------------------------
+// (int)ceil(t[6]/Ts) + 1 of one joint (cc:718), or -1 if any of its switching times is not finite (DEFINED case)
+LTP_DEV int joint_len(const double (&t)[7], double t_sample)
+{
+    bool finite = true;
+#pragma unroll
+    for (int k = 0; k < 7; ++k) finite = finite && dfinite(t[k]);
+    return finite ? (int)dceil(t[6] / t_sample) + 1 : -1;
+}
+
 constexpr int kLaneDeferred = 64;   // lane_flags bit: optSwitchTimes of this lane is still pending in queue A
 
 // wave-level compaction: one atomicAdd per wave, lanes take consecutive slots
@@ -158,9 +167,11 @@ k_reduce_scale(long long n, int dof, double t_sample, Limits lim, Queries in, Re
     }
 
     // cc:43-55 with the closed-form candidates c1, c2 (cc:378-446)
+    int my_len = 0, nonfinite = 0;
     for (int j = y; j < dof; j += JB) {
         const JointLimits L = load_limits(lim, j);
         bool need_slow = false;
+        int lane_len = 0;
         const long long rj = q * dof + j;
         if (live) {
             double ts[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
@@ -198,9 +209,26 @@ k_reduce_scale(long long n, int dof, double t_sample, Limits lim, Queries in, Re
                 for (int k = 0; k < 7; ++k) out.t_scaled[rj * 7 + k] = ts[k];
                 out.v_drive[rj] = vd;
                 out.mod[rj] = (signed char)mod;
+                if (flags == 0) lane_len = joint_len(ts, t_sample);
             }
         }
         wave_push(need_slow, (unsigned long long)rj, queue, queue_count);
+        if (lane_len < 0) nonfinite = 1;
+        else my_len = lane_len > my_len ? lane_len : my_len;
+    }
+    // traj_len (cc:716-719) over the joints finished here; queue-B lanes add theirs with atomicMax later
+    __syncthreads();
+    s_j[y][x] = my_len;
+    s_f[y][x] = nonfinite;
+    __syncthreads();
+    if (live && y == 0) {
+        int len = 0, bad = 0;
+        for (int yy = 0; yy < JB; ++yy) {
+            len = s_j[yy][x] > len ? s_j[yy][x] : len;
+            bad |= s_f[yy][x];
+        }
+        out.traj_len[q] = flags == 0 ? len : 0;
+        if (bad) out.status[q] = flags | kStatusNonFinite;
     }
 }
 
@@ -240,34 +268,80 @@ LTP_DEV bool time_scaling_full(const JointLimits& L, double t_sample, double qg,
     return false;
 }
 
-__global__ void __launch_bounds__(64)
+// Queue B. Block = 64 queued (query, joint) items x 8 waves; wave c evaluates candidate c+1 for all 64 items, so
+// the eight candidates of cc:378-638 (independent computations) run side by side and the kernel's latency is the
+// slowest candidate (the degree-6 solve) instead of their sum. The reference's "first accepted in order" is then a
+// lookup over eight flags in LDS.
+__global__ void __launch_bounds__(kQueriesPerBlock * 8)
 k_scaling_slow(int dof, double t_sample, Limits lim, Queries in, Records out,
                const unsigned long long* __restrict__ queue, const unsigned long long* __restrict__ queue_count)
 {
+    __shared__ int s_acc[8][kQueriesPerBlock];
+    const int x = threadIdx.x;
+    const int c = __builtin_amdgcn_readfirstlane(threadIdx.y);
     const unsigned long long count = *queue_count;
-    for (unsigned long long it = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; it < count;
-         it += (unsigned long long)gridDim.x * blockDim.x) {
-        const long long rj = (long long)queue[it];
-        const long long q = rj / dof;
-        const int j = (int)(rj - q * dof);
-        const JointLimits L = load_limits(lim, j);
-        const long long ix = q * in.sq + (long long)j * in.sj;
+    for (unsigned long long base = (unsigned long long)blockIdx.x * kQueriesPerBlock; base < count;
+         base += (unsigned long long)gridDim.x * kQueriesPerBlock) {
+        const unsigned long long it = base + x;
+        const bool live = it < count;
+        bool acc = false;
         double ts[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-        double vd;
-        int mod = 0, which;
-        time_scaling_full(L, t_sample, in.q_goal[ix], in.q_0[ix], in.v_0[ix], in.a_0[ix], out.dir[rj], out.t_required[q], vd, ts,
-                          mod, which);
-        double mx = ts[0];
-#pragma unroll
-        for (int k = 1; k < 7; ++k) if (mx < ts[k]) mx = ts[k];
-        if (mx <= 0.0) {
-#pragma unroll
-            for (int k = 0; k < 7; ++k) ts[k] = out.t_opt[rj * 7 + k];
+        double vd = 0.0;
+        int mod = 0, j = 0;
+        long long rj = 0, q = 0;
+        JointLimits L = {0.0, 0.0, 0.0, 0.0, 0.0};
+        if (live) {
+            rj = (long long)queue[it];
+            q = rj / dof;
+            j = (int)(rj - q * dof);
+            L = load_limits(lim, j);
+            const long long ix = q * in.sq + (long long)j * in.sj;
+            const double qg = in.q_goal[ix], q0 = in.q_0[ix];
+            double v0 = in.v_0[ix], a0 = in.a_0[ix];
+            const double dir = out.dir[rj], tr = out.t_required[q];
+            if (dir < 0.0) { v0 = -v0; a0 = -a0; }   // cc:372-375
+            switch (c) {
+            case 0: acc = scaling_case<1>(L, t_sample, qg, q0, v0, a0, dir, tr, vd, ts, mod); break;
+            case 1: acc = scaling_case<2>(L, t_sample, qg, q0, v0, a0, dir, tr, vd, ts, mod); break;
+            case 2: acc = scaling_case<3>(L, t_sample, qg, q0, v0, a0, dir, tr, vd, ts, mod); break;
+            case 3: acc = scaling_case<4>(L, t_sample, qg, q0, v0, a0, dir, tr, vd, ts, mod); break;
+            case 4: acc = scaling_case<5>(L, t_sample, qg, q0, v0, a0, dir, tr, vd, ts, mod); break;
+            case 5: acc = scaling_case<6>(L, t_sample, qg, q0, v0, a0, dir, tr, vd, ts, mod); break;
+            case 6: acc = scaling_case<7>(L, t_sample, qg, q0, v0, a0, dir, tr, vd, ts, mod); break;
+            default: acc = scaling_case<8>(L, t_sample, qg, q0, v0, a0, dir, tr, vd, ts, mod); break;
+            }
         }
+        s_acc[c][x] = acc ? 1 : 0;
+        __syncthreads();
+        if (live) {
+            int first = -1;
 #pragma unroll
-        for (int k = 0; k < 7; ++k) out.t_scaled[rj * 7 + k] = ts[k];
-        out.v_drive[rj] = vd;
-        out.mod[rj] = (signed char)mod;
+            for (int cc = 7; cc >= 0; --cc) if (s_acc[cc][x]) first = cc;
+            const bool winner = (first == c);
+            const bool reset = (first < 0 && c == 0);   // cc:640-644
+            if (reset) {
+                mod = 0;
+                zero7(ts);
+                vd = L.v_max;
+            }
+            if (winner || reset) {
+                double mx = ts[0];
+#pragma unroll
+                for (int k = 1; k < 7; ++k) if (mx < ts[k]) mx = ts[k];
+                if (mx <= 0.0) {   // cc:50-55
+#pragma unroll
+                    for (int k = 0; k < 7; ++k) ts[k] = out.t_opt[rj * 7 + k];
+                }
+#pragma unroll
+                for (int k = 0; k < 7; ++k) out.t_scaled[rj * 7 + k] = ts[k];
+                out.v_drive[rj] = vd;
+                out.mod[rj] = (signed char)mod;
+                const int l = joint_len(ts, t_sample);
+                if (l < 0) atomicOr(&out.status[q], kStatusNonFinite);
+                else atomicMax(&out.traj_len[q], l);
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -305,6 +379,30 @@ k_finalize(long long n, int dof, double t_sample, Records rec, unsigned long lon
                 if (!finite) { len = 0; st |= kStatusNonFinite; rec.status[q] = st; }
             }
             rec.traj_len[q] = len;
+            local += plan_size(len, dof);
+        }
+    }
+    s_part[threadIdx.x] = local;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) s_part[threadIdx.x] += s_part[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = s_part[0];
+}
+
+// batched path: traj_len/status were already reduced by k_reduce_scale / k_scaling_slow
+__global__ void __launch_bounds__(256)
+k_finalize_lens(long long n, int dof, Records rec, unsigned long long* __restrict__ block_sums)
+{
+    __shared__ unsigned long long s_part[256];
+    const long long base = (long long)blockIdx.x * kScanBlock;
+    unsigned long long local = 0ull;
+    for (int e = 0; e < kScanBlock / 256; ++e) {
+        const long long q = base + e * 256 + threadIdx.x;
+        if (q < n) {
+            int len = rec.traj_len[q];
+            if (rec.status[q] != 0) { len = 0; rec.traj_len[q] = 0; }   // failed or non-finite: nothing to sample
             local += plan_size(len, dof);
         }
     }
@@ -787,15 +885,19 @@ void launch_switch_times(hipStream_t s, long long n, int dof, double t_sample, L
     hipLaunchKernelGGL(k_opt_fast, grid, block, 0, s, n, dof, t_sample, lim, in, out, lane_flags, queue_a, counts);
     hipLaunchKernelGGL(k_opt_slow, dim3((unsigned)slow_blocks), dim3(64), 0, s, dof, t_sample, lim, in, out, lane_flags, queue_a, counts);
     hipLaunchKernelGGL(k_reduce_scale, grid, block, 0, s, n, dof, t_sample, lim, in, out, lane_flags, queue_b, counts + 1);
-    hipLaunchKernelGGL(k_scaling_slow, dim3((unsigned)slow_blocks), dim3(64), 0, s, dof, t_sample, lim, in, out, queue_b, counts + 1);
+    long long b_blocks = (n * dof + kQueriesPerBlock - 1) / kQueriesPerBlock;
+    if (b_blocks > 1024) b_blocks = 1024;
+    hipLaunchKernelGGL(k_scaling_slow, dim3((unsigned)b_blocks), dim3(kQueriesPerBlock, 8), 0, s, dof, t_sample, lim, in, out, queue_b,
+                       counts + 1);
 }
 
 void launch_offsets(hipStream_t s, long long n, int dof, double t_sample, Records rec,
-                    unsigned long long* block_sums, unsigned long long* offsets)
+                    unsigned long long* block_sums, unsigned long long* offsets, bool lens_ready)
 {
     if (n <= 0) return;
     const long long nb = (n + kScanBlock - 1) / kScanBlock;
-    hipLaunchKernelGGL(k_finalize, dim3((unsigned)nb), dim3(256), 0, s, n, dof, t_sample, rec, block_sums);
+    if (lens_ready) hipLaunchKernelGGL(k_finalize_lens, dim3((unsigned)nb), dim3(256), 0, s, n, dof, rec, block_sums);
+    else hipLaunchKernelGGL(k_finalize, dim3((unsigned)nb), dim3(256), 0, s, n, dof, t_sample, rec, block_sums);
     hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, s, nb, block_sums);
     hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nb), dim3(256), 0, s, n, dof, rec.traj_len, block_sums, offsets);
 }

@@ -68,7 +68,7 @@ void launch_switch_times(hipStream_t s, long long n, int dof, double t_sample, L
                          signed char* lane_flags, unsigned long long* queue_a, unsigned long long* queue_b,
                          unsigned long long* counts);
 void launch_offsets(hipStream_t s, long long n, int dof, double t_sample, Records rec,
-                    unsigned long long* block_sums, unsigned long long* offsets);
+                    unsigned long long* block_sums, unsigned long long* offsets, bool lens_ready);
 void launch_sample(hipStream_t s, long long first, long long count, int dof, double t_sample, Limits lim, Queries in,
                    Records rec, const unsigned long long* offsets, double* out, unsigned long long capacity,
                    int flags, unsigned long long* stamps = nullptr);
