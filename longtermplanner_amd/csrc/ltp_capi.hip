@@ -17,12 +17,13 @@ struct ltp_planner {
     std::vector<double> h_lim[5];          // q_min, q_max, v_max, a_max, j_max as given (any length)
     double* d_lim = nullptr;               // 5 * lim_cap doubles
     int lim_cap = 0;
-    unsigned long long* d_queue = nullptr; // two compaction queues of (query*dof + joint), ws_items entries each
-    unsigned long long* d_queue_count = nullptr;   // [2]
+    unsigned long long* d_queue = nullptr; // two compaction queues of (query*dof + joint), 8 shards each
+    unsigned long long* d_queue_count = nullptr;   // [16]
     signed char* d_lane_flags = nullptr;   // per (query, joint) status bits of stage 1
     unsigned long long* d_block_sums = nullptr;
     unsigned long long* d_offsets_scratch = nullptr;
-    long long ws_items = 0;                // capacity in (query, joint) items
+    long long ws_items = 0;                // capacity of d_lane_flags in (query, joint) items
+    long long ws_queue_entries = 0;        // capacity of d_queue in u64 entries
     long long ws_queries = 0;
     double* d_small = nullptr;             // 16 doubles for the one-lane entry points
     unsigned long long* dbg_stamps = nullptr; // diagnostic: per-block start/end stamps of k_sample (caller-owned)
@@ -96,15 +97,20 @@ int reserve(ltp_planner* p, long long n)
 {
     const long long items = n * (long long)(p->dof > 0 ? p->dof : 1);
     LTP_HIP_TRY(p, hipSetDevice(p->device));
-    if (!p->d_queue_count) LTP_HIP_TRY(p, hipMalloc((void**)&p->d_queue_count, 2 * sizeof(unsigned long long)));
+    if (!p->d_queue_count) LTP_HIP_TRY(p, hipMalloc((void**)&p->d_queue_count, 16 * sizeof(unsigned long long)));
     if (!p->d_small) LTP_HIP_TRY(p, hipMalloc((void**)&p->d_small, sizeof(double) * 16));
-    if (items > p->ws_items) {
+    const long long queue_entries = 16 * ltp::queue_segment(n, p->dof > 0 ? p->dof : 1);
+    if (queue_entries > p->ws_queue_entries) {
         if (p->d_queue) LTP_HIP_TRY(p, hipFree(p->d_queue));
-        if (p->d_lane_flags) LTP_HIP_TRY(p, hipFree(p->d_lane_flags));
         p->d_queue = nullptr;
+        p->ws_queue_entries = 0;
+        LTP_HIP_TRY(p, hipMalloc((void**)&p->d_queue, sizeof(unsigned long long) * (size_t)queue_entries));
+        p->ws_queue_entries = queue_entries;
+    }
+    if (items > p->ws_items) {
+        if (p->d_lane_flags) LTP_HIP_TRY(p, hipFree(p->d_lane_flags));
         p->d_lane_flags = nullptr;
         p->ws_items = 0;
-        LTP_HIP_TRY(p, hipMalloc((void**)&p->d_queue, sizeof(unsigned long long) * 2 * (size_t)items));
         LTP_HIP_TRY(p, hipMalloc((void**)&p->d_lane_flags, (size_t)items));
         p->ws_items = items;
     }
@@ -275,9 +281,8 @@ int ltp_plan_switch_times_batch(ltp_planner* p, long long n, const ltp_queries* 
     const ltp::Limits L = dev_limits(p);
     const ltp::Queries q = to_dev(in);
     const ltp::Records r = to_dev(out);
-    LTP_HIP_TRY(p, hipMemsetAsync(p->d_queue_count, 0, 2 * sizeof(unsigned long long), s));
-    ltp::launch_switch_times(s, n, p->dof, p->t_sample, L, q, r, p->d_lane_flags, p->d_queue, p->d_queue + p->ws_items,
-                             p->d_queue_count);
+    LTP_HIP_TRY(p, hipMemsetAsync(p->d_queue_count, 0, 16 * sizeof(unsigned long long), s));
+    ltp::launch_switch_times(s, n, p->dof, p->t_sample, L, q, r, p->d_lane_flags, p->d_queue, p->d_queue_count);
     ltp::launch_offsets(s, n, p->dof, p->t_sample, r, p->d_block_sums, offsets ? offsets : p->d_offsets_scratch, true);
     LTP_HIP_TRY(p, hipGetLastError());
     return LTP_OK;

@@ -44,18 +44,58 @@ LTP_DEV int joint_len(const double (&t)[7], double t_sample)
 
 constexpr int kLaneDeferred = 64;   // lane_flags bit: optSwitchTimes of this lane is still pending in queue A
 
-// wave-level compaction: one atomicAdd per wave, lanes take consecutive slots
-LTP_DEV void wave_push(bool want, unsigned long long item, unsigned long long* __restrict__ queue,
-                       unsigned long long* __restrict__ queue_count)
+// Compaction queues. A single device-scope counter saturates near 90 atomics/us on MI355X, which a kernel that
+// pushes from ~10^5 waves would run into; so a queue has kQueueShards segments with one counter each (shard =
+// blockIdx & 7, i.e. the blocks that share an XCD under round-robin dispatch), and a block aggregates its waves'
+// ballots in LDS and issues ONE atomicAdd per push round.
+constexpr int kQueueShards = 8;
+
+struct Queue {
+    unsigned long long* items;    // kQueueShards segments of `segment` entries
+    unsigned long long* counts;   // [kQueueShards]
+    unsigned long long segment;
+};
+
+// Must be called by every thread of a (64, JB) block (contains barriers). s_cnt: >= kMaxJointSlots + 1 words of LDS.
+LTP_DEV void block_push(bool want, unsigned long long item, const Queue& Q, unsigned long long* s_cnt)
 {
+    const int lane = threadIdx.x, wave = threadIdx.y, nw = blockDim.y;
+    const int shard = blockIdx.x & (kQueueShards - 1);
     const unsigned long long mask = __ballot(want);
-    if (mask == 0ull) return;
-    const int lane = threadIdx.x & 63;
-    const int leader = __ffsll((long long)mask) - 1;
-    unsigned long long base = 0ull;
-    if (lane == leader) base = atomicAdd(queue_count, (unsigned long long)__popcll(mask));
-    base = __shfl(base, leader);
-    if (want) queue[base + __popcll(mask & ((1ull << lane) - 1ull))] = item;
+    if (lane == 0) s_cnt[wave] = (unsigned long long)__popcll(mask);
+    __syncthreads();
+    if (wave == 0 && lane == 0) {
+        unsigned long long total = 0ull;
+        for (int w = 0; w < nw; ++w) total += s_cnt[w];
+        s_cnt[kMaxJointSlots] = total ? atomicAdd(&Q.counts[shard], total) : 0ull;
+    }
+    __syncthreads();
+    if (want) {
+        unsigned long long off = s_cnt[kMaxJointSlots];
+        for (int w = 0; w < wave; ++w) off += s_cnt[w];
+        off += (unsigned long long)__popcll(mask & ((1ull << lane) - 1ull));
+        Q.items[(unsigned long long)shard * Q.segment + off] = item;
+    }
+    __syncthreads();
+}
+
+// item `it` of the concatenated shards (it < queue_total)
+LTP_DEV unsigned long long queue_item(const Queue& Q, const unsigned long long (&cnt)[kQueueShards], unsigned long long it)
+{
+    int sh = 0;
+#pragma unroll
+    for (int k = 0; k < kQueueShards - 1; ++k) {
+        if (sh == k && it >= cnt[k]) { it -= cnt[k]; sh = k + 1; }
+    }
+    return Q.items[(unsigned long long)sh * Q.segment + it];
+}
+
+LTP_DEV unsigned long long queue_total(const Queue& Q, unsigned long long (&cnt)[kQueueShards])
+{
+    unsigned long long total = 0ull;
+#pragma unroll
+    for (int k = 0; k < kQueueShards; ++k) { cnt[k] = Q.counts[k]; total += cnt[k]; }
+    return total;
 }
 
 LTP_DEV void store_opt_record(const Records& out, long long rj, const double (&t)[7], double dir, int mod)
@@ -68,16 +108,20 @@ LTP_DEV void store_opt_record(const Records& out, long long rj, const double (&t
 
 __global__ void __launch_bounds__(kQueriesPerBlock* kMaxJointSlots)
 k_opt_fast(long long n, int dof, double t_sample, Limits lim, Queries in, Records out, signed char* __restrict__ lane_flags,
-           unsigned long long* __restrict__ queue, unsigned long long* __restrict__ queue_count)
+           Queue queue)
 {
+    __shared__ unsigned long long s_cnt[kMaxJointSlots + 1];
     const int x = threadIdx.x, y = threadIdx.y, JB = blockDim.y;
     const long long q = (long long)blockIdx.x * kQueriesPerBlock + x;
     const bool live = q < n;
-    for (int j = y; j < dof; j += JB) {
-        const JointLimits L = load_limits(lim, j);
+    // every wave runs the same number of rounds: block_push() contains barriers
+    for (int jb = 0; jb < dof; jb += JB) {
+        const int j = jb + y;
+        const bool active = live && j < dof;
+        const JointLimits L = load_limits(lim, j < dof ? j : dof - 1);
         const long long rj = q * dof + j;
         bool defer = false;
-        if (live) {
+        if (active) {
             const long long ix = q * in.sq + (long long)j * in.sj;
             const double qg = in.q_goal[ix], q0 = in.q_0[ix], v0 = in.v_0[ix], a0 = in.a_0[ix];
             int flags = check_inputs_joint(L, q0, v0, a0) ? 0 : kStatusInvalidInput;
@@ -94,18 +138,18 @@ k_opt_fast(long long n, int dof, double t_sample, Limits lim, Queries in, Record
             }
             lane_flags[rj] = (signed char)flags;
         }
-        wave_push(defer, (unsigned long long)rj, queue, queue_count);
+        block_push(defer, (unsigned long long)rj, queue, s_cnt);
     }
 }
 
 __global__ void __launch_bounds__(64)
-k_opt_slow(int dof, double t_sample, Limits lim, Queries in, Records out, signed char* __restrict__ lane_flags,
-           const unsigned long long* __restrict__ queue, const unsigned long long* __restrict__ queue_count)
+k_opt_slow(int dof, double t_sample, Limits lim, Queries in, Records out, signed char* __restrict__ lane_flags, Queue queue)
 {
-    const unsigned long long count = *queue_count;
+    unsigned long long cnt[kQueueShards];
+    const unsigned long long count = queue_total(queue, cnt);
     for (unsigned long long it = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; it < count;
          it += (unsigned long long)gridDim.x * blockDim.x) {
-        const long long rj = (long long)queue[it];
+        const long long rj = (long long)queue_item(queue, cnt, it);
         const long long q = rj / dof;
         const int j = (int)(rj - q * dof);
         const JointLimits L = load_limits(lim, j);
@@ -124,9 +168,9 @@ k_opt_slow(int dof, double t_sample, Limits lim, Queries in, Records out, signed
 
 __global__ void __launch_bounds__(kQueriesPerBlock* kMaxJointSlots)
 k_reduce_scale(long long n, int dof, double t_sample, Limits lim, Queries in, Records out,
-               const signed char* __restrict__ lane_flags,
-               unsigned long long* __restrict__ queue, unsigned long long* __restrict__ queue_count)
+               const signed char* __restrict__ lane_flags, Queue queue)
 {
+    __shared__ unsigned long long s_cnt[kMaxJointSlots + 1];
     __shared__ double s_t[kMaxJointSlots][kQueriesPerBlock];
     __shared__ int s_j[kMaxJointSlots][kQueriesPerBlock];
     __shared__ int s_f[kMaxJointSlots][kQueriesPerBlock];
@@ -168,12 +212,14 @@ k_reduce_scale(long long n, int dof, double t_sample, Limits lim, Queries in, Re
 
     // cc:43-55 with the closed-form candidates c1, c2 (cc:378-446)
     int my_len = 0, nonfinite = 0;
-    for (int j = y; j < dof; j += JB) {
-        const JointLimits L = load_limits(lim, j);
+    for (int jb = 0; jb < dof; jb += JB) {   // same number of rounds in every wave: block_push() contains barriers
+        const int j = jb + y;
+        const bool active = live && j < dof;
+        const JointLimits L = load_limits(lim, j < dof ? j : dof - 1);
         bool need_slow = false;
         int lane_len = 0;
         const long long rj = q * dof + j;
-        if (live) {
+        if (active) {
             double ts[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
             double vd = L.v_max;
             int mod = 0;   // failed query: zero record, never sampled
@@ -212,7 +258,7 @@ k_reduce_scale(long long n, int dof, double t_sample, Limits lim, Queries in, Re
                 if (flags == 0) lane_len = joint_len(ts, t_sample);
             }
         }
-        wave_push(need_slow, (unsigned long long)rj, queue, queue_count);
+        block_push(need_slow, (unsigned long long)rj, queue, s_cnt);
         if (lane_len < 0) nonfinite = 1;
         else my_len = lane_len > my_len ? lane_len : my_len;
     }
@@ -273,13 +319,13 @@ LTP_DEV bool time_scaling_full(const JointLimits& L, double t_sample, double qg,
 // slowest candidate (the degree-6 solve) instead of their sum. The reference's "first accepted in order" is then a
 // lookup over eight flags in LDS.
 __global__ void __launch_bounds__(kQueriesPerBlock * 8)
-k_scaling_slow(int dof, double t_sample, Limits lim, Queries in, Records out,
-               const unsigned long long* __restrict__ queue, const unsigned long long* __restrict__ queue_count)
+k_scaling_slow(int dof, double t_sample, Limits lim, Queries in, Records out, Queue queue)
 {
     __shared__ int s_acc[8][kQueriesPerBlock];
     const int x = threadIdx.x;
     const int c = __builtin_amdgcn_readfirstlane(threadIdx.y);
-    const unsigned long long count = *queue_count;
+    unsigned long long cnt[kQueueShards];
+    const unsigned long long count = queue_total(queue, cnt);
     for (unsigned long long base = (unsigned long long)blockIdx.x * kQueriesPerBlock; base < count;
          base += (unsigned long long)gridDim.x * kQueriesPerBlock) {
         const unsigned long long it = base + x;
@@ -291,7 +337,7 @@ k_scaling_slow(int dof, double t_sample, Limits lim, Queries in, Records out,
         long long rj = 0, q = 0;
         JointLimits L = {0.0, 0.0, 0.0, 0.0, 0.0};
         if (live) {
-            rj = (long long)queue[it];
+            rj = (long long)queue_item(queue, cnt, it);
             q = rj / dof;
             j = (int)(rj - q * dof);
             L = load_limits(lim, j);
@@ -871,24 +917,32 @@ __global__ void k_roots_probe(long long n, int degree, const double* coef, doubl
 // ---------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------
+long long queue_segment(long long n, int dof)
+{
+    const long long nblocks = (n + kQueriesPerBlock - 1) / kQueriesPerBlock;
+    return (nblocks + kQueueShards - 1) / kQueueShards * kQueriesPerBlock * (long long)dof;
+}
+
 void launch_switch_times(hipStream_t s, long long n, int dof, double t_sample, Limits lim, Queries in, Records out,
-                         signed char* lane_flags, unsigned long long* queue_a, unsigned long long* queue_b,
-                         unsigned long long* counts /* [2], zeroed by the caller on the same stream */)
+                         signed char* lane_flags, unsigned long long* queue_items /* 2 * 8 * queue_segment(n, dof) */,
+                         unsigned long long* counts /* [16], zeroed by the caller on the same stream */)
 {
     if (n <= 0) return;
     const int jb = dof < kMaxJointSlots ? dof : kMaxJointSlots;
     const dim3 block(kQueriesPerBlock, jb);
     const dim3 grid((unsigned)((n + kQueriesPerBlock - 1) / kQueriesPerBlock));
+    const unsigned long long seg = (unsigned long long)queue_segment(n, dof);
+    const Queue qa{queue_items, counts, seg};
+    const Queue qb{queue_items + kQueueShards * seg, counts + kQueueShards, seg};
     // queue lengths are only known on the device: fixed grids, grid-stride over the queues
-    long long slow_blocks = (n * dof + 63) / 64;
-    if (slow_blocks > 4096) slow_blocks = 4096;
-    hipLaunchKernelGGL(k_opt_fast, grid, block, 0, s, n, dof, t_sample, lim, in, out, lane_flags, queue_a, counts);
-    hipLaunchKernelGGL(k_opt_slow, dim3((unsigned)slow_blocks), dim3(64), 0, s, dof, t_sample, lim, in, out, lane_flags, queue_a, counts);
-    hipLaunchKernelGGL(k_reduce_scale, grid, block, 0, s, n, dof, t_sample, lim, in, out, lane_flags, queue_b, counts + 1);
+    long long a_blocks = (n * dof + 63) / 64;
+    if (a_blocks > 4096) a_blocks = 4096;
     long long b_blocks = (n * dof + kQueriesPerBlock - 1) / kQueriesPerBlock;
     if (b_blocks > 1024) b_blocks = 1024;
-    hipLaunchKernelGGL(k_scaling_slow, dim3((unsigned)b_blocks), dim3(kQueriesPerBlock, 8), 0, s, dof, t_sample, lim, in, out, queue_b,
-                       counts + 1);
+    hipLaunchKernelGGL(k_opt_fast, grid, block, 0, s, n, dof, t_sample, lim, in, out, lane_flags, qa);
+    hipLaunchKernelGGL(k_opt_slow, dim3((unsigned)a_blocks), dim3(64), 0, s, dof, t_sample, lim, in, out, lane_flags, qa);
+    hipLaunchKernelGGL(k_reduce_scale, grid, block, 0, s, n, dof, t_sample, lim, in, out, lane_flags, qb);
+    hipLaunchKernelGGL(k_scaling_slow, dim3((unsigned)b_blocks), dim3(kQueriesPerBlock, 8), 0, s, dof, t_sample, lim, in, out, qb);
 }
 
 void launch_offsets(hipStream_t s, long long n, int dof, double t_sample, Records rec,

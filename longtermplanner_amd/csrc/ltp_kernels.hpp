@@ -64,9 +64,9 @@ struct Records {           // query-major outputs of stages 1-3
     int* status;           // [n]
 };
 
+long long queue_segment(long long n, int dof);   // entries per queue shard; a batch needs 2 * 8 * this many u64
 void launch_switch_times(hipStream_t s, long long n, int dof, double t_sample, Limits lim, Queries in, Records out,
-                         signed char* lane_flags, unsigned long long* queue_a, unsigned long long* queue_b,
-                         unsigned long long* counts);
+                         signed char* lane_flags, unsigned long long* queue_items, unsigned long long* counts);
 void launch_offsets(hipStream_t s, long long n, int dof, double t_sample, Records rec,
                     unsigned long long* block_sums, unsigned long long* offsets, bool lens_ready);
 void launch_sample(hipStream_t s, long long first, long long count, int dof, double t_sample, Limits lim, Queries in,
