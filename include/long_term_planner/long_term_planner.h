@@ -61,21 +61,22 @@ struct BatchTrajectory {
   std::vector<double> t_required;   ///< [n]
   std::vector<int> slowest;         ///< [n]
   std::vector<int> length;          ///< [n] Trajectory::length, 0 if the plan failed before sampling
+  std::vector<int> stored;          ///< [n] samples stored per row: length, or less when setMaxSamples() is in effect
   std::vector<int> status;          ///< [n] LTP_STATUS_* bits; planTrajectory's bool is (status == 0)
   std::vector<unsigned long long> offsets;  ///< [n+1] plan p occupies packed[offsets[p], offsets[p+1])
   std::vector<double> packed;       ///< per plan: [q,v,a,j][joint][ltp_row_stride(length)]
   /// pointer to sample 0 of array `arr` (0=q,1=v,2=a,3=j) of joint `joint` of plan `p`
   const double* row(long long p, int arr, int joint) const {
-    return packed.data() + offsets[p] + (static_cast<std::size_t>(arr) * dof + joint) * ltp_row_stride(length[p]);
+    return packed.data() + offsets[p] + (static_cast<std::size_t>(arr) * dof + joint) * ltp_row_stride(stored[p]);
   }
   /// copy plan p out as a reference-style Trajectory
   Trajectory trajectory(long long p) const {
     Trajectory t;
-    t.dof = dof; t.t_sample = t_sample; t.length = length[p];
+    t.dof = dof; t.t_sample = t_sample; t.length = stored[p];
     std::vector<std::vector<double>>* dst[4] = {&t.q, &t.v, &t.a, &t.j};
     for (int arr = 0; arr < 4; ++arr) {
       dst[arr]->resize(dof);
-      for (int i = 0; i < dof; ++i) (*dst[arr])[i].assign(row(p, arr, i), row(p, arr, i) + length[p]);
+      for (int i = 0; i < dof; ++i) (*dst[arr])[i].assign(row(p, arr, i), row(p, arr, i) + stored[p]);
     }
     return t;
   }
@@ -182,7 +183,11 @@ class LongTermPlanner {
       ltp_free_host(packed);
     }
     long long ok = 0;
-    for (long long p = 0; p < n; ++p) ok += out.status[p] == 0;
+    out.stored.resize(n);
+    for (long long p = 0; p < n; ++p) {
+      ok += out.status[p] == 0;
+      out.stored[p] = ltp_stored_samples(h, out.length[p]);
+    }
     return ok;
   }
 
@@ -207,6 +212,12 @@ class LongTermPlanner {
 
   /** @brief reference long_term_planner.h:203-205 (takes a double there as well) */
   inline void setDoF(double dof) { dof_ = dof; dirty_ = true; }
+
+  /** @brief NEW: store only the first `max_samples` samples of each trajectory (0 = all, the reference's behaviour). */
+  inline void setMaxSamples(int max_samples) {
+    const int rc = ltp_set_max_samples(handle(), max_samples);
+    if (rc != LTP_OK) raise(handle_, rc, "ltp_set_max_samples");
+  }
 
   /** @brief NEW: HIP device ordinal used by this planner (default 0). */
   inline void setDevice(int device) { if (device != device_) { release(); device_ = device; dirty_ = true; } }
@@ -251,7 +262,7 @@ class LongTermPlanner {
     ltp_planner* h = handle();
     BatchTrajectory b;
     b.n = 1; b.dof = dof_; b.t_sample = t_sample_;
-    b.length.assign(1, 0); b.status.assign(1, 0); b.offsets.assign(2, 0ull);
+    b.length.assign(1, 0); b.status.assign(1, 0); b.offsets.assign(2, 0ull); b.stored.assign(1, 0);
     std::vector<signed char> mod(mod_jerk_profile.begin(), mod_jerk_profile.end());
     double* packed = nullptr;
     const int rc = ltp_get_trajectory_host(h, 1, t.empty() ? nullptr : t[0].data(), dir.data(), mod.data(), q_0.data(), v_0.data(),
@@ -261,6 +272,7 @@ class LongTermPlanner {
       b.packed.assign(packed, packed + b.offsets[1]);
       ltp_free_host(packed);
     }
+    b.stored[0] = ltp_stored_samples(h, b.length[0]);
     return b.trajectory(0);
   }
 };

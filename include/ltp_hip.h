@@ -84,7 +84,14 @@ int ltp_get_dof(const ltp_planner* p);
 double ltp_get_sample_time(const ltp_planner* p);
 const char* ltp_last_error(const ltp_planner* p);
 /* rows of the packed trajectory layout are padded to this many doubles */
-int ltp_row_stride(int traj_len);
+int ltp_row_stride(int stored_samples);
+/* SURVEY.md §8(f).2 "first N samples only": store min(traj_len, max_samples) samples per row (0 = all of them, which
+ * is the reference's behaviour and the default). traj_len in the records stays Trajectory::length; offsets, row
+ * strides and the sampler follow the stored length ltp_stored_samples(p, traj_len). The end-limit check (cc:59-61)
+ * still refers to the last sample of the whole trajectory. */
+int ltp_set_max_samples(ltp_planner* p, int max_samples);
+int ltp_get_max_samples(const ltp_planner* p);
+int ltp_stored_samples(const ltp_planner* p, int traj_len);
 
 /* ---- batched hot path (device pointers, asynchronous on `stream`) -------------------------- */
 
@@ -104,6 +111,14 @@ int ltp_plan_switch_times_batch(ltp_planner* p, long long n, const ltp_queries* 
  * written with the default interleave reach the HBM fill ceiling; see DESIGN.md. */
 int ltp_sample_batch(ltp_planner* p, long long first, long long count, const ltp_queries* in, const ltp_records* rec,
                      const unsigned long long* offsets, double* out, unsigned long long capacity, int flags, void* stream);
+
+/* SURVEY.md §8(f).1 receding horizon (reference README.md:10-13): start states of the next plans = sample k of the
+ * trajectories sampled into `tile` by ltp_sample_batch(first, count, ...). sample_index: device int[count] or NULL
+ * (then uniform_index for all); k is clamped to the stored samples; plans that were not sampled keep the start
+ * state they had in `in`. Output element (local plan i, joint j) at ptr[i*query_stride + j*joint_stride]. */
+int ltp_replan_states_batch(ltp_planner* p, long long first, long long count, const ltp_queries* in, const ltp_records* rec,
+                            const unsigned long long* offsets, const double* tile, const int* sample_index, int uniform_index,
+                            double* q_0, double* v_0, double* a_0, long long query_stride, long long joint_stride, void* stream);
 
 /* Synthetic queries of SURVEY.md §8(d) (distribution of tests/randomConfiguration.m:14-34 with per-joint
  * limits), counter-based: query index first_query+p, so shards of one batch can be generated anywhere. */

@@ -65,6 +65,12 @@ _SIGNATURES = {
     "ltp_get_sample_time": (C.c_double, [C.c_void_p]),
     "ltp_last_error": (C.c_char_p, [C.c_void_p]),
     "ltp_row_stride": (C.c_int, [C.c_int]),
+    "ltp_set_max_samples": (C.c_int, [C.c_void_p, C.c_int]),
+    "ltp_get_max_samples": (C.c_int, [C.c_void_p]),
+    "ltp_stored_samples": (C.c_int, [C.c_void_p, C.c_int]),
+    "ltp_replan_states_batch": (C.c_int, [C.c_void_p, C.c_longlong, C.c_longlong, C.POINTER(Queries), C.POINTER(Records), C.c_void_p,
+                                          C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong,
+                                          C.c_longlong, C.c_void_p]),
     "ltp_plan_switch_times_batch": (C.c_int, [C.c_void_p, C.c_longlong, C.POINTER(Queries), C.POINTER(Records), C.c_void_p, C.c_void_p]),
     "ltp_sample_batch": (C.c_int, [C.c_void_p, C.c_longlong, C.c_longlong, C.POINTER(Queries), C.POINTER(Records), C.c_void_p,
                                    C.c_void_p, C.c_ulonglong, C.c_int, C.c_void_p]),

@@ -14,6 +14,7 @@ struct ltp_planner {
     int dof = 0;
     double t_sample = 0.001;
     int device = 0;
+    int max_samples = 0;                   // 0 = store whole trajectories (reference behaviour)
     std::vector<double> h_lim[5];          // q_min, q_max, v_max, a_max, j_max as given (any length)
     double* d_lim = nullptr;               // 5 * lim_cap doubles
     int lim_cap = 0;
@@ -244,6 +245,20 @@ int ltp_set_dof(ltp_planner* p, int dof)
     return LTP_OK;
 }
 
+int ltp_set_max_samples(ltp_planner* p, int max_samples)
+{
+    if (!p || max_samples < 0) return fail(p, LTP_ERR_INVALID_ARGUMENT, "max_samples < 0");
+    std::lock_guard<std::mutex> g(p->mu);
+    p->max_samples = max_samples;
+    return LTP_OK;
+}
+int ltp_get_max_samples(const ltp_planner* p) { return p ? p->max_samples : -1; }
+int ltp_stored_samples(const ltp_planner* p, int traj_len)
+{
+    if (!p || traj_len <= 0) return 0;
+    return (p->max_samples > 0 && traj_len > p->max_samples) ? p->max_samples : traj_len;
+}
+
 int ltp_get_dof(const ltp_planner* p) { return p ? p->dof : -1; }
 double ltp_get_sample_time(const ltp_planner* p) { return p ? p->t_sample : 0.0; }
 const char* ltp_last_error(const ltp_planner* p) { return p ? p->err.c_str() : "null planner"; }
@@ -283,7 +298,7 @@ int ltp_plan_switch_times_batch(ltp_planner* p, long long n, const ltp_queries* 
     const ltp::Records r = to_dev(out);
     LTP_HIP_TRY(p, hipMemsetAsync(p->d_queue_count, 0, 16 * sizeof(unsigned long long), s));
     ltp::launch_switch_times(s, n, p->dof, p->t_sample, L, q, r, p->d_lane_flags, p->d_queue, p->d_queue_count);
-    ltp::launch_offsets(s, n, p->dof, p->t_sample, r, p->d_block_sums, offsets ? offsets : p->d_offsets_scratch, true);
+    ltp::launch_offsets(s, n, p->dof, p->t_sample, r, p->d_block_sums, offsets ? offsets : p->d_offsets_scratch, true, p->max_samples);
     LTP_HIP_TRY(p, hipGetLastError());
     return LTP_OK;
 }
@@ -300,7 +315,23 @@ int ltp_sample_batch(ltp_planner* p, long long first, long long count, const ltp
     if (count == 0 || p->dof == 0) return LTP_OK;
     LTP_HIP_TRY(p, hipSetDevice(p->device));
     ltp::launch_sample((hipStream_t)stream, first, count, p->dof, p->t_sample, dev_limits(p), to_dev(in), to_dev(rec), offsets,
-                       out, capacity, flags, p->dbg_stamps);
+                       out, capacity, flags, p->max_samples, p->dbg_stamps);
+    LTP_HIP_TRY(p, hipGetLastError());
+    return LTP_OK;
+}
+
+int ltp_replan_states_batch(ltp_planner* p, long long first, long long count, const ltp_queries* in, const ltp_records* rec,
+                            const unsigned long long* offsets, const double* tile, const int* sample_index, int uniform_index,
+                            double* q_0, double* v_0, double* a_0, long long query_stride, long long joint_stride, void* stream)
+{
+    if (!p || first < 0 || count < 0 || !in || !records_complete(rec) || !offsets || !tile || !q_0 || !v_0 || !a_0)
+        return fail(p, LTP_ERR_INVALID_ARGUMENT, "null argument");
+    std::lock_guard<std::mutex> g(p->mu);
+    int rc = check_config(p);
+    if (rc != LTP_OK) return rc;
+    LTP_HIP_TRY(p, hipSetDevice(p->device));
+    ltp::launch_replan_states((hipStream_t)stream, first, count, p->dof, p->max_samples, to_dev(in), to_dev(rec), offsets, tile,
+                              sample_index, uniform_index, q_0, v_0, a_0, query_stride, joint_stride);
     LTP_HIP_TRY(p, hipGetLastError());
     return LTP_OK;
 }
@@ -437,7 +468,7 @@ int ltp_get_trajectory_host(ltp_planner* p, long long n, const double* t, const 
     ltp_queries dq{d_in[0], d_in[0], d_in[1], d_in[2], dof, 1};   // q_goal is not used by the sampler
     if (n > 0 && dof > 0) {
         std::lock_guard<std::mutex> g(p->mu);
-        ltp::launch_offsets(nullptr, n, dof, p->t_sample, to_dev(&dr.r), p->d_block_sums, d_off, false);
+        ltp::launch_offsets(nullptr, n, dof, p->t_sample, to_dev(&dr.r), p->d_block_sums, d_off, false, p->max_samples);
         LTP_HIP_TRY(p, hipGetLastError());
     }
     LTP_HIP_TRY(p, hipDeviceSynchronize());

@@ -396,6 +396,12 @@ k_scaling_slow(int dof, double t_sample, Limits lim, Queries in, Records out, Qu
 // Packed layout of plan p at out + offsets[p]: [array q,v,a,j][joint][row_stride] doubles,
 // row_stride = round_up(traj_len, 16) so that every row starts 128-B aligned.
 // ---------------------------------------------------------------------------------------
+// rows hold min(traj_len, max_samples) samples (max_samples == 0: all of them, the reference's behaviour)
+LTP_DEV int stored_len(int len, int max_samples)
+{
+    return (max_samples > 0 && len > max_samples) ? max_samples : len;
+}
+
 LTP_DEV unsigned long long plan_size(int len, int dof)
 {
     if (len <= 0) return 0ull;
@@ -404,7 +410,7 @@ LTP_DEV unsigned long long plan_size(int len, int dof)
 }
 
 __global__ void __launch_bounds__(256)
-k_finalize(long long n, int dof, double t_sample, Records rec, unsigned long long* __restrict__ block_sums)
+k_finalize(long long n, int dof, double t_sample, int max_samples, Records rec, unsigned long long* __restrict__ block_sums)
 {
     __shared__ unsigned long long s_part[256];
     const long long base = (long long)blockIdx.x * kScanBlock;
@@ -425,7 +431,7 @@ k_finalize(long long n, int dof, double t_sample, Records rec, unsigned long lon
                 if (!finite) { len = 0; st |= kStatusNonFinite; rec.status[q] = st; }
             }
             rec.traj_len[q] = len;
-            local += plan_size(len, dof);
+            local += plan_size(stored_len(len, max_samples), dof);
         }
     }
     s_part[threadIdx.x] = local;
@@ -439,7 +445,7 @@ k_finalize(long long n, int dof, double t_sample, Records rec, unsigned long lon
 
 // batched path: traj_len/status were already reduced by k_reduce_scale / k_scaling_slow
 __global__ void __launch_bounds__(256)
-k_finalize_lens(long long n, int dof, Records rec, unsigned long long* __restrict__ block_sums)
+k_finalize_lens(long long n, int dof, int max_samples, Records rec, unsigned long long* __restrict__ block_sums)
 {
     __shared__ unsigned long long s_part[256];
     const long long base = (long long)blockIdx.x * kScanBlock;
@@ -449,7 +455,7 @@ k_finalize_lens(long long n, int dof, Records rec, unsigned long long* __restric
         if (q < n) {
             int len = rec.traj_len[q];
             if (rec.status[q] != 0) { len = 0; rec.traj_len[q] = 0; }   // failed or non-finite: nothing to sample
-            local += plan_size(len, dof);
+            local += plan_size(stored_len(len, max_samples), dof);
         }
     }
     s_part[threadIdx.x] = local;
@@ -488,8 +494,8 @@ k_scan_top(long long nb, unsigned long long* __restrict__ block_sums)
 }
 
 __global__ void __launch_bounds__(256)
-k_scan_apply(long long n, int dof, const int* __restrict__ traj_len, const unsigned long long* __restrict__ block_sums,
-             unsigned long long* __restrict__ offsets)
+k_scan_apply(long long n, int dof, int max_samples, const int* __restrict__ traj_len,
+             const unsigned long long* __restrict__ block_sums, unsigned long long* __restrict__ offsets)
 {
     __shared__ unsigned long long s[256];
     const long long base = (long long)blockIdx.x * kScanBlock;
@@ -499,7 +505,7 @@ k_scan_apply(long long n, int dof, const int* __restrict__ traj_len, const unsig
 #pragma unroll
     for (int e = 0; e < E; ++e) {
         const long long q = base + (long long)threadIdx.x * E + e;
-        sz[e] = q < n ? plan_size(traj_len[q], dof) : 0ull;
+        sz[e] = q < n ? plan_size(stored_len(traj_len[q], max_samples), dof) : 0ull;
         local += sz[e];
     }
     s[threadIdx.x] = local;
@@ -632,7 +638,7 @@ template <bool STREAMING, bool DRY>
 __global__ void __launch_bounds__(kSampleThreads)
 k_sample(long long first, long long count, int dof, double t_sample, Limits lim, Queries in, Records rec,
          const unsigned long long* __restrict__ offsets, double* __restrict__ out, unsigned long long capacity,
-         unsigned long long* __restrict__ stamps, int spread)
+         unsigned long long* __restrict__ stamps, int spread, int max_samples)
 {
     __shared__ SegTable tab;
     // Block -> plan map. spread > 1 deals consecutive blocks to plans count/spread apart, so the blocks that are
@@ -650,7 +656,8 @@ k_sample(long long first, long long count, int dof, double t_sample, Limits lim,
     if (len <= 0) return;   // failed / non-finite query: nothing to sample (uniform per block)
     const unsigned long long off0 = offsets[first];
     const unsigned long long rel = offsets[p] - off0;
-    const unsigned long long stride = ((unsigned long long)len + (kRowAlign - 1)) / kRowAlign * kRowAlign;
+    const int slen = stored_len(len, max_samples);   // samples actually stored per row
+    const unsigned long long stride = ((unsigned long long)slen + (kRowAlign - 1)) / kRowAlign * kRowAlign;
     if (rel + 4ull * dof * stride > capacity) {
         if (threadIdx.x == 0 && blockIdx.y == 0) atomicOr(&rec.status[p], kStatusOverflow);
         return;
@@ -749,7 +756,7 @@ k_sample(long long first, long long count, int dof, double t_sample, Limits lim,
     // one after the other is slower.)
     double* const plan_base = out + rel;
     const unsigned long long arr_stride = (unsigned long long)dof * stride;   // distance between q, v, a, j blocks
-    const int npairs = (len + 1) >> 1;
+    const int npairs = (slen + 1) >> 1;
     for (int jl = 0; jl < nj; ++jl) {
         double* const row = plan_base + (unsigned long long)(j0 + jl) * stride;
         const int* st = tab.start[jl];
@@ -764,7 +771,7 @@ k_sample(long long first, long long count, int dof, double t_sample, Limits lim,
                 while (k + 1 < ns && st[k + 1] <= i0) ++k;
                 const int k1 = (k + 1 < ns && st[k + 1] <= i1) ? k + 1 : k;
                 const int m0 = i0 - st[k] + 1, m1 = i1 - st[k1] + 1;
-                const bool pad = i1 >= len;   // odd length: second half of the last slot is row padding
+                const bool pad = i1 >= slen;   // odd length: second half of the last slot is row padding
 #pragma unroll
                 for (int x = 0; x < 4; ++x) {
                     const double x0 = run_eval(tab.c[jl][k][x], m0);
@@ -780,6 +787,40 @@ k_sample(long long first, long long count, int dof, double t_sample, Limits lim,
         __syncthreads();
         if (threadIdx.x == 0 && blockIdx.y == 0) stamps[2 * local + 1] = wall_clock64();
     }
+}
+
+// ---------------------------------------------------------------------------------------
+// Receding horizon (reference README.md:10-13): the start state of the next plan is the state
+// at sample k of the previous trajectory, gathered on the device without a host round trip.
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_replan_states(long long first, long long count, int dof, int max_samples, Queries in, Records rec,
+                const unsigned long long* __restrict__ offsets, const double* __restrict__ tile,
+                const int* __restrict__ sample_index, int uniform_index,
+                double* __restrict__ q_0, double* __restrict__ v_0, double* __restrict__ a_0, long long sq, long long sj)
+{
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= count * dof) return;
+    const long long local = idx / dof;
+    const int j = (int)(idx - local * dof);
+    const long long p = first + local;
+    const long long dst = local * sq + (long long)j * sj;
+    const int slen = stored_len(rec.traj_len[p], max_samples);
+    if (slen <= 0) {   // plan was not sampled: carry its start state over unchanged
+        const long long ix = p * in.sq + (long long)j * in.sj;
+        q_0[dst] = in.q_0[ix];
+        v_0[dst] = in.v_0[ix];
+        a_0[dst] = in.a_0[ix];
+        return;
+    }
+    int k = sample_index ? sample_index[local] : uniform_index;
+    k = k < 0 ? 0 : (k >= slen ? slen - 1 : k);   // beyond the stored samples: the last stored state
+    const unsigned long long stride = ((unsigned long long)slen + (kRowAlign - 1)) / kRowAlign * kRowAlign;
+    const double* row = tile + (offsets[p] - offsets[first]) + (unsigned long long)j * stride + k;
+    const unsigned long long arr = (unsigned long long)dof * stride;
+    q_0[dst] = row[0];
+    v_0[dst] = row[arr];
+    a_0[dst] = row[2 * arr];
 }
 
 // ---------------------------------------------------------------------------------------
@@ -946,19 +987,19 @@ void launch_switch_times(hipStream_t s, long long n, int dof, double t_sample, L
 }
 
 void launch_offsets(hipStream_t s, long long n, int dof, double t_sample, Records rec,
-                    unsigned long long* block_sums, unsigned long long* offsets, bool lens_ready)
+                    unsigned long long* block_sums, unsigned long long* offsets, bool lens_ready, int max_samples)
 {
     if (n <= 0) return;
     const long long nb = (n + kScanBlock - 1) / kScanBlock;
-    if (lens_ready) hipLaunchKernelGGL(k_finalize_lens, dim3((unsigned)nb), dim3(256), 0, s, n, dof, rec, block_sums);
-    else hipLaunchKernelGGL(k_finalize, dim3((unsigned)nb), dim3(256), 0, s, n, dof, t_sample, rec, block_sums);
+    if (lens_ready) hipLaunchKernelGGL(k_finalize_lens, dim3((unsigned)nb), dim3(256), 0, s, n, dof, max_samples, rec, block_sums);
+    else hipLaunchKernelGGL(k_finalize, dim3((unsigned)nb), dim3(256), 0, s, n, dof, t_sample, max_samples, rec, block_sums);
     hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, s, nb, block_sums);
-    hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nb), dim3(256), 0, s, n, dof, rec.traj_len, block_sums, offsets);
+    hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nb), dim3(256), 0, s, n, dof, max_samples, rec.traj_len, block_sums, offsets);
 }
 
 void launch_sample(hipStream_t s, long long first, long long count, int dof, double t_sample, Limits lim, Queries in,
                    Records rec, const unsigned long long* offsets, double* out, unsigned long long capacity,
-                   int flags, unsigned long long* stamps)
+                   int flags, int max_samples, unsigned long long* stamps)
 {
     if (count <= 0) return;
     int spread = (flags >> 8) & 0xFFFF;
@@ -970,7 +1011,7 @@ void launch_sample(hipStream_t s, long long first, long long count, int dof, dou
     const dim3 block(kSampleThreads);
     // flags bit 0: non-temporal stores; bit 1 (diagnostic): skip the arithmetic and store sample indices, which
     // measures the ceiling of this store pattern; bits 8..23: block interleave factor (0 = default 64, 1 = plan order)
-#define LTP_SAMPLE_CASE(ST, DR) hipLaunchKernelGGL((k_sample<ST, DR>), grid, block, 0, s, first, count, dof, t_sample, lim, in, rec, offsets, out, capacity, stamps, spread)
+#define LTP_SAMPLE_CASE(ST, DR) hipLaunchKernelGGL((k_sample<ST, DR>), grid, block, 0, s, first, count, dof, t_sample, lim, in, rec, offsets, out, capacity, stamps, spread, max_samples)
     switch (flags & 3) {
     case 0: LTP_SAMPLE_CASE(false, false); break;
     case 1: LTP_SAMPLE_CASE(true, false); break;
@@ -978,6 +1019,16 @@ void launch_sample(hipStream_t s, long long first, long long count, int dof, dou
     default: LTP_SAMPLE_CASE(true, true); break;
     }
 #undef LTP_SAMPLE_CASE
+}
+
+void launch_replan_states(hipStream_t s, long long first, long long count, int dof, int max_samples, Queries in, Records rec,
+                          const unsigned long long* offsets, const double* tile, const int* sample_index, int uniform_index,
+                          double* q_0, double* v_0, double* a_0, long long sq, long long sj)
+{
+    if (count <= 0 || dof <= 0) return;
+    const long long total = count * dof;
+    hipLaunchKernelGGL(k_replan_states, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, first, count, dof, max_samples, in, rec,
+                       offsets, tile, sample_index, uniform_index, q_0, v_0, a_0, sq, sj);
 }
 
 void launch_generate(hipStream_t s, long long n, int dof, Limits lim, unsigned long long seed, long long first_query,

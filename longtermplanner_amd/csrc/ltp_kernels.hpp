@@ -68,10 +68,13 @@ long long queue_segment(long long n, int dof);   // entries per queue shard; a b
 void launch_switch_times(hipStream_t s, long long n, int dof, double t_sample, Limits lim, Queries in, Records out,
                          signed char* lane_flags, unsigned long long* queue_items, unsigned long long* counts);
 void launch_offsets(hipStream_t s, long long n, int dof, double t_sample, Records rec,
-                    unsigned long long* block_sums, unsigned long long* offsets, bool lens_ready);
+                    unsigned long long* block_sums, unsigned long long* offsets, bool lens_ready, int max_samples);
 void launch_sample(hipStream_t s, long long first, long long count, int dof, double t_sample, Limits lim, Queries in,
                    Records rec, const unsigned long long* offsets, double* out, unsigned long long capacity,
-                   int flags, unsigned long long* stamps = nullptr);
+                   int flags, int max_samples, unsigned long long* stamps = nullptr);
+void launch_replan_states(hipStream_t s, long long first, long long count, int dof, int max_samples, Queries in, Records rec,
+                          const unsigned long long* offsets, const double* tile, const int* sample_index, int uniform_index,
+                          double* q_0, double* v_0, double* a_0, long long sq, long long sj);
 void launch_generate(hipStream_t s, long long n, int dof, Limits lim, unsigned long long seed, long long first_query,
                      double* q_goal, double* q_0, double* v_0, double* a_0, long long sq, long long sj);
 

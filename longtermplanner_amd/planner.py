@@ -104,6 +104,13 @@ class LongTermPlanner:
     def setDoF(self, dof):
         self._check(self._lib.ltp_set_dof(self._h, int(dof)))
 
+    def setMaxSamples(self, max_samples):
+        """NEW: store only the first max_samples samples of every trajectory; 0 = all (reference)."""
+        self._check(self._lib.ltp_set_max_samples(self._h, int(max_samples)))
+
+    def storedSamples(self, traj_len):
+        return self._lib.ltp_stored_samples(self._h, int(traj_len))
+
     @property
     def dof(self):
         return self._lib.ltp_get_dof(self._h)
@@ -237,6 +244,22 @@ class LongTermPlanner:
         rec = batch.c_records()
         self._check(self._lib.ltp_sample_batch(self._h, first, count, C.byref(batch.queries), C.byref(rec), batch.offsets.data_ptr(),
                                                out.data_ptr(), out.numel(), (1 if streaming else 0) | (2 if dry else 0) | (int(spread) << 8), self._stream()))
+
+    def replanStates(self, batch: DeviceBatch, first, count, tile, sample_index, layout="query_major"):
+        """NEW: start states (q_0, v_0, a_0) of the next plans = sample k of the trajectories that
+        sampleBatch(batch, first, count, tile) wrote. sample_index: int or int32 CUDA tensor [count]."""
+        import torch
+        D = self.dof
+        shape = (count, D) if layout == "query_major" else (D, count)
+        sq, sj = (D, 1) if layout == "query_major" else (1, count)
+        out = [torch.empty(shape, dtype=torch.float64, device=tile.device) for _ in range(3)]
+        rec = batch.c_records()
+        per_plan = None if isinstance(sample_index, int) else sample_index
+        self._check(self._lib.ltp_replan_states_batch(self._h, first, count, C.byref(batch.queries), C.byref(rec), batch.offsets.data_ptr(),
+                                                      tile.data_ptr(), per_plan.data_ptr() if per_plan is not None else None,
+                                                      sample_index if per_plan is None else 0, *[x.data_ptr() for x in out], sq, sj,
+                                                      self._stream()))
+        return out
 
     # ---- diagnostics for the parity tests ----
     def debugMathProbe(self, x, y):

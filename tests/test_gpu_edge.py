@@ -164,3 +164,73 @@ def test_layouts_chunking_overflow_and_determinism(amd, ref7):
     fits = (off[1:] - off[0]) <= cap
     assert np.array_equal((st & amd.STATUS_OVERFLOW) != 0, ~fits & (b1.traj_len.cpu().numpy() > 0))
     assert torch.all(guard[cap:] == 7.0)
+
+
+def test_first_n_samples_and_replanning(amd, ref7, oracle_mod):
+    # "first N samples only" rows and the on-device receding-horizon gather
+    import torch
+    D, lim, ltp, orc = ref7
+    n, cap, k = 500, 200, 150
+    qm = ltp.generateQueries(n, seed=9)
+    b = ltp.planSwitchTimesBatch(*qm)
+    torch.cuda.synchronize()
+    off_full = b.offsets.cpu().numpy().view(np.uint64).copy()
+    full = torch.zeros(int(off_full[-1]), dtype=torch.float64, device="cuda")
+    ltp.sampleBatch(b, 0, n, full)
+    torch.cuda.synchronize()
+    status_full = b.status.cpu().numpy().copy()
+    lens = b.traj_len.cpu().numpy()
+    try:
+        ltp.setMaxSamples(cap)
+        b2 = ltp.planSwitchTimesBatch(*qm)
+        torch.cuda.synchronize()
+        assert torch.equal(b2.traj_len, b.traj_len), "traj_len keeps the reference's Trajectory::length"
+        off_cap = b2.offsets.cpu().numpy().view(np.uint64)
+        stored = np.minimum(lens, cap)
+        assert np.array_equal(np.diff(off_cap.astype(np.int64)), 4 * D * ((stored + 15) // 16 * 16) * (lens > 0))
+        capped = torch.zeros(int(off_cap[-1]), dtype=torch.float64, device="cuda")
+        ltp.sampleBatch(b2, 0, n, capped)
+        torch.cuda.synchronize()
+        assert np.array_equal(b2.status.cpu().numpy(), status_full), "the end-limit check still sees the whole trajectory"
+        hf, hc = full.cpu().numpy(), capped.cpu().numpy()
+        for p in range(0, n, 7):
+            if lens[p] <= 0:
+                continue
+            want = amd.unpack_trajectory(hf, int(off_full[p]), D, int(lens[p]))
+            got = amd.unpack_trajectory(hc, int(off_cap[p]), D, int(stored[p]))
+            for w, g in zip(want, got):
+                assert np.array_equal(w[:, : stored[p]], g)
+        # receding horizon: state at sample k of every capped trajectory, gathered on the device
+        q1, v1, a1 = ltp.replanStates(b2, 0, n, capped, k)
+        idx = torch.randint(0, cap, (n,), dtype=torch.int32, device="cuda")
+        q2, v2, a2 = ltp.replanStates(b2, 0, n, capped, idx, layout="joint_major")
+        torch.cuda.synchronize()
+        hi = idx.cpu().numpy()
+        for p in range(0, n, 5):
+            if lens[p] <= 0:
+                for t1, src in ((q1, qm[1]), (v1, qm[2]), (a1, qm[3])):
+                    assert torch.equal(t1[p], src[p])
+                continue
+            q, v, a, _ = amd.unpack_trajectory(hc, int(off_cap[p]), D, int(stored[p]))
+            kk = min(k, stored[p] - 1)
+            assert np.array_equal(q1[p].cpu().numpy(), q[:, kk]) and np.array_equal(v1[p].cpu().numpy(), v[:, kk])
+            assert np.array_equal(a1[p].cpu().numpy(), a[:, kk])
+            k2 = min(int(hi[p]), stored[p] - 1)
+            assert np.array_equal(q2[:, p].cpu().numpy(), q[:, k2]) and np.array_equal(a2[:, p].cpu().numpy(), a[:, k2])
+        # and the replanned batch agrees with the oracle replanning from ITS trajectory's sample k
+        b3 = ltp.planSwitchTimesBatch(qm[0], q1, v1, a1)
+        torch.cuda.synchronize()
+        host = [x.cpu().numpy() for x in qm]
+        o = orc.plan_batch(*host, sample=False)
+        for p in range(0, n, 25):
+            if o["status"][p] == 0:
+                continue
+            L, q, v, a, j = orc.get_trajectory(o["t_scaled"][p], o["dir"][p], o["mod"][p], host[1][p], host[2][p], host[3][p], o["v_drive"][p])
+            kk = min(k, min(L, cap) - 1)
+            o2 = orc.plan_batch(host[0][p], q[:, kk], v[:, kk], a[:, kk], sample=False)
+            if o2["status"][0] == 0:
+                assert b3.status[p].item() & 7
+                continue
+            assert np.max(np.abs(b3.t_scaled[p].cpu().numpy() - o2["t_scaled"][0])) <= TOL
+    finally:
+        ltp.setMaxSamples(0)
