@@ -74,6 +74,7 @@ def main():
     ap.add_argument("--t-sample", type=float, default=0.001)
     ap.add_argument("--tile-gib", type=float, default=192.0, help="size of the reused trajectory output tile")
     ap.add_argument("--seed", type=int, default=12345)
+    ap.add_argument("--max-samples", type=int, default=0, help="store only the first N samples per row (0 = whole trajectories, the reference behaviour)")
     ap.add_argument("--switch-only", action="store_true", help="config[1]: stages 1-3 only, no sampling")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--plain-stores", action="store_true", help="sampler uses plain instead of non-temporal stores")
@@ -112,9 +113,21 @@ def main():
     n = args.batch
     # this rank's shard of the global batch: query indices [rank*n, (rank+1)*n), generated on the device
     qg, q0, v0, a0 = ltp.generateQueries(n, seed=args.seed, first_query=rank * n)
+    if args.max_samples:
+        ltp.setMaxSamples(args.max_samples)
     tile = None
     if not args.switch_only:
-        tile = torch.empty(int(args.tile_gib * (1 << 30)) // 8, dtype=torch.float64, device=dev)
+        # one big reused output tile; if this GPU cannot give 192 GiB right now, halve until it can
+        gib = args.tile_gib
+        while tile is None:
+            try:
+                tile = torch.empty(int(gib * (1 << 30)) // 8, dtype=torch.float64, device=dev)
+            except torch.OutOfMemoryError:
+                if gib <= 8:
+                    raise
+                gib /= 2
+                torch.cuda.empty_cache()
+        args.tile_gib = gib
     offsets_pinned = torch.empty(n + 1, dtype=torch.int64, pin_memory=True)
     batch = None
     gather_buf = [torch.empty(n, dtype=torch.float64, device=cdev) for _ in range(world)] if (args.gather and world > 1) else None
@@ -167,7 +180,8 @@ def main():
     # bookkeeping outside the timed region
     status = batch.status.cpu().numpy()
     traj_len = batch.traj_len.cpu().numpy().astype(np.int64)
-    alg_bytes_per_step = int(32 * dof * traj_len.sum())              # 32*D*traj_len per plan
+    stored = np.minimum(traj_len, args.max_samples) if args.max_samples else traj_len
+    alg_bytes_per_step = int(32 * dof * stored.sum())                # 32*D*traj_len per plan (stored samples)
     roofline = None
     if ev_pairs:
         kern_ms = sum(a.elapsed_time(b) for a, b in ev_pairs)
@@ -204,7 +218,8 @@ def main():
             "config": {
                 "workload": (f"{n} x {dof}-DoF queries per GPU per step, limits '{args.limits}', Tsample {args.t_sample} s, "
                              + ("switching times only (stages 1-3)" if args.switch_only else
-                                f"full q/v/a/j sampling into a reused {args.tile_gib} GiB tile ({n_chunks} chunks per step)")),
+                                (f"full q/v/a/j sampling" if not args.max_samples else f"first {args.max_samples} q/v/a/j samples per row")
+                                + f" into a reused {args.tile_gib} GiB tile ({n_chunks} chunks per step)")),
                 "batch_per_gpu": n, "dof": dof, "t_sample": args.t_sample, "limits": args.limits,
                 "sharding": "contiguous query ranges per rank, no data-path collective" + (", RCCL all_gather of t_required" if gather_buf else ""),
                 "plans_ok_frac": round(float((status == 0).mean()), 5),

@@ -126,3 +126,63 @@ def test_device_generator_matches_host(amd, oracle_mod):
         for h, d in zip(host, dev):
             d = d.cpu().numpy()
             assert np.array_equal(h, d if layout == "query_major" else d.T)
+
+
+def test_switch_times_parity_large(amd, oracle_mod):
+    # 400k queries (2.8M joint lanes) per limit set: records must still agree exactly where they are integers and
+    # to 1e-9 where they are times; reports the worst deviation actually seen
+    from concurrent.futures import ThreadPoolExecutor
+    for name in ("panda", "ref"):
+        D, lim, ltp, orc = _mk(amd, oracle_mod, name)
+        n = 400000
+        qg, q0, v0, a0 = amd.generate_queries(n, lim, seed=2026)
+        r = ltp.planBatchHost(qg, q0, v0, a0, sample=False)
+        parts = 16
+        with ThreadPoolExecutor(parts) as ex:
+            outs = list(ex.map(lambda i: orc.plan_batch(qg[i::parts], q0[i::parts], v0[i::parts], a0[i::parts], sample=False), range(parts)))
+        worst = 0.0
+        for i, o in enumerate(outs):
+            sl = slice(i, None, parts)
+            ok = o["status"] != 0
+            assert np.array_equal((r["status"][sl] & 7) == 0, ok)
+            for k in ("slowest", "mod", "dir", "traj_len"):
+                assert np.array_equal(r[k][sl][ok], o[k][ok]), k
+            for k in ("t_opt", "t_scaled", "v_drive", "t_required"):
+                d = np.abs(r[k][sl][ok] - o[k][ok])
+                d = d[np.isfinite(d)]
+                worst = max(worst, float(d.max()))
+        print(f"{name}: worst |device - oracle| over 400k plans = {worst:.3e}")
+        assert worst <= TOL
+
+
+def test_fuzzed_limit_sets(amd, oracle_mod):
+    # random dof, per-joint limits and sample times: the kernels take nothing about the named limit sets for granted
+    rng = np.random.default_rng(99)
+    worst_t, worst_x = 0.0, 0.0
+    for trial in range(24):
+        D = int(rng.integers(1, 13))
+        ts = float(rng.choice([0.001, 0.002, 0.004, 0.01]))
+        v_max = rng.uniform(0.5, 3.0, D)
+        a_max = rng.uniform(1.0, 20.0, D)
+        j_max = a_max * rng.uniform(5.0, 600.0, D)
+        q_hi = rng.uniform(1.0, 3.5, D)
+        lim = dict(q_min=list(-q_hi), q_max=list(q_hi), v_max=list(v_max), a_max=list(a_max), j_max=list(j_max))
+        ltp = amd.LongTermPlanner(D, ts, device=0, **lim)
+        orc = oracle_mod.Oracle(D, ts, **lim)
+        n = 1500
+        qg, q0, v0, a0 = amd.generate_queries(n, lim, seed=1000 + trial)
+        r = ltp.planBatchHost(qg, q0, v0, a0, sample=True)
+        o = orc.plan_batch(qg, q0, v0, a0, sample=True)
+        assert np.array_equal(r["traj_len"], o["traj_len"]), trial
+        assert np.array_equal(r["status"] == 0, o["status"] == 1), trial
+        ran = o["status"] != 0
+        assert np.array_equal(r["slowest"][ran], o["slowest"][ran]) and np.array_equal(r["mod"][ran], o["mod"][ran])
+        d = np.abs(r["t_scaled"][ran] - o["t_scaled"][ran])
+        worst_t = max(worst_t, float(np.nanmax(d)))
+        for p in np.nonzero(ran)[0][::50]:
+            L, q, v, a, j = orc.get_trajectory(o["t_scaled"][p], o["dir"][p], o["mod"][p], q0[p], v0[p], a0[p], o["v_drive"][p])
+            g = amd.unpack_trajectory(r["packed"], int(r["offsets"][p]), D, L)
+            for got, ref in zip(g, (q, v, a, j)):
+                worst_x = max(worst_x, float(np.max(np.abs(got - ref))))
+    print(f"fuzz: worst |dt| {worst_t:.3e}, worst |d(q,v,a,j)| {worst_x:.3e}")
+    assert worst_t <= TOL and worst_x <= TOL
