@@ -28,6 +28,14 @@ struct ltp_planner {
     long long ws_queries = 0;
     double* d_small = nullptr;             // 16 doubles for the one-lane entry points
     unsigned long long* dbg_stamps = nullptr; // diagnostic: per-block start/end stamps of k_sample (caller-owned)
+    // persistent buffers of the small synchronous host-pointer calls (no hipMalloc per call)
+    std::mutex host_mu;
+    unsigned char* d_arena = nullptr;
+    unsigned char* h_arena = nullptr;      // pinned mirror of d_arena
+    size_t arena_bytes = 0;
+    double* d_traj = nullptr;
+    double* h_traj = nullptr;              // pinned
+    size_t traj_doubles = 0;
     std::mutex mu;
     std::string err;
 };
@@ -214,6 +222,10 @@ void ltp_destroy(ltp_planner* p)
     if (p->d_block_sums) (void)hipFree(p->d_block_sums);
     if (p->d_offsets_scratch) (void)hipFree(p->d_offsets_scratch);
     if (p->d_small) (void)hipFree(p->d_small);
+    if (p->d_arena) (void)hipFree(p->d_arena);
+    if (p->h_arena) (void)hipHostFree(p->h_arena);
+    if (p->d_traj) (void)hipFree(p->d_traj);
+    if (p->h_traj) (void)hipHostFree(p->h_traj);
     delete p;
 }
 
@@ -399,6 +411,131 @@ static int download_records(ltp_planner* p, long long n, int dof, const ltp_reco
     return LTP_OK;
 }
 
+// ---- small-batch host path: one persistent device arena + pinned mirror, one H2D and one D2H per call ----
+namespace {
+
+constexpr size_t kSmallHostBytes = 8u << 20;   // batches whose arena fits in 8 MiB take the staged path
+
+struct ArenaLayout {
+    size_t in[4], t_opt, t_scaled, dir, v_drive, t_required, offsets, slowest, traj_len, status, mod, end, rec_begin;
+};
+
+ArenaLayout arena_layout(long long n, int dof)
+{
+    const size_t nd = (size_t)n * dof;
+    ArenaLayout L;
+    size_t o = 0;
+    auto take = [&](size_t bytes) { const size_t at = o; o += (bytes + 15) & ~(size_t)15; return at; };
+    for (int k = 0; k < 4; ++k) L.in[k] = take(sizeof(double) * nd);
+    L.rec_begin = o;
+    L.t_opt = take(sizeof(double) * nd * 7);
+    L.t_scaled = take(sizeof(double) * nd * 7);
+    L.dir = take(sizeof(double) * nd);
+    L.v_drive = take(sizeof(double) * nd);
+    L.t_required = take(sizeof(double) * (size_t)n);
+    L.offsets = take(sizeof(unsigned long long) * ((size_t)n + 1));
+    L.slowest = take(sizeof(int) * (size_t)n);
+    L.traj_len = take(sizeof(int) * (size_t)n);
+    L.status = take(sizeof(int) * (size_t)n);
+    L.mod = take(nd);
+    L.end = o;
+    return L;
+}
+
+int ensure_arena(ltp_planner* p, size_t bytes)
+{
+    if (bytes <= p->arena_bytes) return LTP_OK;
+    if (p->d_arena) LTP_HIP_TRY(p, hipFree(p->d_arena));
+    if (p->h_arena) LTP_HIP_TRY(p, hipHostFree(p->h_arena));
+    p->d_arena = nullptr; p->h_arena = nullptr; p->arena_bytes = 0;
+    const size_t cap = bytes < 65536 ? 65536 : bytes;
+    LTP_HIP_TRY(p, hipMalloc((void**)&p->d_arena, cap));
+    LTP_HIP_TRY(p, hipHostMalloc((void**)&p->h_arena, cap, hipHostMallocDefault));
+    p->arena_bytes = cap;
+    return LTP_OK;
+}
+
+constexpr size_t kPinnedTrajDoubles = (32u << 20) / sizeof(double);   // pinned staging only for small results
+
+int ensure_traj(ltp_planner* p, size_t doubles)
+{
+    if (doubles <= p->traj_doubles) return LTP_OK;
+    if (p->d_traj) LTP_HIP_TRY(p, hipFree(p->d_traj));
+    if (p->h_traj) LTP_HIP_TRY(p, hipHostFree(p->h_traj));
+    p->d_traj = nullptr; p->h_traj = nullptr; p->traj_doubles = 0;
+    LTP_HIP_TRY(p, hipMalloc((void**)&p->d_traj, sizeof(double) * doubles));
+    if (doubles <= kPinnedTrajDoubles) LTP_HIP_TRY(p, hipHostMalloc((void**)&p->h_traj, sizeof(double) * doubles, hipHostMallocDefault));
+    p->traj_doubles = doubles;
+    return LTP_OK;
+}
+
+ltp_records arena_records(unsigned char* base, const ArenaLayout& L)
+{
+    ltp_records r;
+    r.t_opt = (double*)(base + L.t_opt); r.t_scaled = (double*)(base + L.t_scaled); r.dir = (double*)(base + L.dir);
+    r.v_drive = (double*)(base + L.v_drive); r.mod = (signed char*)(base + L.mod); r.t_required = (double*)(base + L.t_required);
+    r.slowest = (int*)(base + L.slowest); r.traj_len = (int*)(base + L.traj_len); r.status = (int*)(base + L.status);
+    return r;
+}
+
+// the staged path of ltp_plan_batch_host; caller holds host_mu
+int plan_batch_host_small(ltp_planner* p, long long n, const double* const (&h_in)[4], const ltp_records* host_records,
+                          unsigned long long* offsets, double** packed)
+{
+    const int dof = p->dof;
+    const size_t nd = (size_t)n * dof;
+    const ArenaLayout L = arena_layout(n, dof);
+    int rc = ensure_arena(p, L.end);
+    if (rc != LTP_OK) return rc;
+    for (int k = 0; k < 4; ++k)
+        if (nd) memcpy(p->h_arena + L.in[k], h_in[k], sizeof(double) * nd);
+    if (L.rec_begin) LTP_HIP_TRY(p, hipMemcpyAsync(p->d_arena, p->h_arena, L.rec_begin, hipMemcpyHostToDevice, nullptr));
+    const ltp_queries dq{(double*)(p->d_arena + L.in[0]), (double*)(p->d_arena + L.in[1]), (double*)(p->d_arena + L.in[2]),
+                         (double*)(p->d_arena + L.in[3]), dof, 1};
+    const ltp_records dr = arena_records(p->d_arena, L);
+    unsigned long long* d_off = (unsigned long long*)(p->d_arena + L.offsets);
+    rc = ltp_plan_switch_times_batch(p, n, &dq, &dr, d_off, nullptr);
+    if (rc != LTP_OK) return rc;
+    LTP_HIP_TRY(p, hipMemcpyAsync(p->h_arena + L.rec_begin, p->d_arena + L.rec_begin, L.end - L.rec_begin, hipMemcpyDeviceToHost, nullptr));
+    LTP_HIP_TRY(p, hipStreamSynchronize(nullptr));
+    const unsigned long long* h_off = (const unsigned long long*)(p->h_arena + L.offsets);
+    if (packed) {
+        const unsigned long long total = h_off[n];
+        rc = ensure_traj(p, (size_t)(total ? total : 2));
+        if (rc != LTP_OK) return rc;
+        // padding between rows is never written by the sampler: make the host copy deterministic
+        LTP_HIP_TRY(p, hipMemsetAsync(p->d_traj, 0, sizeof(double) * (size_t)(total ? total : 2), nullptr));
+        rc = ltp_sample_batch(p, 0, n, &dq, &dr, d_off, p->d_traj, total, 0, nullptr);
+        if (rc != LTP_OK) return rc;
+        double* h = (double*)malloc(sizeof(double) * (size_t)(total ? total : 1));
+        if (!h) return fail(p, LTP_ERR_OUT_OF_MEMORY, "malloc");
+        double* landing = p->h_traj ? p->h_traj : h;   // pinned staging when the result is small
+        hipError_t e = total ? hipMemcpyAsync(landing, p->d_traj, sizeof(double) * (size_t)total, hipMemcpyDeviceToHost, nullptr) : hipSuccess;
+        // the sampler may have set LTP_STATUS_END_LIMIT
+        if (e == hipSuccess) e = hipMemcpyAsync(p->h_arena + L.status, p->d_arena + L.status, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, nullptr);
+        if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+        if (e != hipSuccess) { free(h); return hip_fail(p, e, "trajectory download"); }
+        if (total && landing != h) memcpy(h, landing, sizeof(double) * (size_t)total);
+        *packed = h;
+    }
+    if (offsets) memcpy(offsets, h_off, sizeof(unsigned long long) * ((size_t)n + 1));
+    if (host_records) {
+        const ltp_records hr = arena_records(p->h_arena, L);
+        if (host_records->t_opt) memcpy(host_records->t_opt, hr.t_opt, sizeof(double) * nd * 7);
+        if (host_records->t_scaled) memcpy(host_records->t_scaled, hr.t_scaled, sizeof(double) * nd * 7);
+        if (host_records->dir) memcpy(host_records->dir, hr.dir, sizeof(double) * nd);
+        if (host_records->v_drive) memcpy(host_records->v_drive, hr.v_drive, sizeof(double) * nd);
+        if (host_records->mod) memcpy(host_records->mod, hr.mod, nd);
+        if (host_records->t_required) memcpy(host_records->t_required, hr.t_required, sizeof(double) * (size_t)n);
+        if (host_records->slowest) memcpy(host_records->slowest, hr.slowest, sizeof(int) * (size_t)n);
+        if (host_records->traj_len) memcpy(host_records->traj_len, hr.traj_len, sizeof(int) * (size_t)n);
+        if (host_records->status) memcpy(host_records->status, hr.status, sizeof(int) * (size_t)n);
+    }
+    return LTP_OK;
+}
+
+}  // namespace
+
 int ltp_plan_batch_host(ltp_planner* p, long long n, const double* q_goal, const double* q_0, const double* v_0,
                         const double* a_0, const ltp_records* host_records, unsigned long long* offsets, double** packed)
 {
@@ -411,10 +548,14 @@ int ltp_plan_batch_host(ltp_planner* p, long long n, const double* q_goal, const
     LTP_HIP_TRY(p, hipSetDevice(p->device));
     const int dof = p->dof;
     const size_t nd = (size_t)n * dof;
+    const double* const h_in[4] = {q_goal, q_0, v_0, a_0};
+    if (n > 0 && dof > 0 && arena_layout(n, dof).end <= kSmallHostBytes) {
+        std::lock_guard<std::mutex> hg(p->host_mu);
+        return plan_batch_host_small(p, n, h_in, host_records, offsets, packed);
+    }
     DevRecords dr;
     LTP_HIP_TRY(p, dr.alloc_all(n, dof));
     double* d_in[4] = {nullptr, nullptr, nullptr, nullptr};
-    const double* h_in[4] = {q_goal, q_0, v_0, a_0};
     for (int k = 0; k < 4; ++k) {
         LTP_HIP_TRY(p, dr.alloc(&d_in[k], nd));
         if (nd) LTP_HIP_TRY(p, hipMemcpy(d_in[k], h_in[k], sizeof(double) * nd, hipMemcpyHostToDevice));
@@ -484,15 +625,27 @@ void ltp_free_host(void* ptr) { free(ptr); }
 int ltp_check_inputs_host(ltp_planner* p, const double* q_0, const double* v_0, const double* a_0, int* ok)
 {
     if (!p || !ok) return fail(p, LTP_ERR_INVALID_ARGUMENT, "null argument");
-    // checkInputs is stage 0 of the batched kernel: run one query through it with q_goal = q_0
-    const int dof = p->dof;
-    std::vector<double> topt((size_t)dof * 7 + 1), tsc((size_t)dof * 7 + 1), dir((size_t)dof + 1), vd((size_t)dof + 1);
-    std::vector<signed char> mod((size_t)dof + 1);
-    double tr; int slow, len, st;
-    ltp_records r{topt.data(), tsc.data(), dir.data(), vd.data(), mod.data(), &tr, &slow, &len, &st};
-    const int rc = ltp_plan_batch_host(p, 1, q_0, q_0, v_0, a_0, &r, nullptr, nullptr);
+    int rc;
+    { std::lock_guard<std::mutex> g(p->mu); rc = check_config(p); }
     if (rc != LTP_OK) return rc;
-    *ok = (st & LTP_STATUS_INVALID_INPUT) ? 0 : 1;
+    const int dof = p->dof;
+    if (dof == 0) { *ok = 1; return LTP_OK; }   // the reference's loop over zero joints (cc:72-76)
+    if (!q_0 || !v_0 || !a_0) return fail(p, LTP_ERR_INVALID_ARGUMENT, "null argument");
+    std::lock_guard<std::mutex> hg(p->host_mu);
+    LTP_HIP_TRY(p, hipSetDevice(p->device));
+    const size_t row = ((sizeof(double) * dof) + 15) & ~(size_t)15;
+    rc = ensure_arena(p, 3 * row + 16);
+    if (rc != LTP_OK) return rc;
+    memcpy(p->h_arena, q_0, sizeof(double) * dof);
+    memcpy(p->h_arena + row, v_0, sizeof(double) * dof);
+    memcpy(p->h_arena + 2 * row, a_0, sizeof(double) * dof);
+    LTP_HIP_TRY(p, hipMemcpyAsync(p->d_arena, p->h_arena, 3 * row, hipMemcpyHostToDevice, nullptr));
+    ltp::launch_check_inputs(nullptr, dof, dev_limits(p), (const double*)p->d_arena, (const double*)(p->d_arena + row),
+                             (const double*)(p->d_arena + 2 * row), (int*)(p->d_arena + 3 * row));
+    LTP_HIP_TRY(p, hipGetLastError());
+    LTP_HIP_TRY(p, hipMemcpyAsync(p->h_arena + 3 * row, p->d_arena + 3 * row, sizeof(int), hipMemcpyDeviceToHost, nullptr));
+    LTP_HIP_TRY(p, hipStreamSynchronize(nullptr));
+    *ok = *(const int*)(p->h_arena + 3 * row);
     return LTP_OK;
 }
 

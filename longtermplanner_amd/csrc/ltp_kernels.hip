@@ -874,6 +874,15 @@ k_generate(long long n, int dof, Limits lim, unsigned long long seed, long long 
 // ---------------------------------------------------------------------------------------
 // One-lane mirrors of the protected member functions (for the reference's KAT-style tests).
 // ---------------------------------------------------------------------------------------
+// LongTermPlanner::checkInputs (cc:68-77) for one query
+__global__ void k_check_inputs(int dof, Limits lim, const double* q_0, const double* v_0, const double* a_0, int* ok)
+{
+    int good = 1;
+    for (int j = 0; j < dof; ++j)
+        if (!check_inputs_joint(load_limits(lim, j), q_0[j], v_0[j], a_0[j])) good = 0;
+    *ok = good;
+}
+
 __global__ void k_single_opt_braking(int joint, double t_sample, Limits lim, double v_0, double a_0, double* out)
 {
     const JointLimits L = load_limits(lim, joint);
@@ -1040,6 +1049,10 @@ void launch_generate(hipStream_t s, long long n, int dof, Limits lim, unsigned l
                        q_goal, q_0, v_0, a_0, sq, sj);
 }
 
+void launch_check_inputs(hipStream_t s, int dof, Limits lim, const double* q_0, const double* v_0, const double* a_0, int* ok)
+{
+    hipLaunchKernelGGL(k_check_inputs, dim3(1), dim3(1), 0, s, dof, lim, q_0, v_0, a_0, ok);
+}
 void launch_single_opt_braking(hipStream_t s, int joint, double t_sample, Limits lim, double v_0, double a_0, double* out10)
 {
     hipLaunchKernelGGL(k_single_opt_braking, dim3(1), dim3(1), 0, s, joint, t_sample, lim, v_0, a_0, out10);
