@@ -153,7 +153,8 @@ int ltp_time_scaling_host(ltp_planner* p, int joint, double q_goal, double q_0, 
                           double t_required, double* scaled_t, double* v_drive, char* mod, int* ok, int* accepted_case);
 
 /* ---- diagnostics used by the parity tests ---------------------------------------------------- */
-/* device_buffer (2 x count u64, or NULL to switch off): k_sample block start/end on the 100 MHz wall clock */
+/* device_buffer (3 x count u64, or NULL to switch off): k_sample block start / run tables ready / end on the
+ * 100 MHz wall clock */
 int ltp_debug_set_sample_stamps(ltp_planner* p, unsigned long long* device_buffer);
 /* out[i*8 + {0..7}] = x/y, sqrt|x|, x^3, x^4, x^6, floor(x/y), ceil(x/y), x*y+x computed on the device */
 int ltp_debug_math_probe_host(ltp_planner* p, long long n, const double* x, const double* y, double* out);

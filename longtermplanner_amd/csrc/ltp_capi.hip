@@ -15,6 +15,9 @@ struct ltp_planner {
     double t_sample = 0.001;
     int device = 0;
     int max_samples = 0;                   // 0 = store whole trajectories (reference behaviour)
+    int sample_blocks = 0;                 // resident k_sample blocks on this device (work-queue grid)
+    unsigned long long* d_sample_next = nullptr;   // ring of work-queue heads, one per in-flight sampler launch
+    unsigned sample_next_slot = 0;
     std::vector<double> h_lim[5];          // q_min, q_max, v_max, a_max, j_max as given (any length)
     double* d_lim = nullptr;               // 5 * lim_cap doubles
     int lim_cap = 0;
@@ -108,6 +111,8 @@ int reserve(ltp_planner* p, long long n)
     LTP_HIP_TRY(p, hipSetDevice(p->device));
     if (!p->d_queue_count) LTP_HIP_TRY(p, hipMalloc((void**)&p->d_queue_count, 16 * sizeof(unsigned long long)));
     if (!p->d_small) LTP_HIP_TRY(p, hipMalloc((void**)&p->d_small, sizeof(double) * 16));
+    if (!p->d_sample_next) LTP_HIP_TRY(p, hipMalloc((void**)&p->d_sample_next, sizeof(unsigned long long) * 64));
+    if (p->sample_blocks == 0) p->sample_blocks = ltp::sample_resident_blocks(p->device);
     const long long queue_entries = 16 * ltp::queue_segment(n, p->dof > 0 ? p->dof : 1);
     if (queue_entries > p->ws_queue_entries) {
         if (p->d_queue) LTP_HIP_TRY(p, hipFree(p->d_queue));
@@ -222,6 +227,7 @@ void ltp_destroy(ltp_planner* p)
     if (p->d_block_sums) (void)hipFree(p->d_block_sums);
     if (p->d_offsets_scratch) (void)hipFree(p->d_offsets_scratch);
     if (p->d_small) (void)hipFree(p->d_small);
+    if (p->d_sample_next) (void)hipFree(p->d_sample_next);
     if (p->d_arena) (void)hipFree(p->d_arena);
     if (p->h_arena) (void)hipHostFree(p->h_arena);
     if (p->d_traj) (void)hipFree(p->d_traj);
@@ -326,8 +332,11 @@ int ltp_sample_batch(ltp_planner* p, long long first, long long count, const ltp
     if (rc != LTP_OK) return rc;
     if (count == 0 || p->dof == 0) return LTP_OK;
     LTP_HIP_TRY(p, hipSetDevice(p->device));
+    // each launch gets its own work-queue head from a ring of 64, zeroed in stream order just before the kernel
+    unsigned long long* head = p->d_sample_next + (p->sample_next_slot++ & 63u);
+    LTP_HIP_TRY(p, hipMemsetAsync(head, 0, sizeof(unsigned long long), (hipStream_t)stream));
     ltp::launch_sample((hipStream_t)stream, first, count, p->dof, p->t_sample, dev_limits(p), to_dev(in), to_dev(rec), offsets,
-                       out, capacity, flags, p->max_samples, p->dbg_stamps);
+                       out, capacity, flags, p->max_samples, head, p->sample_blocks, p->dbg_stamps);
     LTP_HIP_TRY(p, hipGetLastError());
     return LTP_OK;
 }

@@ -634,35 +634,28 @@ LTP_DEV void store2(double2_t* dst, double2_t val)
 // then all 256 lanes stream the rows. Blocks are dealt to plans `count/spread` apart (spread = 64 by default):
 // on MI355X a narrow moving write front only reaches ~5.2 TB/s, while blocks that write all over a >= 64 GiB
 // tile at the same time reach the fill-kernel ceiling (~6.6 TB/s) — see DESIGN.md, "What bounds the sampler".
+// The body of one work item = one plan x one group of <= 8 joints. Every thread of the block calls it; all early
+// exits are block-uniform.
 template <bool STREAMING, bool DRY>
-__global__ void __launch_bounds__(kSampleThreads)
-k_sample(long long first, long long count, int dof, double t_sample, Limits lim, Queries in, Records rec,
-         const unsigned long long* __restrict__ offsets, double* __restrict__ out, unsigned long long capacity,
-         unsigned long long* __restrict__ stamps, int spread, int max_samples)
+LTP_DEV void sample_plan(SegTable& tab, long long first, long long local, int group, int dof, double t_sample, const Limits& lim,
+                         const Queries& in, const Records& rec, const unsigned long long* __restrict__ offsets,
+                         double* __restrict__ out, unsigned long long capacity, unsigned long long* __restrict__ stamps,
+                         int max_samples)
 {
-    __shared__ SegTable tab;
-    // Block -> plan map. spread > 1 deals consecutive blocks to plans count/spread apart, so the blocks that are
-    // resident at the same time write all over the output tile instead of one narrow moving front.
-    long long local = blockIdx.x;
-    if (spread > 1) {
-        const long long per = (count + spread - 1) / spread;
-        local = (long long)(blockIdx.x % spread) * per + blockIdx.x / spread;
-    }
-    if (local >= count) return;
     const long long p = first + local;
-    // diagnostic only (stamps == nullptr in every product call): block start/end on the 100 MHz wall clock
-    if (stamps && threadIdx.x == 0 && blockIdx.y == 0) stamps[2 * local] = wall_clock64();
+    // diagnostic only (stamps == nullptr in every product call): start / tables ready / end on the 100 MHz wall clock
+    if (stamps && threadIdx.x == 0 && group == 0) stamps[3 * local] = wall_clock64();
     const int len = rec.traj_len[p];
-    if (len <= 0) return;   // failed / non-finite query: nothing to sample (uniform per block)
+    if (len <= 0) return;   // failed / non-finite query: nothing to sample
     const unsigned long long off0 = offsets[first];
     const unsigned long long rel = offsets[p] - off0;
     const int slen = stored_len(len, max_samples);   // samples actually stored per row
     const unsigned long long stride = ((unsigned long long)slen + (kRowAlign - 1)) / kRowAlign * kRowAlign;
     if (rel + 4ull * dof * stride > capacity) {
-        if (threadIdx.x == 0 && blockIdx.y == 0) atomicOr(&rec.status[p], kStatusOverflow);
+        if (threadIdx.x == 0 && group == 0) atomicOr(&rec.status[p], kStatusOverflow);
         return;
     }
-    const int j0 = blockIdx.y * kSampleJointGroup;
+    const int j0 = group * kSampleJointGroup;
     const int nj = (dof - j0) < kSampleJointGroup ? (dof - j0) : kSampleJointGroup;
     const double Ts = t_sample;
 
@@ -749,6 +742,7 @@ k_sample(long long first, long long count, int dof, double t_sample, Limits lim,
         if (q < lim.q_min[j] || q > lim.q_max[j]) atomicOr(&rec.status[p], kStatusEndLimit);
     }
     __syncthreads();
+    if (stamps && threadIdx.x == 0 && group == 0) stamps[3 * local + 1] = wall_clock64();   // run tables ready
 
     // Streaming: per joint, every lane produces q, v, a and j of two consecutive samples and issues four 16-B
     // stores, i.e. four 1 KiB wave stores into the four rows of that joint. (Measured on MI355X: this runs at
@@ -785,7 +779,40 @@ k_sample(long long first, long long count, int dof, double t_sample, Limits lim,
     }
     if (stamps) {
         __syncthreads();
-        if (threadIdx.x == 0 && blockIdx.y == 0) stamps[2 * local + 1] = wall_clock64();
+        if (threadIdx.x == 0 && group == 0) stamps[3 * local + 2] = wall_clock64();
+    }
+}
+
+// Persistent work-queue form: as many blocks as the chip holds, each pulling (plan, joint group) items from one
+// counter until it runs dry. With static round-robin dispatch the eight XCDs finish their equal shares up to 15 %
+// apart (they do not write to all HBM channels at the same speed), which left a 2-4 ms tail of a 23-29 ms launch at
+// reduced bandwidth; pulling keeps every XCD busy to the end. The counter sees ~20 pulls/us, far below the
+// ~90/us a single word sustains. Exit: every block leaves as soon as it draws an item >= total.
+// Item order: item i -> plan (i % spread) * ceil(count/spread) + i / spread, so blocks that are resident together
+// write all over the output tile (see the comment above sample_plan and DESIGN.md).
+template <bool STREAMING, bool DRY>
+__global__ void __launch_bounds__(kSampleThreads)
+k_sample(long long first, long long count, int dof, double t_sample, Limits lim, Queries in, Records rec,
+         const unsigned long long* __restrict__ offsets, double* __restrict__ out, unsigned long long capacity,
+         unsigned long long* __restrict__ stamps, int spread, int max_samples, unsigned long long* __restrict__ next_item)
+{
+    __shared__ SegTable tab;
+    __shared__ unsigned long long s_item;
+    const int ngroups = (dof + kSampleJointGroup - 1) / kSampleJointGroup;
+    const long long per = (count + spread - 1) / spread;
+    const unsigned long long total = (unsigned long long)per * spread * ngroups;
+    for (;;) {
+        __syncthreads();   // the previous item's LDS tables and s_item are no longer in use
+        if (threadIdx.x == 0) s_item = atomicAdd(next_item, 1ull);
+        __syncthreads();
+        const unsigned long long item = s_item;
+        if (item >= total) break;
+        const int group = (int)(item % ngroups);
+        const long long slot = (long long)(item / ngroups);
+        const long long local = (slot % spread) * per + slot / spread;
+        if (local < count)
+            sample_plan<STREAMING, DRY>(tab, first, local, group, dof, t_sample, lim, in, rec, offsets, out, capacity, stamps,
+                                        max_samples);
     }
 }
 
@@ -1006,21 +1033,31 @@ void launch_offsets(hipStream_t s, long long n, int dof, double t_sample, Record
     hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nb), dim3(256), 0, s, n, dof, max_samples, rec.traj_len, block_sums, offsets);
 }
 
+// how many k_sample blocks the device holds at once (the work-queue grid)
+int sample_resident_blocks(int device)
+{
+    int cus = 0, per_cu = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus <= 0) cus = 256;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_sample<true, false>, kSampleThreads, 0) != hipSuccess || per_cu <= 0) per_cu = 6;
+    return cus * per_cu;
+}
+
 void launch_sample(hipStream_t s, long long first, long long count, int dof, double t_sample, Limits lim, Queries in,
                    Records rec, const unsigned long long* offsets, double* out, unsigned long long capacity,
-                   int flags, int max_samples, unsigned long long* stamps)
+                   int flags, int max_samples, unsigned long long* next_item, int resident_blocks, unsigned long long* stamps)
 {
     if (count <= 0) return;
     int spread = (flags >> 8) & 0xFFFF;
     if (spread == 0) spread = kSampleSpread;
     if ((long long)spread > count) spread = (int)count;
-    long long gx = count;
-    if (spread > 1) gx = ((count + spread - 1) / spread) * spread;
-    const dim3 grid((unsigned)gx, (unsigned)((dof + kSampleJointGroup - 1) / kSampleJointGroup));
+    const int ngroups = (dof + kSampleJointGroup - 1) / kSampleJointGroup;
+    long long blocks = resident_blocks > 0 ? resident_blocks : 1536;
+    if (blocks > count * ngroups) blocks = count * ngroups;
+    const dim3 grid((unsigned)blocks);
     const dim3 block(kSampleThreads);
     // flags bit 0: non-temporal stores; bit 1 (diagnostic): skip the arithmetic and store sample indices, which
     // measures the ceiling of this store pattern; bits 8..23: block interleave factor (0 = default 64, 1 = plan order)
-#define LTP_SAMPLE_CASE(ST, DR) hipLaunchKernelGGL((k_sample<ST, DR>), grid, block, 0, s, first, count, dof, t_sample, lim, in, rec, offsets, out, capacity, stamps, spread, max_samples)
+#define LTP_SAMPLE_CASE(ST, DR) hipLaunchKernelGGL((k_sample<ST, DR>), grid, block, 0, s, first, count, dof, t_sample, lim, in, rec, offsets, out, capacity, stamps, spread, max_samples, next_item)
     switch (flags & 3) {
     case 0: LTP_SAMPLE_CASE(false, false); break;
     case 1: LTP_SAMPLE_CASE(true, false); break;

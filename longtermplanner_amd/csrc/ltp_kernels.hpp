@@ -71,7 +71,9 @@ void launch_offsets(hipStream_t s, long long n, int dof, double t_sample, Record
                     unsigned long long* block_sums, unsigned long long* offsets, bool lens_ready, int max_samples);
 void launch_sample(hipStream_t s, long long first, long long count, int dof, double t_sample, Limits lim, Queries in,
                    Records rec, const unsigned long long* offsets, double* out, unsigned long long capacity,
-                   int flags, int max_samples, unsigned long long* stamps = nullptr);
+                   int flags, int max_samples, unsigned long long* next_item /* zeroed on the same stream */,
+                   int resident_blocks, unsigned long long* stamps = nullptr);
+int sample_resident_blocks(int device);
 void launch_replan_states(hipStream_t s, long long first, long long count, int dof, int max_samples, Queries in, Records rec,
                           const unsigned long long* offsets, const double* tile, const int* sample_index, int uniform_index,
                           double* q_0, double* v_0, double* a_0, long long sq, long long sj);

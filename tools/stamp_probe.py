@@ -11,7 +11,7 @@ b = ltp.planSwitchTimesBatch(qg, q0, v0, a0)
 torch.cuda.synchronize()
 off = b.offsets.cpu().numpy().view(np.uint64)
 tile = torch.empty(int(off[-1]), dtype=torch.float64, device="cuda")
-stamps = torch.zeros(2 * n, dtype=torch.int64, device="cuda")
+stamps = torch.zeros(3 * n, dtype=torch.int64, device="cuda")
 variant = sys.argv[2] if len(sys.argv) > 2 else "0"
 L = b.traj_len.cpu().numpy().astype(np.int64)
 byt = 32 * dof * L
@@ -21,7 +21,10 @@ ltp._lib.ltp_debug_set_sample_stamps(ltp._h, stamps.data_ptr())
 for rep in range(3):
     ltp.sampleBatch(b, 0, n, tile, spread=int(variant))
     torch.cuda.synchronize()
-    st = stamps.cpu().numpy().reshape(n, 2)
+    st3 = stamps.cpu().numpy().reshape(n, 3)
+    st = st3[:, [0, 2]]
+    live = st3[:, 2] > 0
+    print(f"   table build: mean {((st3[live, 1] - st3[live, 0]) / 100).mean():.1f} us of a mean block lifetime {((st3[live, 2] - st3[live, 0]) / 100).mean():.1f} us")
     t0 = st[:, 0].min(); t1 = st[:, 1].max()
     bins = ((st[:, 1] - t0) // 100000).astype(int)
     agg = np.bincount(bins, weights=byt)
