@@ -558,38 +558,54 @@ struct SegTable {
     int start[kSampleJointGroup][kMaxSegments + 1];
     double c[kSampleJointGroup][kMaxSegments][4][4];
     int nseg[kSampleJointGroup];
+    // scratch of the cooperative table build
+    int s[kSampleJointGroup][8];            // sampled switch indices (cc:751-757)
+    double fr[kSampleJointGroup][8];        // fractions lost to sampling (cc:747)
+    double frts[kSampleJointGroup][8];      // fr / Ts
+    double misc[kSampleJointGroup][8];      // dir*j_max, v_drive*dir, q_0, v_0, a_0, mod
+    double Jp[kSampleJointGroup][8];        // jerk of the seven phases (cc:735-744)
+    double corr[kSampleJointGroup][10];     // the nine possible "+=" correction terms (cc:771-807)
+    int cand[kSampleJointGroup][kMaxSegments];
+    double runJ[kSampleJointGroup][kMaxSegments];
+    int runMode[kSampleJointGroup][kMaxSegments];
+    double state[kSampleJointGroup][kMaxSegments][3];
 };
 
-struct JerkPlan {   // everything jerk_at() needs, per joint (registers of the prep lane)
-    int s[7];
-    double Jp[7];
-    double c_s0p1, c_s1, c_s2p1, c_s1_merged, c_s3, c_s4p1, c_s4_merged, c_s5, c_s6p1;
-};
+// candidate cut points: slot 0 is index 0, slot c >= 1 is s[kCutBase[c]] + kCutDelta[c]; every index where the jerk
+// array or a snap rule (cc:815-829) can change is among them
+constexpr int kCutSlots = 20;
+__device__ const signed char kCutBase[kCutSlots] = {0, 0, 0, 0, 1, 1, 2, 2, 2, 3, 3, 3, 4, 4, 4, 5, 5, 6, 6, 6};
+__device__ const signed char kCutDelta[kCutSlots] = {0, 0, 1, 2, 0, 1, 0, 1, 2, -1, 0, 1, 0, 1, 2, 0, 1, 0, 1, 2};
 
-// value of the reference's j_traj[joint][i] after fills and corrections
-LTP_DEV double jerk_at(const JerkPlan& P, int i)
+// value of the reference's j_traj[joint][i] after the seven range fills (cc:759-766, last writer wins) and the up
+// to eight "+=" fractional corrections (cc:768-807), applied in the reference's order. s = sampled switch indices,
+// Jp = jerk of the seven phases, corr = the nine possible correction terms, all in LDS.
+LTP_DEV double jerk_at(const int* s, const double* Jp, const double* corr, int i)
 {
-    const int* s = P.s;
+    const int s0 = s[0], s1 = s[1], s2 = s[2], s3 = s[3], s4 = s[4], s5 = s[5], s6 = s[6];
     double val = 0.0;
-    if (s[0] > 0 && i < s[0]) val = P.Jp[0];
-#pragma unroll
-    for (int k = 1; k < 7; ++k)
-        if (s[k] - s[k - 1] > 0 && i >= s[k - 1] && i < s[k]) val = P.Jp[k];
-    if (s[2] >= s[1]) {
-        if (i == s[0] + 1) val = val + P.c_s0p1;
-        if (s[1] > 0 && i == s[1]) val = val + P.c_s1;
-        if (i == s[2] + 1) val = val + P.c_s2p1;
+    if (s0 > 0 && i < s0) val = Jp[0];
+    if (s1 - s0 > 0 && i >= s0 && i < s1) val = Jp[1];
+    if (s2 - s1 > 0 && i >= s1 && i < s2) val = Jp[2];
+    if (s3 - s2 > 0 && i >= s2 && i < s3) val = Jp[3];
+    if (s4 - s3 > 0 && i >= s3 && i < s4) val = Jp[4];
+    if (s5 - s4 > 0 && i >= s4 && i < s5) val = Jp[5];
+    if (s6 - s5 > 0 && i >= s5 && i < s6) val = Jp[6];
+    if (s2 >= s1) {
+        if (i == s0 + 1) val = val + corr[0];
+        if (s1 > 0 && i == s1) val = val + corr[1];
+        if (i == s2 + 1) val = val + corr[2];
     } else {
-        if (s[1] > 0 && i == s[1]) val = val + P.c_s1_merged;
+        if (s1 > 0 && i == s1) val = val + corr[3];
     }
-    if (s[3] > 0 && i == s[3]) val = val + P.c_s3;
-    if (s[2] - s[0] > 0) {
-        if (i == s[4] + 1) val = val + P.c_s4p1;
+    if (s3 > 0 && i == s3) val = val + corr[4];
+    if (s2 - s0 > 0) {
+        if (i == s4 + 1) val = val + corr[5];
     } else {
-        if (s[4] > 0 && i == s[4]) val = val + P.c_s4_merged;
+        if (s4 > 0 && i == s4) val = val + corr[6];
     }
-    if (s[5] > 0 && i == s[5]) val = val + P.c_s5;
-    if (i == s[6] + 1) val = val + P.c_s6p1;
+    if (s5 > 0 && i == s5) val = val + corr[7];
+    if (i == s6 + 1) val = val + corr[8];
     return val;
 }
 
@@ -630,8 +646,8 @@ LTP_DEV void store2(double2_t* dst, double2_t val)
     else *dst = val;
 }
 
-// One block = one plan (x one group of <= 8 joints): lanes 0..nj-1 build the run tables of their joints in LDS,
-// then all 256 lanes stream the rows. Blocks are dealt to plans `count/spread` apart (spread = 64 by default):
+// One block = one plan (x one group of <= 8 joints): the 256 lanes first build the run tables of the joints in LDS
+// together (32 lanes per joint: one per candidate cut point / run), then stream the rows. Blocks are dealt to plans `count/spread` apart (spread = 64 by default):
 // on MI355X a narrow moving write front only reaches ~5.2 TB/s, while blocks that write all over a >= 64 GiB
 // tile at the same time reach the fill-kernel ceiling (~6.6 TB/s) — see DESIGN.md, "What bounds the sampler".
 // The body of one work item = one plan x one group of <= 8 joints. Every thread of the block calls it; all early
@@ -659,87 +675,112 @@ LTP_DEV void sample_plan(SegTable& tab, long long first, long long local, int gr
     const int nj = (dof - j0) < kSampleJointGroup ? (dof - j0) : kSampleJointGroup;
     const double Ts = t_sample;
 
-    if ((int)threadIdx.x < nj) {
-        const int jl = threadIdx.x, j = j0 + jl;
-        const long long rj = p * dof + j;
+    // ---- cooperative table build: thread t -> joint slot jl = t / 32, slot k = t % 32 ----
+    const int jl = threadIdx.x >> 5, k = threadIdx.x & 31;
+    const bool jact = jl < nj;
+    const int j = j0 + (jact ? jl : 0);
+    const long long rj = p * dof + j;
+    // (1) lane k < 7: one switching time each -> sampled index, lost fraction; lane 7: per-joint scalars
+    if (jact && k < 7) {
+        const double tk = rec.t_scaled[rj * 7 + k];
+        const double fr = tk - Ts * dfloor(tk / Ts);                                   // cc:747
+        tab.fr[jl][k] = fr;
+        tab.frts[jl][k] = fr / Ts;
+        tab.s[jl][k] = (k & 1) ? (int)dceil(tk / Ts) : (int)dfloor(tk / Ts);         // cc:751-757
+    } else if (jact && k == 7) {
         const long long ix = p * in.sq + (long long)j * in.sj;
-        const double* t = rec.t_scaled + rj * 7;
         const double dir = rec.dir[rj];
-        const int mod = rec.mod[rj];
-        const double jm = lim.j_max[j];
-        JerkPlan P;
-        double fr[7];
-        {
-            const double dj = dir * jm;
-            // cc:735-744: profile {1,0,-1,0,-1,0,1}, or {-1,0,1,0,-1,0,1} for the modified profile
-            P.Jp[0] = dj * (mod == 1 ? -1.0 : 1.0);
-            P.Jp[1] = dj * 0.0;
-            P.Jp[2] = dj * (mod == 1 ? 1.0 : -1.0);
-            P.Jp[3] = dj * 0.0;
-            P.Jp[4] = dj * -1.0;
-            P.Jp[5] = dj * 0.0;
-            P.Jp[6] = dj * 1.0;
+        tab.misc[jl][0] = dir * lim.j_max[j];
+        tab.misc[jl][1] = rec.v_drive[rj] * dir;                                       // cc:823
+        tab.misc[jl][2] = in.q_0[ix];
+        tab.misc[jl][3] = in.v_0[ix];
+        tab.misc[jl][4] = in.a_0[ix];
+        tab.misc[jl][5] = (double)rec.mod[rj];
+    }
+    __syncthreads();
+    // (2) lane 8: phase jerks and the nine correction terms of the joint; lanes < 20: one candidate cut point each
+    int cval = -1;
+    if (jact && k == 8) {
+        const double dj = tab.misc[jl][0];
+        const bool modp = tab.misc[jl][5] == 1.0;
+        // cc:735-744: profile {1,0,-1,0,-1,0,1}, or {-1,0,1,0,-1,0,1} for the modified profile
+        const double J0 = dj * (modp ? -1.0 : 1.0), J2 = dj * (modp ? 1.0 : -1.0), J4 = dj * -1.0, J6 = dj * 1.0;
+        tab.Jp[jl][0] = J0; tab.Jp[jl][1] = dj * 0.0; tab.Jp[jl][2] = J2; tab.Jp[jl][3] = dj * 0.0;
+        tab.Jp[jl][4] = J4; tab.Jp[jl][5] = dj * 0.0; tab.Jp[jl][6] = J6;
+        const double* ft = tab.frts[jl];
+        const double d20 = (tab.fr[jl][2] - tab.fr[jl][0]) / Ts;
+        tab.corr[jl][0] = ft[0] * J0;                                   // j[s0+1]   cc:771
+        tab.corr[jl][1] = (1 - ft[1]) * J2;                             // j[s1]     cc:773
+        tab.corr[jl][2] = ft[2] * J2;                                   // j[s2+1]   cc:776
+        tab.corr[jl][3] = ft[0] * J0 + d20 * J2;                        // j[s1]     cc:781 (phase 2 absent)
+        tab.corr[jl][4] = (1 - ft[3]) * J4;                             // j[s3]     cc:787
+        tab.corr[jl][5] = ft[4] * J4;                                   // j[s4+1]   cc:793
+        tab.corr[jl][6] = ft[4] * J4 + ft[0] * J0 + d20 * J2;           // j[s4]     cc:798 (phases 2, 3 absent)
+        tab.corr[jl][7] = (1 - ft[5]) * J6;                             // j[s5]     cc:804
+        tab.corr[jl][8] = ft[6] * J6;                                   // j[s6+1]   cc:807
+    }
+    if (jact && k < kCutSlots) {
+        const int c = k == 0 ? 0 : tab.s[jl][kCutBase[k]] + kCutDelta[k];
+        cval = (k == 0 || (c > 0 && c < len)) ? c : -1;
+        tab.cand[jl][k] = cval;
+    }
+    __syncthreads();
+    // (3) sort + unique by counting: drop duplicates, then position = number of distinct valid values below
+    if (jact && k < kCutSlots) {
+        bool first = cval >= 0;
+        for (int m = 0; m < k; ++m) first = first && tab.cand[jl][m] != cval;
+        tab.runMode[jl][k] = first ? cval : -1;   // runMode doubles as scratch until step (4)
+    }
+    __syncthreads();
+    if (jact && k < kCutSlots) {
+        const bool mine = tab.runMode[jl][k] >= 0;
+        int pos = 0, distinct = 0;
+        for (int m = 0; m < kCutSlots; ++m) {
+            const int cm = tab.runMode[jl][m];
+            if (cm >= 0) { ++distinct; if (cm < cval) ++pos; }
         }
-#pragma unroll
-        for (int k = 0; k < 7; ++k) {
-            const double tk = t[k];
-            fr[k] = tk - Ts * dfloor(tk / Ts);                                   // cc:747
-            P.s[k] = (k & 1) ? (int)dceil(tk / Ts) : (int)dfloor(tk / Ts);       // cc:751-757
-        }
-        // the nine possible correction terms (cc:771-807)
-        P.c_s0p1 = fr[0] / Ts * P.Jp[0];
-        P.c_s1 = (1 - fr[1] / Ts) * P.Jp[2];
-        P.c_s2p1 = fr[2] / Ts * P.Jp[2];
-        P.c_s1_merged = fr[0] / Ts * P.Jp[0] + (fr[2] - fr[0]) / Ts * P.Jp[2];
-        P.c_s3 = (1 - fr[3] / Ts) * P.Jp[4];
-        P.c_s4p1 = fr[4] / Ts * P.Jp[4];
-        P.c_s4_merged = fr[4] / Ts * P.Jp[4] + fr[0] / Ts * P.Jp[0] + (fr[2] - fr[0]) / Ts * P.Jp[2];
-        P.c_s5 = (1 - fr[5] / Ts) * P.Jp[6];
-        P.c_s6p1 = fr[6] / Ts * P.Jp[6];
-
-        const int* s = P.s;
-        const bool phase4 = s[3] - s[2] > 2;                                     // cc:813
-        // candidate cut points: every index where the jerk or a snap rule can change
-        const int cand[19] = {s[0], s[0] + 1, s[0] + 2, s[1], s[1] + 1, s[2], s[2] + 1, s[2] + 2, s[3] - 1, s[3],
-                              s[3] + 1, s[4], s[4] + 1, s[4] + 2, s[5], s[5] + 1, s[6], s[6] + 1, s[6] + 2};
-        int* st = tab.start[jl];
-        int ns = 1;
-        st[0] = 0;
-#pragma unroll
-        for (int c = 0; c < 19; ++c) {
-            const int b = cand[c];
-            if (b > 0 && b < len) {
-                // sorted insert without duplicates (the list is nearly sorted already)
-                int pos = ns;
-                while (pos > 0 && st[pos - 1] > b) --pos;
-                if (!(pos > 0 && st[pos - 1] == b) && ns < kMaxSegments) {
-                    for (int m = ns; m > pos; --m) st[m] = st[m - 1];
-                    st[pos] = b;
-                    ++ns;
-                }
-            }
-        }
-        st[ns] = len;
-        tab.nseg[jl] = ns;
-        const double vsnap = rec.v_drive[rj] * dir;                              // cc:823
-        double a = in.a_0[ix], v = in.v_0[ix], q = in.q_0[ix];                   // state "before sample 0" (cc:810-812)
-        for (int k = 0; k < ns; ++k) {
-            const int b = st[k], e = st[k + 1];
-            int mode = 0;
-            if (b > s[6]) mode |= kModeTail;
-            if (phase4 && b >= s[2] + 1 && b < s[3] - 1) mode |= kModeVSnap;
-            const RunCoef rc = run_coef(mode, jerk_at(P, b), a, v, q, vsnap, Ts);
-#pragma unroll
-            for (int x = 0; x < 4; ++x)
-#pragma unroll
-                for (int y = 0; y < 4; ++y) tab.c[jl][k][x][y] = rc.c[x][y];
+        if (mine) tab.start[jl][pos] = cval;
+        if (k == 0) { tab.start[jl][distinct] = len; tab.nseg[jl] = distinct; }
+    }
+    __syncthreads();
+    // (4) lane k < ns: mode and jerk of run k (independent across runs)
+    const int ns = jact ? tab.nseg[jl] : 0;
+    if (k < ns) {
+        const int b = tab.start[jl][k];
+        const int* sj = tab.s[jl];
+        const bool phase4 = sj[3] - sj[2] > 2;                                         // cc:813
+        int mode = 0;
+        if (b > sj[6]) mode |= kModeTail;
+        if (phase4 && b >= sj[2] + 1 && b < sj[3] - 1) mode |= kModeVSnap;
+        tab.runMode[jl][k] = mode;
+        tab.runJ[jl][k] = jerk_at(sj, tab.Jp[jl], tab.corr[jl], b);
+    }
+    __syncthreads();
+    // (5) lane 0 of the joint: the state before each run (the only serial part), and the end-limit check
+    if (jact && k == 0) {
+        const double vsnap = tab.misc[jl][1];
+        double q = tab.misc[jl][2], v = tab.misc[jl][3], a = tab.misc[jl][4];   // state "before sample 0" (cc:810-812)
+        for (int m = 0; m < ns; ++m) {
+            tab.state[jl][m][0] = a; tab.state[jl][m][1] = v; tab.state[jl][m][2] = q;
+            const RunCoef rc = run_coef(tab.runMode[jl][m], tab.runJ[jl][m], a, v, q, vsnap, Ts);
+            const int cnt = tab.start[jl][m + 1] - tab.start[jl][m];
             // state at the run's last sample = what the streaming loop will store there
-            q = run_eval(rc.c[0], e - b);
-            v = run_eval(rc.c[1], e - b);
-            a = run_eval(rc.c[2], e - b);
+            q = run_eval(rc.c[0], cnt);
+            v = run_eval(rc.c[1], cnt);
+            a = run_eval(rc.c[2], cnt);
         }
         // cc:59-61: q now holds sample len-1
         if (q < lim.q_min[j] || q > lim.q_max[j]) atomicOr(&rec.status[p], kStatusEndLimit);
+    }
+    __syncthreads();
+    // (6) lane k < ns: the 16 coefficients of run k
+    if (k < ns) {
+        const RunCoef rc = run_coef(tab.runMode[jl][k], tab.runJ[jl][k], tab.state[jl][k][0], tab.state[jl][k][1],
+                                    tab.state[jl][k][2], tab.misc[jl][1], Ts);
+#pragma unroll
+        for (int x = 0; x < 4; ++x)
+#pragma unroll
+            for (int y = 0; y < 4; ++y) tab.c[jl][k][x][y] = rc.c[x][y];
     }
     __syncthreads();
     if (stamps && threadIdx.x == 0 && group == 0) stamps[3 * local + 1] = wall_clock64();   // run tables ready
