@@ -534,9 +534,10 @@ k_scan_apply(long long n, int dof, int max_samples, const int* __restrict__ traj
 // The reference integrates a piecewise-constant jerk sample by sample. Here the jerk array of
 // one joint (seven range fills cc:759-766, then up to eight "+=" fractional corrections
 // cc:768-807) is cut at every index where it, or one of the three snap rules (cc:815-829),
-// can change: at most kMaxSegments runs of constant jerk and constant mode. One lane per joint
-// walks those runs once and leaves, per run, the state before its first sample in LDS. After
-// that every sample is independent: within a run that starts after state (a_s, v_s, q_s),
+// can change: at most 20 runs of constant jerk and constant mode. The block builds the list of
+// runs cooperatively, one lane per joint walks the runs once and leaves the state before each
+// run's first sample in LDS, and after that every sample is independent: within a run that
+// starts after state (a_s, v_s, q_s),
 //     a[m] = a_s + m*Ts*J
 //     v[m] = v_s + Ts*(m*a_s + Ts*J*m(m+1)/2)
 //     q[m] = q_s + Ts*(m*v_s + Ts*(a_s*m(m+1)/2 + Ts*J*m(m+1)(m+2)/6))
@@ -646,12 +647,9 @@ LTP_DEV void store2(double2_t* dst, double2_t val)
     else *dst = val;
 }
 
-// One block = one plan (x one group of <= 8 joints): the 256 lanes first build the run tables of the joints in LDS
-// together (32 lanes per joint: one per candidate cut point / run), then stream the rows. Blocks are dealt to plans `count/spread` apart (spread = 64 by default):
-// on MI355X a narrow moving write front only reaches ~5.2 TB/s, while blocks that write all over a >= 64 GiB
-// tile at the same time reach the fill-kernel ceiling (~6.6 TB/s) — see DESIGN.md, "What bounds the sampler".
-// The body of one work item = one plan x one group of <= 8 joints. Every thread of the block calls it; all early
-// exits are block-uniform.
+// One work item = one plan x one group of <= 8 joints. The 256 lanes of the block first build the run tables of
+// those joints in LDS together (32 lanes per joint: one per sampled switching time / candidate cut point / run),
+// then stream the rows. Every thread of the block calls this; all early exits are block-uniform.
 template <bool STREAMING, bool DRY>
 LTP_DEV void sample_plan(SegTable& tab, long long first, long long local, int group, int dof, double t_sample, const Limits& lim,
                          const Queries& in, const Records& rec, const unsigned long long* __restrict__ offsets,
@@ -829,8 +827,9 @@ LTP_DEV void sample_plan(SegTable& tab, long long first, long long local, int gr
 // apart (they do not write to all HBM channels at the same speed), which left a 2-4 ms tail of a 23-29 ms launch at
 // reduced bandwidth; pulling keeps every XCD busy to the end. The counter sees ~20 pulls/us, far below the
 // ~90/us a single word sustains. Exit: every block leaves as soon as it draws an item >= total.
-// Item order: item i -> plan (i % spread) * ceil(count/spread) + i / spread, so blocks that are resident together
-// write all over the output tile (see the comment above sample_plan and DESIGN.md).
+// Item order: item i -> plan (i % spread) * ceil(count/spread) + i / spread (spread = 64 by default), so blocks that
+// are resident together write all over the output tile: on MI355X a narrow moving write front only reaches
+// ~5.2 TB/s while writes spread over a large tile reach the fill-kernel ceiling ("What bounds the sampler").
 template <bool STREAMING, bool DRY>
 __global__ void __launch_bounds__(kSampleThreads)
 k_sample(long long first, long long count, int dof, double t_sample, Limits lim, Queries in, Records rec,
