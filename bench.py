@@ -75,6 +75,7 @@ def main():
     ap.add_argument("--tile-gib", type=float, default=192.0, help="size of the reused trajectory output tile")
     ap.add_argument("--seed", type=int, default=12345)
     ap.add_argument("--max-samples", type=int, default=0, help="store only the first N samples per row (0 = whole trajectories, the reference behaviour)")
+    ap.add_argument("--f32", action="store_true", help="store float32 rows (same binary64 results, rounded once); default float64 as the reference")
     ap.add_argument("--switch-only", action="store_true", help="config[1]: stages 1-3 only, no sampling")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--plain-stores", action="store_true", help="sampler uses plain instead of non-temporal stores")
@@ -121,7 +122,7 @@ def main():
         gib = args.tile_gib
         while tile is None:
             try:
-                tile = torch.empty(int(gib * (1 << 30)) // 8, dtype=torch.float64, device=dev)
+                tile = torch.empty(int(gib * (1 << 30)) // (4 if args.f32 else 8), dtype=torch.float32 if args.f32 else torch.float64, device=dev)
             except torch.OutOfMemoryError:
                 if gib <= 8:
                     raise
@@ -181,7 +182,7 @@ def main():
     status = batch.status.cpu().numpy()
     traj_len = batch.traj_len.cpu().numpy().astype(np.int64)
     stored = np.minimum(traj_len, args.max_samples) if args.max_samples else traj_len
-    alg_bytes_per_step = int(32 * dof * stored.sum())                # 32*D*traj_len per plan (stored samples)
+    alg_bytes_per_step = int((16 if args.f32 else 32) * dof * stored.sum())   # 32*D*traj_len per plan (f64; stored samples)
     roofline = None
     if ev_pairs:
         kern_ms = sum(a.elapsed_time(b) for a, b in ev_pairs)
@@ -213,7 +214,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f64",
+            "dtype": "f64" if not args.f32 else "f64 (rows stored as f32)",
             "data": "synthetic" if not args.dry_sampler else "DIAGNOSTIC dry sampler: NOT a valid result",
             "config": {
                 "workload": (f"{n} x {dof}-DoF queries per GPU per step, limits '{args.limits}', Tsample {args.t_sample} s, "

@@ -83,7 +83,7 @@ int ltp_set_dof(ltp_planner* p, int dof);
 int ltp_get_dof(const ltp_planner* p);
 double ltp_get_sample_time(const ltp_planner* p);
 const char* ltp_last_error(const ltp_planner* p);
-/* rows of the packed trajectory layout are padded to this many doubles */
+/* rows of the packed trajectory layout are padded to this many elements (a multiple of 32) */
 int ltp_row_stride(int stored_samples);
 /* SURVEY.md §8(f).2 "first N samples only": store min(traj_len, max_samples) samples per row (0 = all of them, which
  * is the reference's behaviour and the default). traj_len in the records stays Trajectory::length; offsets, row
@@ -98,8 +98,8 @@ int ltp_stored_samples(const ltp_planner* p, int traj_len);
 /* planTrajectory stages 1-3 for n queries (cc:14-55): checkInputs, optSwitchTimes per joint,
  * slowest-joint reduction, timeScaling per other joint, fallback copy; then traj_len (cc:716-719).
  * offsets (device, [n+1], may be NULL) receives the exclusive scan of the packed trajectory sizes
- * in doubles: plan p occupies [offsets[p], offsets[p+1]) of a packed buffer, laid out
- * [q,v,a,j][joint][ltp_row_stride(traj_len[p])]. */
+ * in elements (doubles, or floats for ltp_sample_batch_f32): plan p occupies [offsets[p], offsets[p+1]) of a packed
+ * buffer, laid out [q,v,a,j][joint][ltp_row_stride(stored samples of p)]. */
 int ltp_plan_switch_times_batch(ltp_planner* p, long long n, const ltp_queries* in, const ltp_records* out,
                                 unsigned long long* offsets, void* stream);
 
@@ -111,6 +111,10 @@ int ltp_plan_switch_times_batch(ltp_planner* p, long long n, const ltp_queries* 
  * written with the default interleave reach the HBM fill ceiling; see DESIGN.md. */
 int ltp_sample_batch(ltp_planner* p, long long first, long long count, const ltp_queries* in, const ltp_records* rec,
                      const unsigned long long* offsets, double* out, unsigned long long capacity, int flags, void* stream);
+/* SURVEY.md §8(f).2 float32 rows: the same binary64 results, rounded once to float when stored. offsets, row strides
+ * and capacity are in ELEMENTS and identical for both formats (rows are padded to 32 elements). */
+int ltp_sample_batch_f32(ltp_planner* p, long long first, long long count, const ltp_queries* in, const ltp_records* rec,
+                         const unsigned long long* offsets, float* out, unsigned long long capacity, int flags, void* stream);
 
 /* SURVEY.md §8(f).1 receding horizon (reference README.md:10-13): start states of the next plans = sample k of the
  * trajectories sampled into `tile` by ltp_sample_batch(first, count, ...). sample_index: device int[count] or NULL
@@ -119,6 +123,9 @@ int ltp_sample_batch(ltp_planner* p, long long first, long long count, const ltp
 int ltp_replan_states_batch(ltp_planner* p, long long first, long long count, const ltp_queries* in, const ltp_records* rec,
                             const unsigned long long* offsets, const double* tile, const int* sample_index, int uniform_index,
                             double* q_0, double* v_0, double* a_0, long long query_stride, long long joint_stride, void* stream);
+int ltp_replan_states_f32_batch(ltp_planner* p, long long first, long long count, const ltp_queries* in, const ltp_records* rec,
+                                const unsigned long long* offsets, const float* tile, const int* sample_index, int uniform_index,
+                                double* q_0, double* v_0, double* a_0, long long query_stride, long long joint_stride, void* stream);
 
 /* Synthetic queries of SURVEY.md §8(d) (distribution of tests/randomConfiguration.m:14-34 with per-joint
  * limits), counter-based: query index first_query+p, so shards of one batch can be generated anywhere. */

@@ -74,6 +74,11 @@ _SIGNATURES = {
     "ltp_plan_switch_times_batch": (C.c_int, [C.c_void_p, C.c_longlong, C.POINTER(Queries), C.POINTER(Records), C.c_void_p, C.c_void_p]),
     "ltp_sample_batch": (C.c_int, [C.c_void_p, C.c_longlong, C.c_longlong, C.POINTER(Queries), C.POINTER(Records), C.c_void_p,
                                    C.c_void_p, C.c_ulonglong, C.c_int, C.c_void_p]),
+    "ltp_sample_batch_f32": (C.c_int, [C.c_void_p, C.c_longlong, C.c_longlong, C.POINTER(Queries), C.POINTER(Records), C.c_void_p,
+                                       C.c_void_p, C.c_ulonglong, C.c_int, C.c_void_p]),
+    "ltp_replan_states_f32_batch": (C.c_int, [C.c_void_p, C.c_longlong, C.c_longlong, C.POINTER(Queries), C.POINTER(Records), C.c_void_p,
+                                              C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong,
+                                              C.c_longlong, C.c_void_p]),
     "ltp_generate_queries_batch": (C.c_int, [C.c_void_p, C.c_longlong, C.c_ulonglong, C.c_longlong, C.c_void_p, C.c_void_p,
                                              C.c_void_p, C.c_void_p, C.c_longlong, C.c_longlong, C.c_void_p]),
     "ltp_plan_batch_host": (C.c_int, [C.c_void_p, C.c_longlong, _dp, _dp, _dp, _dp, C.POINTER(Records), _up, C.POINTER(_dp)]),

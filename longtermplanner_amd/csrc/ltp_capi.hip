@@ -321,8 +321,9 @@ int ltp_plan_switch_times_batch(ltp_planner* p, long long n, const ltp_queries* 
     return LTP_OK;
 }
 
-int ltp_sample_batch(ltp_planner* p, long long first, long long count, const ltp_queries* in, const ltp_records* rec,
-                     const unsigned long long* offsets, double* out, unsigned long long capacity, int flags, void* stream)
+static int sample_batch_any(ltp_planner* p, long long first, long long count, const ltp_queries* in, const ltp_records* rec,
+                            const unsigned long long* offsets, void* out, bool f32, unsigned long long capacity, int flags,
+                            void* stream)
 {
     if (!p || first < 0 || count < 0 || !in || !records_complete(rec) || !offsets || (!out && capacity > 0))
         return fail(p, LTP_ERR_INVALID_ARGUMENT, "null argument");
@@ -336,7 +337,36 @@ int ltp_sample_batch(ltp_planner* p, long long first, long long count, const ltp
     unsigned long long* head = p->d_sample_next + (p->sample_next_slot++ & 63u);
     LTP_HIP_TRY(p, hipMemsetAsync(head, 0, sizeof(unsigned long long), (hipStream_t)stream));
     ltp::launch_sample((hipStream_t)stream, first, count, p->dof, p->t_sample, dev_limits(p), to_dev(in), to_dev(rec), offsets,
-                       out, capacity, flags, p->max_samples, head, p->sample_blocks, p->dbg_stamps);
+                       out, f32, capacity, flags, p->max_samples, head, p->sample_blocks, p->dbg_stamps);
+    LTP_HIP_TRY(p, hipGetLastError());
+    return LTP_OK;
+}
+
+int ltp_sample_batch(ltp_planner* p, long long first, long long count, const ltp_queries* in, const ltp_records* rec,
+                     const unsigned long long* offsets, double* out, unsigned long long capacity, int flags, void* stream)
+{
+    return sample_batch_any(p, first, count, in, rec, offsets, out, false, capacity, flags, stream);
+}
+
+int ltp_sample_batch_f32(ltp_planner* p, long long first, long long count, const ltp_queries* in, const ltp_records* rec,
+                         const unsigned long long* offsets, float* out, unsigned long long capacity, int flags, void* stream)
+{
+    return sample_batch_any(p, first, count, in, rec, offsets, out, true, capacity, flags, stream);
+}
+
+static int replan_states_any(ltp_planner* p, long long first, long long count, const ltp_queries* in, const ltp_records* rec,
+                             const unsigned long long* offsets, const void* tile, bool f32, const int* sample_index,
+                             int uniform_index, double* q_0, double* v_0, double* a_0, long long query_stride,
+                             long long joint_stride, void* stream)
+{
+    if (!p || first < 0 || count < 0 || !in || !records_complete(rec) || !offsets || !tile || !q_0 || !v_0 || !a_0)
+        return fail(p, LTP_ERR_INVALID_ARGUMENT, "null argument");
+    std::lock_guard<std::mutex> g(p->mu);
+    int rc = check_config(p);
+    if (rc != LTP_OK) return rc;
+    LTP_HIP_TRY(p, hipSetDevice(p->device));
+    ltp::launch_replan_states((hipStream_t)stream, first, count, p->dof, p->max_samples, to_dev(in), to_dev(rec), offsets, tile, f32,
+                              sample_index, uniform_index, q_0, v_0, a_0, query_stride, joint_stride);
     LTP_HIP_TRY(p, hipGetLastError());
     return LTP_OK;
 }
@@ -345,16 +375,16 @@ int ltp_replan_states_batch(ltp_planner* p, long long first, long long count, co
                             const unsigned long long* offsets, const double* tile, const int* sample_index, int uniform_index,
                             double* q_0, double* v_0, double* a_0, long long query_stride, long long joint_stride, void* stream)
 {
-    if (!p || first < 0 || count < 0 || !in || !records_complete(rec) || !offsets || !tile || !q_0 || !v_0 || !a_0)
-        return fail(p, LTP_ERR_INVALID_ARGUMENT, "null argument");
-    std::lock_guard<std::mutex> g(p->mu);
-    int rc = check_config(p);
-    if (rc != LTP_OK) return rc;
-    LTP_HIP_TRY(p, hipSetDevice(p->device));
-    ltp::launch_replan_states((hipStream_t)stream, first, count, p->dof, p->max_samples, to_dev(in), to_dev(rec), offsets, tile,
-                              sample_index, uniform_index, q_0, v_0, a_0, query_stride, joint_stride);
-    LTP_HIP_TRY(p, hipGetLastError());
-    return LTP_OK;
+    return replan_states_any(p, first, count, in, rec, offsets, tile, false, sample_index, uniform_index, q_0, v_0, a_0,
+                             query_stride, joint_stride, stream);
+}
+
+int ltp_replan_states_f32_batch(ltp_planner* p, long long first, long long count, const ltp_queries* in, const ltp_records* rec,
+                                const unsigned long long* offsets, const float* tile, const int* sample_index, int uniform_index,
+                                double* q_0, double* v_0, double* a_0, long long query_stride, long long joint_stride, void* stream)
+{
+    return replan_states_any(p, first, count, in, rec, offsets, tile, true, sample_index, uniform_index, q_0, v_0, a_0,
+                             query_stride, joint_stride, stream);
 }
 
 int ltp_generate_queries_batch(ltp_planner* p, long long n, unsigned long long seed, long long first_query,

@@ -7,6 +7,12 @@
 namespace ltp {
 
 typedef double double2_t __attribute__((ext_vector_type(2)));
+typedef float float4_t __attribute__((ext_vector_type(4)));
+
+// 16-byte store unit of an output row: 2 doubles or 4 floats
+template <typename T> struct OutVec;
+template <> struct OutVec<double> { typedef double2_t type; static constexpr int N = 2; };
+template <> struct OutVec<float> { typedef float4_t type; static constexpr int N = 4; };
 
 LTP_DEV JointLimits load_limits(const Limits& lim, int j)
 {
@@ -640,8 +646,8 @@ LTP_DEV double run_eval(const double (&c)[4], int m)
     return c[0] + (c[1] * md + (c[2] * s1 + c[3] * s2));
 }
 
-template <bool STREAMING>
-LTP_DEV void store2(double2_t* dst, double2_t val)
+template <bool STREAMING, typename V>
+LTP_DEV void store16(V* dst, V val)
 {
     if constexpr (STREAMING) __builtin_nontemporal_store(val, dst);
     else *dst = val;
@@ -650,10 +656,10 @@ LTP_DEV void store2(double2_t* dst, double2_t val)
 // One work item = one plan x one group of <= 8 joints. The 256 lanes of the block first build the run tables of
 // those joints in LDS together (32 lanes per joint: one per sampled switching time / candidate cut point / run),
 // then stream the rows. Every thread of the block calls this; all early exits are block-uniform.
-template <bool STREAMING, bool DRY>
+template <bool STREAMING, bool DRY, typename T>
 LTP_DEV void sample_plan(SegTable& tab, long long first, long long local, int group, int dof, double t_sample, const Limits& lim,
                          const Queries& in, const Records& rec, const unsigned long long* __restrict__ offsets,
-                         double* __restrict__ out, unsigned long long capacity, unsigned long long* __restrict__ stamps,
+                         T* __restrict__ out, unsigned long long capacity, unsigned long long* __restrict__ stamps,
                          int max_samples)
 {
     const long long p = first + local;
@@ -783,37 +789,68 @@ LTP_DEV void sample_plan(SegTable& tab, long long first, long long local, int gr
     __syncthreads();
     if (stamps && threadIdx.x == 0 && group == 0) stamps[3 * local + 1] = wall_clock64();   // run tables ready
 
-    // Streaming: per joint, every lane produces q, v, a and j of two consecutive samples and issues four 16-B
-    // stores, i.e. four 1 KiB wave stores into the four rows of that joint. (Measured on MI355X: this runs at
-    // the same rate as the identical store pattern without any arithmetic; deeper unrolling or writing the rows
-    // one after the other is slower.)
-    double* const plan_base = out + rel;
+    // Streaming: per joint, every lane produces q, v, a and j of N consecutive samples (N = 2 doubles or 4 floats)
+    // and issues four 16-B stores, i.e. four 1 KiB wave stores into the four rows of that joint. (Measured on
+    // MI355X: this runs at the same rate as the identical store pattern without any arithmetic; deeper unrolling or
+    // writing the rows one after the other is slower.) float rows hold the binary64 results rounded once.
+    typedef typename OutVec<T>::type V;
+    constexpr int N = OutVec<T>::N;
+    T* const plan_base = out + rel;
     const unsigned long long arr_stride = (unsigned long long)dof * stride;   // distance between q, v, a, j blocks
-    const int npairs = (slen + 1) >> 1;
-    for (int jl = 0; jl < nj; ++jl) {
-        double* const row = plan_base + (unsigned long long)(j0 + jl) * stride;
-        const int* st = tab.start[jl];
-        const int ns = tab.nseg[jl];
-        int k = 0;
-        for (int pr = threadIdx.x; pr < npairs; pr += kSampleThreads) {
-            const int i0 = 2 * pr, i1 = i0 + 1;
-            double2_t o[4];
+    const int nslots = (slen + N - 1) / N;
+    for (int jl2 = 0; jl2 < nj; ++jl2) {
+        T* const row = plan_base + (unsigned long long)(j0 + jl2) * stride;
+        const int* st = tab.start[jl2];
+        const int nruns = tab.nseg[jl2];
+        // run cursor of this lane: samples [cur, nxt) belong to run kr (nxt = INT_MAX for the last run)
+        int kr = 0, cur = 0, nxt = nruns > 1 ? st[1] : 0x7fffffff;
+        for (int slot = threadIdx.x; slot < nslots; slot += kSampleThreads) {
+            const int i0 = N * slot;
+            V o[4];
             if constexpr (DRY) {
-                o[0] = o[1] = o[2] = o[3] = double2_t{(double)i0, (double)i1};
-            } else {
-                while (k + 1 < ns && st[k + 1] <= i0) ++k;
-                const int k1 = (k + 1 < ns && st[k + 1] <= i1) ? k + 1 : k;
-                const int m0 = i0 - st[k] + 1, m1 = i1 - st[k1] + 1;
-                const bool pad = i1 >= slen;   // odd length: second half of the last slot is row padding
 #pragma unroll
-                for (int x = 0; x < 4; ++x) {
-                    const double x0 = run_eval(tab.c[jl][k][x], m0);
-                    const double x1 = run_eval(tab.c[jl][k1][x], m1);
-                    o[x] = double2_t{x0, pad ? 0.0 : x1};
+                for (int x = 0; x < 4; ++x)
+#pragma unroll
+                    for (int h = 0; h < N; ++h) o[x][h] = (T)(i0 + h);
+            } else {
+                while (nxt <= i0) {
+                    ++kr;
+                    cur = nxt;
+                    nxt = kr + 1 < nruns ? st[kr + 1] : 0x7fffffff;
+                }
+                if (i0 + N - 1 < nxt) {
+                    // common case: the N samples of this slot lie in one run -> its 16 coefficients are read once
+                    double c[4][4];
+#pragma unroll
+                    for (int x = 0; x < 4; ++x)
+#pragma unroll
+                        for (int y = 0; y < 4; ++y) c[x][y] = tab.c[jl2][kr][x][y];
+#pragma unroll
+                    for (int h = 0; h < N; ++h) {
+                        const int i = i0 + h;
+                        const bool pad = i >= slen;   // the tail of the last slot is row padding
+#pragma unroll
+                        for (int x = 0; x < 4; ++x) o[x][h] = pad ? (T)0 : (T)run_eval(c[x], i - cur + 1);
+                    }
+                } else {
+                    // a run boundary inside the slot (at most ~20 slots per row)
+                    int kh = kr, ch = cur, nh = nxt;
+#pragma unroll
+                    for (int h = 0; h < N; ++h) {
+                        const int i = i0 + h;
+                        if (nh <= i) {   // consecutive samples: at most one run further
+                            ++kh;
+                            ch = nh;
+                            nh = kh + 1 < nruns ? st[kh + 1] : 0x7fffffff;
+                        }
+                        const bool pad = i >= slen;
+#pragma unroll
+                        for (int x = 0; x < 4; ++x) o[x][h] = pad ? (T)0 : (T)run_eval(tab.c[jl2][kh][x], i - ch + 1);
+                    }
                 }
             }
 #pragma unroll
-            for (int x = 0; x < 4; ++x) store2<STREAMING>(reinterpret_cast<double2_t*>(row + x * arr_stride + i0), o[x]);
+            for (int x = 0; x < 4; ++x) store16<STREAMING>(reinterpret_cast<V*>(row + x * arr_stride + i0), o[x]);
         }
     }
     if (stamps) {
@@ -830,10 +867,10 @@ LTP_DEV void sample_plan(SegTable& tab, long long first, long long local, int gr
 // Item order: item i -> plan (i % spread) * ceil(count/spread) + i / spread (spread = 64 by default), so blocks that
 // are resident together write all over the output tile: on MI355X a narrow moving write front only reaches
 // ~5.2 TB/s while writes spread over a large tile reach the fill-kernel ceiling ("What bounds the sampler").
-template <bool STREAMING, bool DRY>
+template <bool STREAMING, bool DRY, typename T>
 __global__ void __launch_bounds__(kSampleThreads)
 k_sample(long long first, long long count, int dof, double t_sample, Limits lim, Queries in, Records rec,
-         const unsigned long long* __restrict__ offsets, double* __restrict__ out, unsigned long long capacity,
+         const unsigned long long* __restrict__ offsets, T* __restrict__ out, unsigned long long capacity,
          unsigned long long* __restrict__ stamps, int spread, int max_samples, unsigned long long* __restrict__ next_item)
 {
     __shared__ SegTable tab;
@@ -851,7 +888,7 @@ k_sample(long long first, long long count, int dof, double t_sample, Limits lim,
         const long long slot = (long long)(item / ngroups);
         const long long local = (slot % spread) * per + slot / spread;
         if (local < count)
-            sample_plan<STREAMING, DRY>(tab, first, local, group, dof, t_sample, lim, in, rec, offsets, out, capacity, stamps,
+            sample_plan<STREAMING, DRY, T>(tab, first, local, group, dof, t_sample, lim, in, rec, offsets, out, capacity, stamps,
                                         max_samples);
     }
 }
@@ -860,9 +897,10 @@ k_sample(long long first, long long count, int dof, double t_sample, Limits lim,
 // Receding horizon (reference README.md:10-13): the start state of the next plan is the state
 // at sample k of the previous trajectory, gathered on the device without a host round trip.
 // ---------------------------------------------------------------------------------------
+template <typename T>
 __global__ void __launch_bounds__(256)
 k_replan_states(long long first, long long count, int dof, int max_samples, Queries in, Records rec,
-                const unsigned long long* __restrict__ offsets, const double* __restrict__ tile,
+                const unsigned long long* __restrict__ offsets, const T* __restrict__ tile,
                 const int* __restrict__ sample_index, int uniform_index,
                 double* __restrict__ q_0, double* __restrict__ v_0, double* __restrict__ a_0, long long sq, long long sj)
 {
@@ -883,11 +921,11 @@ k_replan_states(long long first, long long count, int dof, int max_samples, Quer
     int k = sample_index ? sample_index[local] : uniform_index;
     k = k < 0 ? 0 : (k >= slen ? slen - 1 : k);   // beyond the stored samples: the last stored state
     const unsigned long long stride = ((unsigned long long)slen + (kRowAlign - 1)) / kRowAlign * kRowAlign;
-    const double* row = tile + (offsets[p] - offsets[first]) + (unsigned long long)j * stride + k;
+    const T* row = tile + (offsets[p] - offsets[first]) + (unsigned long long)j * stride + k;
     const unsigned long long arr = (unsigned long long)dof * stride;
-    q_0[dst] = row[0];
-    v_0[dst] = row[arr];
-    a_0[dst] = row[2 * arr];
+    q_0[dst] = (double)row[0];
+    v_0[dst] = (double)row[arr];
+    a_0[dst] = (double)row[2 * arr];
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1078,12 +1116,12 @@ int sample_resident_blocks(int device)
 {
     int cus = 0, per_cu = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus <= 0) cus = 256;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_sample<true, false>, kSampleThreads, 0) != hipSuccess || per_cu <= 0) per_cu = 6;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_sample<true, false, double>, kSampleThreads, 0) != hipSuccess || per_cu <= 0) per_cu = 4;
     return cus * per_cu;
 }
 
 void launch_sample(hipStream_t s, long long first, long long count, int dof, double t_sample, Limits lim, Queries in,
-                   Records rec, const unsigned long long* offsets, double* out, unsigned long long capacity,
+                   Records rec, const unsigned long long* offsets, void* out, bool f32, unsigned long long capacity,
                    int flags, int max_samples, unsigned long long* next_item, int resident_blocks, unsigned long long* stamps)
 {
     if (count <= 0) return;
@@ -1097,24 +1135,33 @@ void launch_sample(hipStream_t s, long long first, long long count, int dof, dou
     const dim3 block(kSampleThreads);
     // flags bit 0: non-temporal stores; bit 1 (diagnostic): skip the arithmetic and store sample indices, which
     // measures the ceiling of this store pattern; bits 8..23: block interleave factor (0 = default 64, 1 = plan order)
-#define LTP_SAMPLE_CASE(ST, DR) hipLaunchKernelGGL((k_sample<ST, DR>), grid, block, 0, s, first, count, dof, t_sample, lim, in, rec, offsets, out, capacity, stamps, spread, max_samples, next_item)
-    switch (flags & 3) {
-    case 0: LTP_SAMPLE_CASE(false, false); break;
-    case 1: LTP_SAMPLE_CASE(true, false); break;
-    case 2: LTP_SAMPLE_CASE(false, true); break;
-    default: LTP_SAMPLE_CASE(true, true); break;
+#define LTP_SAMPLE_CASE(ST, DR, TY) hipLaunchKernelGGL((k_sample<ST, DR, TY>), grid, block, 0, s, first, count, dof, t_sample, lim, in, rec, offsets, (TY*)out, capacity, stamps, spread, max_samples, next_item)
+    switch ((flags & 3) | (f32 ? 4 : 0)) {
+    case 0: LTP_SAMPLE_CASE(false, false, double); break;
+    case 1: LTP_SAMPLE_CASE(true, false, double); break;
+    case 2: LTP_SAMPLE_CASE(false, true, double); break;
+    case 3: LTP_SAMPLE_CASE(true, true, double); break;
+    case 4: LTP_SAMPLE_CASE(false, false, float); break;
+    case 5: LTP_SAMPLE_CASE(true, false, float); break;
+    case 6: LTP_SAMPLE_CASE(false, true, float); break;
+    default: LTP_SAMPLE_CASE(true, true, float); break;
     }
 #undef LTP_SAMPLE_CASE
 }
 
 void launch_replan_states(hipStream_t s, long long first, long long count, int dof, int max_samples, Queries in, Records rec,
-                          const unsigned long long* offsets, const double* tile, const int* sample_index, int uniform_index,
+                          const unsigned long long* offsets, const void* tile, bool f32, const int* sample_index, int uniform_index,
                           double* q_0, double* v_0, double* a_0, long long sq, long long sj)
 {
     if (count <= 0 || dof <= 0) return;
     const long long total = count * dof;
-    hipLaunchKernelGGL(k_replan_states, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, first, count, dof, max_samples, in, rec,
-                       offsets, tile, sample_index, uniform_index, q_0, v_0, a_0, sq, sj);
+    const dim3 grid((unsigned)((total + 255) / 256)), block(256);
+    if (f32)
+        hipLaunchKernelGGL(k_replan_states<float>, grid, block, 0, s, first, count, dof, max_samples, in, rec, offsets,
+                           (const float*)tile, sample_index, uniform_index, q_0, v_0, a_0, sq, sj);
+    else
+        hipLaunchKernelGGL(k_replan_states<double>, grid, block, 0, s, first, count, dof, max_samples, in, rec, offsets,
+                           (const double*)tile, sample_index, uniform_index, q_0, v_0, a_0, sq, sj);
 }
 
 void launch_generate(hipStream_t s, long long n, int dof, Limits lim, unsigned long long seed, long long first_query,

@@ -29,7 +29,7 @@ enum : int {
 
 constexpr int kQueriesPerBlock = 64;   // one wave = 64 queries of one joint
 constexpr int kMaxJointSlots = 8;      // blockDim.y of k_switch_times
-constexpr int kRowAlign = 16;          // trajectory rows padded to 16 doubles (128 B)
+constexpr int kRowAlign = 32;          // trajectory rows padded to 32 elements (256 B of doubles, 128 B of floats)
 constexpr int kSampleJointGroup = 8;   // joints handled by one k_sample block
 constexpr int kMaxSegments = 24;       // piecewise-constant jerk segments per joint
 constexpr int kSampleThreads = 256;
@@ -70,12 +70,12 @@ void launch_switch_times(hipStream_t s, long long n, int dof, double t_sample, L
 void launch_offsets(hipStream_t s, long long n, int dof, double t_sample, Records rec,
                     unsigned long long* block_sums, unsigned long long* offsets, bool lens_ready, int max_samples);
 void launch_sample(hipStream_t s, long long first, long long count, int dof, double t_sample, Limits lim, Queries in,
-                   Records rec, const unsigned long long* offsets, double* out, unsigned long long capacity,
+                   Records rec, const unsigned long long* offsets, void* out, bool f32, unsigned long long capacity,
                    int flags, int max_samples, unsigned long long* next_item /* zeroed on the same stream */,
                    int resident_blocks, unsigned long long* stamps = nullptr);
 int sample_resident_blocks(int device);
 void launch_replan_states(hipStream_t s, long long first, long long count, int dof, int max_samples, Queries in, Records rec,
-                          const unsigned long long* offsets, const double* tile, const int* sample_index, int uniform_index,
+                          const unsigned long long* offsets, const void* tile, bool f32, const int* sample_index, int uniform_index,
                           double* q_0, double* v_0, double* a_0, long long sq, long long sj);
 void launch_generate(hipStream_t s, long long n, int dof, Limits lim, unsigned long long seed, long long first_query,
                      double* q_goal, double* q_0, double* v_0, double* a_0, long long sq, long long sj);

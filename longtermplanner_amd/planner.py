@@ -241,9 +241,12 @@ class LongTermPlanner:
     def sampleBatch(self, batch: DeviceBatch, first, count, out, streaming=True, dry=False, spread=0):
         """getTrajectory for plans [first, first+count) into the float64 CUDA tensor `out` (ltp_sample_batch).
         dry=True is a diagnostic: same stores, no arithmetic (ceiling of the store pattern)."""
+        import torch
         rec = batch.c_records()
-        self._check(self._lib.ltp_sample_batch(self._h, first, count, C.byref(batch.queries), C.byref(rec), batch.offsets.data_ptr(),
-                                               out.data_ptr(), out.numel(), (1 if streaming else 0) | (2 if dry else 0) | (int(spread) << 8), self._stream()))
+        fn = self._lib.ltp_sample_batch_f32 if out.dtype == torch.float32 else self._lib.ltp_sample_batch   # float32 tile -> float rows
+        assert out.dtype in (torch.float32, torch.float64)
+        self._check(fn(self._h, first, count, C.byref(batch.queries), C.byref(rec), batch.offsets.data_ptr(),
+                       out.data_ptr(), out.numel(), (1 if streaming else 0) | (2 if dry else 0) | (int(spread) << 8), self._stream()))
 
     def replanStates(self, batch: DeviceBatch, first, count, tile, sample_index, layout="query_major"):
         """NEW: start states (q_0, v_0, a_0) of the next plans = sample k of the trajectories that
@@ -255,10 +258,10 @@ class LongTermPlanner:
         out = [torch.empty(shape, dtype=torch.float64, device=tile.device) for _ in range(3)]
         rec = batch.c_records()
         per_plan = None if isinstance(sample_index, int) else sample_index
-        self._check(self._lib.ltp_replan_states_batch(self._h, first, count, C.byref(batch.queries), C.byref(rec), batch.offsets.data_ptr(),
-                                                      tile.data_ptr(), per_plan.data_ptr() if per_plan is not None else None,
-                                                      sample_index if per_plan is None else 0, *[x.data_ptr() for x in out], sq, sj,
-                                                      self._stream()))
+        fn = self._lib.ltp_replan_states_f32_batch if tile.dtype == torch.float32 else self._lib.ltp_replan_states_batch
+        self._check(fn(self._h, first, count, C.byref(batch.queries), C.byref(rec), batch.offsets.data_ptr(),
+                       tile.data_ptr(), per_plan.data_ptr() if per_plan is not None else None,
+                       sample_index if per_plan is None else 0, *[x.data_ptr() for x in out], sq, sj, self._stream()))
         return out
 
     # ---- diagnostics for the parity tests ----

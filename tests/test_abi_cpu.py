@@ -36,7 +36,7 @@ def test_library_exports_every_declared_symbol(abi):
 def test_row_stride(abi):
     lib = abi.lib()
     assert lib.ltp_row_stride(0) == 0 and lib.ltp_row_stride(-3) == 0
-    assert lib.ltp_row_stride(1) == 16 and lib.ltp_row_stride(16) == 16 and lib.ltp_row_stride(17) == 32
+    assert lib.ltp_row_stride(1) == 32 and lib.ltp_row_stride(32) == 32 and lib.ltp_row_stride(33) == 64
     assert lib.ltp_row_stride(1718) == 1728
 
 

@@ -187,7 +187,7 @@ def test_first_n_samples_and_replanning(amd, ref7, oracle_mod):
         assert torch.equal(b2.traj_len, b.traj_len), "traj_len keeps the reference's Trajectory::length"
         off_cap = b2.offsets.cpu().numpy().view(np.uint64)
         stored = np.minimum(lens, cap)
-        assert np.array_equal(np.diff(off_cap.astype(np.int64)), 4 * D * ((stored + 15) // 16 * 16) * (lens > 0))
+        assert np.array_equal(np.diff(off_cap.astype(np.int64)), 4 * D * ((stored + 31) // 32 * 32) * (lens > 0))
         capped = torch.zeros(int(off_cap[-1]), dtype=torch.float64, device="cuda")
         ltp.sampleBatch(b2, 0, n, capped)
         torch.cuda.synchronize()
@@ -234,3 +234,27 @@ def test_first_n_samples_and_replanning(amd, ref7, oracle_mod):
             assert np.max(np.abs(b3.t_scaled[p].cpu().numpy() - o2["t_scaled"][0])) <= TOL
     finally:
         ltp.setMaxSamples(0)
+
+
+def test_float32_rows_are_the_rounded_float64_rows(amd, ref7):
+    # float rows = the same binary64 results rounded once; offsets are format-independent
+    import torch
+    D, lim, ltp, orc = ref7
+    n = 400
+    qm = ltp.generateQueries(n, seed=17)
+    b = ltp.planSwitchTimesBatch(*qm)
+    torch.cuda.synchronize()
+    total = int(b.offsets[-1].item())
+    f64 = torch.zeros(total, dtype=torch.float64, device="cuda")
+    f32 = torch.zeros(total, dtype=torch.float32, device="cuda")
+    ltp.sampleBatch(b, 0, n, f64)
+    st64 = b.status.clone()
+    ltp.sampleBatch(b, 0, n, f32)
+    torch.cuda.synchronize()
+    assert torch.equal(b.status, st64)
+    assert torch.equal(f32, f64.to(torch.float32)), "float rows must be the double rows rounded to nearest"
+    q1, v1, a1 = ltp.replanStates(b, 0, n, f32, 40)
+    q2, v2, a2 = ltp.replanStates(b, 0, n, f64, 40)
+    torch.cuda.synchronize()
+    live = (b.traj_len > 0)
+    assert torch.equal(q1[live], q2[live].to(torch.float32).to(torch.float64)) and torch.equal(a1[live], a2[live].to(torch.float32).to(torch.float64))

@@ -49,7 +49,7 @@ def test_one_million_plans(oracle_mod):
     want_len = torch.ceil(ts[..., 6] / Ts).max(dim=1).values.int() + 1
     assert torch.equal(b.traj_len[ran], want_len)
     assert torch.all(b.traj_len[~ran] == 0)
-    stride = (b.traj_len.long() + 15) // 16 * 16
+    stride = (b.traj_len.long() + 31) // 32 * 32
     off = b.offsets.cpu().numpy().view(np.uint64)
     assert np.array_equal(np.diff(off.astype(np.int64)), (4 * D * stride).cpu().numpy())
 

@@ -61,7 +61,7 @@ def test_chunk_bounds_cover_every_plan_once():
 
 def test_unpack_trajectory_layout():
     from longtermplanner_amd import unpack_trajectory
-    dof, length, stride = 3, 20, 32
+    dof, length, stride = 3, 20, 32   # ltp_row_stride(20)
     packed = np.arange(1000, dtype=np.float64)
     q, v, a, j = unpack_trajectory(packed, 100, dof, length)
     assert q.shape == (dof, length)
