@@ -680,6 +680,9 @@ LTP_DEV void sample_plan(SegTable& tab, long long first, long long local, int gr
     const double Ts = t_sample;
 
     // ---- cooperative table build: thread t -> joint slot jl = t / 32, slot k = t % 32 ----
+    // The build is a short, latency-bound prologue that shares its SIMDs with other blocks' streaming waves:
+    // give it issue priority, the bandwidth-bound streaming loop runs at the default priority.
+    __builtin_amdgcn_s_setprio(3);
     const int jl = threadIdx.x >> 5, k = threadIdx.x & 31;
     const bool jact = jl < nj;
     const int j = j0 + (jact ? jl : 0);
@@ -732,13 +735,15 @@ LTP_DEV void sample_plan(SegTable& tab, long long first, long long local, int gr
     // (3) sort + unique by counting: drop duplicates, then position = number of distinct valid values below
     if (jact && k < kCutSlots) {
         bool first = cval >= 0;
-        for (int m = 0; m < k; ++m) first = first && tab.cand[jl][m] != cval;
+#pragma unroll
+        for (int m = 0; m < kCutSlots; ++m) first = first && (m >= k || tab.cand[jl][m] != cval);   // fixed trip count: loads pipeline
         tab.runMode[jl][k] = first ? cval : -1;   // runMode doubles as scratch until step (4)
     }
     __syncthreads();
     if (jact && k < kCutSlots) {
         const bool mine = tab.runMode[jl][k] >= 0;
         int pos = 0, distinct = 0;
+#pragma unroll
         for (int m = 0; m < kCutSlots; ++m) {
             const int cm = tab.runMode[jl][m];
             if (cm >= 0) { ++distinct; if (cm < cval) ++pos; }
@@ -764,6 +769,7 @@ LTP_DEV void sample_plan(SegTable& tab, long long first, long long local, int gr
     if (jact && k == 0) {
         const double vsnap = tab.misc[jl][1];
         double q = tab.misc[jl][2], v = tab.misc[jl][3], a = tab.misc[jl][4];   // state "before sample 0" (cc:810-812)
+#pragma unroll 4
         for (int m = 0; m < ns; ++m) {
             tab.state[jl][m][0] = a; tab.state[jl][m][1] = v; tab.state[jl][m][2] = q;
             const RunCoef rc = run_coef(tab.runMode[jl][m], tab.runJ[jl][m], a, v, q, vsnap, Ts);
@@ -787,6 +793,7 @@ LTP_DEV void sample_plan(SegTable& tab, long long first, long long local, int gr
             for (int y = 0; y < 4; ++y) tab.c[jl][k][x][y] = rc.c[x][y];
     }
     __syncthreads();
+    __builtin_amdgcn_s_setprio(0);
     if (stamps && threadIdx.x == 0 && group == 0) stamps[3 * local + 1] = wall_clock64();   // run tables ready
 
     // Streaming: per joint, every lane produces q, v, a and j of N consecutive samples (N = 2 doubles or 4 floats)
