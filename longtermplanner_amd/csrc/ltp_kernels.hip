@@ -553,17 +553,20 @@ k_scan_apply(long long n, int dof, int max_samples, const int* __restrict__ traj
 constexpr int kModeTail = 1;    // i > s6: a = 0, v = 0 (cc:815-829)
 constexpr int kModeVSnap = 2;   // phase 4 interior: v = v_drive*dir (cc:822-823)
 
-// Inside one run, with m = 1-based position in the run, S1 = m(m+1)/2 and S2 = m(m+1)(m+2)/6, every
-// output row is  x(m) = c0 + (c1*m + (c2*S1 + c3*S2)):
-//   q: {q_s, Ts*v_s, Ts*Ts*a_s, Ts*Ts*Ts*J}   v: {v_s, Ts*a_s, Ts*Ts*J, 0}   a: {a_s, Ts*J, 0, 0}   j: {J, 0, 0, 0}
+// Inside one run, with m = 1-based position in the run, S1 = m(m+1)/2 and S2 = m(m+1)(m+2)/6:
+//   q(m) = q0 + (q1*m + (q2*S1 + q3*S2))   {q_s, Ts*v_s, Ts*Ts*a_s, Ts*Ts*Ts*J}
+//   v(m) = v0 + (v1*m + v2*S1)             {v_s, Ts*a_s, Ts*Ts*J}
+//   a(m) = a0 + a1*m                       {a_s, Ts*J}
+//   j(m) = J
 // and the three snap rules of cc:815-829 only change coefficients, so the streaming loop is branch-free.
+constexpr int kRunCoefs = 10;   // q0..q3, v0..v2, a0, a1, J
 struct RunCoef {
-    double c[4][4];   // [q, v, a, j][c0..c3]
+    double c[kRunCoefs];
 };
 
 struct SegTable {
     int start[kSampleJointGroup][kMaxSegments + 1];
-    double c[kSampleJointGroup][kMaxSegments][4][4];
+    double c[kSampleJointGroup][kMaxSegments][kRunCoefs];
     int nseg[kSampleJointGroup];
     // scratch of the cooperative table build
     int s[kSampleJointGroup][8];            // sampled switch indices (cc:751-757)
@@ -621,29 +624,31 @@ LTP_DEV RunCoef run_coef(int mode, double J, double a_s, double v_s, double q_s,
 {
     RunCoef r;
 #pragma unroll
-    for (int x = 0; x < 4; ++x)
-#pragma unroll
-        for (int y = 0; y < 4; ++y) r.c[x][y] = 0.0;
+    for (int x = 0; x < kRunCoefs; ++x) r.c[x] = 0.0;
     const double tj = Ts * J;
-    r.c[3][0] = J;
-    if (!(mode & kModeTail)) { r.c[2][0] = a_s; r.c[2][1] = tj; }
-    r.c[0][0] = q_s;
+    r.c[9] = J;
+    if (!(mode & kModeTail)) { r.c[7] = a_s; r.c[8] = tj; }
+    r.c[0] = q_s;
     if (mode & kModeVSnap) {
-        r.c[1][0] = vsnap;
-        r.c[0][1] = Ts * vsnap;
+        r.c[4] = vsnap;
+        r.c[1] = Ts * vsnap;
     } else if (!(mode & kModeTail)) {
-        r.c[1][0] = v_s; r.c[1][1] = Ts * a_s; r.c[1][2] = Ts * tj;
-        r.c[0][1] = Ts * v_s; r.c[0][2] = Ts * (Ts * a_s); r.c[0][3] = Ts * (Ts * tj);
+        r.c[4] = v_s; r.c[5] = Ts * a_s; r.c[6] = Ts * tj;
+        r.c[1] = Ts * v_s; r.c[2] = Ts * (Ts * a_s); r.c[3] = Ts * (Ts * tj);
     }
     return r;
 }
 
-LTP_DEV double run_eval(const double (&c)[4], int m)
+// the four outputs at position m of a run; the streaming loop and the state propagation both use exactly this
+LTP_DEV void run_eval(const double (&c)[kRunCoefs], int m, double& q, double& v, double& a, double& j)
 {
     const double md = (double)m;
     const double s1 = 0.5 * (md * (md + 1.0));
     const double s2 = s1 * (md + 2.0) * (1.0 / 3.0);
-    return c[0] + (c[1] * md + (c[2] * s1 + c[3] * s2));
+    q = c[0] + (c[1] * md + (c[2] * s1 + c[3] * s2));
+    v = c[4] + (c[5] * md + c[6] * s1);
+    a = c[7] + c[8] * md;
+    j = c[9];
 }
 
 template <bool STREAMING, typename V>
@@ -775,9 +780,8 @@ LTP_DEV void sample_plan(SegTable& tab, long long first, long long local, int gr
             const RunCoef rc = run_coef(tab.runMode[jl][m], tab.runJ[jl][m], a, v, q, vsnap, Ts);
             const int cnt = tab.start[jl][m + 1] - tab.start[jl][m];
             // state at the run's last sample = what the streaming loop will store there
-            q = run_eval(rc.c[0], cnt);
-            v = run_eval(rc.c[1], cnt);
-            a = run_eval(rc.c[2], cnt);
+            double jj;
+            run_eval(rc.c, cnt, q, v, a, jj);
         }
         // cc:59-61: q now holds sample len-1
         if (q < lim.q_min[j] || q > lim.q_max[j]) atomicOr(&rec.status[p], kStatusEndLimit);
@@ -788,9 +792,7 @@ LTP_DEV void sample_plan(SegTable& tab, long long first, long long local, int gr
         const RunCoef rc = run_coef(tab.runMode[jl][k], tab.runJ[jl][k], tab.state[jl][k][0], tab.state[jl][k][1],
                                     tab.state[jl][k][2], tab.misc[jl][1], Ts);
 #pragma unroll
-        for (int x = 0; x < 4; ++x)
-#pragma unroll
-            for (int y = 0; y < 4; ++y) tab.c[jl][k][x][y] = rc.c[x][y];
+        for (int x = 0; x < kRunCoefs; ++x) tab.c[jl][k][x] = rc.c[x];
     }
     __syncthreads();
     __builtin_amdgcn_s_setprio(0);
@@ -826,18 +828,18 @@ LTP_DEV void sample_plan(SegTable& tab, long long first, long long local, int gr
                     nxt = kr + 1 < nruns ? st[kr + 1] : 0x7fffffff;
                 }
                 if (i0 + N - 1 < nxt) {
-                    // common case: the N samples of this slot lie in one run -> its 16 coefficients are read once
-                    double c[4][4];
+                    // common case: the N samples of this slot lie in one run -> its coefficients are read once
+                    double c[kRunCoefs];
 #pragma unroll
-                    for (int x = 0; x < 4; ++x)
-#pragma unroll
-                        for (int y = 0; y < 4; ++y) c[x][y] = tab.c[jl2][kr][x][y];
+                    for (int x = 0; x < kRunCoefs; ++x) c[x] = tab.c[jl2][kr][x];
 #pragma unroll
                     for (int h = 0; h < N; ++h) {
                         const int i = i0 + h;
                         const bool pad = i >= slen;   // the tail of the last slot is row padding
+                        double x4[4];
+                        run_eval(c, i - cur + 1, x4[0], x4[1], x4[2], x4[3]);
 #pragma unroll
-                        for (int x = 0; x < 4; ++x) o[x][h] = pad ? (T)0 : (T)run_eval(c[x], i - cur + 1);
+                        for (int x = 0; x < 4; ++x) o[x][h] = pad ? (T)0 : (T)x4[x];
                     }
                 } else {
                     // a run boundary inside the slot (at most ~20 slots per row)
@@ -851,8 +853,10 @@ LTP_DEV void sample_plan(SegTable& tab, long long first, long long local, int gr
                             nh = kh + 1 < nruns ? st[kh + 1] : 0x7fffffff;
                         }
                         const bool pad = i >= slen;
+                        double x4[4];
+                        run_eval(tab.c[jl2][kh], i - ch + 1, x4[0], x4[1], x4[2], x4[3]);
 #pragma unroll
-                        for (int x = 0; x < 4; ++x) o[x][h] = pad ? (T)0 : (T)run_eval(tab.c[jl2][kh][x], i - ch + 1);
+                        for (int x = 0; x < 4; ++x) o[x][h] = pad ? (T)0 : (T)x4[x];
                     }
                 }
             }
@@ -875,7 +879,7 @@ LTP_DEV void sample_plan(SegTable& tab, long long first, long long local, int gr
 // are resident together write all over the output tile: on MI355X a narrow moving write front only reaches
 // ~5.2 TB/s while writes spread over a large tile reach the fill-kernel ceiling ("What bounds the sampler").
 template <bool STREAMING, bool DRY, typename T>
-__global__ void __launch_bounds__(kSampleThreads)
+__global__ void __launch_bounds__(kSampleThreads, kSampleBlocksPerCU)
 k_sample(long long first, long long count, int dof, double t_sample, Limits lim, Queries in, Records rec,
          const unsigned long long* __restrict__ offsets, T* __restrict__ out, unsigned long long capacity,
          unsigned long long* __restrict__ stamps, int spread, int max_samples, unsigned long long* __restrict__ next_item)

@@ -31,8 +31,12 @@ constexpr int kQueriesPerBlock = 64;   // one wave = 64 queries of one joint
 constexpr int kMaxJointSlots = 8;      // blockDim.y of k_switch_times
 constexpr int kRowAlign = 32;          // trajectory rows padded to 32 elements (256 B of doubles, 128 B of floats)
 constexpr int kSampleJointGroup = 8;   // joints handled by one k_sample block
-constexpr int kMaxSegments = 24;       // piecewise-constant jerk segments per joint
+constexpr int kMaxSegments = 20;       // runs of constant jerk and mode per joint (1 + 19 cut points)
 constexpr int kSampleThreads = 256;
+#ifndef LTP_SAMPLE_BLOCKS_PER_CU
+#define LTP_SAMPLE_BLOCKS_PER_CU 5
+#endif
+constexpr int kSampleBlocksPerCU = LTP_SAMPLE_BLOCKS_PER_CU;   // register budget of k_sample (512 / this many VGPRs); measured best of 4..7
 constexpr int kSampleSpread = 64;      // default block->plan interleave of k_sample
 constexpr int kScanBlock = 1024;       // plans per finalize/scan block
 
