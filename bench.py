@@ -75,6 +75,7 @@ def main():
     ap.add_argument("--tile-gib", type=float, default=192.0, help="size of the reused trajectory output tile")
     ap.add_argument("--seed", type=int, default=12345)
     ap.add_argument("--max-samples", type=int, default=0, help="store only the first N samples per row (0 = whole trajectories, the reference behaviour)")
+    ap.add_argument("--sample-stride", type=int, default=1, help="store every N-th sample per row (1 = every sample, the reference behaviour)")
     ap.add_argument("--f32", action="store_true", help="store float32 rows (same binary64 results, rounded once); default float64 as the reference")
     ap.add_argument("--switch-only", action="store_true", help="config[1]: stages 1-3 only, no sampling")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -116,6 +117,8 @@ def main():
     qg, q0, v0, a0 = ltp.generateQueries(n, seed=args.seed, first_query=rank * n)
     if args.max_samples:
         ltp.setMaxSamples(args.max_samples)
+    if args.sample_stride > 1:
+        ltp.setSampleStride(args.sample_stride)
     tile = None
     if not args.switch_only:
         # one big reused output tile; if this GPU cannot give 192 GiB right now, halve until it can
@@ -181,7 +184,8 @@ def main():
     # bookkeeping outside the timed region
     status = batch.status.cpu().numpy()
     traj_len = batch.traj_len.cpu().numpy().astype(np.int64)
-    stored = np.minimum(traj_len, args.max_samples) if args.max_samples else traj_len
+    stored = -(-traj_len // args.sample_stride)
+    stored = np.minimum(stored, args.max_samples) if args.max_samples else stored
     alg_bytes_per_step = int((16 if args.f32 else 32) * dof * stored.sum())   # 32*D*traj_len per plan (f64; stored samples)
     roofline = None
     if ev_pairs:
@@ -219,7 +223,8 @@ def main():
             "config": {
                 "workload": (f"{n} x {dof}-DoF queries per GPU per step, limits '{args.limits}', Tsample {args.t_sample} s, "
                              + ("switching times only (stages 1-3)" if args.switch_only else
-                                (f"full q/v/a/j sampling" if not args.max_samples else f"first {args.max_samples} q/v/a/j samples per row")
+                                (f"full q/v/a/j sampling" if not (args.max_samples or args.sample_stride > 1) else
+                                 f"q/v/a/j rows: every {args.sample_stride}-th sample" + (f", first {args.max_samples} stored" if args.max_samples else ""))
                                 + f" into a reused {args.tile_gib} GiB tile ({n_chunks} chunks per step)")),
                 "batch_per_gpu": n, "dof": dof, "t_sample": args.t_sample, "limits": args.limits,
                 "sharding": "contiguous query ranges per rank, no data-path collective" + (", RCCL all_gather of t_required" if gather_buf else ""),

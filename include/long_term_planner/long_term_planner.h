@@ -219,6 +219,12 @@ class LongTermPlanner {
     if (rc != LTP_OK) raise(handle_, rc, "ltp_set_max_samples");
   }
 
+  /** @brief NEW: store every `stride`-th sample of each trajectory (1 = every sample, the reference's behaviour). */
+  inline void setSampleStride(int stride) {
+    const int rc = ltp_set_sample_stride(handle(), stride);
+    if (rc != LTP_OK) raise(handle_, rc, "ltp_set_sample_stride");
+  }
+
   /** @brief NEW: HIP device ordinal used by this planner (default 0). */
   inline void setDevice(int device) { if (device != device_) { release(); device_ = device; dirty_ = true; } }
 

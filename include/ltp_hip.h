@@ -92,6 +92,10 @@ int ltp_row_stride(int stored_samples);
 int ltp_set_max_samples(ltp_planner* p, int max_samples);
 int ltp_get_max_samples(const ltp_planner* p);
 int ltp_stored_samples(const ltp_planner* p, int traj_len);
+/* SURVEY.md §8(f).2 strided rows: store samples 0, stride, 2*stride, ... (default 1 = every sample); combined with
+ * max_samples the cap counts STORED samples. ltp_replan_states_batch's sample index is a stored-sample index. */
+int ltp_set_sample_stride(ltp_planner* p, int stride);
+int ltp_get_sample_stride(const ltp_planner* p);
 
 /* ---- batched hot path (device pointers, asynchronous on `stream`) -------------------------- */
 

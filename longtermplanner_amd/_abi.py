@@ -68,6 +68,8 @@ _SIGNATURES = {
     "ltp_set_max_samples": (C.c_int, [C.c_void_p, C.c_int]),
     "ltp_get_max_samples": (C.c_int, [C.c_void_p]),
     "ltp_stored_samples": (C.c_int, [C.c_void_p, C.c_int]),
+    "ltp_set_sample_stride": (C.c_int, [C.c_void_p, C.c_int]),
+    "ltp_get_sample_stride": (C.c_int, [C.c_void_p]),
     "ltp_replan_states_batch": (C.c_int, [C.c_void_p, C.c_longlong, C.c_longlong, C.POINTER(Queries), C.POINTER(Records), C.c_void_p,
                                           C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong,
                                           C.c_longlong, C.c_void_p]),

@@ -15,6 +15,7 @@ struct ltp_planner {
     double t_sample = 0.001;
     int device = 0;
     int max_samples = 0;                   // 0 = store whole trajectories (reference behaviour)
+    int sample_stride = 1;                 // store every sample_stride-th sample
     int sample_blocks = 0;                 // resident k_sample blocks on this device (work-queue grid)
     unsigned long long* d_sample_next = nullptr;   // ring of work-queue heads, one per in-flight sampler launch
     unsigned sample_next_slot = 0;
@@ -271,10 +272,19 @@ int ltp_set_max_samples(ltp_planner* p, int max_samples)
     return LTP_OK;
 }
 int ltp_get_max_samples(const ltp_planner* p) { return p ? p->max_samples : -1; }
+int ltp_set_sample_stride(ltp_planner* p, int stride)
+{
+    if (!p || stride < 1) return fail(p, LTP_ERR_INVALID_ARGUMENT, "stride < 1");
+    std::lock_guard<std::mutex> g(p->mu);
+    p->sample_stride = stride;
+    return LTP_OK;
+}
+int ltp_get_sample_stride(const ltp_planner* p) { return p ? p->sample_stride : -1; }
 int ltp_stored_samples(const ltp_planner* p, int traj_len)
 {
     if (!p || traj_len <= 0) return 0;
-    return (p->max_samples > 0 && traj_len > p->max_samples) ? p->max_samples : traj_len;
+    const int cnt = (traj_len + p->sample_stride - 1) / p->sample_stride;
+    return (p->max_samples > 0 && cnt > p->max_samples) ? p->max_samples : cnt;
 }
 
 int ltp_get_dof(const ltp_planner* p) { return p ? p->dof : -1; }
@@ -316,7 +326,7 @@ int ltp_plan_switch_times_batch(ltp_planner* p, long long n, const ltp_queries* 
     const ltp::Records r = to_dev(out);
     LTP_HIP_TRY(p, hipMemsetAsync(p->d_queue_count, 0, 16 * sizeof(unsigned long long), s));
     ltp::launch_switch_times(s, n, p->dof, p->t_sample, L, q, r, p->d_lane_flags, p->d_queue, p->d_queue_count);
-    ltp::launch_offsets(s, n, p->dof, p->t_sample, r, p->d_block_sums, offsets ? offsets : p->d_offsets_scratch, true, p->max_samples);
+    ltp::launch_offsets(s, n, p->dof, p->t_sample, r, p->d_block_sums, offsets ? offsets : p->d_offsets_scratch, true, ltp::RowSpec{p->max_samples, p->sample_stride});
     LTP_HIP_TRY(p, hipGetLastError());
     return LTP_OK;
 }
@@ -337,7 +347,7 @@ static int sample_batch_any(ltp_planner* p, long long first, long long count, co
     unsigned long long* head = p->d_sample_next + (p->sample_next_slot++ & 63u);
     LTP_HIP_TRY(p, hipMemsetAsync(head, 0, sizeof(unsigned long long), (hipStream_t)stream));
     ltp::launch_sample((hipStream_t)stream, first, count, p->dof, p->t_sample, dev_limits(p), to_dev(in), to_dev(rec), offsets,
-                       out, f32, capacity, flags, p->max_samples, head, p->sample_blocks, p->dbg_stamps);
+                       out, f32, capacity, flags, ltp::RowSpec{p->max_samples, p->sample_stride}, head, p->sample_blocks, p->dbg_stamps);
     LTP_HIP_TRY(p, hipGetLastError());
     return LTP_OK;
 }
@@ -365,7 +375,7 @@ static int replan_states_any(ltp_planner* p, long long first, long long count, c
     int rc = check_config(p);
     if (rc != LTP_OK) return rc;
     LTP_HIP_TRY(p, hipSetDevice(p->device));
-    ltp::launch_replan_states((hipStream_t)stream, first, count, p->dof, p->max_samples, to_dev(in), to_dev(rec), offsets, tile, f32,
+    ltp::launch_replan_states((hipStream_t)stream, first, count, p->dof, ltp::RowSpec{p->max_samples, p->sample_stride}, to_dev(in), to_dev(rec), offsets, tile, f32,
                               sample_index, uniform_index, q_0, v_0, a_0, query_stride, joint_stride);
     LTP_HIP_TRY(p, hipGetLastError());
     return LTP_OK;
@@ -648,7 +658,7 @@ int ltp_get_trajectory_host(ltp_planner* p, long long n, const double* t, const 
     ltp_queries dq{d_in[0], d_in[0], d_in[1], d_in[2], dof, 1};   // q_goal is not used by the sampler
     if (n > 0 && dof > 0) {
         std::lock_guard<std::mutex> g(p->mu);
-        ltp::launch_offsets(nullptr, n, dof, p->t_sample, to_dev(&dr.r), p->d_block_sums, d_off, false, p->max_samples);
+        ltp::launch_offsets(nullptr, n, dof, p->t_sample, to_dev(&dr.r), p->d_block_sums, d_off, false, ltp::RowSpec{p->max_samples, p->sample_stride});
         LTP_HIP_TRY(p, hipGetLastError());
     }
     LTP_HIP_TRY(p, hipDeviceSynchronize());

@@ -402,10 +402,14 @@ k_scaling_slow(int dof, double t_sample, Limits lim, Queries in, Records out, Qu
 // Packed layout of plan p at out + offsets[p]: [array q,v,a,j][joint][row_stride] doubles,
 // row_stride = round_up(traj_len, 16) so that every row starts 128-B aligned.
 // ---------------------------------------------------------------------------------------
-// rows hold min(traj_len, max_samples) samples (max_samples == 0: all of them, the reference's behaviour)
-LTP_DEV int stored_len(int len, int max_samples)
+// Samples stored per row: every rows.stride-th sample (0, stride, 2*stride, ...), at most rows.max_samples of them.
+// {0, 1} stores whole trajectories, which is the reference's behaviour.
+LTP_HD int stored_len(int len, RowSpec rows)
 {
-    return (max_samples > 0 && len > max_samples) ? max_samples : len;
+    if (len <= 0) return 0;
+    const int st = rows.stride > 1 ? rows.stride : 1;
+    const int cnt = (len + st - 1) / st;
+    return (rows.max_samples > 0 && cnt > rows.max_samples) ? rows.max_samples : cnt;
 }
 
 LTP_DEV unsigned long long plan_size(int len, int dof)
@@ -416,7 +420,7 @@ LTP_DEV unsigned long long plan_size(int len, int dof)
 }
 
 __global__ void __launch_bounds__(256)
-k_finalize(long long n, int dof, double t_sample, int max_samples, Records rec, unsigned long long* __restrict__ block_sums)
+k_finalize(long long n, int dof, double t_sample, RowSpec rows, Records rec, unsigned long long* __restrict__ block_sums)
 {
     __shared__ unsigned long long s_part[256];
     const long long base = (long long)blockIdx.x * kScanBlock;
@@ -437,7 +441,7 @@ k_finalize(long long n, int dof, double t_sample, int max_samples, Records rec, 
                 if (!finite) { len = 0; st |= kStatusNonFinite; rec.status[q] = st; }
             }
             rec.traj_len[q] = len;
-            local += plan_size(stored_len(len, max_samples), dof);
+            local += plan_size(stored_len(len, rows), dof);
         }
     }
     s_part[threadIdx.x] = local;
@@ -451,7 +455,7 @@ k_finalize(long long n, int dof, double t_sample, int max_samples, Records rec, 
 
 // batched path: traj_len/status were already reduced by k_reduce_scale / k_scaling_slow
 __global__ void __launch_bounds__(256)
-k_finalize_lens(long long n, int dof, int max_samples, Records rec, unsigned long long* __restrict__ block_sums)
+k_finalize_lens(long long n, int dof, RowSpec rows, Records rec, unsigned long long* __restrict__ block_sums)
 {
     __shared__ unsigned long long s_part[256];
     const long long base = (long long)blockIdx.x * kScanBlock;
@@ -461,7 +465,7 @@ k_finalize_lens(long long n, int dof, int max_samples, Records rec, unsigned lon
         if (q < n) {
             int len = rec.traj_len[q];
             if (rec.status[q] != 0) { len = 0; rec.traj_len[q] = 0; }   // failed or non-finite: nothing to sample
-            local += plan_size(stored_len(len, max_samples), dof);
+            local += plan_size(stored_len(len, rows), dof);
         }
     }
     s_part[threadIdx.x] = local;
@@ -500,7 +504,7 @@ k_scan_top(long long nb, unsigned long long* __restrict__ block_sums)
 }
 
 __global__ void __launch_bounds__(256)
-k_scan_apply(long long n, int dof, int max_samples, const int* __restrict__ traj_len,
+k_scan_apply(long long n, int dof, RowSpec rows, const int* __restrict__ traj_len,
              const unsigned long long* __restrict__ block_sums, unsigned long long* __restrict__ offsets)
 {
     __shared__ unsigned long long s[256];
@@ -511,7 +515,7 @@ k_scan_apply(long long n, int dof, int max_samples, const int* __restrict__ traj
 #pragma unroll
     for (int e = 0; e < E; ++e) {
         const long long q = base + (long long)threadIdx.x * E + e;
-        sz[e] = q < n ? plan_size(stored_len(traj_len[q], max_samples), dof) : 0ull;
+        sz[e] = q < n ? plan_size(stored_len(traj_len[q], rows), dof) : 0ull;
         local += sz[e];
     }
     s[threadIdx.x] = local;
@@ -665,7 +669,7 @@ template <bool STREAMING, bool DRY, typename T>
 LTP_DEV void sample_plan(SegTable& tab, long long first, long long local, int group, int dof, double t_sample, const Limits& lim,
                          const Queries& in, const Records& rec, const unsigned long long* __restrict__ offsets,
                          T* __restrict__ out, unsigned long long capacity, unsigned long long* __restrict__ stamps,
-                         int max_samples)
+                         RowSpec rows)
 {
     const long long p = first + local;
     // diagnostic only (stamps == nullptr in every product call): start / tables ready / end on the 100 MHz wall clock
@@ -674,7 +678,7 @@ LTP_DEV void sample_plan(SegTable& tab, long long first, long long local, int gr
     if (len <= 0) return;   // failed / non-finite query: nothing to sample
     const unsigned long long off0 = offsets[first];
     const unsigned long long rel = offsets[p] - off0;
-    const int slen = stored_len(len, max_samples);   // samples actually stored per row
+    const int slen = stored_len(len, rows);   // samples actually stored per row
     const unsigned long long stride = ((unsigned long long)slen + (kRowAlign - 1)) / kRowAlign * kRowAlign;
     if (rel + 4ull * dof * stride > capacity) {
         if (threadIdx.x == 0 && group == 0) atomicOr(&rec.status[p], kStatusOverflow);
@@ -807,6 +811,7 @@ LTP_DEV void sample_plan(SegTable& tab, long long first, long long local, int gr
     T* const plan_base = out + rel;
     const unsigned long long arr_stride = (unsigned long long)dof * stride;   // distance between q, v, a, j blocks
     const int nslots = (slen + N - 1) / N;
+    const int sstride = rows.stride > 1 ? rows.stride : 1;
     for (int jl2 = 0; jl2 < nj; ++jl2) {
         T* const row = plan_base + (unsigned long long)(j0 + jl2) * stride;
         const int* st = tab.start[jl2];
@@ -814,7 +819,7 @@ LTP_DEV void sample_plan(SegTable& tab, long long first, long long local, int gr
         // run cursor of this lane: samples [cur, nxt) belong to run kr (nxt = INT_MAX for the last run)
         int kr = 0, cur = 0, nxt = nruns > 1 ? st[1] : 0x7fffffff;
         for (int slot = threadIdx.x; slot < nslots; slot += kSampleThreads) {
-            const int i0 = N * slot;
+            const int i0 = N * slot;                  // first stored sample of this slot; it is sample i0*sstride of the trajectory
             V o[4];
             if constexpr (DRY) {
 #pragma unroll
@@ -822,22 +827,22 @@ LTP_DEV void sample_plan(SegTable& tab, long long first, long long local, int gr
 #pragma unroll
                     for (int h = 0; h < N; ++h) o[x][h] = (T)(i0 + h);
             } else {
-                while (nxt <= i0) {
+                const int t0 = i0 * sstride;
+                while (nxt <= t0) {
                     ++kr;
                     cur = nxt;
                     nxt = kr + 1 < nruns ? st[kr + 1] : 0x7fffffff;
                 }
-                if (i0 + N - 1 < nxt) {
+                if (t0 + (N - 1) * sstride < nxt) {
                     // common case: the N samples of this slot lie in one run -> its coefficients are read once
                     double c[kRunCoefs];
 #pragma unroll
                     for (int x = 0; x < kRunCoefs; ++x) c[x] = tab.c[jl2][kr][x];
 #pragma unroll
                     for (int h = 0; h < N; ++h) {
-                        const int i = i0 + h;
-                        const bool pad = i >= slen;   // the tail of the last slot is row padding
+                        const bool pad = i0 + h >= slen;   // the tail of the last slot is row padding
                         double x4[4];
-                        run_eval(c, i - cur + 1, x4[0], x4[1], x4[2], x4[3]);
+                        run_eval(c, t0 + h * sstride - cur + 1, x4[0], x4[1], x4[2], x4[3]);
 #pragma unroll
                         for (int x = 0; x < 4; ++x) o[x][h] = pad ? (T)0 : (T)x4[x];
                     }
@@ -846,13 +851,13 @@ LTP_DEV void sample_plan(SegTable& tab, long long first, long long local, int gr
                     int kh = kr, ch = cur, nh = nxt;
 #pragma unroll
                     for (int h = 0; h < N; ++h) {
-                        const int i = i0 + h;
-                        if (nh <= i) {   // consecutive samples: at most one run further
+                        const int i = t0 + h * sstride;
+                        while (nh <= i) {
                             ++kh;
                             ch = nh;
                             nh = kh + 1 < nruns ? st[kh + 1] : 0x7fffffff;
                         }
-                        const bool pad = i >= slen;
+                        const bool pad = i0 + h >= slen;
                         double x4[4];
                         run_eval(tab.c[jl2][kh], i - ch + 1, x4[0], x4[1], x4[2], x4[3]);
 #pragma unroll
@@ -882,7 +887,7 @@ template <bool STREAMING, bool DRY, typename T>
 __global__ void __launch_bounds__(kSampleThreads, kSampleBlocksPerCU)
 k_sample(long long first, long long count, int dof, double t_sample, Limits lim, Queries in, Records rec,
          const unsigned long long* __restrict__ offsets, T* __restrict__ out, unsigned long long capacity,
-         unsigned long long* __restrict__ stamps, int spread, int max_samples, unsigned long long* __restrict__ next_item)
+         unsigned long long* __restrict__ stamps, int spread, RowSpec rows, unsigned long long* __restrict__ next_item)
 {
     __shared__ SegTable tab;
     __shared__ unsigned long long s_item;
@@ -900,7 +905,7 @@ k_sample(long long first, long long count, int dof, double t_sample, Limits lim,
         const long long local = (slot % spread) * per + slot / spread;
         if (local < count)
             sample_plan<STREAMING, DRY, T>(tab, first, local, group, dof, t_sample, lim, in, rec, offsets, out, capacity, stamps,
-                                        max_samples);
+                                        rows);
     }
 }
 
@@ -910,7 +915,7 @@ k_sample(long long first, long long count, int dof, double t_sample, Limits lim,
 // ---------------------------------------------------------------------------------------
 template <typename T>
 __global__ void __launch_bounds__(256)
-k_replan_states(long long first, long long count, int dof, int max_samples, Queries in, Records rec,
+k_replan_states(long long first, long long count, int dof, RowSpec rows, Queries in, Records rec,
                 const unsigned long long* __restrict__ offsets, const T* __restrict__ tile,
                 const int* __restrict__ sample_index, int uniform_index,
                 double* __restrict__ q_0, double* __restrict__ v_0, double* __restrict__ a_0, long long sq, long long sj)
@@ -921,7 +926,7 @@ k_replan_states(long long first, long long count, int dof, int max_samples, Quer
     const int j = (int)(idx - local * dof);
     const long long p = first + local;
     const long long dst = local * sq + (long long)j * sj;
-    const int slen = stored_len(rec.traj_len[p], max_samples);
+    const int slen = stored_len(rec.traj_len[p], rows);
     if (slen <= 0) {   // plan was not sampled: carry its start state over unchanged
         const long long ix = p * in.sq + (long long)j * in.sj;
         q_0[dst] = in.q_0[ix];
@@ -1112,14 +1117,14 @@ void launch_switch_times(hipStream_t s, long long n, int dof, double t_sample, L
 }
 
 void launch_offsets(hipStream_t s, long long n, int dof, double t_sample, Records rec,
-                    unsigned long long* block_sums, unsigned long long* offsets, bool lens_ready, int max_samples)
+                    unsigned long long* block_sums, unsigned long long* offsets, bool lens_ready, RowSpec rows)
 {
     if (n <= 0) return;
     const long long nb = (n + kScanBlock - 1) / kScanBlock;
-    if (lens_ready) hipLaunchKernelGGL(k_finalize_lens, dim3((unsigned)nb), dim3(256), 0, s, n, dof, max_samples, rec, block_sums);
-    else hipLaunchKernelGGL(k_finalize, dim3((unsigned)nb), dim3(256), 0, s, n, dof, t_sample, max_samples, rec, block_sums);
+    if (lens_ready) hipLaunchKernelGGL(k_finalize_lens, dim3((unsigned)nb), dim3(256), 0, s, n, dof, rows, rec, block_sums);
+    else hipLaunchKernelGGL(k_finalize, dim3((unsigned)nb), dim3(256), 0, s, n, dof, t_sample, rows, rec, block_sums);
     hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, s, nb, block_sums);
-    hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nb), dim3(256), 0, s, n, dof, max_samples, rec.traj_len, block_sums, offsets);
+    hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nb), dim3(256), 0, s, n, dof, rows, rec.traj_len, block_sums, offsets);
 }
 
 // how many k_sample blocks the device holds at once (the work-queue grid)
@@ -1133,7 +1138,7 @@ int sample_resident_blocks(int device)
 
 void launch_sample(hipStream_t s, long long first, long long count, int dof, double t_sample, Limits lim, Queries in,
                    Records rec, const unsigned long long* offsets, void* out, bool f32, unsigned long long capacity,
-                   int flags, int max_samples, unsigned long long* next_item, int resident_blocks, unsigned long long* stamps)
+                   int flags, RowSpec rows, unsigned long long* next_item, int resident_blocks, unsigned long long* stamps)
 {
     if (count <= 0) return;
     int spread = (flags >> 8) & 0xFFFF;
@@ -1146,7 +1151,7 @@ void launch_sample(hipStream_t s, long long first, long long count, int dof, dou
     const dim3 block(kSampleThreads);
     // flags bit 0: non-temporal stores; bit 1 (diagnostic): skip the arithmetic and store sample indices, which
     // measures the ceiling of this store pattern; bits 8..23: block interleave factor (0 = default 64, 1 = plan order)
-#define LTP_SAMPLE_CASE(ST, DR, TY) hipLaunchKernelGGL((k_sample<ST, DR, TY>), grid, block, 0, s, first, count, dof, t_sample, lim, in, rec, offsets, (TY*)out, capacity, stamps, spread, max_samples, next_item)
+#define LTP_SAMPLE_CASE(ST, DR, TY) hipLaunchKernelGGL((k_sample<ST, DR, TY>), grid, block, 0, s, first, count, dof, t_sample, lim, in, rec, offsets, (TY*)out, capacity, stamps, spread, rows, next_item)
     switch ((flags & 3) | (f32 ? 4 : 0)) {
     case 0: LTP_SAMPLE_CASE(false, false, double); break;
     case 1: LTP_SAMPLE_CASE(true, false, double); break;
@@ -1160,7 +1165,7 @@ void launch_sample(hipStream_t s, long long first, long long count, int dof, dou
 #undef LTP_SAMPLE_CASE
 }
 
-void launch_replan_states(hipStream_t s, long long first, long long count, int dof, int max_samples, Queries in, Records rec,
+void launch_replan_states(hipStream_t s, long long first, long long count, int dof, RowSpec rows, Queries in, Records rec,
                           const unsigned long long* offsets, const void* tile, bool f32, const int* sample_index, int uniform_index,
                           double* q_0, double* v_0, double* a_0, long long sq, long long sj)
 {
@@ -1168,10 +1173,10 @@ void launch_replan_states(hipStream_t s, long long first, long long count, int d
     const long long total = count * dof;
     const dim3 grid((unsigned)((total + 255) / 256)), block(256);
     if (f32)
-        hipLaunchKernelGGL(k_replan_states<float>, grid, block, 0, s, first, count, dof, max_samples, in, rec, offsets,
+        hipLaunchKernelGGL(k_replan_states<float>, grid, block, 0, s, first, count, dof, rows, in, rec, offsets,
                            (const float*)tile, sample_index, uniform_index, q_0, v_0, a_0, sq, sj);
     else
-        hipLaunchKernelGGL(k_replan_states<double>, grid, block, 0, s, first, count, dof, max_samples, in, rec, offsets,
+        hipLaunchKernelGGL(k_replan_states<double>, grid, block, 0, s, first, count, dof, rows, in, rec, offsets,
                            (const double*)tile, sample_index, uniform_index, q_0, v_0, a_0, sq, sj);
 }
 

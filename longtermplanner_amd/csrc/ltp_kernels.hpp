@@ -40,6 +40,12 @@ constexpr int kSampleBlocksPerCU = LTP_SAMPLE_BLOCKS_PER_CU;   // register budge
 constexpr int kSampleSpread = 64;      // default block->plan interleave of k_sample
 constexpr int kScanBlock = 1024;       // plans per finalize/scan block
 
+// which samples of a trajectory are stored in its rows
+struct RowSpec {
+    int max_samples;   // at most this many stored samples per row; 0 = no cap
+    int stride;        // every stride-th sample (0, stride, 2*stride, ...); <= 1 = every sample
+};
+
 struct Limits {            // device pointers, [dof] each
     const double* q_min;
     const double* q_max;
@@ -72,13 +78,13 @@ long long queue_segment(long long n, int dof);   // entries per queue shard; a b
 void launch_switch_times(hipStream_t s, long long n, int dof, double t_sample, Limits lim, Queries in, Records out,
                          signed char* lane_flags, unsigned long long* queue_items, unsigned long long* counts);
 void launch_offsets(hipStream_t s, long long n, int dof, double t_sample, Records rec,
-                    unsigned long long* block_sums, unsigned long long* offsets, bool lens_ready, int max_samples);
+                    unsigned long long* block_sums, unsigned long long* offsets, bool lens_ready, RowSpec rows);
 void launch_sample(hipStream_t s, long long first, long long count, int dof, double t_sample, Limits lim, Queries in,
                    Records rec, const unsigned long long* offsets, void* out, bool f32, unsigned long long capacity,
-                   int flags, int max_samples, unsigned long long* next_item /* zeroed on the same stream */,
+                   int flags, RowSpec rows, unsigned long long* next_item /* zeroed on the same stream */,
                    int resident_blocks, unsigned long long* stamps = nullptr);
 int sample_resident_blocks(int device);
-void launch_replan_states(hipStream_t s, long long first, long long count, int dof, int max_samples, Queries in, Records rec,
+void launch_replan_states(hipStream_t s, long long first, long long count, int dof, RowSpec rows, Queries in, Records rec,
                           const unsigned long long* offsets, const void* tile, bool f32, const int* sample_index, int uniform_index,
                           double* q_0, double* v_0, double* a_0, long long sq, long long sj);
 void launch_generate(hipStream_t s, long long n, int dof, Limits lim, unsigned long long seed, long long first_query,

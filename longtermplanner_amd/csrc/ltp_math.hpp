@@ -16,6 +16,7 @@
 namespace ltp {
 
 #define LTP_DEV __device__ __forceinline__
+#define LTP_HD __host__ __device__ inline
 
 constexpr double kInf = __builtin_huge_val();
 

@@ -108,6 +108,10 @@ class LongTermPlanner:
         """NEW: store only the first max_samples samples of every trajectory; 0 = all (reference)."""
         self._check(self._lib.ltp_set_max_samples(self._h, int(max_samples)))
 
+    def setSampleStride(self, stride):
+        """NEW: store every stride-th sample (0, stride, 2*stride, ...); 1 = every sample (reference)."""
+        self._check(self._lib.ltp_set_sample_stride(self._h, int(stride)))
+
     def storedSamples(self, traj_len):
         return self._lib.ltp_stored_samples(self._h, int(traj_len))
 

@@ -258,3 +258,47 @@ def test_float32_rows_are_the_rounded_float64_rows(amd, ref7):
     torch.cuda.synchronize()
     live = (b.traj_len > 0)
     assert torch.equal(q1[live], q2[live].to(torch.float32).to(torch.float64)) and torch.equal(a1[live], a2[live].to(torch.float32).to(torch.float64))
+
+
+@pytest.mark.parametrize("stride,cap", [(4, 0), (7, 50), (1000000, 0)])
+def test_strided_rows_are_a_decimation_of_the_full_rows(amd, ref7, stride, cap):
+    # rows that store samples 0, stride, 2*stride, ... (optionally capped) hold exactly those samples
+    import torch
+    D, lim, ltp, orc = ref7
+    n = 300
+    qm = ltp.generateQueries(n, seed=23)
+    b = ltp.planSwitchTimesBatch(*qm)
+    torch.cuda.synchronize()
+    off_full = b.offsets.cpu().numpy().view(np.uint64).copy()
+    full = torch.zeros(int(off_full[-1]), dtype=torch.float64, device="cuda")
+    ltp.sampleBatch(b, 0, n, full)
+    torch.cuda.synchronize()
+    status_full = b.status.cpu().numpy().copy()
+    lens = b.traj_len.cpu().numpy()
+    hf = full.cpu().numpy()
+    try:
+        ltp.setSampleStride(stride)
+        ltp.setMaxSamples(cap)
+        b2 = ltp.planSwitchTimesBatch(*qm)
+        torch.cuda.synchronize()
+        off = b2.offsets.cpu().numpy().view(np.uint64)
+        for dtype in (torch.float64, torch.float32):
+            dec = torch.zeros(int(off[-1]), dtype=dtype, device="cuda")
+            ltp.sampleBatch(b2, 0, n, dec)
+            torch.cuda.synchronize()
+            assert np.array_equal(b2.status.cpu().numpy(), status_full)
+            hd = dec.cpu().numpy()
+            for p in range(0, n, 3):
+                if lens[p] <= 0:
+                    continue
+                stored = ltp.storedSamples(int(lens[p]))
+                want_cnt = -(-int(lens[p]) // stride)
+                assert stored == (min(want_cnt, cap) if cap else want_cnt)
+                want = amd.unpack_trajectory(hf, int(off_full[p]), D, int(lens[p]))
+                got = amd.unpack_trajectory(hd, int(off[p]), D, stored)
+                for w, g in zip(want, got):
+                    ref = w[:, ::stride][:, :stored]
+                    assert np.array_equal(ref.astype(hd.dtype), g)
+    finally:
+        ltp.setSampleStride(1)
+        ltp.setMaxSamples(0)
