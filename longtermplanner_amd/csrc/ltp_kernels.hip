@@ -761,7 +761,8 @@ LTP_DEV void sample_plan(SegTable& tab, long long first, long long local, int gr
         if (k == 0) { tab.start[jl][distinct] = len; tab.nseg[jl] = distinct; }
     }
     __syncthreads();
-    // (4) lane k < ns: mode and jerk of run k (independent across runs)
+    // (4) lane k < ns: mode and jerk of run k, and everything of the run's end-state update that does not depend
+    //     on the state (parked in tab.c[.][k][0..5] until step (6) overwrites it with the coefficients)
     const int ns = jact ? tab.nseg[jl] : 0;
     if (k < ns) {
         const int b = tab.start[jl][k];
@@ -770,28 +771,51 @@ LTP_DEV void sample_plan(SegTable& tab, long long first, long long local, int gr
         int mode = 0;
         if (b > sj[6]) mode |= kModeTail;
         if (phase4 && b >= sj[2] + 1 && b < sj[3] - 1) mode |= kModeVSnap;
+        const double J = jerk_at(sj, tab.Jp[jl], tab.corr[jl], b);
         tab.runMode[jl][k] = mode;
-        tab.runJ[jl][k] = jerk_at(sj, tab.Jp[jl], tab.corr[jl], b);
+        tab.runJ[jl][k] = J;
+        const double md = (double)(tab.start[jl][k + 1] - b);     // samples in the run
+        const double s1 = 0.5 * (md * (md + 1.0));
+        const double tj = Ts * J;
+        double* pre = tab.c[jl][k];
+        pre[0] = md;
+        pre[1] = s1;
+        pre[2] = s1 * (md + 2.0) * (1.0 / 3.0);
+        pre[3] = tj;
+        pre[4] = Ts * tj;
+        pre[5] = Ts * (Ts * tj);
     }
     __syncthreads();
-    // (5) lane 0 of the joint: the state before each run (the only serial part), and the end-limit check
+    // (5) lane 0 of the joint: the state before each run — the only serial part. Each step is run_eval(run_coef(..))
+    //     at the run's last sample, i.e. exactly what the streaming loop will store there, with the state-independent
+    //     factors taken from step (4).
     if (jact && k == 0) {
         const double vsnap = tab.misc[jl][1];
         double q = tab.misc[jl][2], v = tab.misc[jl][3], a = tab.misc[jl][4];   // state "before sample 0" (cc:810-812)
-#pragma unroll 4
         for (int m = 0; m < ns; ++m) {
             tab.state[jl][m][0] = a; tab.state[jl][m][1] = v; tab.state[jl][m][2] = q;
-            const RunCoef rc = run_coef(tab.runMode[jl][m], tab.runJ[jl][m], a, v, q, vsnap, Ts);
-            const int cnt = tab.start[jl][m + 1] - tab.start[jl][m];
-            // state at the run's last sample = what the streaming loop will store there
-            double jj;
-            run_eval(rc.c, cnt, q, v, a, jj);
+            const double* pre = tab.c[jl][m];
+            const double md = pre[0], s1 = pre[1], s2 = pre[2];
+            const int mode = tab.runMode[jl][m];
+            double qn, vn, an;
+            if (mode & kModeVSnap) {
+                vn = vsnap + (0.0 * md + 0.0 * s1);
+                qn = q + ((Ts * vsnap) * md + (0.0 * s1 + 0.0 * s2));
+            } else if (mode & kModeTail) {
+                vn = 0.0 + (0.0 * md + 0.0 * s1);
+                qn = q + (0.0 * md + (0.0 * s1 + 0.0 * s2));
+            } else {
+                vn = v + ((Ts * a) * md + pre[4] * s1);
+                qn = q + ((Ts * v) * md + ((Ts * (Ts * a)) * s1 + pre[5] * s2));
+            }
+            an = (mode & kModeTail) ? 0.0 + 0.0 * md : a + pre[3] * md;
+            q = qn; v = vn; a = an;
         }
         // cc:59-61: q now holds sample len-1
         if (q < lim.q_min[j] || q > lim.q_max[j]) atomicOr(&rec.status[p], kStatusEndLimit);
     }
     __syncthreads();
-    // (6) lane k < ns: the 16 coefficients of run k
+    // (6) lane k < ns: the coefficients of run k
     if (k < ns) {
         const RunCoef rc = run_coef(tab.runMode[jl][k], tab.runJ[jl][k], tab.state[jl][k][0], tab.state[jl][k][1],
                                     tab.state[jl][k][2], tab.misc[jl][1], Ts);
