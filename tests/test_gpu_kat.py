@@ -156,3 +156,18 @@ def test_cpp_dropin_class_runs_reference_scenarios():
     r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "0 failures" in r.stdout
+
+
+def test_reference_own_test_suite_against_the_dropin():
+    """The reference's OWN tests/src/long_term_planner_tests.cc (+ its fixture header), compiled unmodified where it
+    lies against this repository's drop-in header and libltp_hip.so (tests/cpp/Makefile target `reference_tests`,
+    built by __graft_entry__.build() wherever /root/reference exists; the binary travels, the sources do not).
+    All 10 tests — the KAT tables, the three end-point suites and both grid sweeps, 755 090 expectations, the same
+    count SURVEY.md App. B reports for the compiled reference — must pass on the GPU."""
+    exe = os.path.join(ROOT, "tests", "cpp", "reference_tests")
+    if not os.path.exists(exe):
+        pytest.skip("tests/cpp/reference_tests was not built (needs /root/reference at build time)")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=1500)
+    tail = r.stdout[-1500:]
+    assert r.returncode == 0, tail
+    assert "10 tests, 755090 checks, 0 failures" in r.stdout, tail
