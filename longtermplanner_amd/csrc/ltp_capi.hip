@@ -527,6 +527,29 @@ ltp_records arena_records(unsigned char* base, const ArenaLayout& L)
     return r;
 }
 
+// sample all n plans of an arena batch into the cached device buffer and hand back a malloc'ed host copy;
+// also refreshes the arena's host copy of `status` (the sampler may set LTP_STATUS_END_LIMIT)
+int sample_to_host_small(ltp_planner* p, long long n, const ArenaLayout& L, const ltp_queries& dq, const ltp_records& dr,
+                         unsigned long long* d_off, unsigned long long total, double** packed)
+{
+    int rc = ensure_traj(p, (size_t)(total ? total : 2));
+    if (rc != LTP_OK) return rc;
+    // padding between rows is never written by the sampler: make the host copy deterministic
+    LTP_HIP_TRY(p, hipMemsetAsync(p->d_traj, 0, sizeof(double) * (size_t)(total ? total : 2), nullptr));
+    rc = ltp_sample_batch(p, 0, n, &dq, &dr, d_off, p->d_traj, total, 0, nullptr);
+    if (rc != LTP_OK) return rc;
+    double* h = (double*)malloc(sizeof(double) * (size_t)(total ? total : 1));
+    if (!h) return fail(p, LTP_ERR_OUT_OF_MEMORY, "malloc");
+    double* landing = p->h_traj ? p->h_traj : h;   // pinned staging when the result is small
+    hipError_t e = total ? hipMemcpyAsync(landing, p->d_traj, sizeof(double) * (size_t)total, hipMemcpyDeviceToHost, nullptr) : hipSuccess;
+    if (e == hipSuccess) e = hipMemcpyAsync(p->h_arena + L.status, p->d_arena + L.status, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, nullptr);
+    if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+    if (e != hipSuccess) { free(h); return hip_fail(p, e, "trajectory download"); }
+    if (total && landing != h) memcpy(h, landing, sizeof(double) * (size_t)total);
+    *packed = h;
+    return LTP_OK;
+}
+
 // the staged path of ltp_plan_batch_host; caller holds host_mu
 int plan_batch_host_small(ltp_planner* p, long long n, const double* const (&h_in)[4], const ltp_records* host_records,
                           unsigned long long* offsets, double** packed)
@@ -549,23 +572,8 @@ int plan_batch_host_small(ltp_planner* p, long long n, const double* const (&h_i
     LTP_HIP_TRY(p, hipStreamSynchronize(nullptr));
     const unsigned long long* h_off = (const unsigned long long*)(p->h_arena + L.offsets);
     if (packed) {
-        const unsigned long long total = h_off[n];
-        rc = ensure_traj(p, (size_t)(total ? total : 2));
+        rc = sample_to_host_small(p, n, L, dq, dr, d_off, h_off[n], packed);
         if (rc != LTP_OK) return rc;
-        // padding between rows is never written by the sampler: make the host copy deterministic
-        LTP_HIP_TRY(p, hipMemsetAsync(p->d_traj, 0, sizeof(double) * (size_t)(total ? total : 2), nullptr));
-        rc = ltp_sample_batch(p, 0, n, &dq, &dr, d_off, p->d_traj, total, 0, nullptr);
-        if (rc != LTP_OK) return rc;
-        double* h = (double*)malloc(sizeof(double) * (size_t)(total ? total : 1));
-        if (!h) return fail(p, LTP_ERR_OUT_OF_MEMORY, "malloc");
-        double* landing = p->h_traj ? p->h_traj : h;   // pinned staging when the result is small
-        hipError_t e = total ? hipMemcpyAsync(landing, p->d_traj, sizeof(double) * (size_t)total, hipMemcpyDeviceToHost, nullptr) : hipSuccess;
-        // the sampler may have set LTP_STATUS_END_LIMIT
-        if (e == hipSuccess) e = hipMemcpyAsync(p->h_arena + L.status, p->d_arena + L.status, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, nullptr);
-        if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
-        if (e != hipSuccess) { free(h); return hip_fail(p, e, "trajectory download"); }
-        if (total && landing != h) memcpy(h, landing, sizeof(double) * (size_t)total);
-        *packed = h;
     }
     if (offsets) memcpy(offsets, h_off, sizeof(unsigned long long) * ((size_t)n + 1));
     if (host_records) {
@@ -582,6 +590,25 @@ int plan_batch_host_small(ltp_planner* p, long long n, const double* const (&h_i
     }
     return LTP_OK;
 }
+
+// one-lane entry points: 16 doubles up, kernel, 16 doubles down, through the pinned arena
+extern "C++" {
+template <class Launch>
+int run_one_lane(ltp_planner* p, double (&buf)[16], Launch launch)
+{
+    std::lock_guard<std::mutex> hg(p->host_mu);
+    int rc = ensure_arena(p, sizeof(buf));
+    if (rc != LTP_OK) return rc;
+    memcpy(p->h_arena, buf, sizeof(buf));
+    LTP_HIP_TRY(p, hipMemcpyAsync(p->d_small, p->h_arena, sizeof(buf), hipMemcpyHostToDevice, nullptr));
+    launch();
+    LTP_HIP_TRY(p, hipGetLastError());
+    LTP_HIP_TRY(p, hipMemcpyAsync(p->h_arena, p->d_small, sizeof(buf), hipMemcpyDeviceToHost, nullptr));
+    LTP_HIP_TRY(p, hipStreamSynchronize(nullptr));
+    memcpy(buf, p->h_arena, sizeof(buf));
+    return LTP_OK;
+}
+}  // extern "C++"
 
 }  // namespace
 
@@ -637,6 +664,41 @@ int ltp_get_trajectory_host(ltp_planner* p, long long n, const double* t, const 
     LTP_HIP_TRY(p, hipSetDevice(p->device));
     const int dof = p->dof;
     const size_t nd = (size_t)n * dof;
+    if (n > 0 && dof > 0 && arena_layout(n, dof).end <= kSmallHostBytes) {
+        // staged path: persistent arena + pinned mirror, one upload, one download
+        std::lock_guard<std::mutex> hg(p->host_mu);
+        const ArenaLayout L = arena_layout(n, dof);
+        rc = ensure_arena(p, L.end);
+        if (rc != LTP_OK) return rc;
+        memset(p->h_arena, 0, L.end);
+        memcpy(p->h_arena + L.in[1], q_0, sizeof(double) * nd);
+        memcpy(p->h_arena + L.in[2], v_0, sizeof(double) * nd);
+        memcpy(p->h_arena + L.in[3], a_0, sizeof(double) * nd);
+        memcpy(p->h_arena + L.t_scaled, t, sizeof(double) * nd * 7);
+        memcpy(p->h_arena + L.dir, dir, sizeof(double) * nd);
+        memcpy(p->h_arena + L.v_drive, v_drive, sizeof(double) * nd);
+        memcpy(p->h_arena + L.mod, mod, nd);
+        LTP_HIP_TRY(p, hipMemcpyAsync(p->d_arena, p->h_arena, L.end, hipMemcpyHostToDevice, nullptr));
+        const ltp_queries dq{(double*)(p->d_arena + L.in[1]), (double*)(p->d_arena + L.in[1]), (double*)(p->d_arena + L.in[2]),
+                             (double*)(p->d_arena + L.in[3]), dof, 1};   // q_goal is not used by the sampler
+        const ltp_records dr = arena_records(p->d_arena, L);
+        unsigned long long* d_off = (unsigned long long*)(p->d_arena + L.offsets);
+        {
+            std::lock_guard<std::mutex> g(p->mu);
+            ltp::launch_offsets(nullptr, n, dof, p->t_sample, to_dev(&dr), p->d_block_sums, d_off, false,
+                                ltp::RowSpec{p->max_samples, p->sample_stride});
+            LTP_HIP_TRY(p, hipGetLastError());
+        }
+        LTP_HIP_TRY(p, hipMemcpyAsync(p->h_arena + L.rec_begin, p->d_arena + L.rec_begin, L.end - L.rec_begin, hipMemcpyDeviceToHost, nullptr));
+        LTP_HIP_TRY(p, hipStreamSynchronize(nullptr));
+        const unsigned long long* h_off = (const unsigned long long*)(p->h_arena + L.offsets);
+        rc = sample_to_host_small(p, n, L, dq, dr, d_off, h_off[n], packed);
+        if (rc != LTP_OK) return rc;
+        memcpy(offsets, h_off, sizeof(unsigned long long) * ((size_t)n + 1));
+        if (traj_len) memcpy(traj_len, p->h_arena + L.traj_len, sizeof(int) * (size_t)n);
+        if (status) memcpy(status, p->h_arena + L.status, sizeof(int) * (size_t)n);
+        return LTP_OK;
+    }
     DevRecords dr;
     LTP_HIP_TRY(p, dr.alloc_all(n, dof));
     if (nd) {
@@ -706,10 +768,8 @@ int ltp_opt_braking_host(ltp_planner* p, int joint, double v_0, double a_0, doub
     LTP_HIP_TRY(p, hipSetDevice(p->device));
     double buf[16] = {0};
     memcpy(buf, t_rel, sizeof(double) * 7);
-    LTP_HIP_TRY(p, hipMemcpy(p->d_small, buf, sizeof(buf), hipMemcpyHostToDevice));
-    ltp::launch_single_opt_braking(nullptr, joint, p->t_sample, dev_limits(p), v_0, a_0, p->d_small);
-    LTP_HIP_TRY(p, hipGetLastError());
-    LTP_HIP_TRY(p, hipMemcpy(buf, p->d_small, sizeof(buf), hipMemcpyDeviceToHost));
+    const int rc = run_one_lane(p, buf, [&] { ltp::launch_single_opt_braking(nullptr, joint, p->t_sample, dev_limits(p), v_0, a_0, p->d_small); });
+    if (rc != LTP_OK) return rc;
     memcpy(t_rel, buf, sizeof(double) * 7);
     *q = buf[7];
     *dir = buf[8];
@@ -725,10 +785,8 @@ int ltp_opt_switch_times_host(ltp_planner* p, int joint, double q_goal, double q
     LTP_HIP_TRY(p, hipSetDevice(p->device));
     double buf[16] = {0};
     memcpy(buf, t, sizeof(double) * 7);
-    LTP_HIP_TRY(p, hipMemcpy(p->d_small, buf, sizeof(buf), hipMemcpyHostToDevice));
-    ltp::launch_single_opt_switch(nullptr, joint, p->t_sample, dev_limits(p), q_goal, q_0, v_0, a_0, v_drive, p->d_small);
-    LTP_HIP_TRY(p, hipGetLastError());
-    LTP_HIP_TRY(p, hipMemcpy(buf, p->d_small, sizeof(buf), hipMemcpyDeviceToHost));
+    const int rc = run_one_lane(p, buf, [&] { ltp::launch_single_opt_switch(nullptr, joint, p->t_sample, dev_limits(p), q_goal, q_0, v_0, a_0, v_drive, p->d_small); });
+    if (rc != LTP_OK) return rc;
     memcpy(t, buf, sizeof(double) * 7);
     *dir = buf[7];
     *mod = (char)(int)buf[8];
@@ -745,10 +803,8 @@ int ltp_time_scaling_host(ltp_planner* p, int joint, double q_goal, double q_0, 
     LTP_HIP_TRY(p, hipSetDevice(p->device));
     double buf[16] = {0};
     memcpy(buf, scaled_t, sizeof(double) * 7);
-    LTP_HIP_TRY(p, hipMemcpy(p->d_small, buf, sizeof(buf), hipMemcpyHostToDevice));
-    ltp::launch_single_time_scaling(nullptr, joint, p->t_sample, dev_limits(p), q_goal, q_0, v_0, a_0, dir, t_required, p->d_small);
-    LTP_HIP_TRY(p, hipGetLastError());
-    LTP_HIP_TRY(p, hipMemcpy(buf, p->d_small, sizeof(buf), hipMemcpyDeviceToHost));
+    const int rc = run_one_lane(p, buf, [&] { ltp::launch_single_time_scaling(nullptr, joint, p->t_sample, dev_limits(p), q_goal, q_0, v_0, a_0, dir, t_required, p->d_small); });
+    if (rc != LTP_OK) return rc;
     memcpy(scaled_t, buf, sizeof(double) * 7);
     *v_drive = buf[7];
     *mod = (char)(int)buf[8];
