@@ -74,6 +74,8 @@ def main():
     ap.add_argument("--t-sample", type=float, default=0.001)
     ap.add_argument("--tile-gib", type=float, default=192.0, help="size of the reused trajectory output tile")
     ap.add_argument("--seed", type=int, default=12345)
+    ap.add_argument("--layout", default="query_major", choices=["query_major", "joint_major"],
+                    help="input arrays [n][dof] (the reference's per-query vectors) or SoA [dof][n]")
     ap.add_argument("--max-samples", type=int, default=0, help="store only the first N samples per row (0 = whole trajectories, the reference behaviour)")
     ap.add_argument("--sample-stride", type=int, default=1, help="store every N-th sample per row (1 = every sample, the reference behaviour)")
     ap.add_argument("--f32", action="store_true", help="store float32 rows (same binary64 results, rounded once); default float64 as the reference")
@@ -114,7 +116,7 @@ def main():
     ltp = LongTermPlanner(dof, args.t_sample, device=local_rank, **lim)
     n = args.batch
     # this rank's shard of the global batch: query indices [rank*n, (rank+1)*n), generated on the device
-    qg, q0, v0, a0 = ltp.generateQueries(n, seed=args.seed, first_query=rank * n)
+    qg, q0, v0, a0 = ltp.generateQueries(n, seed=args.seed, first_query=rank * n, layout=args.layout)
     if args.max_samples:
         ltp.setMaxSamples(args.max_samples)
     if args.sample_stride > 1:
@@ -140,7 +142,7 @@ def main():
 
     def step(timed):
         nonlocal batch, n_chunks
-        batch = ltp.planSwitchTimesBatch(qg, q0, v0, a0, batch=batch)
+        batch = ltp.planSwitchTimesBatch(qg, q0, v0, a0, layout=args.layout, batch=batch)
         if gather_buf is not None:
             dist.all_gather(gather_buf, batch.t_required.to(cdev))
         if args.switch_only:
@@ -226,7 +228,7 @@ def main():
                                 (f"full q/v/a/j sampling" if not (args.max_samples or args.sample_stride > 1) else
                                  f"q/v/a/j rows: every {args.sample_stride}-th sample" + (f", first {args.max_samples} stored" if args.max_samples else ""))
                                 + f" into a reused {args.tile_gib} GiB tile ({n_chunks} chunks per step)")),
-                "batch_per_gpu": n, "dof": dof, "t_sample": args.t_sample, "limits": args.limits,
+                "batch_per_gpu": n, "dof": dof, "t_sample": args.t_sample, "limits": args.limits, "input_layout": args.layout,
                 "sharding": "contiguous query ranges per rank, no data-path collective" + (", RCCL all_gather of t_required" if gather_buf else ""),
                 "plans_ok_frac": round(float((status == 0).mean()), 5),
                 "mean_traj_len": round(float(traj_len.mean()), 1),
