@@ -238,6 +238,7 @@ class LongTermPlanner:
         if batch is None or batch.n != n or batch.dof != self.dof:
             batch = DeviceBatch(n, self.dof, q_0.device)
         batch.queries = q
+        batch.inputs = (q_goal, q_0, v_0, a_0)   # the sampler reads q_0/v_0/a_0 again: keep the tensors alive with the batch
         rec = batch.c_records()
         self._check(self._lib.ltp_plan_switch_times_batch(self._h, n, C.byref(q), C.byref(rec), batch.offsets.data_ptr(), self._stream()))
         return batch
