@@ -58,7 +58,12 @@ def cpu_baseline(dof, lim, t_sample, seed, sample_switch_only):
     with ThreadPoolExecutor(cores) as ex:
         list(ex.map(work, range(cores)))
     dt = time.perf_counter() - t0
+    n1 = min(per_thread, 32768 if not sample_switch_only else 262144)
+    t1 = time.perf_counter()
+    orc.plan_batch(qg, q0, v0, a0, sample=not sample_switch_only, first=0, count=n1, want_records=False)
+    dt1 = time.perf_counter() - t1
     return {"value": n / dt, "unit": "plans/s", "cores": cores, "kind": "port",
+            "one_thread": {"value": n1 / dt1, "unit": "plans/s", "sample": f"first {n1} queries, {dt1:.1f} s"},
             "sample": f"first {n} queries of the same synthetic batch, {per_thread} per thread, "
                       f"{'switching times only' if sample_switch_only else 'full planTrajectory incl. per-plan allocation'}, "
                       f"{dt:.1f} s wall"}

@@ -153,7 +153,8 @@ class LongTermPlanner {
     planTrajectoryBatch(1, q_goal.data(), q_0.data(), v_0.data(), a_0.data(), b);
     const int st = b.status[0];
     // the reference leaves `traj` untouched when it returns false before sampling (cc:14-39)
-    if (st & (LTP_STATUS_INVALID_INPUT | LTP_STATUS_OPT_FAILED | LTP_STATUS_NO_SLOWEST | LTP_STATUS_NONFINITE)) return false;
+    if (st & (LTP_STATUS_INVALID_INPUT | LTP_STATUS_OPT_FAILED | LTP_STATUS_NO_SLOWEST | LTP_STATUS_NONFINITE | LTP_STATUS_GOAL_OUTSIDE))
+      return false;
     traj = b.trajectory(0);
     return st == 0;   // LTP_STATUS_END_LIMIT: false with the trajectory filled (cc:59-61)
   }
@@ -223,6 +224,13 @@ class LongTermPlanner {
   inline void setSampleStride(int stride) {
     const int rc = ltp_set_sample_stride(handle(), stride);
     if (rc != LTP_OK) raise(handle_, rc, "ltp_set_sample_stride");
+  }
+
+  /** @brief NEW, off by default: reject a q_goal outside [q_min, q_max] before planning (LTP_STATUS_GOAL_OUTSIDE;
+   * planTrajectory then returns false with traj untouched). The reference leaves q_goal unchecked (cc:68-77). */
+  inline void setGoalCheck(bool enabled) {
+    const int rc = ltp_set_goal_check(handle(), enabled ? 1 : 0);
+    if (rc != LTP_OK) raise(handle_, rc, "ltp_set_goal_check");
   }
 
   /** @brief NEW: HIP device ordinal used by this planner (default 0). */

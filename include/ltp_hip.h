@@ -40,6 +40,7 @@ typedef enum {
 #define LTP_STATUS_END_LIMIT     8  /* last q outside [q_min,q_max] (cc:59-61); trajectory IS filled      */
 #define LTP_STATUS_NONFINITE    16  /* defined here: non-finite switching times, traj_len = 0 (ref.: UB)  */
 #define LTP_STATUS_OVERFLOW     32  /* trajectory did not fit the output tile passed to ltp_sample_batch  */
+#define LTP_STATUS_GOAL_OUTSIDE 64  /* only with ltp_set_goal_check(p, 1): q_goal outside [q_min,q_max]   */
 
 /* Queries: element (query p, joint j) of each array is ptr[p*query_stride + j*joint_stride].
  * Row-major [n][dof] (the reference's vector-per-query view): query_stride = dof, joint_stride = 1.
@@ -96,6 +97,12 @@ int ltp_stored_samples(const ltp_planner* p, int traj_len);
  * max_samples the cap counts STORED samples. ltp_replan_states_batch's sample index is a stored-sample index. */
 int ltp_set_sample_stride(ltp_planner* p, int stride);
 int ltp_get_sample_stride(const ltp_planner* p);
+/* SURVEY.md §8(f).3 q_goal pre-check, off by default. The reference validates q_0, v_0, a_0 (cc:68-77) but not
+ * q_goal: a goal beyond the joint range is planned, sampled and only then reported by the end-limit check (cc:59-61).
+ * With enabled != 0 such a query (or a NaN goal) gets LTP_STATUS_GOAL_OUTSIDE, traj_len 0 and is not sampled; every
+ * other query is planned exactly as before. */
+int ltp_set_goal_check(ltp_planner* p, int enabled);
+int ltp_get_goal_check(const ltp_planner* p);
 
 /* ---- batched hot path (device pointers, asynchronous on `stream`) -------------------------- */
 

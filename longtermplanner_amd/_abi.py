@@ -19,6 +19,7 @@ STATUS_NO_SLOWEST = 4
 STATUS_END_LIMIT = 8
 STATUS_NONFINITE = 16
 STATUS_OVERFLOW = 32
+STATUS_GOAL_OUTSIDE = 64
 
 ERROR_NAMES = {1: "LTP_ERR_INVALID_ARGUMENT", 2: "LTP_ERR_NO_DEVICE", 3: "LTP_ERR_OUT_OF_MEMORY", 4: "LTP_ERR_HIP"}
 
@@ -70,6 +71,8 @@ _SIGNATURES = {
     "ltp_stored_samples": (C.c_int, [C.c_void_p, C.c_int]),
     "ltp_set_sample_stride": (C.c_int, [C.c_void_p, C.c_int]),
     "ltp_get_sample_stride": (C.c_int, [C.c_void_p]),
+    "ltp_set_goal_check": (C.c_int, [C.c_void_p, C.c_int]),
+    "ltp_get_goal_check": (C.c_int, [C.c_void_p]),
     "ltp_replan_states_batch": (C.c_int, [C.c_void_p, C.c_longlong, C.c_longlong, C.POINTER(Queries), C.POINTER(Records), C.c_void_p,
                                           C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong,
                                           C.c_longlong, C.c_void_p]),

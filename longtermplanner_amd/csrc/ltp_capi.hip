@@ -16,6 +16,7 @@ struct ltp_planner {
     int device = 0;
     int max_samples = 0;                   // 0 = store whole trajectories (reference behaviour)
     int sample_stride = 1;                 // store every sample_stride-th sample
+    int goal_check = 0;                    // 1 = reject q_goal outside [q_min,q_max] up front (reference: unchecked)
     int sample_blocks = 0;                 // resident k_sample blocks on this device (work-queue grid)
     unsigned long long* d_sample_next = nullptr;   // ring of work-queue heads, one per in-flight sampler launch
     unsigned sample_next_slot = 0;
@@ -280,6 +281,14 @@ int ltp_set_sample_stride(ltp_planner* p, int stride)
     return LTP_OK;
 }
 int ltp_get_sample_stride(const ltp_planner* p) { return p ? p->sample_stride : -1; }
+int ltp_set_goal_check(ltp_planner* p, int enabled)
+{
+    if (!p) return LTP_ERR_INVALID_ARGUMENT;
+    std::lock_guard<std::mutex> g(p->mu);
+    p->goal_check = enabled ? 1 : 0;
+    return LTP_OK;
+}
+int ltp_get_goal_check(const ltp_planner* p) { return p ? p->goal_check : -1; }
 int ltp_stored_samples(const ltp_planner* p, int traj_len)
 {
     if (!p || traj_len <= 0) return 0;
@@ -325,7 +334,7 @@ int ltp_plan_switch_times_batch(ltp_planner* p, long long n, const ltp_queries* 
     const ltp::Queries q = to_dev(in);
     const ltp::Records r = to_dev(out);
     LTP_HIP_TRY(p, hipMemsetAsync(p->d_queue_count, 0, 16 * sizeof(unsigned long long), s));
-    ltp::launch_switch_times(s, n, p->dof, p->t_sample, L, q, r, p->d_lane_flags, p->d_queue, p->d_queue_count);
+    ltp::launch_switch_times(s, n, p->dof, p->t_sample, p->goal_check, L, q, r, p->d_lane_flags, p->d_queue, p->d_queue_count);
     ltp::launch_offsets(s, n, p->dof, p->t_sample, r, p->d_block_sums, offsets ? offsets : p->d_offsets_scratch, true, ltp::RowSpec{p->max_samples, p->sample_stride});
     LTP_HIP_TRY(p, hipGetLastError());
     return LTP_OK;

@@ -48,6 +48,7 @@ LTP_DEV int joint_len(const double (&t)[7], double t_sample)
     return finite ? (int)dceil(t[6] / t_sample) + 1 : -1;
 }
 
+constexpr int kLaneGoalOutside = 128; // lane_flags bit: q_goal outside [q_min, q_max] (only with the opt-in goal check)
 constexpr int kLaneDeferred = 64;   // lane_flags bit: optSwitchTimes of this lane is still pending in queue A
 
 // Compaction queues. A single device-scope counter saturates near 90 atomics/us on MI355X, which a kernel that
@@ -113,8 +114,8 @@ LTP_DEV void store_opt_record(const Records& out, long long rj, const double (&t
 }
 
 __global__ void __launch_bounds__(kQueriesPerBlock* kMaxJointSlots)
-k_opt_fast(long long n, int dof, double t_sample, Limits lim, Queries in, Records out, signed char* __restrict__ lane_flags,
-           Queue queue)
+k_opt_fast(long long n, int dof, double t_sample, int goal_check, Limits lim, Queries in, Records out,
+           signed char* __restrict__ lane_flags, Queue queue)
 {
     __shared__ unsigned long long s_cnt[kMaxJointSlots + 1];
     const int x = threadIdx.x, y = threadIdx.y, JB = blockDim.y;
@@ -131,6 +132,8 @@ k_opt_fast(long long n, int dof, double t_sample, Limits lim, Queries in, Record
             const long long ix = q * in.sq + (long long)j * in.sj;
             const double qg = in.q_goal[ix], q0 = in.q_0[ix], v0 = in.v_0[ix], a0 = in.a_0[ix];
             int flags = check_inputs_joint(L, q0, v0, a0) ? 0 : kStatusInvalidInput;
+            // NEW, opt-in: the reference never checks q_goal (cc:68-77), only the last sample (cc:59-61)
+            if (goal_check && !(qg >= L.q_min && qg <= L.q_max)) flags |= kLaneGoalOutside;
             double t[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
             double dir = 0.0;
             int mod = 0;
@@ -192,7 +195,7 @@ k_reduce_scale(long long n, int dof, double t_sample, Limits lim, Queries in, Re
         for (int j = y; j < dof; j += JB) {
             const long long rj = q * dof + j;
             const double t6 = out.t_opt[rj * 7 + 6];
-            flags |= lane_flags[rj];
+            flags |= lane_flags[rj] & 0xff;
             if (t6 > best_t) { best_t = t6; best_j = j; }
         }
     }
@@ -210,6 +213,7 @@ k_reduce_scale(long long n, int dof, double t_sample, Limits lim, Queries in, Re
         if (bj >= 0 && (bt > t_required || (bt == t_required && bj < slowest))) { t_required = bt; slowest = bj; }
     }
     if (slowest < 0) flags |= kStatusNoSlowest;
+    if (flags & kLaneGoalOutside) flags = (flags & ~kLaneGoalOutside) | kStatusGoalOutside;
     if (live && y == 0) {
         out.t_required[q] = t_required;
         out.slowest[q] = slowest;
@@ -1119,8 +1123,8 @@ long long queue_segment(long long n, int dof)
     return (nblocks + kQueueShards - 1) / kQueueShards * kQueriesPerBlock * (long long)dof;
 }
 
-void launch_switch_times(hipStream_t s, long long n, int dof, double t_sample, Limits lim, Queries in, Records out,
-                         signed char* lane_flags, unsigned long long* queue_items /* 2 * 8 * queue_segment(n, dof) */,
+void launch_switch_times(hipStream_t s, long long n, int dof, double t_sample, int goal_check, Limits lim, Queries in,
+                         Records out, signed char* lane_flags, unsigned long long* queue_items /* 2 * 8 * queue_segment(n, dof) */,
                          unsigned long long* counts /* [16], zeroed by the caller on the same stream */)
 {
     if (n <= 0) return;
@@ -1135,7 +1139,7 @@ void launch_switch_times(hipStream_t s, long long n, int dof, double t_sample, L
     if (a_blocks > 4096) a_blocks = 4096;
     long long b_blocks = (n * dof + kQueriesPerBlock - 1) / kQueriesPerBlock;
     if (b_blocks > 1024) b_blocks = 1024;
-    hipLaunchKernelGGL(k_opt_fast, grid, block, 0, s, n, dof, t_sample, lim, in, out, lane_flags, qa);
+    hipLaunchKernelGGL(k_opt_fast, grid, block, 0, s, n, dof, t_sample, goal_check, lim, in, out, lane_flags, qa);
     hipLaunchKernelGGL(k_opt_slow, dim3((unsigned)a_blocks), dim3(64), 0, s, dof, t_sample, lim, in, out, lane_flags, qa);
     hipLaunchKernelGGL(k_reduce_scale, grid, block, 0, s, n, dof, t_sample, lim, in, out, lane_flags, qb);
     hipLaunchKernelGGL(k_scaling_slow, dim3((unsigned)b_blocks), dim3(kQueriesPerBlock, 8), 0, s, dof, t_sample, lim, in, out, qb);

@@ -25,6 +25,7 @@ enum : int {
     kStatusEndLimit = 8,       // last q sample outside [q_min,q_max] (cc:59-61); trajectory is filled
     kStatusNonFinite = 16,     // DEFINED: non-finite switching times -> traj_len 0 (reference: UB)
     kStatusOverflow = 32,      // trajectory does not fit the caller's output tile; not sampled
+    kStatusGoalOutside = 64,   // NEW, opt-in: q_goal outside [q_min,q_max]; rejected before planning (reference: unchecked)
 };
 
 constexpr int kQueriesPerBlock = 64;   // one wave = 64 queries of one joint
@@ -75,8 +76,8 @@ struct Records {           // query-major outputs of stages 1-3
 };
 
 long long queue_segment(long long n, int dof);   // entries per queue shard; a batch needs 2 * 8 * this many u64
-void launch_switch_times(hipStream_t s, long long n, int dof, double t_sample, Limits lim, Queries in, Records out,
-                         signed char* lane_flags, unsigned long long* queue_items, unsigned long long* counts);
+void launch_switch_times(hipStream_t s, long long n, int dof, double t_sample, int goal_check, Limits lim, Queries in,
+                         Records out, signed char* lane_flags, unsigned long long* queue_items, unsigned long long* counts);
 void launch_offsets(hipStream_t s, long long n, int dof, double t_sample, Records rec,
                     unsigned long long* block_sums, unsigned long long* offsets, bool lens_ready, RowSpec rows);
 void launch_sample(hipStream_t s, long long first, long long count, int dof, double t_sample, Limits lim, Queries in,

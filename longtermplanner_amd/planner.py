@@ -112,6 +112,11 @@ class LongTermPlanner:
         """NEW: store every stride-th sample (0, stride, 2*stride, ...); 1 = every sample (reference)."""
         self._check(self._lib.ltp_set_sample_stride(self._h, int(stride)))
 
+    def setGoalCheck(self, enabled=True):
+        """NEW, off by default: reject queries whose q_goal lies outside [q_min, q_max] up front with
+        LTP_STATUS_GOAL_OUTSIDE (64) instead of planning them and failing the end-limit check (cc:59-61)."""
+        self._check(self._lib.ltp_set_goal_check(self._h, 1 if enabled else 0))
+
     def storedSamples(self, traj_len):
         return self._lib.ltp_stored_samples(self._h, int(traj_len))
 
@@ -134,7 +139,7 @@ class LongTermPlanner:
         reference would have overwritten it (status has none of the pre-sampling failure bits)."""
         r = self.planBatchHost(q_goal, q_0, v_0, a_0, sample=True)
         st = int(r["status"][0])
-        if st & (_abi.STATUS_INVALID_INPUT | _abi.STATUS_OPT_FAILED | _abi.STATUS_NO_SLOWEST | _abi.STATUS_NONFINITE):
+        if st & (_abi.STATUS_INVALID_INPUT | _abi.STATUS_OPT_FAILED | _abi.STATUS_NO_SLOWEST | _abi.STATUS_NONFINITE | _abi.STATUS_GOAL_OUTSIDE):
             return False
         n = int(r["traj_len"][0])
         q, v, a, j = unpack_trajectory(r["packed"], int(r["offsets"][0]), self.dof, n)

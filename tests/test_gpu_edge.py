@@ -302,3 +302,34 @@ def test_strided_rows_are_a_decimation_of_the_full_rows(amd, ref7, stride, cap):
     finally:
         ltp.setSampleStride(1)
         ltp.setMaxSamples(0)
+
+
+def test_goal_precheck_is_opt_in_and_changes_nothing_else(amd, ref7):
+    """with setGoalCheck a q_goal outside [q_min, q_max] is rejected up front (status 64); by default
+    the reference's behaviour stands (planned, sampled, END_LIMIT false, cc:59-61)."""
+    D, lim, _, orc = ref7
+    ltp = amd.LongTermPlanner(D, 0.001, device=0, **lim)
+    qg, q0, v0, a0 = amd.generate_queries(200, lim, seed=31)
+    outside = [5, 17, 64, 199]
+    qg[5, 0] = 3.3; qg[17, 6] = -3.2; qg[64, 3] = 4.0; qg[199, 2] = np.nan
+    base = ltp.planBatchHost(qg, q0, v0, a0, sample=True)
+    assert not np.any(base["status"] & amd.STATUS_GOAL_OUTSIDE)
+    for p in outside[:3]:
+        assert base["status"][p] == amd.STATUS_END_LIMIT and base["traj_len"][p] > 0     # reference behaviour
+    ltp.setGoalCheck(True)
+    r = ltp.planBatchHost(qg, q0, v0, a0, sample=True)
+    for p in range(200):
+        if p in outside:
+            assert r["status"][p] & amd.STATUS_GOAL_OUTSIDE
+            assert r["traj_len"][p] == 0 and r["offsets"][p + 1] == r["offsets"][p]
+        else:
+            assert r["status"][p] == base["status"][p] and r["traj_len"][p] == base["traj_len"][p]
+            assert np.array_equal(r["t_scaled"][p], base["t_scaled"][p], equal_nan=True)
+            a = r["packed"][int(r["offsets"][p]):int(r["offsets"][p + 1])]
+            b = base["packed"][int(base["offsets"][p]):int(base["offsets"][p + 1])]
+            assert np.array_equal(a, b)
+    # single-call API: false, trajectory untouched
+    t = amd.Trajectory()
+    assert ltp.planTrajectory(qg[5], q0[5], v0[5], a0[5], t) is False and t.length == 0
+    ltp.setGoalCheck(False)
+    assert np.array_equal(ltp.planBatchHost(qg, q0, v0, a0, sample=True)["status"], base["status"])
