@@ -93,6 +93,9 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for the barrier / timing reduction (gloo: rehearsal of N ranks on one GPU)")
     ap.add_argument("--device", type=int, default=None, help="HIP device ordinal for every rank (default: LOCAL_RANK)")
+    ap.add_argument("--envelope", default="", metavar="WINDOW:COUNT",
+                    help="VARIANT: instead of dense rows, reduce each plan on the device to per-joint [min q, max q] over COUNT windows of WINDOW samples (ltp_envelope_batch)")
+    ap.add_argument("--sample-blocks", type=int, default=0, help="TUNING: size of the sampler's persistent grid (0 = library default)")
     ap.add_argument("--gather", action="store_true", help="also all_gather t_required over RCCL each step (optional path)")
     args = ap.parse_args()
 
@@ -126,8 +129,12 @@ def main():
         ltp.setMaxSamples(args.max_samples)
     if args.sample_stride > 1:
         ltp.setSampleStride(args.sample_stride)
+    if args.sample_blocks:
+        ltp._check(ltp._lib.ltp_debug_set_sample_blocks(ltp._h, args.sample_blocks))
+    env_spec = tuple(int(x) for x in args.envelope.split(":")) if args.envelope else None
+    env_out = torch.empty((n, dof, env_spec[1], 2), dtype=torch.float64, device=dev) if env_spec else None
     tile = None
-    if not args.switch_only:
+    if not args.switch_only and not env_spec:
         # one big reused output tile; if this GPU cannot give 192 GiB right now, halve until it can
         gib = args.tile_gib
         while tile is None:
@@ -151,6 +158,16 @@ def main():
         if gather_buf is not None:
             dist.all_gather(gather_buf, batch.t_required.to(cdev))
         if args.switch_only:
+            return
+        if env_spec:
+            if timed:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            ltp.envelopeBatch(batch, 0, n, env_spec[0], env_spec[1], out=env_out)
+            if timed:
+                e1.record()
+                ev_pairs.append((e0, e1))
+            n_chunks = 1
             return
         offsets_pinned.copy_(batch.offsets, non_blocking=True)
         torch.cuda.current_stream().synchronize()       # chunk boundaries depend on this batch's trajectory lengths
@@ -194,6 +211,8 @@ def main():
     stored = -(-traj_len // args.sample_stride)
     stored = np.minimum(stored, args.max_samples) if args.max_samples else stored
     alg_bytes_per_step = int((16 if args.f32 else 32) * dof * stored.sum())   # 32*D*traj_len per plan (f64; stored samples)
+    if env_spec:
+        alg_bytes_per_step = 16 * dof * env_spec[1] * n                         # what the consumer writes: [min, max] per window
     roofline = None
     if ev_pairs:
         kern_ms = sum(a.elapsed_time(b) for a, b in ev_pairs)
@@ -208,7 +227,7 @@ def main():
                     traffic = rec.get("write_bytes_per_launch")
             except Exception:
                 traffic = None
-        roofline = {"kernel": "k_sample", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        roofline = {"kernel": "k_envelope" if env_spec else "k_sample", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "algorithmic_bytes_per_launch": alg_bytes_per_step // max(n_chunks, 1),
                     "avg_launch_ms": round(kern_ms / launches, 4), "launches_timed": launches}
@@ -230,6 +249,7 @@ def main():
             "config": {
                 "workload": (f"{n} x {dof}-DoF queries per GPU per step, limits '{args.limits}', Tsample {args.t_sample} s, "
                              + ("switching times only (stages 1-3)" if args.switch_only else
+                                f"on-device envelope consumer: [min q, max q] over {env_spec[1]} windows of {env_spec[0]} samples per joint, no dense rows" if env_spec else
                                 (f"full q/v/a/j sampling" if not (args.max_samples or args.sample_stride > 1) else
                                  f"q/v/a/j rows: every {args.sample_stride}-th sample" + (f", first {args.max_samples} stored" if args.max_samples else ""))
                                 + f" into a reused {args.tile_gib} GiB tile ({n_chunks} chunks per step)")),

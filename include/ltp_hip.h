@@ -127,6 +127,16 @@ int ltp_sample_batch(ltp_planner* p, long long first, long long count, const ltp
 int ltp_sample_batch_f32(ltp_planner* p, long long first, long long count, const ltp_queries* in, const ltp_records* rec,
                          const unsigned long long* offsets, float* out, unsigned long long capacity, int flags, void* stream);
 
+/* SURVEY.md §8(f).2 on-device consumer: position envelopes instead of dense rows. For plans [first, first+count) of
+ * a batch planned by ltp_plan_switch_times_batch, env[((i*dof + j)*n_windows + w)*2 + {0,1}] = {min, max} of the q
+ * samples w*window .. (w+1)*window-1 of joint j of local plan i — exactly the values getTrajectory (cc:706-841) /
+ * ltp_sample_batch would have stored, reduced on the fly, so the dense trajectories (32*dof*traj_len bytes per plan)
+ * never exist. Windows that start at or after traj_len hold the last position twice; plans with traj_len 0 (failed or
+ * rejected) hold NaN. The end-limit check (cc:59-61) sets LTP_STATUS_END_LIMIT as the sampler does. max_samples and
+ * sample_stride do not apply. env: device, count*dof*n_windows*2 doubles, 16-byte aligned. */
+int ltp_envelope_batch(ltp_planner* p, long long first, long long count, const ltp_queries* in, const ltp_records* rec,
+                       int window, int n_windows, double* env, void* stream);
+
 /* SURVEY.md §8(f).1 receding horizon (reference README.md:10-13): start states of the next plans = sample k of the
  * trajectories sampled into `tile` by ltp_sample_batch(first, count, ...). sample_index: device int[count] or NULL
  * (then uniform_index for all); k is clamped to the stored samples; plans that were not sampled keep the start
@@ -172,8 +182,11 @@ int ltp_time_scaling_host(ltp_planner* p, int joint, double q_goal, double q_0, 
 
 /* ---- diagnostics used by the parity tests ---------------------------------------------------- */
 /* device_buffer (3 x count u64, or NULL to switch off): k_sample block start / run tables ready / end on the
- * 100 MHz wall clock */
+ * 100 MHz wall clock; ltp_envelope_batch writes 16 u64 per (plan, joint group) item instead: loop top, item drawn,
+ * traj_len read, after each of the seven table-build barriers, reduction done */
 int ltp_debug_set_sample_stamps(ltp_planner* p, unsigned long long* device_buffer);
+/* tuning aid: size of the persistent k_sample / k_envelope grid (0 = what the device holds at once, the default) */
+int ltp_debug_set_sample_blocks(ltp_planner* p, int blocks);
 /* out[i*8 + {0..7}] = x/y, sqrt|x|, x^3, x^4, x^6, floor(x/y), ceil(x/y), x*y+x computed on the device */
 int ltp_debug_math_probe_host(ltp_planner* p, long long n, const double* x, const double* y, double* out);
 /* root[i] = smallest positive exactly-real root of the degree-`degree` polynomial coef[i*7 .. i*7+degree]

@@ -373,6 +373,25 @@ int ltp_sample_batch_f32(ltp_planner* p, long long first, long long count, const
     return sample_batch_any(p, first, count, in, rec, offsets, out, true, capacity, flags, stream);
 }
 
+int ltp_envelope_batch(ltp_planner* p, long long first, long long count, const ltp_queries* in, const ltp_records* rec,
+                       int window, int n_windows, double* env, void* stream)
+{
+    if (!p || first < 0 || count < 0 || !in || !records_complete(rec) || !env) return fail(p, LTP_ERR_INVALID_ARGUMENT, "null argument");
+    if (window < 1 || n_windows < 1) return fail(p, LTP_ERR_INVALID_ARGUMENT, "window and n_windows must be >= 1");
+    if (((uintptr_t)env & 15u) != 0) return fail(p, LTP_ERR_INVALID_ARGUMENT, "envelope buffer must be 16-byte aligned");
+    std::lock_guard<std::mutex> g(p->mu);
+    int rc = check_config(p);
+    if (rc != LTP_OK) return rc;
+    if (count == 0 || p->dof == 0) return LTP_OK;
+    LTP_HIP_TRY(p, hipSetDevice(p->device));
+    unsigned long long* head = p->d_sample_next + (p->sample_next_slot++ & 63u);
+    LTP_HIP_TRY(p, hipMemsetAsync(head, 0, sizeof(unsigned long long), (hipStream_t)stream));
+    ltp::launch_envelope((hipStream_t)stream, first, count, p->dof, p->t_sample, dev_limits(p), to_dev(in), to_dev(rec), window,
+                         n_windows, env, head, p->sample_blocks, p->dbg_stamps);
+    LTP_HIP_TRY(p, hipGetLastError());
+    return LTP_OK;
+}
+
 static int replan_states_any(ltp_planner* p, long long first, long long count, const ltp_queries* in, const ltp_records* rec,
                              const unsigned long long* offsets, const void* tile, bool f32, const int* sample_index,
                              int uniform_index, double* q_0, double* v_0, double* a_0, long long query_stride,
@@ -827,6 +846,14 @@ int ltp_debug_set_sample_stamps(ltp_planner* p, unsigned long long* device_buffe
     if (!p) return LTP_ERR_INVALID_ARGUMENT;
     std::lock_guard<std::mutex> g(p->mu);
     p->dbg_stamps = device_buffer;
+    return LTP_OK;
+}
+
+int ltp_debug_set_sample_blocks(ltp_planner* p, int blocks)
+{
+    if (!p || blocks < 0) return LTP_ERR_INVALID_ARGUMENT;
+    std::lock_guard<std::mutex> g(p->mu);
+    p->sample_blocks = blocks > 0 ? blocks : ltp::sample_resident_blocks(p->device);
     return LTP_OK;
 }
 

@@ -666,33 +666,25 @@ LTP_DEV void store16(V* dst, V val)
     else *dst = val;
 }
 
-// One work item = one plan x one group of <= 8 joints. The 256 lanes of the block first build the run tables of
-// those joints in LDS together (32 lanes per joint: one per sampled switching time / candidate cut point / run),
-// then stream the rows. Every thread of the block calls this; all early exits are block-uniform.
-template <bool STREAMING, bool DRY, typename T>
-LTP_DEV void sample_plan(SegTable& tab, long long first, long long local, int group, int dof, double t_sample, const Limits& lim,
-                         const Queries& in, const Records& rec, const unsigned long long* __restrict__ offsets,
-                         T* __restrict__ out, unsigned long long capacity, unsigned long long* __restrict__ stamps,
-                         RowSpec rows)
+// The run tables of one plan x one group of <= 8 joints, built in LDS by the 256 lanes of the block together
+// (32 lanes per joint: one per sampled switching time / candidate cut point / run). len = traj_len of the plan (> 0).
+// Also applies the end-limit check of cc:59-61. Every thread of the block calls this.
+// Orders the LDS traffic of the lanes of ONE wavefront (no s_barrier: the LDS serves a wave's requests in order).
+LTP_DEV void wave_sync()
 {
-    const long long p = first + local;
-    // diagnostic only (stamps == nullptr in every product call): start / tables ready / end on the 100 MHz wall clock
-    if (stamps && threadIdx.x == 0 && group == 0) stamps[3 * local] = wall_clock64();
-    const int len = rec.traj_len[p];
-    if (len <= 0) return;   // failed / non-finite query: nothing to sample
-    const unsigned long long off0 = offsets[first];
-    const unsigned long long rel = offsets[p] - off0;
-    const int slen = stored_len(len, rows);   // samples actually stored per row
-    const unsigned long long stride = ((unsigned long long)slen + (kRowAlign - 1)) / kRowAlign * kRowAlign;
-    if (rel + 4ull * dof * stride > capacity) {
-        if (threadIdx.x == 0 && group == 0) atomicOr(&rec.status[p], kStatusOverflow);
-        return;
-    }
-    const int j0 = group * kSampleJointGroup;
-    const int nj = (dof - j0) < kSampleJointGroup ? (dof - j0) : kSampleJointGroup;
-    const double Ts = t_sample;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
+template <bool PROBE = false>
+LTP_DEV void build_run_tables(SegTable& tab, long long p, int j0, int nj, int dof, int len, double Ts, const Limits& lim,
+                              const Queries& in, const Records& rec, unsigned long long* probe = nullptr)
+{
     // ---- cooperative table build: thread t -> joint slot jl = t / 32, slot k = t % 32 ----
+    // The 32 lanes of a joint slot sit in one wavefront and only ever exchange data with each other, so the steps
+    // are separated by wave-level synchronisation (LDS operations of one wave complete in order); the whole block
+    // meets once, at the end, before any wave reads another wave's tables.
     // The build is a short, latency-bound prologue that shares its SIMDs with other blocks' streaming waves:
     // give it issue priority, the bandwidth-bound streaming loop runs at the default priority.
     __builtin_amdgcn_s_setprio(3);
@@ -717,7 +709,8 @@ LTP_DEV void sample_plan(SegTable& tab, long long first, long long local, int gr
         tab.misc[jl][4] = in.a_0[ix];
         tab.misc[jl][5] = (double)rec.mod[rj];
     }
-    __syncthreads();
+    wave_sync();
+    if constexpr (PROBE) { if (threadIdx.x == 0) probe[3] = wall_clock64(); }
     // (2) lane 8: phase jerks and the nine correction terms of the joint; lanes < 20: one candidate cut point each
     int cval = -1;
     if (jact && k == 8) {
@@ -744,7 +737,8 @@ LTP_DEV void sample_plan(SegTable& tab, long long first, long long local, int gr
         cval = (k == 0 || (c > 0 && c < len)) ? c : -1;
         tab.cand[jl][k] = cval;
     }
-    __syncthreads();
+    wave_sync();
+    if constexpr (PROBE) { if (threadIdx.x == 0) probe[4] = wall_clock64(); }
     // (3) sort + unique by counting: drop duplicates, then position = number of distinct valid values below
     if (jact && k < kCutSlots) {
         bool first = cval >= 0;
@@ -752,7 +746,8 @@ LTP_DEV void sample_plan(SegTable& tab, long long first, long long local, int gr
         for (int m = 0; m < kCutSlots; ++m) first = first && (m >= k || tab.cand[jl][m] != cval);   // fixed trip count: loads pipeline
         tab.runMode[jl][k] = first ? cval : -1;   // runMode doubles as scratch until step (4)
     }
-    __syncthreads();
+    wave_sync();
+    if constexpr (PROBE) { if (threadIdx.x == 0) probe[5] = wall_clock64(); }
     if (jact && k < kCutSlots) {
         const bool mine = tab.runMode[jl][k] >= 0;
         int pos = 0, distinct = 0;
@@ -764,7 +759,8 @@ LTP_DEV void sample_plan(SegTable& tab, long long first, long long local, int gr
         if (mine) tab.start[jl][pos] = cval;
         if (k == 0) { tab.start[jl][distinct] = len; tab.nseg[jl] = distinct; }
     }
-    __syncthreads();
+    wave_sync();
+    if constexpr (PROBE) { if (threadIdx.x == 0) probe[6] = wall_clock64(); }
     // (4) lane k < ns: mode and jerk of run k, and everything of the run's end-state update that does not depend
     //     on the state (parked in tab.c[.][k][0..5] until step (6) overwrites it with the coefficients)
     const int ns = jact ? tab.nseg[jl] : 0;
@@ -789,18 +785,25 @@ LTP_DEV void sample_plan(SegTable& tab, long long first, long long local, int gr
         pre[4] = Ts * tj;
         pre[5] = Ts * (Ts * tj);
     }
-    __syncthreads();
+    wave_sync();
+    if constexpr (PROBE) { if (threadIdx.x == 0) probe[7] = wall_clock64(); }
     // (5) lane 0 of the joint: the state before each run — the only serial part. Each step is run_eval(run_coef(..))
     //     at the run's last sample, i.e. exactly what the streaming loop will store there, with the state-independent
     //     factors taken from step (4).
     if (jact && k == 0) {
         const double vsnap = tab.misc[jl][1];
         double q = tab.misc[jl][2], v = tab.misc[jl][3], a = tab.misc[jl][4];   // state "before sample 0" (cc:810-812)
+        // software-pipelined by hand: the state-independent factors of run m+1 are fetched from LDS while the
+        // dependent chain of run m executes (the chain is ~5 binary64 operations, an LDS round trip is longer)
+        const double* pre = tab.c[jl][0];
+        double md = pre[0], s1 = pre[1], s2 = pre[2], p3 = pre[3], p4 = pre[4], p5 = pre[5];
+        int mode = tab.runMode[jl][0];
         for (int m = 0; m < ns; ++m) {
+            const int mn = m + 1 < ns ? m + 1 : m;
+            const double* nx = tab.c[jl][mn];
+            const double md_n = nx[0], s1_n = nx[1], s2_n = nx[2], p3_n = nx[3], p4_n = nx[4], p5_n = nx[5];
+            const int mode_n = tab.runMode[jl][mn];
             tab.state[jl][m][0] = a; tab.state[jl][m][1] = v; tab.state[jl][m][2] = q;
-            const double* pre = tab.c[jl][m];
-            const double md = pre[0], s1 = pre[1], s2 = pre[2];
-            const int mode = tab.runMode[jl][m];
             double qn, vn, an;
             if (mode & kModeVSnap) {
                 vn = vsnap + (0.0 * md + 0.0 * s1);
@@ -809,16 +812,18 @@ LTP_DEV void sample_plan(SegTable& tab, long long first, long long local, int gr
                 vn = 0.0 + (0.0 * md + 0.0 * s1);
                 qn = q + (0.0 * md + (0.0 * s1 + 0.0 * s2));
             } else {
-                vn = v + ((Ts * a) * md + pre[4] * s1);
-                qn = q + ((Ts * v) * md + ((Ts * (Ts * a)) * s1 + pre[5] * s2));
+                vn = v + ((Ts * a) * md + p4 * s1);
+                qn = q + ((Ts * v) * md + ((Ts * (Ts * a)) * s1 + p5 * s2));
             }
-            an = (mode & kModeTail) ? 0.0 + 0.0 * md : a + pre[3] * md;
+            an = (mode & kModeTail) ? 0.0 + 0.0 * md : a + p3 * md;
             q = qn; v = vn; a = an;
+            md = md_n; s1 = s1_n; s2 = s2_n; p3 = p3_n; p4 = p4_n; p5 = p5_n; mode = mode_n;
         }
         // cc:59-61: q now holds sample len-1
         if (q < lim.q_min[j] || q > lim.q_max[j]) atomicOr(&rec.status[p], kStatusEndLimit);
     }
-    __syncthreads();
+    wave_sync();
+    if constexpr (PROBE) { if (threadIdx.x == 0) probe[8] = wall_clock64(); }
     // (6) lane k < ns: the coefficients of run k
     if (k < ns) {
         const RunCoef rc = run_coef(tab.runMode[jl][k], tab.runJ[jl][k], tab.state[jl][k][0], tab.state[jl][k][1],
@@ -827,7 +832,34 @@ LTP_DEV void sample_plan(SegTable& tab, long long first, long long local, int gr
         for (int x = 0; x < kRunCoefs; ++x) tab.c[jl][k][x] = rc.c[x];
     }
     __syncthreads();
+    if constexpr (PROBE) { if (threadIdx.x == 0) probe[9] = wall_clock64(); }
     __builtin_amdgcn_s_setprio(0);
+}
+
+// One work item = one plan x one group of <= 8 joints: build the run tables, then stream the rows. Every thread of
+// the block calls this; all early exits are block-uniform.
+template <bool STREAMING, bool DRY, typename T>
+LTP_DEV void sample_plan(SegTable& tab, long long first, long long local, int group, int dof, double t_sample, const Limits& lim,
+                         const Queries& in, const Records& rec, const unsigned long long* __restrict__ offsets,
+                         T* __restrict__ out, unsigned long long capacity, unsigned long long* __restrict__ stamps,
+                         RowSpec rows)
+{
+    const long long p = first + local;
+    // diagnostic only (stamps == nullptr in every product call): start / tables ready / end on the 100 MHz wall clock
+    if (stamps && threadIdx.x == 0 && group == 0) stamps[3 * local] = wall_clock64();
+    const int len = rec.traj_len[p];
+    if (len <= 0) return;   // failed / non-finite query: nothing to sample
+    const unsigned long long off0 = offsets[first];
+    const unsigned long long rel = offsets[p] - off0;
+    const int slen = stored_len(len, rows);   // samples actually stored per row
+    const unsigned long long stride = ((unsigned long long)slen + (kRowAlign - 1)) / kRowAlign * kRowAlign;
+    if (rel + 4ull * dof * stride > capacity) {
+        if (threadIdx.x == 0 && group == 0) atomicOr(&rec.status[p], kStatusOverflow);
+        return;
+    }
+    const int j0 = group * kSampleJointGroup;
+    const int nj = (dof - j0) < kSampleJointGroup ? (dof - j0) : kSampleJointGroup;
+    build_run_tables(tab, p, j0, nj, dof, len, t_sample, lim, in, rec);
     if (stamps && threadIdx.x == 0 && group == 0) stamps[3 * local + 1] = wall_clock64();   // run tables ready
 
     // Streaming: per joint, every lane produces q, v, a and j of N consecutive samples (N = 2 doubles or 4 floats)
@@ -935,6 +967,105 @@ k_sample(long long first, long long count, int dof, double t_sample, Limits lim,
         if (local < count)
             sample_plan<STREAMING, DRY, T>(tab, first, local, group, dof, t_sample, lim, in, rec, offsets, out, capacity, stamps,
                                         rows);
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// On-device consumer: position envelopes instead of dense rows. A caller that only needs to
+// know where each joint can be during each time window of the plan (reachability / limit / collision checks of a
+// safety shield, reference README.md:10-13) gets, per plan and joint, [min q, max q] over the samples of each of
+// n_windows windows of `window` samples — 16 bytes per window instead of 32 bytes per sample, so nothing the size
+// of the dense trajectories ever exists. The values are the minimum and maximum of exactly the q samples k_sample
+// would have stored (same run tables, same run_eval expression). Windows that start after the end of the trajectory
+// hold its last position (the joint rests there); plans without a trajectory (traj_len 0) get NaN.
+// Item = plan x joint group as in k_sample; lane -> (joint, window) task, each walking its samples in order.
+// ---------------------------------------------------------------------------------------
+LTP_DEV double run_eval_q(const double* c, int m)
+{
+    const double md = (double)m;
+    const double s1 = 0.5 * (md * (md + 1.0));
+    const double s2 = s1 * (md + 2.0) * (1.0 / 3.0);
+    return c[0] + (c[1] * md + (c[2] * s1 + c[3] * s2));   // the q line of run_eval
+}
+
+template <bool PROBE>
+__global__ void __launch_bounds__(kSampleThreads, kSampleBlocksPerCU)
+k_envelope(long long first, long long count, int dof, double t_sample, Limits lim, Queries in, Records rec, int window,
+           int n_windows, int lg, double* __restrict__ env, unsigned long long* __restrict__ next_item,
+           unsigned long long* __restrict__ probe_buf /* diagnostic, PROBE only: 16 stamps per item */)
+{
+    __shared__ SegTable tab;
+    __shared__ unsigned long long s_item;
+    const int ngroups = (dof + kSampleJointGroup - 1) / kSampleJointGroup;
+    const unsigned long long total = (unsigned long long)count * ngroups;
+    for (;;) {
+        __syncthreads();
+        unsigned long long t_top = 0ull;
+        if constexpr (PROBE) t_top = wall_clock64();
+        if (threadIdx.x == 0) s_item = atomicAdd(next_item, 1ull);
+        __syncthreads();
+        const unsigned long long item = s_item;
+        if (item >= total) break;
+        unsigned long long* probe = nullptr;
+        if constexpr (PROBE) {
+            probe = probe_buf + item * 16;
+            if (threadIdx.x == 0) { probe[0] = t_top; probe[1] = wall_clock64(); }
+        }
+        const int group = (int)(item % ngroups);
+        const long long local = (long long)(item / ngroups);
+        const long long p = first + local;
+        const int j0 = group * kSampleJointGroup;
+        const int nj = (dof - j0) < kSampleJointGroup ? (dof - j0) : kSampleJointGroup;
+        const int len = rec.traj_len[p];
+        const int tasks = nj * n_windows;
+        double2_t* const dst = reinterpret_cast<double2_t*>(env) + ((unsigned long long)local * dof + j0) * n_windows;
+        if (len <= 0) {
+            const double nan = __builtin_nan("");
+            for (int task = threadIdx.x; task < tasks; task += kSampleThreads) dst[task] = double2_t{nan, nan};
+            continue;
+        }
+        if constexpr (PROBE) { if (threadIdx.x == 0) probe[2] = wall_clock64(); }
+        build_run_tables<PROBE>(tab, p, j0, nj, dof, len, t_sample, lim, in, rec, probe);
+        // g lanes share one (joint, window) task (g = 2^lg divides 64, chosen by the host so that the block has
+        // work for all its lanes); lane r of the task takes samples b + r, b + r + g, ... and the g partial results
+        // meet in a butterfly. Minimum and maximum do not depend on the order, so any g gives the same bits.
+        const int g = 1 << lg;
+        for (int base = 0; base < tasks * g; base += kSampleThreads) {
+            const int idx = base + (int)threadIdx.x;
+            const int task = idx >> lg, r = idx & (g - 1);
+            const bool live = task < tasks;
+            double lo = __builtin_huge_val(), hi = -__builtin_huge_val();
+            if (live) {
+                const int jl = task / n_windows, w = task - jl * n_windows;
+                const int* st = tab.start[jl];
+                const int nruns = tab.nseg[jl];
+                const long long b = (long long)w * window;
+                const bool past = b >= (long long)len;                            // past the end: the last sample only
+                int i = past ? len - 1 + r : (int)b + r;
+                const int e = (b + window < (long long)len) ? (int)(b + window) : len;
+                int kr = 0, cur = 0, nxt = nruns > 1 ? st[1] : 0x7fffffff;
+                for (; i < e; i += g) {
+                    while (nxt <= i) {
+                        ++kr;
+                        cur = nxt;
+                        nxt = kr + 1 < nruns ? st[kr + 1] : 0x7fffffff;
+                    }
+                    const double q = run_eval_q(tab.c[jl][kr], i - cur + 1);
+                    lo = q < lo ? q : lo;
+                    hi = q > hi ? q : hi;
+                }
+            }
+            for (int d = 1; d < g; d <<= 1) {
+                const double lo2 = __shfl_xor(lo, d), hi2 = __shfl_xor(hi, d);
+                lo = lo2 < lo ? lo2 : lo;
+                hi = hi2 > hi ? hi2 : hi;
+            }
+            if (live && r == 0) dst[task] = double2_t{lo, hi};
+        }
+        if constexpr (PROBE) {
+            __syncthreads();
+            if (threadIdx.x == 0) probe[10] = wall_clock64();
+        }
     }
 }
 
@@ -1192,6 +1323,26 @@ void launch_sample(hipStream_t s, long long first, long long count, int dof, dou
     default: LTP_SAMPLE_CASE(true, true, float); break;
     }
 #undef LTP_SAMPLE_CASE
+}
+
+void launch_envelope(hipStream_t s, long long first, long long count, int dof, double t_sample, Limits lim, Queries in,
+                     Records rec, int window, int n_windows, double* env, unsigned long long* next_item, int resident_blocks,
+                     unsigned long long* probe)
+{
+    if (count <= 0 || n_windows <= 0) return;
+    const int ngroups = (dof + kSampleJointGroup - 1) / kSampleJointGroup;
+    long long blocks = resident_blocks > 0 ? resident_blocks : 1536;
+    if (blocks > count * ngroups) blocks = count * ngroups;
+    // lanes per (joint, window) task: the largest power of two <= 64 that still gives every lane of a block a task
+    const long long tasks = (long long)(dof < kSampleJointGroup ? dof : kSampleJointGroup) * n_windows;
+    int lg = 0;
+    while (lg < 6 && (tasks << (lg + 1)) <= kSampleThreads && (2 << lg) <= window) ++lg;
+    if (probe)
+        hipLaunchKernelGGL(k_envelope<true>, dim3((unsigned)blocks), dim3(kSampleThreads), 0, s, first, count, dof, t_sample, lim, in,
+                           rec, window, n_windows, lg, env, next_item, probe);
+    else
+        hipLaunchKernelGGL(k_envelope<false>, dim3((unsigned)blocks), dim3(kSampleThreads), 0, s, first, count, dof, t_sample, lim, in,
+                           rec, window, n_windows, lg, env, next_item, probe);
 }
 
 void launch_replan_states(hipStream_t s, long long first, long long count, int dof, RowSpec rows, Queries in, Records rec,

@@ -258,6 +258,18 @@ class LongTermPlanner:
         self._check(fn(self._h, first, count, C.byref(batch.queries), C.byref(rec), batch.offsets.data_ptr(),
                        out.data_ptr(), out.numel(), (1 if streaming else 0) | (2 if dry else 0) | (int(spread) << 8), self._stream()))
 
+    def envelopeBatch(self, batch: DeviceBatch, first, count, window, n_windows, out=None):
+        """NEW (on-device consumer): [count, dof, n_windows, 2] = min / max of q over windows of `window`
+        samples of plans [first, first+count), without storing the trajectories (ltp_envelope_batch)."""
+        import torch
+        if out is None:
+            out = torch.empty((count, self.dof, n_windows, 2), dtype=torch.float64, device=batch.offsets.device)
+        assert out.is_cuda and out.is_contiguous() and out.dtype == torch.float64 and out.numel() >= count * self.dof * n_windows * 2
+        rec = batch.c_records()
+        self._check(self._lib.ltp_envelope_batch(self._h, first, count, C.byref(batch.queries), C.byref(rec), int(window),
+                                                 int(n_windows), out.data_ptr(), self._stream()))
+        return out
+
     def replanStates(self, batch: DeviceBatch, first, count, tile, sample_index, layout="query_major"):
         """NEW: start states (q_0, v_0, a_0) of the next plans = sample k of the trajectories that
         sampleBatch(batch, first, count, tile) wrote. sample_index: int or int32 CUDA tensor [count]."""

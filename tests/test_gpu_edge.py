@@ -333,3 +333,61 @@ def test_goal_precheck_is_opt_in_and_changes_nothing_else(amd, ref7):
     assert ltp.planTrajectory(qg[5], q0[5], v0[5], a0[5], t) is False and t.length == 0
     ltp.setGoalCheck(False)
     assert np.array_equal(ltp.planBatchHost(qg, q0, v0, a0, sample=True)["status"], base["status"])
+
+
+@pytest.mark.parametrize("limits,n,window,n_windows", [("ref", 700, 64, 130), ("ref", 300, 1000, 4), ("panda", 500, 7, 300),
+                                                        ("ref30", 60, 256, 33), ("ref", 200, 1, 40)])
+def test_envelope_consumer_equals_reduced_dense_rows(amd, oracle_mod, limits, n, window, n_windows):
+    """SURVEY §8(f).2 on-device consumer: ltp_envelope_batch == min / max over windows of the rows ltp_sample_batch
+    stores (bit for bit), and within 1e-9 of the same reduction of the oracle's trajectories."""
+    import torch
+    D, lim = amd.limit_set(limits)
+    ltp = amd.LongTermPlanner(D, 0.001, device=0, **lim)
+    orc = oracle_mod.Oracle(D, 0.001, **lim)
+    qg, q0, v0, a0 = amd.generate_queries(n, lim, seed=77)
+    q0[3, 0] = 99.0                                            # one rejected plan -> NaN envelope
+    dev = [torch.from_numpy(x).cuda() for x in (qg, q0, v0, a0)]
+    b = ltp.planSwitchTimesBatch(*dev)
+    first, count = 2, n - 5                                    # a sub-range, like a chunk
+    guard = torch.full((count * D * n_windows * 2 + 64,), 7.0, dtype=torch.float64, device="cuda")
+    env = ltp.envelopeBatch(b, first, count, window, n_windows, out=guard[: count * D * n_windows * 2])
+    off = b.offsets.cpu().numpy().view(np.uint64)
+    tile = torch.zeros(int(off[first + count] - off[first]), dtype=torch.float64, device="cuda")
+    ltp.sampleBatch(b, first, count, tile)
+    torch.cuda.synchronize()
+    assert torch.all(guard[count * D * n_windows * 2:] == 7.0)
+    env = env.cpu().numpy().reshape(count, D, n_windows, 2)
+    tile = tile.cpu().numpy()
+    lens = b.traj_len.cpu().numpy()
+    status = b.status.cpu().numpy()
+    assert status[3] & amd.STATUS_INVALID_INPUT and np.all(np.isnan(env[3 - first]))
+    worst = 0.0
+    for i in range(count):
+        p = first + i
+        L = int(lens[p])
+        if L == 0:
+            assert np.all(np.isnan(env[i]))
+            continue
+        q = amd.unpack_trajectory(tile, int(off[p] - off[first]), D, L)[0]            # [D][L] as stored by the sampler
+        pad = np.concatenate([q, np.repeat(q[:, -1:], max(window * n_windows - L, 0) + window, axis=1)], axis=1)
+        win = pad[:, : window * n_windows].reshape(D, n_windows, window)
+        # windows that start inside the trajectory but run past its end only see the samples that exist, which the
+        # padding with the last sample does not change; windows past the end hold the last sample
+        assert np.array_equal(env[i, :, :, 0], win.min(axis=2)), (p, L)
+        assert np.array_equal(env[i, :, :, 1], win.max(axis=2)), (p, L)
+        if i % 16 == 0:
+            o = orc.plan_trajectory(qg[p], q0[p], v0[p], a0[p])
+            assert o["length"] == L
+            qo = o["q"]
+            pad = np.concatenate([qo, np.repeat(qo[:, -1:], max(window * n_windows - L, 0) + window, axis=1)], axis=1)
+            wo = pad[:, : window * n_windows].reshape(D, n_windows, window)
+            worst = max(worst, float(np.max(np.abs(env[i, :, :, 0] - wo.min(axis=2)))), float(np.max(np.abs(env[i, :, :, 1] - wo.max(axis=2)))))
+    assert worst <= TOL
+    # the consumer applies the end-limit check too (cc:59-61), like the sampler
+    b2 = ltp.planSwitchTimesBatch(*dev)
+    ltp.envelopeBatch(b2, 0, n, window, n_windows)
+    b3 = ltp.planSwitchTimesBatch(*dev)
+    t3 = torch.zeros(int(off[n] - off[0]), dtype=torch.float64, device="cuda")
+    ltp.sampleBatch(b3, 0, n, t3)
+    torch.cuda.synchronize()
+    assert torch.equal(b2.status, b3.status)
