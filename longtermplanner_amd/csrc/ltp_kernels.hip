@@ -572,11 +572,7 @@ struct RunCoef {
     double c[kRunCoefs];
 };
 
-struct SegTable {
-    int start[kSampleJointGroup][kMaxSegments + 1];
-    double c[kSampleJointGroup][kMaxSegments][kRunCoefs];
-    int nseg[kSampleJointGroup];
-    // scratch of the cooperative table build
+struct SegScratch {              // scratch of the cooperative table build, dead once the coefficients are written
     int s[kSampleJointGroup][8];            // sampled switch indices (cc:751-757)
     double fr[kSampleJointGroup][8];        // fractions lost to sampling (cc:747)
     double frts[kSampleJointGroup][8];      // fr / Ts
@@ -587,6 +583,16 @@ struct SegTable {
     double runJ[kSampleJointGroup][kMaxSegments];
     int runMode[kSampleJointGroup][kMaxSegments];
     double state[kSampleJointGroup][kMaxSegments][3];
+};
+struct SegTable {
+    int start[kSampleJointGroup][kMaxSegments + 1];
+    double c[kSampleJointGroup][kMaxSegments][kRunCoefs];
+    int nseg[kSampleJointGroup];
+    union {
+        SegScratch w;
+        // the sampler reuses the space for the finished 16-byte slots that contain run boundary k: [q, v, a, j]
+        double2_t bnd[kSampleJointGroup][kMaxSegments][4];
+    };
 };
 
 // candidate cut points: slot 0 is index 0, slot c >= 1 is s[kCutBase[c]] + kCutDelta[c]; every index where the jerk
@@ -677,9 +683,44 @@ LTP_DEV void wave_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// What one lane contributes to the table build of a (plan, joint group) item, fetched ahead of time: lane k < 7 of a
+// joint slot holds one switching time, lanes 7..12 the per-joint scalars; len / off are the plan's traj_len and packed
+// offset (the same in every lane).
+struct ItemRegs {
+    int len;
+    unsigned long long off;
+    double pa, pb;
+};
+
+// Issues the loads of an item (nothing here waits for them). p < 0: no item.
+LTP_DEV ItemRegs fetch_item(long long p, int j0, int nj, int dof, const Limits& lim, const Queries& in, const Records& rec,
+                            const unsigned long long* __restrict__ offsets)
+{
+    ItemRegs r;
+    r.len = 0; r.off = 0ull; r.pa = 0.0; r.pb = 0.0;
+    if (p < 0) return r;
+    r.len = rec.traj_len[p];
+    if (offsets) r.off = offsets[p];
+    const int jl = threadIdx.x >> 5, k = threadIdx.x & 31;
+    if (jl < nj) {
+        const int j = j0 + jl;
+        const long long rj = p * dof + j;
+        const long long ix = p * in.sq + (long long)j * in.sj;
+        if (k < 7) r.pa = rec.t_scaled[rj * 7 + k];
+        else if (k == 7) { r.pa = rec.dir[rj]; r.pb = lim.j_max[j]; }
+        else if (k == 8) { r.pa = rec.v_drive[rj]; r.pb = rec.dir[rj]; }
+        else if (k == 9) r.pa = in.q_0[ix];
+        else if (k == 10) r.pa = in.v_0[ix];
+        else if (k == 11) r.pa = in.a_0[ix];
+        else if (k == 12) r.pa = (double)rec.mod[rj];
+    }
+    return r;
+}
+
+// Leaves the run tables of the item in LDS. The caller must pass a block barrier before any wave reads them.
 template <bool PROBE = false>
-LTP_DEV void build_run_tables(SegTable& tab, long long p, int j0, int nj, int dof, int len, double Ts, const Limits& lim,
-                              const Queries& in, const Records& rec, unsigned long long* probe = nullptr)
+LTP_DEV void build_run_tables(SegTable& tab, long long p, int j0, int nj, int len, double Ts, const Limits& lim,
+                              const Records& rec, double pa, double pb, unsigned long long* probe = nullptr)
 {
     // ---- cooperative table build: thread t -> joint slot jl = t / 32, slot k = t % 32 ----
     // The 32 lanes of a joint slot sit in one wavefront and only ever exchange data with each other, so the steps
@@ -691,51 +732,44 @@ LTP_DEV void build_run_tables(SegTable& tab, long long p, int j0, int nj, int do
     const int jl = threadIdx.x >> 5, k = threadIdx.x & 31;
     const bool jact = jl < nj;
     const int j = j0 + (jact ? jl : 0);
-    const long long rj = p * dof + j;
-    // (1) lane k < 7: one switching time each -> sampled index, lost fraction; lane 7: per-joint scalars
+    // (1) lane k < 7: one switching time each -> sampled index, lost fraction; lanes 7..12: per-joint scalars
     if (jact && k < 7) {
-        const double tk = rec.t_scaled[rj * 7 + k];
+        const double tk = pa;
         const double fr = tk - Ts * dfloor(tk / Ts);                                   // cc:747
-        tab.fr[jl][k] = fr;
-        tab.frts[jl][k] = fr / Ts;
-        tab.s[jl][k] = (k & 1) ? (int)dceil(tk / Ts) : (int)dfloor(tk / Ts);         // cc:751-757
-    } else if (jact && k == 7) {
-        const long long ix = p * in.sq + (long long)j * in.sj;
-        const double dir = rec.dir[rj];
-        tab.misc[jl][0] = dir * lim.j_max[j];
-        tab.misc[jl][1] = rec.v_drive[rj] * dir;                                       // cc:823
-        tab.misc[jl][2] = in.q_0[ix];
-        tab.misc[jl][3] = in.v_0[ix];
-        tab.misc[jl][4] = in.a_0[ix];
-        tab.misc[jl][5] = (double)rec.mod[rj];
+        tab.w.fr[jl][k] = fr;
+        tab.w.frts[jl][k] = fr / Ts;
+        tab.w.s[jl][k] = (k & 1) ? (int)dceil(tk / Ts) : (int)dfloor(tk / Ts);         // cc:751-757
+    } else if (jact && k < 13) {
+        // misc: dir*j_max, v_drive*dir (cc:823), q_0, v_0, a_0, mod
+        tab.w.misc[jl][k - 7] = k < 9 ? pa * pb : pa;
     }
     wave_sync();
     if constexpr (PROBE) { if (threadIdx.x == 0) probe[3] = wall_clock64(); }
     // (2) lane 8: phase jerks and the nine correction terms of the joint; lanes < 20: one candidate cut point each
     int cval = -1;
     if (jact && k == 8) {
-        const double dj = tab.misc[jl][0];
-        const bool modp = tab.misc[jl][5] == 1.0;
+        const double dj = tab.w.misc[jl][0];
+        const bool modp = tab.w.misc[jl][5] == 1.0;
         // cc:735-744: profile {1,0,-1,0,-1,0,1}, or {-1,0,1,0,-1,0,1} for the modified profile
         const double J0 = dj * (modp ? -1.0 : 1.0), J2 = dj * (modp ? 1.0 : -1.0), J4 = dj * -1.0, J6 = dj * 1.0;
-        tab.Jp[jl][0] = J0; tab.Jp[jl][1] = dj * 0.0; tab.Jp[jl][2] = J2; tab.Jp[jl][3] = dj * 0.0;
-        tab.Jp[jl][4] = J4; tab.Jp[jl][5] = dj * 0.0; tab.Jp[jl][6] = J6;
-        const double* ft = tab.frts[jl];
-        const double d20 = (tab.fr[jl][2] - tab.fr[jl][0]) / Ts;
-        tab.corr[jl][0] = ft[0] * J0;                                   // j[s0+1]   cc:771
-        tab.corr[jl][1] = (1 - ft[1]) * J2;                             // j[s1]     cc:773
-        tab.corr[jl][2] = ft[2] * J2;                                   // j[s2+1]   cc:776
-        tab.corr[jl][3] = ft[0] * J0 + d20 * J2;                        // j[s1]     cc:781 (phase 2 absent)
-        tab.corr[jl][4] = (1 - ft[3]) * J4;                             // j[s3]     cc:787
-        tab.corr[jl][5] = ft[4] * J4;                                   // j[s4+1]   cc:793
-        tab.corr[jl][6] = ft[4] * J4 + ft[0] * J0 + d20 * J2;           // j[s4]     cc:798 (phases 2, 3 absent)
-        tab.corr[jl][7] = (1 - ft[5]) * J6;                             // j[s5]     cc:804
-        tab.corr[jl][8] = ft[6] * J6;                                   // j[s6+1]   cc:807
+        tab.w.Jp[jl][0] = J0; tab.w.Jp[jl][1] = dj * 0.0; tab.w.Jp[jl][2] = J2; tab.w.Jp[jl][3] = dj * 0.0;
+        tab.w.Jp[jl][4] = J4; tab.w.Jp[jl][5] = dj * 0.0; tab.w.Jp[jl][6] = J6;
+        const double* ft = tab.w.frts[jl];
+        const double d20 = (tab.w.fr[jl][2] - tab.w.fr[jl][0]) / Ts;
+        tab.w.corr[jl][0] = ft[0] * J0;                                   // j[s0+1]   cc:771
+        tab.w.corr[jl][1] = (1 - ft[1]) * J2;                             // j[s1]     cc:773
+        tab.w.corr[jl][2] = ft[2] * J2;                                   // j[s2+1]   cc:776
+        tab.w.corr[jl][3] = ft[0] * J0 + d20 * J2;                        // j[s1]     cc:781 (phase 2 absent)
+        tab.w.corr[jl][4] = (1 - ft[3]) * J4;                             // j[s3]     cc:787
+        tab.w.corr[jl][5] = ft[4] * J4;                                   // j[s4+1]   cc:793
+        tab.w.corr[jl][6] = ft[4] * J4 + ft[0] * J0 + d20 * J2;           // j[s4]     cc:798 (phases 2, 3 absent)
+        tab.w.corr[jl][7] = (1 - ft[5]) * J6;                             // j[s5]     cc:804
+        tab.w.corr[jl][8] = ft[6] * J6;                                   // j[s6+1]   cc:807
     }
     if (jact && k < kCutSlots) {
-        const int c = k == 0 ? 0 : tab.s[jl][kCutBase[k]] + kCutDelta[k];
+        const int c = k == 0 ? 0 : tab.w.s[jl][kCutBase[k]] + kCutDelta[k];
         cval = (k == 0 || (c > 0 && c < len)) ? c : -1;
-        tab.cand[jl][k] = cval;
+        tab.w.cand[jl][k] = cval;
     }
     wave_sync();
     if constexpr (PROBE) { if (threadIdx.x == 0) probe[4] = wall_clock64(); }
@@ -743,17 +777,17 @@ LTP_DEV void build_run_tables(SegTable& tab, long long p, int j0, int nj, int do
     if (jact && k < kCutSlots) {
         bool first = cval >= 0;
 #pragma unroll
-        for (int m = 0; m < kCutSlots; ++m) first = first && (m >= k || tab.cand[jl][m] != cval);   // fixed trip count: loads pipeline
-        tab.runMode[jl][k] = first ? cval : -1;   // runMode doubles as scratch until step (4)
+        for (int m = 0; m < kCutSlots; ++m) first = first && (m >= k || tab.w.cand[jl][m] != cval);   // fixed trip count: loads pipeline
+        tab.w.runMode[jl][k] = first ? cval : -1;   // runMode doubles as scratch until step (4)
     }
     wave_sync();
     if constexpr (PROBE) { if (threadIdx.x == 0) probe[5] = wall_clock64(); }
     if (jact && k < kCutSlots) {
-        const bool mine = tab.runMode[jl][k] >= 0;
+        const bool mine = tab.w.runMode[jl][k] >= 0;
         int pos = 0, distinct = 0;
 #pragma unroll
         for (int m = 0; m < kCutSlots; ++m) {
-            const int cm = tab.runMode[jl][m];
+            const int cm = tab.w.runMode[jl][m];
             if (cm >= 0) { ++distinct; if (cm < cval) ++pos; }
         }
         if (mine) tab.start[jl][pos] = cval;
@@ -766,14 +800,14 @@ LTP_DEV void build_run_tables(SegTable& tab, long long p, int j0, int nj, int do
     const int ns = jact ? tab.nseg[jl] : 0;
     if (k < ns) {
         const int b = tab.start[jl][k];
-        const int* sj = tab.s[jl];
+        const int* sj = tab.w.s[jl];
         const bool phase4 = sj[3] - sj[2] > 2;                                         // cc:813
         int mode = 0;
         if (b > sj[6]) mode |= kModeTail;
         if (phase4 && b >= sj[2] + 1 && b < sj[3] - 1) mode |= kModeVSnap;
-        const double J = jerk_at(sj, tab.Jp[jl], tab.corr[jl], b);
-        tab.runMode[jl][k] = mode;
-        tab.runJ[jl][k] = J;
+        const double J = jerk_at(sj, tab.w.Jp[jl], tab.w.corr[jl], b);
+        tab.w.runMode[jl][k] = mode;
+        tab.w.runJ[jl][k] = J;
         const double md = (double)(tab.start[jl][k + 1] - b);     // samples in the run
         const double s1 = 0.5 * (md * (md + 1.0));
         const double tj = Ts * J;
@@ -791,19 +825,19 @@ LTP_DEV void build_run_tables(SegTable& tab, long long p, int j0, int nj, int do
     //     at the run's last sample, i.e. exactly what the streaming loop will store there, with the state-independent
     //     factors taken from step (4).
     if (jact && k == 0) {
-        const double vsnap = tab.misc[jl][1];
-        double q = tab.misc[jl][2], v = tab.misc[jl][3], a = tab.misc[jl][4];   // state "before sample 0" (cc:810-812)
+        const double vsnap = tab.w.misc[jl][1];
+        double q = tab.w.misc[jl][2], v = tab.w.misc[jl][3], a = tab.w.misc[jl][4];   // state "before sample 0" (cc:810-812)
         // software-pipelined by hand: the state-independent factors of run m+1 are fetched from LDS while the
         // dependent chain of run m executes (the chain is ~5 binary64 operations, an LDS round trip is longer)
         const double* pre = tab.c[jl][0];
         double md = pre[0], s1 = pre[1], s2 = pre[2], p3 = pre[3], p4 = pre[4], p5 = pre[5];
-        int mode = tab.runMode[jl][0];
+        int mode = tab.w.runMode[jl][0];
         for (int m = 0; m < ns; ++m) {
             const int mn = m + 1 < ns ? m + 1 : m;
             const double* nx = tab.c[jl][mn];
             const double md_n = nx[0], s1_n = nx[1], s2_n = nx[2], p3_n = nx[3], p4_n = nx[4], p5_n = nx[5];
-            const int mode_n = tab.runMode[jl][mn];
-            tab.state[jl][m][0] = a; tab.state[jl][m][1] = v; tab.state[jl][m][2] = q;
+            const int mode_n = tab.w.runMode[jl][mn];
+            tab.w.state[jl][m][0] = a; tab.w.state[jl][m][1] = v; tab.w.state[jl][m][2] = q;
             double qn, vn, an;
             if (mode & kModeVSnap) {
                 vn = vsnap + (0.0 * md + 0.0 * s1);
@@ -826,53 +860,77 @@ LTP_DEV void build_run_tables(SegTable& tab, long long p, int j0, int nj, int do
     if constexpr (PROBE) { if (threadIdx.x == 0) probe[8] = wall_clock64(); }
     // (6) lane k < ns: the coefficients of run k
     if (k < ns) {
-        const RunCoef rc = run_coef(tab.runMode[jl][k], tab.runJ[jl][k], tab.state[jl][k][0], tab.state[jl][k][1],
-                                    tab.state[jl][k][2], tab.misc[jl][1], Ts);
+        const RunCoef rc = run_coef(tab.w.runMode[jl][k], tab.w.runJ[jl][k], tab.w.state[jl][k][0], tab.w.state[jl][k][1],
+                                    tab.w.state[jl][k][2], tab.w.misc[jl][1], Ts);
 #pragma unroll
         for (int x = 0; x < kRunCoefs; ++x) tab.c[jl][k][x] = rc.c[x];
     }
-    __syncthreads();
-    if constexpr (PROBE) { if (threadIdx.x == 0) probe[9] = wall_clock64(); }
     __builtin_amdgcn_s_setprio(0);
 }
 
-// One work item = one plan x one group of <= 8 joints: build the run tables, then stream the rows. Every thread of
-// the block calls this; all early exits are block-uniform.
+// Streams the rows of one item (plan x joint group) from the run tables in LDS. Every thread of the block calls this.
 template <bool STREAMING, bool DRY, typename T>
-LTP_DEV void sample_plan(SegTable& tab, long long first, long long local, int group, int dof, double t_sample, const Limits& lim,
-                         const Queries& in, const Records& rec, const unsigned long long* __restrict__ offsets,
-                         T* __restrict__ out, unsigned long long capacity, unsigned long long* __restrict__ stamps,
+LTP_DEV void stream_rows(SegTable& tab, int j0, int nj, int dof, int slen, unsigned long long stride, T* __restrict__ plan_base,
                          RowSpec rows)
 {
-    const long long p = first + local;
-    // diagnostic only (stamps == nullptr in every product call): start / tables ready / end on the 100 MHz wall clock
-    if (stamps && threadIdx.x == 0 && group == 0) stamps[3 * local] = wall_clock64();
-    const int len = rec.traj_len[p];
-    if (len <= 0) return;   // failed / non-finite query: nothing to sample
-    const unsigned long long off0 = offsets[first];
-    const unsigned long long rel = offsets[p] - off0;
-    const int slen = stored_len(len, rows);   // samples actually stored per row
-    const unsigned long long stride = ((unsigned long long)slen + (kRowAlign - 1)) / kRowAlign * kRowAlign;
-    if (rel + 4ull * dof * stride > capacity) {
-        if (threadIdx.x == 0 && group == 0) atomicOr(&rec.status[p], kStatusOverflow);
-        return;
-    }
-    const int j0 = group * kSampleJointGroup;
-    const int nj = (dof - j0) < kSampleJointGroup ? (dof - j0) : kSampleJointGroup;
-    build_run_tables(tab, p, j0, nj, dof, len, t_sample, lim, in, rec);
-    if (stamps && threadIdx.x == 0 && group == 0) stamps[3 * local + 1] = wall_clock64();   // run tables ready
-
-    // Streaming: per joint, every lane produces q, v, a and j of N consecutive samples (N = 2 doubles or 4 floats)
+    // Per joint, every lane produces q, v, a and j of N consecutive samples (a "slot": N = 2 doubles or 4 floats)
     // and issues four 16-B stores, i.e. four 1 KiB wave stores into the four rows of that joint. (Measured on
-    // MI355X: this runs at the same rate as the identical store pattern without any arithmetic; deeper unrolling,
-    // writing the rows one after the other, and walking the (joint, slot) space as one flat sequence so that no step
-    // has idle lanes are all slower, the last one by 15 %.) float rows hold the binary64 results rounded once.
+    // MI355X: for float64 rows this runs at the same rate as the identical store pattern without any arithmetic;
+    // deeper unrolling, writing the rows one after the other, and walking the (joint, slot) space as one flat sequence
+    // so that no step has idle lanes are all slower, the last one by 15 %.) float rows hold the binary64 results
+    // rounded once.
     typedef typename OutVec<T>::type V;
     constexpr int N = OutVec<T>::N;
-    T* const plan_base = out + rel;
     const unsigned long long arr_stride = (unsigned long long)dof * stride;   // distance between q, v, a, j blocks
     const int nslots = (slen + N - 1) / N;
     const int sstride = rows.stride > 1 ? rows.stride : 1;
+
+    // Pass B, once per item: the slots that contain a run boundary. There are at most 19 per row, but in the
+    // row-by-row loop below most 64-slot wave steps contain one, and a wave that has one would execute the per-sample
+    // path for all its lanes. So lane k of joint slot jl (the mapping of the table build) evaluates the slot of
+    // boundary k, if that slot really straddles it and boundary k-1 has not claimed the same slot, and parks the four
+    // 16-byte results in LDS (in the space of the build scratch); the main loop picks them up, so that it still
+    // writes every row as full contiguous wave stores (leaving holes for scattered 16-byte stores costs 13 % of the
+    // float64 bandwidth).
+    if constexpr (!DRY) {
+        const int jl = threadIdx.x >> 5, k = threadIdx.x & 31;
+        const int nruns = jl < nj ? tab.nseg[jl] : 0;
+        if (k >= 1 && k < nruns) {
+            const int* st = tab.start[jl];
+            const int u = (st[k] + sstride - 1) / sstride;             // first stored sample at or after boundary k
+            bool mine = (u % N) != 0 && u < N * nslots;
+            if (mine && k > 1) {
+                const int up = (st[k - 1] + sstride - 1) / sstride;
+                if ((up % N) != 0 && up / N == u / N) mine = false;     // boundary k-1 owns this slot
+            }
+            if (mine) {
+                const int i0 = u / N * N, t0 = i0 * sstride;
+                int kh = k - 1;
+                while (st[kh] > t0) --kh;                               // run of the slot's first sample (st[0] = 0)
+                int ch = st[kh], nh = kh + 1 < nruns ? st[kh + 1] : 0x7fffffff;
+                V o[4];
+#pragma unroll
+                for (int h = 0; h < N; ++h) {
+                    const int i = t0 + h * sstride;
+                    while (nh <= i) {
+                        ++kh;
+                        ch = nh;
+                        nh = kh + 1 < nruns ? st[kh + 1] : 0x7fffffff;
+                    }
+                    const bool pad = i0 + h >= slen;                    // the tail of the last slot is row padding
+                    double x4[4];
+                    run_eval(tab.c[jl][kh], i - ch + 1, x4[0], x4[1], x4[2], x4[3]);
+#pragma unroll
+                    for (int x = 0; x < 4; ++x) o[x][h] = pad ? (T)0 : (T)x4[x];
+                }
+#pragma unroll
+                for (int x = 0; x < 4; ++x) *reinterpret_cast<V*>(&tab.bnd[jl][k][x]) = o[x];
+            }
+        }
+        __syncthreads();
+    }
+
+    // Pass A: row by row; the N samples of any other slot lie in one run, whose coefficients are read once
     for (int jl2 = 0; jl2 < nj; ++jl2) {
         T* const row = plan_base + (unsigned long long)(j0 + jl2) * stride;
         const int* st = tab.start[jl2];
@@ -894,33 +952,19 @@ LTP_DEV void sample_plan(SegTable& tab, long long first, long long local, int gr
                     cur = nxt;
                     nxt = kr + 1 < nruns ? st[kr + 1] : 0x7fffffff;
                 }
-                if (t0 + (N - 1) * sstride < nxt) {
-                    // common case: the N samples of this slot lie in one run -> its coefficients are read once
+                if (t0 + (N - 1) * sstride >= nxt) {
+                    // run boundary kr+1 lies inside the slot: pass B has left the finished values in LDS
+#pragma unroll
+                    for (int x = 0; x < 4; ++x) o[x] = *reinterpret_cast<const V*>(&tab.bnd[jl2][kr + 1][x]);
+                } else {
                     double c[kRunCoefs];
 #pragma unroll
                     for (int x = 0; x < kRunCoefs; ++x) c[x] = tab.c[jl2][kr][x];
 #pragma unroll
                     for (int h = 0; h < N; ++h) {
-                        const bool pad = i0 + h >= slen;   // the tail of the last slot is row padding
-                        double x4[4];
-                        run_eval(c, t0 + h * sstride - cur + 1, x4[0], x4[1], x4[2], x4[3]);
-#pragma unroll
-                        for (int x = 0; x < 4; ++x) o[x][h] = pad ? (T)0 : (T)x4[x];
-                    }
-                } else {
-                    // a run boundary inside the slot (at most ~20 slots per row)
-                    int kh = kr, ch = cur, nh = nxt;
-#pragma unroll
-                    for (int h = 0; h < N; ++h) {
-                        const int i = t0 + h * sstride;
-                        while (nh <= i) {
-                            ++kh;
-                            ch = nh;
-                            nh = kh + 1 < nruns ? st[kh + 1] : 0x7fffffff;
-                        }
                         const bool pad = i0 + h >= slen;
                         double x4[4];
-                        run_eval(tab.c[jl2][kh], i - ch + 1, x4[0], x4[1], x4[2], x4[3]);
+                        run_eval(c, t0 + h * sstride - cur + 1, x4[0], x4[1], x4[2], x4[3]);
 #pragma unroll
                         for (int x = 0; x < 4; ++x) o[x][h] = pad ? (T)0 : (T)x4[x];
                     }
@@ -929,10 +973,6 @@ LTP_DEV void sample_plan(SegTable& tab, long long first, long long local, int gr
 #pragma unroll
             for (int x = 0; x < 4; ++x) store16<STREAMING>(reinterpret_cast<V*>(row + x * arr_stride + i0), o[x]);
         }
-    }
-    if (stamps) {
-        __syncthreads();
-        if (threadIdx.x == 0 && group == 0) stamps[3 * local + 2] = wall_clock64();
     }
 }
 
@@ -944,6 +984,11 @@ LTP_DEV void sample_plan(SegTable& tab, long long first, long long local, int gr
 // Item order: item i -> plan (i % spread) * ceil(count/spread) + i / spread (spread = 64 by default), so blocks that
 // are resident together write all over the output tile: on MI355X a narrow moving write front only reaches
 // ~5.2 TB/s while writes spread over a large tile reach the fill-kernel ceiling ("What bounds the sampler").
+// The loop runs one item ahead: the next item is drawn while the tables of the current one are being built, and its
+// records are requested just before the current item's rows are streamed, so that the three dependent round trips
+// an item needs (queue counter, traj_len / offset, records) travel under ~10^2 row stores instead of in front of them.
+// (On gfx950 a wave's loads and stores share one in-order counter: a load result consumed behind a run of stores
+// waits for all of them, so an item pays one drain of its own stores either way — but only one.)
 template <bool STREAMING, bool DRY, typename T>
 __global__ void __launch_bounds__(kSampleThreads, kSampleBlocksPerCU)
 k_sample(long long first, long long count, int dof, double t_sample, Limits lim, Queries in, Records rec,
@@ -955,18 +1000,62 @@ k_sample(long long first, long long count, int dof, double t_sample, Limits lim,
     const int ngroups = (dof + kSampleJointGroup - 1) / kSampleJointGroup;
     const long long per = (count + spread - 1) / spread;
     const unsigned long long total = (unsigned long long)per * spread * ngroups;
-    for (;;) {
-        __syncthreads();   // the previous item's LDS tables and s_item are no longer in use
-        if (threadIdx.x == 0) s_item = atomicAdd(next_item, 1ull);
-        __syncthreads();
-        const unsigned long long item = s_item;
-        if (item >= total) break;
+    const unsigned long long off0 = offsets[first];
+
+    // item -> (local plan, joint group); local >= count are the holes of the interleave
+    auto decode = [&](unsigned long long item, long long& local, int& j0, int& nj) {
         const int group = (int)(item % ngroups);
         const long long slot = (long long)(item / ngroups);
-        const long long local = (slot % spread) * per + slot / spread;
-        if (local < count)
-            sample_plan<STREAMING, DRY, T>(tab, first, local, group, dof, t_sample, lim, in, rec, offsets, out, capacity, stamps,
-                                        rows);
+        local = (slot % spread) * per + slot / spread;
+        j0 = group * kSampleJointGroup;
+        nj = (dof - j0) < kSampleJointGroup ? (dof - j0) : kSampleJointGroup;
+    };
+    auto fetch = [&](unsigned long long item) {
+        long long local; int j0, nj;
+        decode(item, local, j0, nj);
+        const bool some = item < total && local < count;
+        return fetch_item(some ? first + local : -1, j0, nj, dof, lim, in, rec, offsets);
+    };
+
+    if (threadIdx.x == 0) s_item = atomicAdd(next_item, 1ull);
+    __syncthreads();
+    unsigned long long item = s_item;
+    ItemRegs cur = fetch(item);
+    __syncthreads();   // s_item may be rewritten
+    while (item < total) {
+        long long local; int j0, nj;
+        decode(item, local, j0, nj);
+        const long long p = first + local;
+        const bool lead = threadIdx.x == 0 && j0 == 0;
+        // diagnostic only (stamps == nullptr in every product call): start / tables ready / end on the 100 MHz wall clock
+        if (stamps && lead && local < count) stamps[3 * local] = wall_clock64();
+        const int len = cur.len;                          // 0: hole, failed or non-finite query -> nothing to sample
+        const unsigned long long rel = cur.off - off0;
+        const int slen = stored_len(len, rows);           // samples actually stored per row
+        const unsigned long long stride = ((unsigned long long)slen + (kRowAlign - 1)) / kRowAlign * kRowAlign;
+        bool ok = len > 0;
+        if (ok && rel + 4ull * dof * stride > capacity) {
+            if (lead) atomicOr(&rec.status[p], kStatusOverflow);
+            ok = false;
+        }
+        unsigned long long drawn = 0ull;
+        if (threadIdx.x == 0) drawn = atomicAdd(next_item, 1ull);      // returns while the tables are built
+#ifdef LTP_EXP_DRY_NOBUILD
+        if constexpr (!DRY)
+#endif
+        if (ok) build_run_tables(tab, p, j0, nj, len, t_sample, lim, rec, cur.pa, cur.pb);
+        if (threadIdx.x == 0) s_item = drawn;
+        __syncthreads();                                               // tables complete, next item known
+        const unsigned long long nitem = s_item;
+        const ItemRegs nxt = fetch(nitem);                             // in flight while this item streams
+        if (ok) {
+            if (stamps && lead) stamps[3 * local + 1] = wall_clock64();   // run tables ready
+            stream_rows<STREAMING, DRY, T>(tab, j0, nj, dof, slen, stride, out + rel, rows);
+        }
+        __syncthreads();                                               // tables and s_item are free again
+        if (stamps && ok && lead) stamps[3 * local + 2] = wall_clock64();
+        item = nitem;
+        cur = nxt;
     }
 }
 
@@ -1025,7 +1114,10 @@ k_envelope(long long first, long long count, int dof, double t_sample, Limits li
             continue;
         }
         if constexpr (PROBE) { if (threadIdx.x == 0) probe[2] = wall_clock64(); }
-        build_run_tables<PROBE>(tab, p, j0, nj, dof, len, t_sample, lim, in, rec, probe);
+        const ItemRegs regs = fetch_item(p, j0, nj, dof, lim, in, rec, nullptr);
+        build_run_tables<PROBE>(tab, p, j0, nj, len, t_sample, lim, rec, regs.pa, regs.pb, probe);
+        __syncthreads();
+        if constexpr (PROBE) { if (threadIdx.x == 0) probe[9] = wall_clock64(); }
         // g lanes share one (joint, window) task (g = 2^lg divides 64, chosen by the host so that the block has
         // work for all its lanes); lane r of the task takes samples b + r, b + r + g, ... and the g partial results
         // meet in a butterfly. Minimum and maximum do not depend on the order, so any g gives the same bits.
