@@ -931,13 +931,17 @@ LTP_DEV void stream_rows(SegTable& tab, int j0, int nj, int dof, int slen, unsig
     }
 
     // Pass A: row by row; the N samples of any other slot lie in one run, whose coefficients are read once
-    for (int jl2 = 0; jl2 < nj; ++jl2) {
+    // Rows shorter than the block (first-N-samples rows) are shared out so that no wave idles: wpr waves per row,
+    // 4 / wpr rows at a time. Long rows: wpr = 4, i.e. all 256 lanes on one row after the other.
+    const int lw = nslots <= 64 ? 0 : (nslots <= 128 ? 1 : 2);                      // wpr = 1 << lw
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    for (int jl2 = wave >> lw; jl2 < nj; jl2 += 4 >> lw) {
         T* const row = plan_base + (unsigned long long)(j0 + jl2) * stride;
         const int* st = tab.start[jl2];
         const int nruns = tab.nseg[jl2];
         // run cursor of this lane: samples [cur, nxt) belong to run kr (nxt = INT_MAX for the last run)
         int kr = 0, cur = 0, nxt = nruns > 1 ? st[1] : 0x7fffffff;
-        for (int slot = threadIdx.x; slot < nslots; slot += kSampleThreads) {
+        for (int slot = ((wave & ((1 << lw) - 1)) << 6) + lane; slot < nslots; slot += 64 << lw) {
             const int i0 = N * slot;                  // first stored sample of this slot; it is sample i0*sstride of the trajectory
             V o[4];
             if constexpr (DRY) {
@@ -1047,7 +1051,9 @@ k_sample(long long first, long long count, int dof, double t_sample, Limits lim,
         if (threadIdx.x == 0) s_item = drawn;
         __syncthreads();                                               // tables complete, next item known
         const unsigned long long nitem = s_item;
+#ifndef LTP_NO_LOOKAHEAD
         const ItemRegs nxt = fetch(nitem);                             // in flight while this item streams
+#endif
         if (ok) {
             if (stamps && lead) stamps[3 * local + 1] = wall_clock64();   // run tables ready
             stream_rows<STREAMING, DRY, T>(tab, j0, nj, dof, slen, stride, out + rel, rows);
@@ -1055,7 +1061,11 @@ k_sample(long long first, long long count, int dof, double t_sample, Limits lim,
         __syncthreads();                                               // tables and s_item are free again
         if (stamps && ok && lead) stamps[3 * local + 2] = wall_clock64();
         item = nitem;
+#ifndef LTP_NO_LOOKAHEAD
         cur = nxt;
+#else
+        cur = fetch(item);
+#endif
     }
 }
 

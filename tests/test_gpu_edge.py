@@ -391,3 +391,39 @@ def test_envelope_consumer_equals_reduced_dense_rows(amd, oracle_mod, limits, n,
     ltp.sampleBatch(b3, 0, n, t3)
     torch.cuda.synchronize()
     assert torch.equal(b2.status, b3.status)
+
+
+@pytest.mark.parametrize("cap", [40, 100, 300])
+def test_short_rows_every_wave_mapping_and_both_row_types(amd, ref7, cap):
+    """First-N-samples rows shorter than the block are shared out over the waves differently (1, 2 or 4 waves per
+    row); every mapping, in float64 and float32, must give the leading samples of the full rows."""
+    import torch
+    D, lim, _, _ = ref7
+    ltp = amd.LongTermPlanner(D, 0.001, device=0, **lim)
+    n = 300
+    qm = ltp.generateQueries(n, seed=23)
+    b = ltp.planSwitchTimesBatch(*qm)
+    total = int(b.offsets[-1].item())
+    full = torch.zeros(total, dtype=torch.float64, device="cuda")
+    ltp.sampleBatch(b, 0, n, full)
+    torch.cuda.synchronize()
+    off_full = b.offsets.cpu().numpy().view(np.uint64).copy()
+    lens = b.traj_len.cpu().numpy()
+    hf = full.cpu().numpy()
+    ltp.setMaxSamples(cap)
+    b2 = ltp.planSwitchTimesBatch(*qm)
+    off = b2.offsets.cpu().numpy().view(np.uint64)
+    for dtype in (torch.float64, torch.float32):
+        guard = torch.full((int(off[-1]) + 256,), 7.0, dtype=dtype, device="cuda")
+        ltp.sampleBatch(b2, 0, n, guard[: int(off[-1])])
+        torch.cuda.synchronize()
+        assert torch.all(guard[int(off[-1]):] == 7.0)
+        hc = guard.cpu().numpy()
+        for p in range(0, n, 3):
+            if lens[p] <= 0:
+                continue
+            stored = min(int(lens[p]), cap)
+            want = amd.unpack_trajectory(hf, int(off_full[p]), D, int(lens[p]))
+            got = amd.unpack_trajectory(hc, int(off[p]), D, stored)
+            for w, g in zip(want, got):
+                assert np.array_equal(w[:, :stored].astype(hc.dtype), g), (p, cap, dtype)
