@@ -17,7 +17,8 @@ struct ltp_planner {
     int max_samples = 0;                   // 0 = store whole trajectories (reference behaviour)
     int sample_stride = 1;                 // store every sample_stride-th sample
     int goal_check = 0;                    // 1 = reject q_goal outside [q_min,q_max] up front (reference: unchecked)
-    int sample_blocks = 0;                 // resident k_sample blocks on this device (work-queue grid)
+    int sample_blocks[3] = {0, 0, 0};      // resident blocks of k_sample f64 / k_sample f32 / k_envelope (work-queue grids)
+    int sample_blocks_override = 0;        // tuning aid (ltp_debug_set_sample_blocks)
     unsigned long long* d_sample_next = nullptr;   // ring of work-queue heads, one per in-flight sampler launch
     unsigned sample_next_slot = 0;
     std::vector<double> h_lim[5];          // q_min, q_max, v_max, a_max, j_max as given (any length)
@@ -114,7 +115,8 @@ int reserve(ltp_planner* p, long long n)
     if (!p->d_queue_count) LTP_HIP_TRY(p, hipMalloc((void**)&p->d_queue_count, 16 * sizeof(unsigned long long)));
     if (!p->d_small) LTP_HIP_TRY(p, hipMalloc((void**)&p->d_small, sizeof(double) * 16));
     if (!p->d_sample_next) LTP_HIP_TRY(p, hipMalloc((void**)&p->d_sample_next, sizeof(unsigned long long) * 64));
-    if (p->sample_blocks == 0) p->sample_blocks = ltp::sample_resident_blocks(p->device);
+    for (int w = 0; w < 3; ++w)
+        if (p->sample_blocks[w] == 0) p->sample_blocks[w] = ltp::sample_resident_blocks(p->device, w);
     const long long queue_entries = 16 * ltp::queue_segment(n, p->dof > 0 ? p->dof : 1);
     if (queue_entries > p->ws_queue_entries) {
         if (p->d_queue) LTP_HIP_TRY(p, hipFree(p->d_queue));
@@ -351,12 +353,13 @@ static int sample_batch_any(ltp_planner* p, long long first, long long count, co
     int rc = check_config(p);
     if (rc != LTP_OK) return rc;
     if (count == 0 || p->dof == 0) return LTP_OK;
-    LTP_HIP_TRY(p, hipSetDevice(p->device));
+    if ((rc = reserve(p, 0)) != LTP_OK) return rc;   // work-queue heads, resident block counts (no-op after the first call)
     // each launch gets its own work-queue head from a ring of 64, zeroed in stream order just before the kernel
     unsigned long long* head = p->d_sample_next + (p->sample_next_slot++ & 63u);
     LTP_HIP_TRY(p, hipMemsetAsync(head, 0, sizeof(unsigned long long), (hipStream_t)stream));
     ltp::launch_sample((hipStream_t)stream, first, count, p->dof, p->t_sample, dev_limits(p), to_dev(in), to_dev(rec), offsets,
-                       out, f32, capacity, flags, ltp::RowSpec{p->max_samples, p->sample_stride}, head, p->sample_blocks, p->dbg_stamps);
+                       out, f32, capacity, flags, ltp::RowSpec{p->max_samples, p->sample_stride}, head,
+                       p->sample_blocks_override > 0 ? p->sample_blocks_override : p->sample_blocks[f32 ? 1 : 0], p->dbg_stamps);
     LTP_HIP_TRY(p, hipGetLastError());
     return LTP_OK;
 }
@@ -383,11 +386,12 @@ int ltp_envelope_batch(ltp_planner* p, long long first, long long count, const l
     int rc = check_config(p);
     if (rc != LTP_OK) return rc;
     if (count == 0 || p->dof == 0) return LTP_OK;
-    LTP_HIP_TRY(p, hipSetDevice(p->device));
+    if ((rc = reserve(p, 0)) != LTP_OK) return rc;
     unsigned long long* head = p->d_sample_next + (p->sample_next_slot++ & 63u);
     LTP_HIP_TRY(p, hipMemsetAsync(head, 0, sizeof(unsigned long long), (hipStream_t)stream));
     ltp::launch_envelope((hipStream_t)stream, first, count, p->dof, p->t_sample, dev_limits(p), to_dev(in), to_dev(rec), window,
-                         n_windows, env, head, p->sample_blocks, p->dbg_stamps);
+                         n_windows, env, head, p->sample_blocks_override > 0 ? p->sample_blocks_override : p->sample_blocks[2],
+                         p->dbg_stamps);
     LTP_HIP_TRY(p, hipGetLastError());
     return LTP_OK;
 }
@@ -853,7 +857,7 @@ int ltp_debug_set_sample_blocks(ltp_planner* p, int blocks)
 {
     if (!p || blocks < 0) return LTP_ERR_INVALID_ARGUMENT;
     std::lock_guard<std::mutex> g(p->mu);
-    p->sample_blocks = blocks > 0 ? blocks : ltp::sample_resident_blocks(p->device);
+    p->sample_blocks_override = blocks;
     return LTP_OK;
 }
 

@@ -988,13 +988,15 @@ LTP_DEV void stream_rows(SegTable& tab, int j0, int nj, int dof, int slen, unsig
 // Item order: item i -> plan (i % spread) * ceil(count/spread) + i / spread (spread = 64 by default), so blocks that
 // are resident together write all over the output tile: on MI355X a narrow moving write front only reaches
 // ~5.2 TB/s while writes spread over a large tile reach the fill-kernel ceiling ("What bounds the sampler").
+// float32 rows need 4 samples per lane in flight: they get the register budget of 4 blocks per CU (with 5 the
+// compiler spills, and a spill reload waits for every outstanding load of the wave, i.e. for the look-ahead).
 // The loop runs one item ahead: the next item is drawn while the tables of the current one are being built, and its
 // records are requested just before the current item's rows are streamed, so that the three dependent round trips
 // an item needs (queue counter, traj_len / offset, records) travel under ~10^2 row stores instead of in front of them.
 // (On gfx950 a wave's loads and stores share one in-order counter: a load result consumed behind a run of stores
 // waits for all of them, so an item pays one drain of its own stores either way — but only one.)
 template <bool STREAMING, bool DRY, typename T>
-__global__ void __launch_bounds__(kSampleThreads, kSampleBlocksPerCU)
+__global__ void __launch_bounds__(kSampleThreads, (sizeof(T) == 4 ? kSampleBlocksPerCU - 1 : kSampleBlocksPerCU))
 k_sample(long long first, long long count, int dof, double t_sample, Limits lim, Queries in, Records rec,
          const unsigned long long* __restrict__ offsets, T* __restrict__ out, unsigned long long capacity,
          unsigned long long* __restrict__ stamps, int spread, RowSpec rows, unsigned long long* __restrict__ next_item)
@@ -1044,16 +1046,11 @@ k_sample(long long first, long long count, int dof, double t_sample, Limits lim,
         }
         unsigned long long drawn = 0ull;
         if (threadIdx.x == 0) drawn = atomicAdd(next_item, 1ull);      // returns while the tables are built
-#ifdef LTP_EXP_DRY_NOBUILD
-        if constexpr (!DRY)
-#endif
         if (ok) build_run_tables(tab, p, j0, nj, len, t_sample, lim, rec, cur.pa, cur.pb);
         if (threadIdx.x == 0) s_item = drawn;
         __syncthreads();                                               // tables complete, next item known
         const unsigned long long nitem = s_item;
-#ifndef LTP_NO_LOOKAHEAD
         const ItemRegs nxt = fetch(nitem);                             // in flight while this item streams
-#endif
         if (ok) {
             if (stamps && lead) stamps[3 * local + 1] = wall_clock64();   // run tables ready
             stream_rows<STREAMING, DRY, T>(tab, j0, nj, dof, slen, stride, out + rel, rows);
@@ -1061,11 +1058,7 @@ k_sample(long long first, long long count, int dof, double t_sample, Limits lim,
         __syncthreads();                                               // tables and s_item are free again
         if (stamps && ok && lead) stamps[3 * local + 2] = wall_clock64();
         item = nitem;
-#ifndef LTP_NO_LOOKAHEAD
         cur = nxt;
-#else
-        cur = fetch(item);
-#endif
     }
 }
 
@@ -1389,12 +1382,17 @@ void launch_offsets(hipStream_t s, long long n, int dof, double t_sample, Record
     hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nb), dim3(256), 0, s, n, dof, rows, rec.traj_len, block_sums, offsets);
 }
 
-// how many k_sample blocks the device holds at once (the work-queue grid)
-int sample_resident_blocks(int device)
+// how many blocks of a persistent (work-queue) kernel the device holds at once: 0 = k_sample float64 rows,
+// 1 = k_sample float32 rows, 2 = k_envelope
+int sample_resident_blocks(int device, int which)
 {
     int cus = 0, per_cu = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus <= 0) cus = 256;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_sample<true, false, double>, kSampleThreads, 0) != hipSuccess || per_cu <= 0) per_cu = 4;
+    hipError_t e;
+    if (which == 1) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_sample<true, false, float>, kSampleThreads, 0);
+    else if (which == 2) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_envelope<false>, kSampleThreads, 0);
+    else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_sample<true, false, double>, kSampleThreads, 0);
+    if (e != hipSuccess || per_cu <= 0) per_cu = 4;
     return cus * per_cu;
 }
 

@@ -84,7 +84,7 @@ void launch_sample(hipStream_t s, long long first, long long count, int dof, dou
                    Records rec, const unsigned long long* offsets, void* out, bool f32, unsigned long long capacity,
                    int flags, RowSpec rows, unsigned long long* next_item /* zeroed on the same stream */,
                    int resident_blocks, unsigned long long* stamps = nullptr);
-int sample_resident_blocks(int device);
+int sample_resident_blocks(int device, int which /* 0 k_sample f64, 1 k_sample f32, 2 k_envelope */);
 void launch_envelope(hipStream_t s, long long first, long long count, int dof, double t_sample, Limits lim, Queries in,
                      Records rec, int window, int n_windows, double* env, unsigned long long* next_item /* zeroed on the same stream */,
                      int resident_blocks, unsigned long long* probe = nullptr /* diagnostic: 16 stamps per item */);

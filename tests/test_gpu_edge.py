@@ -427,3 +427,21 @@ def test_short_rows_every_wave_mapping_and_both_row_types(amd, ref7, cap):
             got = amd.unpack_trajectory(hc, int(off[p]), D, stored)
             for w, g in zip(want, got):
                 assert np.array_equal(w[:, :stored].astype(hc.dtype), g), (p, cap, dtype)
+
+
+def test_a_second_handle_can_sample_what_the_first_one_planned(amd, ref7):
+    """One handle per stream is the documented pattern: a handle that never planned must be able to sample / reduce."""
+    import torch
+    D, lim, ltp, _ = ref7
+    other = amd.LongTermPlanner(D, 0.001, device=0, **lim)
+    qm = ltp.generateQueries(200, seed=3)
+    b = ltp.planSwitchTimesBatch(*qm)
+    total = int(b.offsets[-1].item())
+    t1 = torch.zeros(total, dtype=torch.float64, device="cuda")
+    t2 = torch.zeros(total, dtype=torch.float64, device="cuda")
+    ltp.sampleBatch(b, 0, 200, t1)
+    other.sampleBatch(b, 0, 200, t2)
+    e1 = ltp.envelopeBatch(b, 0, 200, 32, 16)
+    e2 = amd.LongTermPlanner(D, 0.001, device=0, **lim).envelopeBatch(b, 0, 200, 32, 16)
+    torch.cuda.synchronize()
+    assert torch.equal(t1, t2) and torch.equal(e1.nan_to_num(7.0), e2.nan_to_num(7.0))
