@@ -566,7 +566,7 @@ constexpr int kModeVSnap = 2;   // phase 4 interior: v = v_drive*dir (cc:822-823
 //   v(m) = v0 + (v1*m + v2*S1)             {v_s, Ts*a_s, Ts*Ts*J}
 //   a(m) = a0 + a1*m                       {a_s, Ts*J}
 //   j(m) = J
-// and the three snap rules of cc:815-829 only change coefficients, so the streaming loop is branch-free.
+// and the three snap rules of cc:815-829 only change coefficients, so evaluating a sample has no branches.
 constexpr int kRunCoefs = 10;   // q0..q3, v0..v2, a0, a1, J
 struct RunCoef {
     double c[kRunCoefs];
