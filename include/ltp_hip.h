@@ -106,6 +106,12 @@ int ltp_get_goal_check(const ltp_planner* p);
 
 /* ---- batched hot path (device pointers, asynchronous on `stream`) -------------------------- */
 
+/* Allocates the handle's device workspace for batches of up to n queries now. The batched calls below grow it on
+ * demand (hipMalloc / hipFree), which is not allowed while `stream` is being captured into a hipGraph: call this once
+ * before hipStreamBeginCapture, then ltp_plan_switch_times_batch / ltp_sample_batch / ltp_envelope_batch /
+ * ltp_replan_states_batch only enqueue memset and kernel nodes and the graph can be replayed on new inputs in place. */
+int ltp_reserve_batch(ltp_planner* p, long long n);
+
 /* planTrajectory stages 1-3 for n queries (cc:14-55): checkInputs, optSwitchTimes per joint,
  * slowest-joint reduction, timeScaling per other joint, fallback copy; then traj_len (cc:716-719).
  * offsets (device, [n+1], may be NULL) receives the exclusive scan of the packed trajectory sizes

@@ -307,6 +307,15 @@ int ltp_row_stride(int traj_len)
     return (traj_len + ltp::kRowAlign - 1) / ltp::kRowAlign * ltp::kRowAlign;
 }
 
+int ltp_reserve_batch(ltp_planner* p, long long n)
+{
+    if (!p || n < 0) return fail(p, LTP_ERR_INVALID_ARGUMENT, "n < 0");
+    std::lock_guard<std::mutex> g(p->mu);
+    int rc = check_config(p);
+    if (rc != LTP_OK) return rc;
+    return reserve(p, n);
+}
+
 int ltp_plan_switch_times_batch(ltp_planner* p, long long n, const ltp_queries* in, const ltp_records* out,
                                 unsigned long long* offsets, void* stream)
 {

@@ -1,0 +1,214 @@
+// device_api_test — the C ABI of include/ltp_hip.h driven from plain C++ with hipMalloc'd buffers (no PyTorch in the
+// process), the way a C++ user of the reference would call the batched path:
+//   1. generate / plan / sample / reduce a batch through the device-pointer entry points;
+//   2. the host-pointer convenience path (ltp_plan_batch_host) must return the same bits for the same queries;
+//   3. the plan + sample sequence is captured into a hipGraph after ltp_reserve_batch and replayed on new inputs in
+//      place; the replay must equal the eager calls bit for bit;
+//   4. the envelope consumer equals min / max over windows of the sampled rows.
+// Built with g++ against the HIP runtime API only; prints "0 failures" on success.
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "ltp_hip.h"
+
+static int g_failures = 0;
+#define CHECK(cond)                                                              \
+    do {                                                                         \
+        if (!(cond)) {                                                           \
+            ++g_failures;                                                        \
+            std::printf("FAILED %s:%d: %s\n", __FILE__, __LINE__, #cond);        \
+        }                                                                        \
+    } while (0)
+#define HIP(call)                                                                \
+    do {                                                                         \
+        hipError_t e_ = (call);                                                  \
+        if (e_ != hipSuccess) {                                                  \
+            std::printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); \
+            return 2;                                                            \
+        }                                                                        \
+    } while (0)
+#define LTP(call)                                                                \
+    do {                                                                         \
+        int rc_ = (call);                                                        \
+        if (rc_ != LTP_OK) {                                                     \
+            std::printf("ltp error %d (%s) at %s:%d\n", rc_, ltp_last_error(h), __FILE__, __LINE__); \
+            return 2;                                                            \
+        }                                                                        \
+    } while (0)
+
+template <class T>
+static std::vector<T> download(const T* d, size_t n)
+{
+    std::vector<T> v(n);
+    if (n && hipMemcpy(v.data(), d, n * sizeof(T), hipMemcpyDeviceToHost) != hipSuccess) std::printf("download failed\n"), ++g_failures;
+    return v;
+}
+
+int main()
+{
+    const int dof = 7;
+    const long long n = 4000;
+    // the panda-like limit set of SURVEY.md §8(d)
+    const double q_min[dof] = {-2.8973, -1.7628, -2.8973, -3.0718, -2.8973, -0.0175, -2.8973};
+    const double q_max[dof] = {2.8973, 1.7628, 2.8973, -0.0698, 2.8973, 3.7525, 2.8973};
+    const double v_max[dof] = {2.175, 2.175, 2.175, 2.175, 2.61, 2.61, 2.61};
+    const double a_max[dof] = {15, 7.5, 10, 12.5, 15, 20, 20};
+    const double j_max[dof] = {7500, 3750, 5000, 6250, 7500, 10000, 10000};
+    ltp_planner* h = nullptr;
+    int rc = ltp_create(dof, 0.001, q_min, q_max, v_max, a_max, j_max, 0, &h);
+    if (rc != LTP_OK) {
+        std::printf("ltp_create failed with %d (no HIP device? the library has no CPU fallback)\n", rc);
+        return 2;
+    }
+    hipStream_t s;
+    HIP(hipStreamCreate(&s));
+
+    const size_t nd = (size_t)n * dof;
+    double *in[4], *t_opt, *t_scaled, *dir, *v_drive, *t_required;
+    signed char* mod;
+    int *slowest, *traj_len, *status;
+    unsigned long long* offsets;
+    for (auto& p : in) HIP(hipMalloc((void**)&p, nd * sizeof(double)));
+    HIP(hipMalloc((void**)&t_opt, nd * 7 * sizeof(double)));
+    HIP(hipMalloc((void**)&t_scaled, nd * 7 * sizeof(double)));
+    HIP(hipMalloc((void**)&dir, nd * sizeof(double)));
+    HIP(hipMalloc((void**)&v_drive, nd * sizeof(double)));
+    HIP(hipMalloc((void**)&mod, nd));
+    HIP(hipMalloc((void**)&t_required, n * sizeof(double)));
+    HIP(hipMalloc((void**)&slowest, n * sizeof(int)));
+    HIP(hipMalloc((void**)&traj_len, n * sizeof(int)));
+    HIP(hipMalloc((void**)&status, n * sizeof(int)));
+    HIP(hipMalloc((void**)&offsets, (n + 1) * sizeof(unsigned long long)));
+    const ltp_queries q{in[0], in[1], in[2], in[3], dof, 1};
+    const ltp_records rec{t_opt, t_scaled, dir, v_drive, mod, t_required, slowest, traj_len, status};
+
+    // ---- 1. device path ----
+    LTP(ltp_reserve_batch(h, n));
+    LTP(ltp_generate_queries_batch(h, n, 1, 0, in[0], in[1], in[2], in[3], dof, 1, s));
+    LTP(ltp_plan_switch_times_batch(h, n, &q, &rec, offsets, s));
+    HIP(hipStreamSynchronize(s));
+    std::vector<unsigned long long> off = download(offsets, (size_t)n + 1);
+    // room for any batch of this size: rows are padded to 32 samples, plans last a few seconds at most
+    const unsigned long long capacity = off[n] + off[n] / 2;
+    double *tile, *tile2;
+    HIP(hipMalloc((void**)&tile, capacity * sizeof(double)));
+    HIP(hipMalloc((void**)&tile2, capacity * sizeof(double)));
+    LTP(ltp_sample_batch(h, 0, n, &q, &rec, offsets, tile, capacity, 1, s));
+    const int W = 50, K = 40;
+    double* env;
+    HIP(hipMalloc((void**)&env, nd * K * 2 * sizeof(double)));
+    LTP(ltp_envelope_batch(h, 0, n, &q, &rec, W, K, env, s));
+    HIP(hipStreamSynchronize(s));
+    std::vector<double> rows = download(tile, (size_t)off[n]);
+    std::vector<int> len = download(traj_len, (size_t)n), st = download(status, (size_t)n);
+    std::vector<double> ts = download(t_scaled, nd * 7);
+    long long ok = 0;
+    for (long long p = 0; p < n; ++p) ok += st[p] == 0;
+    std::printf("device path: %lld plans, %lld ok, %.1f MB of trajectories\n", n, ok, off[n] * 8 / 1e6);
+    CHECK(ok > n * 9 / 10);
+
+    // ---- 2. host-pointer path on the same queries ----
+    std::vector<double> hq[4];
+    for (int k = 0; k < 4; ++k) hq[k] = download(in[k], nd);
+    {
+        std::vector<double> h_topt(nd * 7), h_ts(nd * 7), h_dir(nd), h_vd(nd), h_treq(n);
+        std::vector<signed char> h_mod(nd);
+        std::vector<int> h_slow(n), h_len(n), h_st(n);
+        std::vector<unsigned long long> h_off(n + 1);
+        ltp_records hr{h_topt.data(), h_ts.data(), h_dir.data(), h_vd.data(), h_mod.data(), h_treq.data(), h_slow.data(), h_len.data(), h_st.data()};
+        double* packed = nullptr;
+        LTP(ltp_plan_batch_host(h, n, hq[0].data(), hq[1].data(), hq[2].data(), hq[3].data(), &hr, h_off.data(), &packed));
+        CHECK(h_off == off);
+        CHECK(h_len == len);
+        CHECK(h_st == st);
+        CHECK(std::memcmp(h_ts.data(), ts.data(), nd * 7 * sizeof(double)) == 0);
+        // compare the rows, not the padding between them (the host path returns a zero-initialised buffer)
+        size_t bad = 0;
+        for (long long p = 0; p < n; ++p) {
+            const int L = len[p];
+            if (L <= 0) continue;
+            const size_t stride = (size_t)ltp_row_stride(L);
+            for (int r = 0; r < 4 * dof; ++r)
+                bad += std::memcmp(packed + off[p] + r * stride, rows.data() + off[p] + r * stride, (size_t)L * sizeof(double)) != 0;
+        }
+        CHECK(bad == 0);
+        ltp_free_host(packed);
+    }
+
+    // ---- 4. envelope == min / max over windows of the sampled q rows ----
+    {
+        std::vector<double> e = download(env, nd * K * 2);
+        size_t bad = 0;
+        for (long long p = 0; p < n; p += 37) {
+            const int L = len[p];
+            for (int j = 0; j < dof; ++j)
+                for (int w = 0; w < K; ++w) {
+                    const double lo = e[((p * dof + j) * K + w) * 2], hi = e[((p * dof + j) * K + w) * 2 + 1];
+                    if (L <= 0) {
+                        bad += !(std::isnan(lo) && std::isnan(hi));
+                        continue;
+                    }
+                    const double* row = rows.data() + off[p] + (size_t)j * ltp_row_stride(L);   // q block comes first
+                    const int b = std::min(w * W, L - 1), en = std::min(w * W + W, L);
+                    double mn = row[b], mx = row[b];
+                    for (int i = b; i < std::max(en, b + 1); ++i) { mn = std::min(mn, row[i]); mx = std::max(mx, row[i]); }
+                    bad += !(mn == lo && mx == hi);
+                }
+        }
+        CHECK(bad == 0);
+    }
+
+    // ---- 3. hipGraph: capture plan + sample, replay on new inputs in place ----
+    {
+        hipGraph_t graph;
+        hipGraphExec_t exec;
+        HIP(hipStreamBeginCapture(s, hipStreamCaptureModeGlobal));
+        int rc1 = ltp_plan_switch_times_batch(h, n, &q, &rec, offsets, s);
+        int rc2 = ltp_sample_batch(h, 0, n, &q, &rec, offsets, tile, capacity, 1, s);
+        HIP(hipStreamEndCapture(s, &graph));
+        CHECK(rc1 == LTP_OK && rc2 == LTP_OK);
+        HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+        for (unsigned long long seed = 2; seed <= 4; ++seed) {
+            LTP(ltp_generate_queries_batch(h, n, seed, 0, in[0], in[1], in[2], in[3], dof, 1, s));
+            HIP(hipMemsetAsync(tile, 0, capacity * sizeof(double), s));
+            HIP(hipGraphLaunch(exec, s));
+            HIP(hipStreamSynchronize(s));
+            std::vector<unsigned long long> off_g = download(offsets, (size_t)n + 1);
+            std::vector<int> st_g = download(status, (size_t)n);
+            CHECK(off_g[n] <= capacity);
+            std::vector<double> rows_g = download(tile, (size_t)off_g[n]);
+            // the same, eagerly
+            HIP(hipMemsetAsync(tile2, 0, capacity * sizeof(double), s));
+            LTP(ltp_plan_switch_times_batch(h, n, &q, &rec, offsets, s));
+            LTP(ltp_sample_batch(h, 0, n, &q, &rec, offsets, tile2, capacity, 1, s));
+            HIP(hipStreamSynchronize(s));
+            CHECK(download(offsets, (size_t)n + 1) == off_g);
+            CHECK(download(status, (size_t)n) == st_g);
+            std::vector<double> rows_e = download(tile2, (size_t)off_g[n]);
+            CHECK(std::memcmp(rows_e.data(), rows_g.data(), rows_e.size() * sizeof(double)) == 0);
+            CHECK(off_g != off);   // really new inputs
+        }
+        // replay rate: launch-bound host work is gone
+        hipEvent_t e0, e1;
+        HIP(hipEventCreate(&e0));
+        HIP(hipEventCreate(&e1));
+        HIP(hipEventRecord(e0, s));
+        for (int i = 0; i < 20; ++i) HIP(hipGraphLaunch(exec, s));
+        HIP(hipEventRecord(e1, s));
+        HIP(hipStreamSynchronize(s));
+        float ms = 0;
+        HIP(hipEventElapsedTime(&ms, e0, e1));
+        std::printf("hipGraph replay of plan + sample, %lld plans: %.3f ms per replay\n", n, ms / 20);
+        HIP(hipGraphExecDestroy(exec));
+        HIP(hipGraphDestroy(graph));
+    }
+
+    ltp_destroy(h);
+    std::printf("%d failures\n", g_failures);
+    return g_failures ? 1 : 0;
+}

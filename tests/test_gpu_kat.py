@@ -158,6 +158,18 @@ def test_cpp_dropin_class_runs_reference_scenarios():
     assert "0 failures" in r.stdout
 
 
+def test_cpp_device_api_without_pytorch_and_hipgraph_replay():
+    """tests/cpp/device_api_test.cc: the device-pointer C ABI from plain C++ (hipMalloc'd buffers, no PyTorch in the
+    process) — device path == host-pointer path bit for bit, envelope == reduced rows, and a hipGraph captured from
+    plan + sample replays on new inputs with the results of the eager calls."""
+    exe = os.path.join(ROOT, "tests", "cpp", "device_api_test")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "cpp"), "-s", "device_api_test"])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "\n0 failures" in r.stdout and "hipGraph replay" in r.stdout
+
+
 def test_reference_own_test_suite_against_the_dropin():
     """The reference's OWN tests/src/long_term_planner_tests.cc (+ its fixture header), compiled unmodified where it
     lies against this repository's drop-in header and libltp_hip.so (tests/cpp/Makefile target `reference_tests`,
