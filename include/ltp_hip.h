@@ -38,7 +38,8 @@ typedef enum {
 #define LTP_STATUS_OPT_FAILED    2  /* optSwitchTimes false         (cc:29)                               */
 #define LTP_STATUS_NO_SLOWEST    4  /* slowest_joint == -1          (cc:39)                               */
 #define LTP_STATUS_END_LIMIT     8  /* last q outside [q_min,q_max] (cc:59-61); trajectory IS filled      */
-#define LTP_STATUS_NONFINITE    16  /* defined here: non-finite switching times, traj_len = 0 (ref.: UB)  */
+#define LTP_STATUS_NONFINITE    16  /* defined here: non-finite switching times or a length beyond int   */
+                                    /* range; traj_len = 0, not sampled (reference: undefined behaviour)  */
 #define LTP_STATUS_OVERFLOW     32  /* trajectory did not fit the output tile passed to ltp_sample_batch  */
 #define LTP_STATUS_GOAL_OUTSIDE 64  /* only with ltp_set_goal_check(p, 1): q_goal outside [q_min,q_max]   */
 

@@ -39,13 +39,15 @@ LTP_DEV JointLimits load_limits(const Limits& lim, int j)
 // Block = 64 queries x JB joint slots; wave y handles joints y, y+JB, ... of 64 consecutive queries, so the
 // joint limits are wave-uniform (SGPRs) and both input layouts are read with one stride per lane.
 // ---------------------------------------------------------------------------------------
-// (int)ceil(t[6]/Ts) + 1 of one joint (cc:718), or -1 if any of its switching times is not finite (DEFINED case)
+// (int)ceil(t[6]/Ts) + 1 of one joint (cc:718), or -1 if any of its switching times is not finite or the length does
+// not fit an int (both DEFINED here: the reference converts out-of-range doubles to int, which is undefined)
 LTP_DEV int joint_len(const double (&t)[7], double t_sample)
 {
     bool finite = true;
 #pragma unroll
     for (int k = 0; k < 7; ++k) finite = finite && dfinite(t[k]);
-    return finite ? (int)dceil(t[6] / t_sample) + 1 : -1;
+    const double len = dceil(t[6] / t_sample) + 1.0;
+    return (finite && len < 2147483647.0) ? (int)len : -1;
 }
 
 constexpr int kLaneGoalOutside = 128; // lane_flags bit: q_goal outside [q_min, q_max] (only with the opt-in goal check)
@@ -437,9 +439,9 @@ k_finalize(long long n, int dof, double t_sample, RowSpec rows, Records rec, uns
                 bool finite = true;
                 for (int j = 0; j < dof; ++j) {
                     const double* t = rec.t_scaled + (q * dof + j) * 7;
-#pragma unroll
-                    for (int k = 0; k < 7; ++k) finite = finite && dfinite(t[k]);
-                    const int l = (int)dceil(t[6] / t_sample) + 1;
+                    const double tj[7] = {t[0], t[1], t[2], t[3], t[4], t[5], t[6]};
+                    const int l = joint_len(tj, t_sample);
+                    finite = finite && l >= 0;
                     len = l > len ? l : len;
                 }
                 if (!finite) { len = 0; st |= kStatusNonFinite; rec.status[q] = st; }

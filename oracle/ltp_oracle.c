@@ -580,6 +580,7 @@ int ltpo_traj_len(const ltpo_planner *P, const double *t /* [dof][7] */)
     for (i = 0; i < P->dof; i++) {
         int k, l;
         for (k = 0; k < 7; k++) if (!isfinite(t[7 * i + k])) return 0;
+        if (!(ceil(t[7 * i + 6] / P->t_sample) + 1.0 < 2147483647.0)) return 0; /* DEFINED: length does not fit an int */
         l = (int)ceil(t[7 * i + 6] / P->t_sample) + 1;
         if (l > len) len = l;
     }

@@ -445,3 +445,24 @@ def test_a_second_handle_can_sample_what_the_first_one_planned(amd, ref7):
     e2 = amd.LongTermPlanner(D, 0.001, device=0, **lim).envelopeBatch(b, 0, 200, 32, 16)
     torch.cuda.synchronize()
     assert torch.equal(t1, t2) and torch.equal(e1.nan_to_num(7.0), e2.nan_to_num(7.0))
+
+
+def test_trajectory_longer_than_int_range_is_flagged_not_sampled(amd, oracle_mod):
+    """DEFINED here (reference: undefined double -> int conversion): a plan whose length does not fit an int is
+    treated like non-finite switching times — LTP_STATUS_NONFINITE, traj_len 0 — in the device path and the oracle."""
+    D, lim = amd.limit_set("ref")
+    ts = 1e-10                                                 # seconds-long motions -> > 2^31 samples
+    ltp = amd.LongTermPlanner(D, ts, device=0, **lim)
+    orc = oracle_mod.Oracle(D, ts, **lim)
+    qg, q0, v0, a0 = amd.generate_queries(70, lim, seed=12)
+    qg[5], v0[5], a0[5] = q0[5], 0.0, 0.0                      # an all-zero plan still has a (short) trajectory
+    r = ltp.planBatchHost(qg, q0, v0, a0, sample=True)
+    o = orc.plan_batch(qg, q0, v0, a0, sample=False)
+    assert np.array_equal(r["traj_len"], o["traj_len"])
+    long_ = np.arange(70) != 5
+    assert np.all(r["traj_len"][long_] == 0) and np.all(r["status"][long_] & amd.STATUS_NONFINITE)
+    assert r["traj_len"][5] > 0 and r["status"][5] == 0
+    assert np.nanmax(np.abs(r["t_scaled"] - o["t_scaled"])) <= TOL
+    # the one-joint getTrajectory entry point defines it the same way
+    g = ltp.getTrajectoryBatchHost(r["t_scaled"][:8], r["dir"][:8], r["mod"][:8], q0[:8], v0[:8], a0[:8], r["v_drive"][:8])
+    assert np.all(g["traj_len"][[0, 1, 2, 3, 4, 6, 7]] == 0) and g["traj_len"][5] == r["traj_len"][5]
