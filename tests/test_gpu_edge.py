@@ -466,3 +466,33 @@ def test_trajectory_longer_than_int_range_is_flagged_not_sampled(amd, oracle_mod
     # the one-joint getTrajectory entry point defines it the same way
     g = ltp.getTrajectoryBatchHost(r["t_scaled"][:8], r["dir"][:8], r["mod"][:8], q0[:8], v0[:8], a0[:8], r["v_drive"][:8])
     assert np.all(g["traj_len"][[0, 1, 2, 3, 4, 6, 7]] == 0) and g["traj_len"][5] == r["traj_len"][5]
+
+
+def test_two_handles_on_two_streams_run_concurrently(amd, ref7):
+    """One handle per stream: concurrent batches on two streams give the results of serial runs."""
+    import torch
+    D, lim, _, _ = ref7
+    planners = [amd.LongTermPlanner(D, 0.001, device=0, **lim) for _ in range(2)]
+    streams = [torch.cuda.Stream() for _ in range(2)]
+    n = 6000
+    queries = [planners[0].generateQueries(n, seed=100 + i) for i in range(2)]
+    serial = []
+    for i in range(2):
+        b = planners[i].planSwitchTimesBatch(*queries[i])
+        t = torch.zeros(int(b.offsets[-1].item()), dtype=torch.float64, device="cuda")
+        planners[i].sampleBatch(b, 0, n, t)
+        torch.cuda.synchronize()
+        serial.append((b.t_scaled.clone(), b.status.clone(), t))
+    torch.cuda.synchronize()
+    out = [None, None]
+    tiles = [torch.zeros_like(serial[i][2]) for i in range(2)]
+    for rep in range(3):
+        for i in range(2):
+            with torch.cuda.stream(streams[i]):
+                b = planners[i].planSwitchTimesBatch(*queries[i])
+                planners[i].sampleBatch(b, 0, n, tiles[i])
+                out[i] = b
+    torch.cuda.synchronize()
+    for i in range(2):
+        assert torch.equal(out[i].t_scaled, serial[i][0]) and torch.equal(out[i].status, serial[i][1])
+        assert torch.equal(tiles[i], serial[i][2])
