@@ -1141,21 +1141,26 @@ k_envelope(long long first, long long count, int dof, double t_sample, Limits li
                 int i = past ? len - 1 + r : (int)b + r;
                 const int e = (b + window < (long long)len) ? (int)(b + window) : len;
                 int kr = 0, cur = 0, nxt = nruns > 1 ? st[1] : 0x7fffffff;
+                // the four q coefficients of the current run stay in registers; they are re-read at a run boundary only
+                double c4[4] = {tab.c[jl][0][0], tab.c[jl][0][1], tab.c[jl][0][2], tab.c[jl][0][3]};
                 for (; i < e; i += g) {
-                    while (nxt <= i) {
-                        ++kr;
-                        cur = nxt;
-                        nxt = kr + 1 < nruns ? st[kr + 1] : 0x7fffffff;
+                    if (nxt <= i) {
+                        do {
+                            ++kr;
+                            cur = nxt;
+                            nxt = kr + 1 < nruns ? st[kr + 1] : 0x7fffffff;
+                        } while (nxt <= i);
+#pragma unroll
+                        for (int x = 0; x < 4; ++x) c4[x] = tab.c[jl][kr][x];
                     }
-                    const double q = run_eval_q(tab.c[jl][kr], i - cur + 1);
-                    lo = q < lo ? q : lo;
-                    hi = q > hi ? q : hi;
+                    const double q = run_eval_q(c4, i - cur + 1);
+                    lo = __builtin_fmin(lo, q);
+                    hi = __builtin_fmax(hi, q);
                 }
             }
             for (int d = 1; d < g; d <<= 1) {
-                const double lo2 = __shfl_xor(lo, d), hi2 = __shfl_xor(hi, d);
-                lo = lo2 < lo ? lo2 : lo;
-                hi = hi2 > hi ? hi2 : hi;
+                lo = __builtin_fmin(lo, __shfl_xor(lo, d));
+                hi = __builtin_fmax(hi, __shfl_xor(hi, d));
             }
             if (live && r == 0) dst[task] = double2_t{lo, hi};
         }
