@@ -62,8 +62,23 @@ def cpu_baseline(dof, lim, t_sample, seed, sample_switch_only):
     t1 = time.perf_counter()
     orc.plan_batch(qg, q0, v0, a0, sample=not sample_switch_only, first=0, count=n1, want_records=False)
     dt1 = time.perf_counter() - t1
+    flat = None
+    if not sample_switch_only:
+        # BASELINE.md §3 second variant: trajectory arrays allocated once per thread and reused ("flat preallocated")
+        def work_flat(t):
+            return orc.plan_batch(qg, q0, v0, a0, sample="flat", first=t * per_thread, count=per_thread // 2, want_records=False)["n_ok"]
+        t2 = time.perf_counter()
+        with ThreadPoolExecutor(cores) as ex:
+            list(ex.map(work_flat, range(cores)))
+        dtf = time.perf_counter() - t2
+        t3 = time.perf_counter()
+        orc.plan_batch(qg, q0, v0, a0, sample="flat", first=0, count=n1, want_records=False)
+        dtf1 = time.perf_counter() - t3
+        flat = {"value": cores * (per_thread // 2) / dtf, "one_thread": n1 / dtf1, "unit": "plans/s",
+                "sample": f"{per_thread // 2} queries per thread on {cores} threads; {n1} on one thread"}
     return {"value": n / dt, "unit": "plans/s", "cores": cores, "kind": "port",
             "one_thread": {"value": n1 / dt1, "unit": "plans/s", "sample": f"first {n1} queries, {dt1:.1f} s"},
+            "flat_preallocated": flat,
             "sample": f"first {n} queries of the same synthetic batch, {per_thread} per thread, "
                       f"{'switching times only' if sample_switch_only else 'full planTrajectory incl. per-plan allocation'}, "
                       f"{dt:.1f} s wall"}

@@ -156,7 +156,8 @@ class Oracle:
         return (n, *out)
 
     def plan_batch(self, q_goal, q_0, v_0, a_0, sample=False, first=0, count=None, want_records=True):
-        """Stages 1-3 (+ sampler when sample=True) for row-major [n][dof] queries."""
+        """Stages 1-3 (+ sampler when sample=True; sample="flat": sampler into arrays allocated once and reused instead
+        of the reference's per-plan allocation) for row-major [n][dof] queries."""
         D = self.dof
         qg = np.ascontiguousarray(np.asarray(q_goal, dtype=np.float64).reshape(-1, D))
         q0 = np.ascontiguousarray(np.asarray(q_0, dtype=np.float64).reshape(-1, D))
@@ -175,7 +176,7 @@ class Oracle:
         def g(k, cast=_dp):
             return r[k].ctypes.data_as(cast) if want_records else C.cast(None, cast)
         n_ok = lib().ltpo_plan_batch(self._ref, C.c_long(first), C.c_long(count), _d(qg), _d(q0), _d(v0), _d(a0),
-                                     C.c_int(1 if sample else 0), g("t_opt"), g("t_scaled"), g("dir"), g("mod", _cp),
+                                     C.c_int(2 if sample == "flat" else (1 if sample else 0)), g("t_opt"), g("t_scaled"), g("dir"), g("mod", _cp),
                                      g("v_drive"), g("t_required"), g("slowest", _ip), g("traj_len", _ip),
                                      g("status", _ip), g("checksum"))
         del null_d

@@ -705,10 +705,11 @@ int ltpo_plan_switch_times(const ltpo_planner *P, const double *q_goal, const do
  * else they are released; *len_out gets traj_len; *checksum (optional) the sum of
  * the last sample of q over joints.
  */
-int ltpo_plan_trajectory(const ltpo_planner *P, const double *q_goal, const double *q_0, const double *v_0,
-                         const double *a_0, double *t_opt, double *t_scaled, double *dirv, char *mod,
-                         double *v_drive, double *t_required, int *slowest, int *len_out,
-                         double **keep /* [4] or NULL */, double *checksum)
+static int plan_trajectory_impl(const ltpo_planner *P, const double *q_goal, const double *q_0, const double *v_0,
+                                const double *a_0, double *t_opt, double *t_scaled, double *dirv, char *mod,
+                                double *v_drive, double *t_required, int *slowest, int *len_out,
+                                double **keep /* [4] or NULL */, double *checksum,
+                                double **reuse /* [4] or NULL: caller-owned arrays grown on demand */, size_t *reuse_cap)
 {
     int D = P->dof, len, i, status = 1;
     double *q, *v, *a, *j;
@@ -717,10 +718,19 @@ int ltpo_plan_trajectory(const ltpo_planner *P, const double *q_goal, const doub
     len = ltpo_traj_len(P, t_scaled);
     *len_out = len;
     if (len <= 0) return 0; /* DEFINED: non-finite switching times */
-    q = (double *)malloc(sizeof(double) * (size_t)D * len);
-    v = (double *)malloc(sizeof(double) * (size_t)D * len);
-    a = (double *)malloc(sizeof(double) * (size_t)D * len);
-    j = (double *)malloc(sizeof(double) * (size_t)D * len);
+    if (reuse) {
+        size_t need = (size_t)D * len;
+        if (need > *reuse_cap) {
+            for (i = 0; i < 4; i++) { free(reuse[i]); reuse[i] = (double *)malloc(sizeof(double) * need); }
+            *reuse_cap = need;
+        }
+        q = reuse[0]; v = reuse[1]; a = reuse[2]; j = reuse[3];
+    } else {
+        q = (double *)malloc(sizeof(double) * (size_t)D * len);
+        v = (double *)malloc(sizeof(double) * (size_t)D * len);
+        a = (double *)malloc(sizeof(double) * (size_t)D * len);
+        j = (double *)malloc(sizeof(double) * (size_t)D * len);
+    }
     ltpo_get_trajectory(P, t_scaled, dirv, mod, q_0, v_0, a_0, v_drive, len, q, v, a, j);
     for (i = 0; i < D; i++) {
         double qe = q[(size_t)i * len + len - 1];
@@ -731,9 +741,19 @@ int ltpo_plan_trajectory(const ltpo_planner *P, const double *q_goal, const doub
         for (i = 0; i < D; i++) s += q[(size_t)i * len + len - 1];
         *checksum = s;
     }
+    if (reuse) return status;
     if (keep) { keep[0] = q; keep[1] = v; keep[2] = a; keep[3] = j; }
     else { free(q); free(v); free(a); free(j); }
     return status;
+}
+
+int ltpo_plan_trajectory(const ltpo_planner *P, const double *q_goal, const double *q_0, const double *v_0,
+                         const double *a_0, double *t_opt, double *t_scaled, double *dirv, char *mod,
+                         double *v_drive, double *t_required, int *slowest, int *len_out,
+                         double **keep /* [4] or NULL */, double *checksum)
+{
+    return plan_trajectory_impl(P, q_goal, q_0, v_0, a_0, t_opt, t_scaled, dirv, mod, v_drive, t_required, slowest, len_out,
+                                keep, checksum, NULL, NULL);
 }
 
 void ltpo_free(void *p) { free(p); }
@@ -741,7 +761,9 @@ void ltpo_free(void *p) { free(p); }
 /*
  * Batch driver used by tests and by bench.py's cpu_baseline: runs queries
  * [first, first+count) of row-major [n][dof] inputs through ltpo_plan_trajectory
- * (or stages 1-3 only when sample == 0). Per-query outputs are optional (NULL).
+ * (or stages 1-3 only when sample == 0; sample == 2 samples into four arrays that
+ * are allocated once and reused, the "flat preallocated" CPU variant of BASELINE.md
+ * §3, instead of the reference's per-plan allocation). Per-query outputs are optional (NULL).
  * Returns the number of queries with status 1.
  */
 long ltpo_plan_batch(const ltpo_planner *P, long first, long count, const double *q_goal, const double *q_0,
@@ -754,6 +776,8 @@ long ltpo_plan_batch(const ltpo_planner *P, long first, long count, const double
     double *b_topt = (double *)malloc(sizeof(double) * 7 * D), *b_tsc = (double *)malloc(sizeof(double) * 7 * D);
     double *b_dir = (double *)malloc(sizeof(double) * D), *b_vd = (double *)malloc(sizeof(double) * D);
     char *b_mod = (char *)malloc(D);
+    double *reuse[4] = {NULL, NULL, NULL, NULL};
+    size_t reuse_cap = 0;
     for (p = first; p < first + count; p++) {
         double treq, cs = 0;
         int slow, len = 0, st;
@@ -763,8 +787,9 @@ long ltpo_plan_batch(const ltpo_planner *P, long first, long count, const double
         double *o_vd = v_drive ? v_drive + (size_t)p * D : b_vd;
         char *o_mod = mod ? mod + (size_t)p * D : b_mod;
         if (sample) {
-            st = ltpo_plan_trajectory(P, q_goal + (size_t)p * D, q_0 + (size_t)p * D, v_0 + (size_t)p * D, a_0 + (size_t)p * D,
-                                      o_topt, o_tsc, o_dir, o_mod, o_vd, &treq, &slow, &len, NULL, &cs);
+            st = plan_trajectory_impl(P, q_goal + (size_t)p * D, q_0 + (size_t)p * D, v_0 + (size_t)p * D, a_0 + (size_t)p * D,
+                                      o_topt, o_tsc, o_dir, o_mod, o_vd, &treq, &slow, &len, NULL, &cs,
+                                      sample == 2 ? reuse : NULL, &reuse_cap);
         } else {
             st = ltpo_plan_switch_times(P, q_goal + (size_t)p * D, q_0 + (size_t)p * D, v_0 + (size_t)p * D, a_0 + (size_t)p * D,
                                         o_topt, o_tsc, o_dir, o_mod, o_vd, &treq, &slow);
@@ -778,5 +803,6 @@ long ltpo_plan_batch(const ltpo_planner *P, long first, long count, const double
         if (st == 1) n_ok++;
     }
     free(b_topt); free(b_tsc); free(b_dir); free(b_vd); free(b_mod);
+    free(reuse[0]); free(reuse[1]); free(reuse[2]); free(reuse[3]);
     return n_ok;
 }
