@@ -110,6 +110,9 @@ def main():
     ap.add_argument("--device", type=int, default=None, help="HIP device ordinal for every rank (default: LOCAL_RANK)")
     ap.add_argument("--envelope", default="", metavar="WINDOW:COUNT",
                     help="VARIANT: instead of dense rows, reduce each plan on the device to per-joint [min q, max q] over COUNT windows of WINDOW samples (ltp_envelope_batch)")
+    ap.add_argument("--receding", default="", metavar="ROUNDS:K",
+                    help="VARIANT (SURVEY §8(f).1): per step ROUNDS receding-horizon cycles on the device — plan, sample the first "
+                         "--max-samples samples, restart every query from stored sample K (ltp_replan_states_batch); value counts every replan")
     ap.add_argument("--sample-blocks", type=int, default=0, help="TUNING: size of the sampler's persistent grid (0 = library default)")
     ap.add_argument("--gather", action="store_true", help="also all_gather t_required over RCCL each step (optional path)")
     args = ap.parse_args()
@@ -146,6 +149,10 @@ def main():
         ltp.setSampleStride(args.sample_stride)
     if args.sample_blocks:
         ltp._check(ltp._lib.ltp_debug_set_sample_blocks(ltp._h, args.sample_blocks))
+    rec_spec = tuple(int(x) for x in args.receding.split(":")) if args.receding else None
+    if rec_spec and not args.max_samples:
+        args.max_samples = 2 * rec_spec[1]
+        ltp.setMaxSamples(args.max_samples)
     env_spec = tuple(int(x) for x in args.envelope.split(":")) if args.envelope else None
     env_out = torch.empty((n, dof, env_spec[1], 2), dtype=torch.float64, device=dev) if env_spec else None
     tile = None
@@ -169,6 +176,21 @@ def main():
 
     def step(timed):
         nonlocal batch, n_chunks
+        if rec_spec:
+            # every round: stages 1-3, first-N rows of all plans into the tile (they fit: N is small), new start states
+            s0, s1, s2 = q0, v0, a0
+            for _ in range(rec_spec[0]):
+                batch = ltp.planSwitchTimesBatch(qg, s0, s1, s2, layout=args.layout, batch=batch)
+                if timed:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                ltp.sampleBatch(batch, 0, n, tile, streaming=not args.plain_stores, spread=args.spread)
+                if timed:
+                    e1.record()
+                    ev_pairs.append((e0, e1))
+                s0, s1, s2 = ltp.replanStates(batch, 0, n, tile, rec_spec[1], layout=args.layout)
+            n_chunks = 1
+            return
         batch = ltp.planSwitchTimesBatch(qg, q0, v0, a0, layout=args.layout, batch=batch)
         if gather_buf is not None:
             dist.all_gather(gather_buf, batch.t_required.to(cdev))
@@ -232,7 +254,8 @@ def main():
     if ev_pairs:
         kern_ms = sum(a.elapsed_time(b) for a, b in ev_pairs)
         launches = len(ev_pairs)
-        achieved = alg_bytes_per_step * args.steps / (kern_ms * 1e-3) / 1e9
+        rounds = rec_spec[0] if rec_spec else 1    # receding variant: the lengths of the last round stand for all rounds
+        achieved = alg_bytes_per_step * rounds * args.steps / (kern_ms * 1e-3) / 1e9
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "sampler_write_bytes.json")
         if os.path.exists(pmc):
@@ -250,7 +273,7 @@ def main():
     if rank == 0:
         out = {
             "metric": "7-DoF trajectory plans/sec (batch 1M)" if dof == 7 else f"{dof}-DoF trajectory plans/sec",
-            "value": round(world * n * args.steps / elapsed, 1),
+            "value": round(world * n * args.steps * (rec_spec[0] if rec_spec else 1) / elapsed, 1),
             "unit": "plans/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -263,6 +286,7 @@ def main():
             "data": "synthetic" if not args.dry_sampler else "DIAGNOSTIC dry sampler: NOT a valid result",
             "config": {
                 "workload": (f"{n} x {dof}-DoF queries per GPU per step, limits '{args.limits}', Tsample {args.t_sample} s, "
+                             + (f"{rec_spec[0]} receding-horizon cycles per step on the device (plan, first {args.max_samples} samples, replan from stored sample {rec_spec[1]}); value counts replans; " if rec_spec else "")
                              + ("switching times only (stages 1-3)" if args.switch_only else
                                 f"on-device envelope consumer: [min q, max q] over {env_spec[1]} windows of {env_spec[0]} samples per joint, no dense rows" if env_spec else
                                 (f"full q/v/a/j sampling" if not (args.max_samples or args.sample_stride > 1) else
