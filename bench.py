@@ -150,13 +150,11 @@ def main():
     if args.sample_blocks:
         ltp._check(ltp._lib.ltp_debug_set_sample_blocks(ltp._h, args.sample_blocks))
     rec_spec = tuple(int(x) for x in args.receding.split(":")) if args.receding else None
-    if rec_spec and not args.max_samples:
-        args.max_samples = 2 * rec_spec[1]
-        ltp.setMaxSamples(args.max_samples)
+    rec_direct = bool(rec_spec) and not args.max_samples      # restart states straight from the records (ltp_state_at_batch)
     env_spec = tuple(int(x) for x in args.envelope.split(":")) if args.envelope else None
     env_out = torch.empty((n, dof, env_spec[1], 2), dtype=torch.float64, device=dev) if env_spec else None
     tile = None
-    if not args.switch_only and not env_spec:
+    if not args.switch_only and not env_spec and not rec_direct:
         # one big reused output tile; if this GPU cannot give 192 GiB right now, halve until it can
         gib = args.tile_gib
         while tile is None:
@@ -181,6 +179,9 @@ def main():
             s0, s1, s2 = q0, v0, a0
             for _ in range(rec_spec[0]):
                 batch = ltp.planSwitchTimesBatch(qg, s0, s1, s2, layout=args.layout, batch=batch)
+                if rec_direct:
+                    s0, s1, s2 = ltp.stateAt(batch, 0, n, rec_spec[1], layout=args.layout)
+                    continue
                 if timed:
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record()
@@ -286,8 +287,9 @@ def main():
             "data": "synthetic" if not args.dry_sampler else "DIAGNOSTIC dry sampler: NOT a valid result",
             "config": {
                 "workload": (f"{n} x {dof}-DoF queries per GPU per step, limits '{args.limits}', Tsample {args.t_sample} s, "
-                             + (f"{rec_spec[0]} receding-horizon cycles per step on the device (plan, first {args.max_samples} samples, replan from stored sample {rec_spec[1]}); value counts replans; " if rec_spec else "")
+                             + (f"{rec_spec[0]} receding-horizon cycles per step on the device (plan, " + ("state at sample" if rec_direct else f"first {args.max_samples} samples, replan from stored sample") + f" {rec_spec[1]}); value counts replans; " if rec_spec else "")
                              + ("switching times only (stages 1-3)" if args.switch_only else
+                                "no rows stored (ltp_state_at_batch)" if rec_direct else
                                 f"on-device envelope consumer: [min q, max q] over {env_spec[1]} windows of {env_spec[0]} samples per joint, no dense rows" if env_spec else
                                 (f"full q/v/a/j sampling" if not (args.max_samples or args.sample_stride > 1) else
                                  f"q/v/a/j rows: every {args.sample_stride}-th sample" + (f", first {args.max_samples} stored" if args.max_samples else ""))

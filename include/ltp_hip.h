@@ -154,6 +154,13 @@ int ltp_replan_states_batch(ltp_planner* p, long long first, long long count, co
 int ltp_replan_states_f32_batch(ltp_planner* p, long long first, long long count, const ltp_queries* in, const ltp_records* rec,
                                 const unsigned long long* offsets, const float* tile, const int* sample_index, int uniform_index,
                                 double* q_0, double* v_0, double* a_0, long long query_stride, long long joint_stride, void* stream);
+/* The same without any sampled rows: the state at TRAJECTORY sample k (0 .. traj_len-1, clamped; not a stored-sample
+ * index) of plans [first, first+count), computed from the switching-time records alone with the sampler's own run
+ * tables, i.e. with the bits ltp_sample_batch would have stored at k. No tile, no offsets: the cheap way to close a
+ * receding-horizon loop on the device when only the restart state is needed. */
+int ltp_state_at_batch(ltp_planner* p, long long first, long long count, const ltp_queries* in, const ltp_records* rec,
+                       const int* sample_index, int uniform_index, double* q_0, double* v_0, double* a_0,
+                       long long query_stride, long long joint_stride, void* stream);
 
 /* Synthetic queries of SURVEY.md §8(d) (distribution of tests/randomConfiguration.m:14-34 with per-joint
  * limits), counter-based: query index first_query+p, so shards of one batch can be generated anywhere. */

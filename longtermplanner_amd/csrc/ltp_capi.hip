@@ -422,6 +422,22 @@ static int replan_states_any(ltp_planner* p, long long first, long long count, c
     return LTP_OK;
 }
 
+int ltp_state_at_batch(ltp_planner* p, long long first, long long count, const ltp_queries* in, const ltp_records* rec,
+                       const int* sample_index, int uniform_index, double* q_0, double* v_0, double* a_0,
+                       long long query_stride, long long joint_stride, void* stream)
+{
+    if (!p || first < 0 || count < 0 || !in || !records_complete(rec) || !q_0 || !v_0 || !a_0)
+        return fail(p, LTP_ERR_INVALID_ARGUMENT, "null argument");
+    std::lock_guard<std::mutex> g(p->mu);
+    int rc = check_config(p);
+    if (rc != LTP_OK) return rc;
+    LTP_HIP_TRY(p, hipSetDevice(p->device));
+    ltp::launch_state_at((hipStream_t)stream, first, count, p->dof, p->t_sample, dev_limits(p), to_dev(in), to_dev(rec), sample_index,
+                         uniform_index, q_0, v_0, a_0, query_stride, joint_stride);
+    LTP_HIP_TRY(p, hipGetLastError());
+    return LTP_OK;
+}
+
 int ltp_replan_states_batch(ltp_planner* p, long long first, long long count, const ltp_queries* in, const ltp_records* rec,
                             const unsigned long long* offsets, const double* tile, const int* sample_index, int uniform_index,
                             double* q_0, double* v_0, double* a_0, long long query_stride, long long joint_stride, void* stream)

@@ -1206,6 +1206,77 @@ k_replan_states(long long first, long long count, int dof, RowSpec rows, Queries
     a_0[dst] = (double)row[2 * arr];
 }
 
+// The same, without any sampled rows: the state (q, v, a) at trajectory sample k of every plan straight from the
+// switching-time records. A receding-horizon caller that only needs the restart state pays neither the table build
+// of a sampler item (~15 us of latency per plan) nor a byte of trajectory traffic: lane = (plan, joint), each lane
+// walks its own runs in order — the same cut points, jerk_at(), run_coef() and run_eval() as k_sample, so the result
+// has the bits of the row element the sampler would have stored at k.
+__global__ void __launch_bounds__(256)
+k_state_at(long long first, long long count, int dof, double t_sample, Limits lim, Queries in, Records rec,
+           const int* __restrict__ sample_index, int uniform_index,
+           double* __restrict__ q_0, double* __restrict__ v_0, double* __restrict__ a_0, long long sq, long long sj)
+{
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= count * dof) return;
+    const long long local = idx / dof;
+    const int j = (int)(idx - local * dof);
+    const long long p = first + local;
+    const long long dst = local * sq + (long long)j * sj;
+    const long long ix = p * in.sq + (long long)j * in.sj;
+    double q = in.q_0[ix], v = in.v_0[ix], a = in.a_0[ix];   // state "before sample 0" (cc:810-812)
+    const int len = rec.traj_len[p];
+    if (len > 0) {
+        int k = sample_index ? sample_index[local] : uniform_index;
+        k = k < 0 ? 0 : (k >= len ? len - 1 : k);             // beyond the end: the last state
+        const double Ts = t_sample;
+        const long long rj = p * dof + j;
+        int sw[7];
+        double fr[7], frts[7];
+#pragma unroll
+        for (int x = 0; x < 7; ++x) {
+            const double tk = rec.t_scaled[rj * 7 + x];
+            fr[x] = tk - Ts * dfloor(tk / Ts);                                        // cc:747
+            frts[x] = fr[x] / Ts;
+            sw[x] = (x & 1) ? (int)dceil(tk / Ts) : (int)dfloor(tk / Ts);           // cc:751-757
+        }
+        const double dir = rec.dir[rj];
+        const double dj = dir * lim.j_max[j];
+        const double vsnap = rec.v_drive[rj] * dir;                                   // cc:823
+        const bool modp = (double)rec.mod[rj] == 1.0;
+        // phase jerks (cc:735-744) and the nine possible correction terms (cc:771-807), as in build_run_tables step (2)
+        const double J0 = dj * (modp ? -1.0 : 1.0), J2 = dj * (modp ? 1.0 : -1.0), J4 = dj * -1.0, J6 = dj * 1.0;
+        const double Jp[7] = {J0, dj * 0.0, J2, dj * 0.0, J4, dj * 0.0, J6};
+        const double d20 = (fr[2] - fr[0]) / Ts;
+        const double corr[9] = {frts[0] * J0, (1 - frts[1]) * J2, frts[2] * J2, frts[0] * J0 + d20 * J2, (1 - frts[3]) * J4,
+                                frts[4] * J4, frts[4] * J4 + frts[0] * J0 + d20 * J2, (1 - frts[5]) * J6, frts[6] * J6};
+        // candidate cut points (slot 0 = index 0 starts the first run and is not needed here)
+        constexpr int cut_base[kCutSlots] = {0, 0, 0, 0, 1, 1, 2, 2, 2, 3, 3, 3, 4, 4, 4, 5, 5, 6, 6, 6};
+        constexpr int cut_delta[kCutSlots] = {0, 0, 1, 2, 0, 1, 0, 1, 2, -1, 0, 1, 0, 1, 2, 0, 1, 0, 1, 2};
+        int cand[kCutSlots];
+#pragma unroll
+        for (int c = 1; c < kCutSlots; ++c) cand[c] = sw[cut_base[c]] + cut_delta[c];
+        const bool phase4 = sw[3] - sw[2] > 2;                                        // cc:813
+        int b = 0;
+        for (int run = 0; run < kMaxSegments; ++run) {
+            int e = len;                                                              // next cut point after b
+#pragma unroll
+            for (int c = 1; c < kCutSlots; ++c) e = (cand[c] > b && cand[c] < e) ? cand[c] : e;
+            int mode = 0;
+            if (b > sw[6]) mode |= kModeTail;
+            if (phase4 && b >= sw[2] + 1 && b < sw[3] - 1) mode |= kModeVSnap;
+            const RunCoef rc = run_coef(mode, jerk_at(sw, Jp, corr, b), a, v, q, vsnap, Ts);
+            const bool last = k < e;
+            double jj;
+            run_eval(rc.c, (last ? k + 1 : e) - b, q, v, a, jj);                      // state at sample k, or at the run's last sample
+            if (last) break;
+            b = e;
+        }
+    }
+    q_0[dst] = q;
+    v_0[dst] = v;
+    a_0[dst] = a;
+}
+
 // ---------------------------------------------------------------------------------------
 // Synthetic queries (distribution of reference tests/randomConfiguration.m:14-34
 // generalised to per-joint limits). Counter-based: value = f(seed, query, joint, field), so any
@@ -1465,6 +1536,16 @@ void launch_replan_states(hipStream_t s, long long first, long long count, int d
     else
         hipLaunchKernelGGL(k_replan_states<double>, grid, block, 0, s, first, count, dof, rows, in, rec, offsets,
                            (const double*)tile, sample_index, uniform_index, q_0, v_0, a_0, sq, sj);
+}
+
+void launch_state_at(hipStream_t s, long long first, long long count, int dof, double t_sample, Limits lim, Queries in,
+                     Records rec, const int* sample_index, int uniform_index, double* q_0, double* v_0, double* a_0,
+                     long long sq, long long sj)
+{
+    if (count <= 0 || dof <= 0) return;
+    const long long total = count * dof;
+    hipLaunchKernelGGL(k_state_at, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, first, count, dof, t_sample, lim, in, rec,
+                       sample_index, uniform_index, q_0, v_0, a_0, sq, sj);
 }
 
 void launch_generate(hipStream_t s, long long n, int dof, Limits lim, unsigned long long seed, long long first_query,

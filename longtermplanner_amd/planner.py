@@ -286,6 +286,21 @@ class LongTermPlanner:
                        sample_index if per_plan is None else 0, *[x.data_ptr() for x in out], sq, sj, self._stream()))
         return out
 
+    def stateAt(self, batch: DeviceBatch, first, count, sample_index, layout="query_major"):
+        """NEW: (q, v, a) at trajectory sample k of plans [first, first+count) straight from the records
+        (ltp_state_at_batch) — no sampled rows needed. sample_index: int or int32 CUDA tensor [count]."""
+        import torch
+        D = self.dof
+        shape = (count, D) if layout == "query_major" else (D, count)
+        sq, sj = (D, 1) if layout == "query_major" else (1, count)
+        out = [torch.empty(shape, dtype=torch.float64, device=batch.offsets.device) for _ in range(3)]
+        rec = batch.c_records()
+        per_plan = None if isinstance(sample_index, int) else sample_index
+        self._check(self._lib.ltp_state_at_batch(self._h, first, count, C.byref(batch.queries), C.byref(rec),
+                                                 per_plan.data_ptr() if per_plan is not None else None,
+                                                 sample_index if per_plan is None else 0, *[x.data_ptr() for x in out], sq, sj, self._stream()))
+        return out
+
     # ---- diagnostics for the parity tests ----
     def debugMathProbe(self, x, y):
         x, y = _vec(x), _vec(y)

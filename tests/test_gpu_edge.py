@@ -496,3 +496,37 @@ def test_two_handles_on_two_streams_run_concurrently(amd, ref7):
     for i in range(2):
         assert torch.equal(out[i].t_scaled, serial[i][0]) and torch.equal(out[i].status, serial[i][1])
         assert torch.equal(tiles[i], serial[i][2])
+
+
+@pytest.mark.parametrize("limits,n", [("ref", 3000), ("panda", 3000), ("ref30", 300)])
+def test_state_at_has_the_bits_of_the_sampled_rows(amd, limits, n):
+    """ltp_state_at_batch (no rows) == the row elements ltp_sample_batch stores at sample k, for every k."""
+    import torch
+    D, lim = amd.limit_set(limits)
+    ltp = amd.LongTermPlanner(D, 0.001, device=0, **lim)
+    qm = ltp.generateQueries(n, seed=41)
+    qm[1][7, 0] = 99.0                                          # a rejected plan keeps its start state
+    b = ltp.planSwitchTimesBatch(*qm)
+    tile = torch.zeros(int(b.offsets[-1].item()), dtype=torch.float64, device="cuda")
+    ltp.sampleBatch(b, 0, n, tile)
+    lens = b.traj_len
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    for mode in ("random", "first", "last", "beyond", "uniform"):
+        if mode == "random":
+            k = (torch.rand(n, device="cuda", generator=gen) * lens.clamp(min=1)).to(torch.int32)
+        elif mode == "first":
+            k = torch.zeros(n, dtype=torch.int32, device="cuda")
+        elif mode == "last":
+            k = (lens - 1).clamp(min=0).to(torch.int32)
+        elif mode == "beyond":
+            k = (lens + 1000).to(torch.int32)
+        else:
+            k = 137
+        want = ltp.replanStates(b, 0, n, tile, k)
+        got = ltp.stateAt(b, 0, n, k)
+        got_jm = ltp.stateAt(b, 3, n - 5, k if isinstance(k, int) else k[3:n - 2].contiguous(), layout="joint_major")
+        torch.cuda.synchronize()
+        for w, g, gj in zip(want, got, got_jm):
+            assert torch.equal(w, g), mode
+            assert torch.equal(w[3:n - 2].t().contiguous(), gj), mode
+    assert torch.equal(got[0][7], qm[1][7])

@@ -11,7 +11,7 @@ echo "default done"; cat $O/bench_default.json
 : > $O/bench_variants.jsonl
 for a in "--limits ref" "--limits ref30 --batch 200000" "--switch-only --batch 100000" "--switch-only" "--switch-only --limits ref" \
          "--max-samples 256" "--sample-stride 4" "--f32" "--f32 --limits ref" "--f32 --max-samples 256" "--envelope 64:32" \
-         "--envelope 64:32 --limits ref" "--receding 10:100 --max-samples 128" "--tile-gib 64" "--layout joint_major"; do
+         "--envelope 64:32 --limits ref" "--receding 10:100" "--receding 10:100 --max-samples 128" "--tile-gib 64" "--layout joint_major"; do
   timeout -k 10 300 python bench.py --no-cpu-baseline $a >> $O/bench_variants.jsonl 2>> $O/bench_variants.err || exit 1
   echo "variant $a done"
 done
