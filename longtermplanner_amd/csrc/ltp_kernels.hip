@@ -1206,11 +1206,63 @@ k_replan_states(long long first, long long count, int dof, RowSpec rows, Queries
     a_0[dst] = (double)row[2 * arr];
 }
 
-// The same, without any sampled rows: the state (q, v, a) at trajectory sample k of every plan straight from the
-// switching-time records. A receding-horizon caller that only needs the restart state pays neither the table build
-// of a sampler item (~15 us of latency per plan) nor a byte of trajectory traffic: lane = (plan, joint), each lane
-// walks its own runs in order — the same cut points, jerk_at(), run_coef() and run_eval() as k_sample, so the result
-// has the bits of the row element the sampler would have stored at k.
+// One lane walks the runs of one joint in order: the same cut points, jerk_at(), run_coef() and run_eval() as the
+// cooperative table build of k_sample, with everything in registers. A kernel whose work per plan is small
+// (k_state_at) uses this instead of LDS tables: no block-level build, no per-item latency, 64 independent
+// (plan, joint) pairs per wave. (For the envelope consumer the same form is slower than the cooperative kernel,
+// 26.8 vs 20.0 ms per 1 M plans: lanes of a wave sit in runs of different lengths.) visit(b, e, rc) is called for every run [b, e) with its
+// coefficients and returns true to stop; (a, v, q) hold the state before the run and are advanced to its last sample
+// (exactly the value the sampler stores there) after each call that returns false.
+template <class Visit>
+LTP_DEV void for_each_run(const Limits& lim, const Records& rec, long long rj, int j, int len, double Ts, double& q, double& v,
+                          double& a, Visit&& visit)
+{
+    int sw[7];                                                                        // sampled switch indices (cc:751-757)
+    double fr[7], frts[7];
+#pragma unroll
+    for (int x = 0; x < 7; ++x) {
+        const double tk = rec.t_scaled[rj * 7 + x];
+        fr[x] = tk - Ts * dfloor(tk / Ts);                                            // cc:747
+        frts[x] = fr[x] / Ts;
+        sw[x] = (x & 1) ? (int)dceil(tk / Ts) : (int)dfloor(tk / Ts);
+    }
+    const double dir = rec.dir[rj];
+    const double dj = dir * lim.j_max[j];
+    const double vsnap = rec.v_drive[rj] * dir;                                       // cc:823
+    const bool modp = (double)rec.mod[rj] == 1.0;
+    // phase jerks (cc:735-744) and the nine possible correction terms (cc:771-807), as in build_run_tables step (2)
+    const double J0 = dj * (modp ? -1.0 : 1.0), J2 = dj * (modp ? 1.0 : -1.0), J4 = dj * -1.0, J6 = dj * 1.0;
+    const double Jp[7] = {J0, dj * 0.0, J2, dj * 0.0, J4, dj * 0.0, J6};
+    const double d20 = (fr[2] - fr[0]) / Ts;
+    const double corr[9] = {frts[0] * J0, (1 - frts[1]) * J2, frts[2] * J2, frts[0] * J0 + d20 * J2, (1 - frts[3]) * J4,
+                            frts[4] * J4, frts[4] * J4 + frts[0] * J0 + d20 * J2, (1 - frts[5]) * J6, frts[6] * J6};
+    // candidate cut points (slot 0 = index 0 starts the first run and is not needed here)
+    constexpr int cut_base[kCutSlots] = {0, 0, 0, 0, 1, 1, 2, 2, 2, 3, 3, 3, 4, 4, 4, 5, 5, 6, 6, 6};
+    constexpr int cut_delta[kCutSlots] = {0, 0, 1, 2, 0, 1, 0, 1, 2, -1, 0, 1, 0, 1, 2, 0, 1, 0, 1, 2};
+    int cand[kCutSlots];
+#pragma unroll
+    for (int c = 1; c < kCutSlots; ++c) cand[c] = sw[cut_base[c]] + cut_delta[c];
+    const bool phase4 = sw[3] - sw[2] > 2;                                            // cc:813
+    int b = 0;
+    for (int run = 0; run < kMaxSegments && b < len; ++run) {
+        int e = len;                                                                  // next cut point after b
+#pragma unroll
+        for (int c = 1; c < kCutSlots; ++c) e = (cand[c] > b && cand[c] < e) ? cand[c] : e;
+        int mode = 0;
+        if (b > sw[6]) mode |= kModeTail;
+        if (phase4 && b >= sw[2] + 1 && b < sw[3] - 1) mode |= kModeVSnap;
+        const RunCoef rc = run_coef(mode, jerk_at(sw, Jp, corr, b), a, v, q, vsnap, Ts);
+        if (visit(b, e, rc)) return;
+        double jj;
+        run_eval(rc.c, e - b, q, v, a, jj);
+        b = e;
+    }
+}
+
+// Receding horizon without any sampled rows: the state (q, v, a) at trajectory sample k of every plan straight from
+// the switching-time records. A caller that only needs the restart state pays neither the table build of a sampler
+// item (~15 us of latency per plan) nor a byte of trajectory traffic. The result has the bits of the row element the
+// sampler would have stored at k.
 __global__ void __launch_bounds__(256)
 k_state_at(long long first, long long count, int dof, double t_sample, Limits lim, Queries in, Records rec,
            const int* __restrict__ sample_index, int uniform_index,
@@ -1228,49 +1280,12 @@ k_state_at(long long first, long long count, int dof, double t_sample, Limits li
     if (len > 0) {
         int k = sample_index ? sample_index[local] : uniform_index;
         k = k < 0 ? 0 : (k >= len ? len - 1 : k);             // beyond the end: the last state
-        const double Ts = t_sample;
-        const long long rj = p * dof + j;
-        int sw[7];
-        double fr[7], frts[7];
-#pragma unroll
-        for (int x = 0; x < 7; ++x) {
-            const double tk = rec.t_scaled[rj * 7 + x];
-            fr[x] = tk - Ts * dfloor(tk / Ts);                                        // cc:747
-            frts[x] = fr[x] / Ts;
-            sw[x] = (x & 1) ? (int)dceil(tk / Ts) : (int)dfloor(tk / Ts);           // cc:751-757
-        }
-        const double dir = rec.dir[rj];
-        const double dj = dir * lim.j_max[j];
-        const double vsnap = rec.v_drive[rj] * dir;                                   // cc:823
-        const bool modp = (double)rec.mod[rj] == 1.0;
-        // phase jerks (cc:735-744) and the nine possible correction terms (cc:771-807), as in build_run_tables step (2)
-        const double J0 = dj * (modp ? -1.0 : 1.0), J2 = dj * (modp ? 1.0 : -1.0), J4 = dj * -1.0, J6 = dj * 1.0;
-        const double Jp[7] = {J0, dj * 0.0, J2, dj * 0.0, J4, dj * 0.0, J6};
-        const double d20 = (fr[2] - fr[0]) / Ts;
-        const double corr[9] = {frts[0] * J0, (1 - frts[1]) * J2, frts[2] * J2, frts[0] * J0 + d20 * J2, (1 - frts[3]) * J4,
-                                frts[4] * J4, frts[4] * J4 + frts[0] * J0 + d20 * J2, (1 - frts[5]) * J6, frts[6] * J6};
-        // candidate cut points (slot 0 = index 0 starts the first run and is not needed here)
-        constexpr int cut_base[kCutSlots] = {0, 0, 0, 0, 1, 1, 2, 2, 2, 3, 3, 3, 4, 4, 4, 5, 5, 6, 6, 6};
-        constexpr int cut_delta[kCutSlots] = {0, 0, 1, 2, 0, 1, 0, 1, 2, -1, 0, 1, 0, 1, 2, 0, 1, 0, 1, 2};
-        int cand[kCutSlots];
-#pragma unroll
-        for (int c = 1; c < kCutSlots; ++c) cand[c] = sw[cut_base[c]] + cut_delta[c];
-        const bool phase4 = sw[3] - sw[2] > 2;                                        // cc:813
-        int b = 0;
-        for (int run = 0; run < kMaxSegments; ++run) {
-            int e = len;                                                              // next cut point after b
-#pragma unroll
-            for (int c = 1; c < kCutSlots; ++c) e = (cand[c] > b && cand[c] < e) ? cand[c] : e;
-            int mode = 0;
-            if (b > sw[6]) mode |= kModeTail;
-            if (phase4 && b >= sw[2] + 1 && b < sw[3] - 1) mode |= kModeVSnap;
-            const RunCoef rc = run_coef(mode, jerk_at(sw, Jp, corr, b), a, v, q, vsnap, Ts);
-            const bool last = k < e;
+        for_each_run(lim, rec, p * dof + j, j, len, t_sample, q, v, a, [&](int b, int e, const RunCoef& rc) {
+            if (k >= e) return false;
             double jj;
-            run_eval(rc.c, (last ? k + 1 : e) - b, q, v, a, jj);                      // state at sample k, or at the run's last sample
-            if (last) break;
-            b = e;
-        }
+            run_eval(rc.c, k + 1 - b, q, v, a, jj);
+            return true;
+        });
     }
     q_0[dst] = q;
     v_0[dst] = v;
