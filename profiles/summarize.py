@@ -21,7 +21,7 @@ def one(pattern):
     g = glob.glob(pattern, recursive=True)
     if not g:
         raise SystemExit(f"no file matches {pattern}")
-    return g[0]
+    return max(g, key=os.path.getmtime)   # gpurun merges new runs into the same directory: take the latest
 
 
 def short(name):
