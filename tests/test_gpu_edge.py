@@ -530,3 +530,20 @@ def test_state_at_has_the_bits_of_the_sampled_rows(amd, limits, n):
             assert torch.equal(w, g), mode
             assert torch.equal(w[3:n - 2].t().contiguous(), gj), mode
     assert torch.equal(got[0][7], qm[1][7])
+
+
+@pytest.mark.parametrize("dof", [17, 64])
+def test_many_joints(amd, oracle_mod, dof):
+    """dof well beyond one joint group (8): several rounds in the stage kernels, several sampler items per plan."""
+    rng = np.random.default_rng(dof)
+    lim = dict(q_min=-rng.uniform(1.0, 3.0, dof), q_max=rng.uniform(1.0, 3.0, dof), v_max=rng.uniform(0.5, 2.5, dof),
+               a_max=rng.uniform(1.0, 10.0, dof), j_max=rng.uniform(10.0, 500.0, dof))
+    ltp = amd.LongTermPlanner(dof, 0.002, device=0, **lim)
+    orc = oracle_mod.Oracle(dof, 0.002, **lim)
+    n = 150
+    qg, q0, v0, a0 = amd.generate_queries(n, lim, seed=dof)
+    r = ltp.planBatchHost(qg, q0, v0, a0, sample=True)
+    o = orc.plan_batch(qg, q0, v0, a0, sample=False)
+    assert np.array_equal(r["slowest"], o["slowest"]) and np.array_equal(r["traj_len"], o["traj_len"])
+    assert np.array_equal(r["mod"], o["mod"])
+    _compare(amd, r, o, dof, q0, v0, a0, orc)
