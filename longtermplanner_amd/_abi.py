@@ -52,7 +52,7 @@ def build(force=False):
     srcs.append(os.path.join(os.path.dirname(_PKG), "include", "ltp_hip.h"))
     newest = max(os.path.getmtime(s) for s in srcs)
     if force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < newest:
-        subprocess.check_call(["make", "-C", CSRC, "-s", "all"])
+        subprocess.check_call(["make", "-C", CSRC, "-s", "-j4", "all"])
     return LIB_PATH
 
 

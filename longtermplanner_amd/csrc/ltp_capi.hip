@@ -1,5 +1,5 @@
 // ltp_capi.hip — the C ABI of libltp_hip.so (include/ltp_hip.h): handle, workspace, launches.
-// Host-side only; every computation is a kernel in ltp_kernels.hip. There is deliberately no CPU
+// Host-side only; every computation is a kernel in ltp_stage_kernels.hip / ltp_sampler.hip / ltp_aux_kernels.hip. There is deliberately no CPU
 // implementation behind these entry points: without a HIP device they fail with LTP_ERR_NO_DEVICE.
 #include "../../include/ltp_hip.h"
 #include "ltp_kernels.hpp"

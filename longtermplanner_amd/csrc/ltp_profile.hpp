@@ -477,4 +477,41 @@ __device__ inline int try_v_drive(double am, double jm, double t_sample, double 
     return kOptFalse;
 }
 
+// ---- timeScaling, all eight candidates in the reference's order (cc:358-645) ----
+template <int C>
+LTP_DEV bool scaling_case(const JointLimits& L, double t_sample, double qg, double q0, double v0, double a0, double dir,
+                          double tr, double& vd, double (&ts)[7], int& mod)
+{
+    vd = v_drive_candidate<C>(L.a_max, L.j_max, qg, q0, v0, a0, dir, tr);
+    return try_v_drive<true>(L.a_max, L.j_max, t_sample, qg, q0, v0, a0, dir, tr, vd, ts, mod) == kOptTrue;
+}
+
+// cc:358-645 for one (query, joint): the eight candidates in the reference's order, then the reset
+LTP_DEV bool time_scaling_full(const JointLimits& L, double t_sample, double qg, double q0, double v0, double a0, double dir,
+                               double tr, double& vd, double (&ts)[7], int& mod, int& which)
+{
+    if (dir < 0.0) { v0 = -v0; a0 = -a0; }   // cc:372-375
+    which = 1;
+    if (scaling_case<1>(L, t_sample, qg, q0, v0, a0, dir, tr, vd, ts, mod)) return true;
+    which = 2;
+    if (scaling_case<2>(L, t_sample, qg, q0, v0, a0, dir, tr, vd, ts, mod)) return true;
+    which = 3;
+    if (scaling_case<3>(L, t_sample, qg, q0, v0, a0, dir, tr, vd, ts, mod)) return true;
+    which = 4;
+    if (scaling_case<4>(L, t_sample, qg, q0, v0, a0, dir, tr, vd, ts, mod)) return true;
+    which = 5;
+    if (scaling_case<5>(L, t_sample, qg, q0, v0, a0, dir, tr, vd, ts, mod)) return true;
+    which = 6;
+    if (scaling_case<6>(L, t_sample, qg, q0, v0, a0, dir, tr, vd, ts, mod)) return true;
+    which = 7;
+    if (scaling_case<7>(L, t_sample, qg, q0, v0, a0, dir, tr, vd, ts, mod)) return true;
+    which = 8;
+    if (scaling_case<8>(L, t_sample, qg, q0, v0, a0, dir, tr, vd, ts, mod)) return true;
+    which = 0;   // cc:640-644
+    mod = 0;
+    zero7(ts);
+    vd = L.v_max;
+    return false;
+}
+
 }  // namespace ltp

@@ -1,548 +1,10 @@
-// ltp_kernels.hip — hand-written CDNA4 (gfx950) kernels for the batched planner.
+// ltp_sampler.hip — getTrajectory (cc:706-841) as the HBM-bound sampler k_sample, and the kernels that share its run
+// tables or run walk (k_envelope, k_replan_states, k_state_at), gfx950.
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (see Makefile). No fast-math:
 // the inf/NaN flow of the reference is part of the contract.
-#include "ltp_kernels.hpp"
-#include "ltp_profile.hpp"
+#include "ltp_device.hpp"
 
 namespace ltp {
-
-typedef double double2_t __attribute__((ext_vector_type(2)));
-typedef float float4_t __attribute__((ext_vector_type(4)));
-
-// 16-byte store unit of an output row: 2 doubles or 4 floats
-template <typename T> struct OutVec;
-template <> struct OutVec<double> { typedef double2_t type; static constexpr int N = 2; };
-template <> struct OutVec<float> { typedef float4_t type; static constexpr int N = 4; };
-
-LTP_DEV JointLimits load_limits(const Limits& lim, int j)
-{
-    JointLimits L;
-    L.q_min = lim.q_min[j];
-    L.q_max = lim.q_max[j];
-    L.v_max = lim.v_max[j];
-    L.a_max = lim.a_max[j];
-    L.j_max = lim.j_max[j];
-    return L;
-}
-
-// ---------------------------------------------------------------------------------------
-// Stages 1-3 of planTrajectory (cc:14-55) as four kernels:
-//   k_opt_fast      every (query, joint) lane: checkInputs + optSwitchTimes(v_max) WITHOUT the quartic sites;
-//                   lanes that reach them are compacted into queue A
-//   k_opt_slow      queue A, densely: optSwitchTimes with the root finder
-//   k_reduce_scale  per query: slowest-joint reduction through LDS (cc:31-39), then timeScaling cases c1/c2
-//                   (closed form) per lane; lanes that need c3..c8 or hit a quartic site go to queue B
-//   k_scaling_slow  queue B, densely: all eight cases in order + reset + fallback
-// The two "fast" kernels carry no polynomial solver (fewer registers, small code); the rare, expensive and
-// divergent paths run with full waves instead of dragging 64-lane waves of the main kernels through them.
-//
-// Block = 64 queries x JB joint slots; wave y handles joints y, y+JB, ... of 64 consecutive queries, so the
-// joint limits are wave-uniform (SGPRs) and both input layouts are read with one stride per lane.
-// ---------------------------------------------------------------------------------------
-// (int)ceil(t[6]/Ts) + 1 of one joint (cc:718), or -1 if any of its switching times is not finite or the length does
-// not fit an int (both DEFINED here: the reference converts out-of-range doubles to int, which is undefined)
-LTP_DEV int joint_len(const double (&t)[7], double t_sample)
-{
-    bool finite = true;
-#pragma unroll
-    for (int k = 0; k < 7; ++k) finite = finite && dfinite(t[k]);
-    const double len = dceil(t[6] / t_sample) + 1.0;
-    return (finite && len < 2147483647.0) ? (int)len : -1;
-}
-
-constexpr int kLaneGoalOutside = 128; // lane_flags bit: q_goal outside [q_min, q_max] (only with the opt-in goal check)
-constexpr int kLaneDeferred = 64;   // lane_flags bit: optSwitchTimes of this lane is still pending in queue A
-
-// Compaction queues. A single device-scope counter saturates near 90 atomics/us on MI355X, which a kernel that
-// pushes from ~10^5 waves would run into; so a queue has kQueueShards segments with one counter each (shard =
-// blockIdx & 7, i.e. the blocks that share an XCD under round-robin dispatch), and a block aggregates its waves'
-// ballots in LDS and issues ONE atomicAdd per push round.
-constexpr int kQueueShards = 8;
-
-struct Queue {
-    unsigned long long* items;    // kQueueShards segments of `segment` entries
-    unsigned long long* counts;   // [kQueueShards]
-    unsigned long long segment;
-};
-
-// Must be called by every thread of a (64, JB) block (contains barriers). s_cnt: >= kMaxJointSlots + 1 words of LDS.
-LTP_DEV void block_push(bool want, unsigned long long item, const Queue& Q, unsigned long long* s_cnt)
-{
-    const int lane = threadIdx.x, wave = threadIdx.y, nw = blockDim.y;
-    const int shard = blockIdx.x & (kQueueShards - 1);
-    const unsigned long long mask = __ballot(want);
-    if (lane == 0) s_cnt[wave] = (unsigned long long)__popcll(mask);
-    __syncthreads();
-    if (wave == 0 && lane == 0) {
-        unsigned long long total = 0ull;
-        for (int w = 0; w < nw; ++w) total += s_cnt[w];
-        s_cnt[kMaxJointSlots] = total ? atomicAdd(&Q.counts[shard], total) : 0ull;
-    }
-    __syncthreads();
-    if (want) {
-        unsigned long long off = s_cnt[kMaxJointSlots];
-        for (int w = 0; w < wave; ++w) off += s_cnt[w];
-        off += (unsigned long long)__popcll(mask & ((1ull << lane) - 1ull));
-        Q.items[(unsigned long long)shard * Q.segment + off] = item;
-    }
-    __syncthreads();
-}
-
-// item `it` of the concatenated shards (it < queue_total)
-LTP_DEV unsigned long long queue_item(const Queue& Q, const unsigned long long (&cnt)[kQueueShards], unsigned long long it)
-{
-    int sh = 0;
-#pragma unroll
-    for (int k = 0; k < kQueueShards - 1; ++k) {
-        if (sh == k && it >= cnt[k]) { it -= cnt[k]; sh = k + 1; }
-    }
-    return Q.items[(unsigned long long)sh * Q.segment + it];
-}
-
-LTP_DEV unsigned long long queue_total(const Queue& Q, unsigned long long (&cnt)[kQueueShards])
-{
-    unsigned long long total = 0ull;
-#pragma unroll
-    for (int k = 0; k < kQueueShards; ++k) { cnt[k] = Q.counts[k]; total += cnt[k]; }
-    return total;
-}
-
-LTP_DEV void store_opt_record(const Records& out, long long rj, const double (&t)[7], double dir, int mod)
-{
-#pragma unroll
-    for (int k = 0; k < 7; ++k) out.t_opt[rj * 7 + k] = t[k];
-    out.dir[rj] = dir;
-    out.mod[rj] = (signed char)mod;
-}
-
-__global__ void __launch_bounds__(kQueriesPerBlock* kMaxJointSlots)
-k_opt_fast(long long n, int dof, double t_sample, int goal_check, Limits lim, Queries in, Records out,
-           signed char* __restrict__ lane_flags, Queue queue)
-{
-    __shared__ unsigned long long s_cnt[kMaxJointSlots + 1];
-    const int x = threadIdx.x, y = threadIdx.y, JB = blockDim.y;
-    const long long q = (long long)blockIdx.x * kQueriesPerBlock + x;
-    const bool live = q < n;
-    // every wave runs the same number of rounds: block_push() contains barriers
-    for (int jb = 0; jb < dof; jb += JB) {
-        const int j = jb + y;
-        const bool active = live && j < dof;
-        const JointLimits L = load_limits(lim, j < dof ? j : dof - 1);
-        const long long rj = q * dof + j;
-        bool defer = false;
-        if (active) {
-            const long long ix = q * in.sq + (long long)j * in.sj;
-            const double qg = in.q_goal[ix], q0 = in.q_0[ix], v0 = in.v_0[ix], a0 = in.a_0[ix];
-            int flags = check_inputs_joint(L, q0, v0, a0) ? 0 : kStatusInvalidInput;
-            // NEW, opt-in: the reference never checks q_goal (cc:68-77), only the last sample (cc:59-61)
-            if (goal_check && !(qg >= L.q_min && qg <= L.q_max)) flags |= kLaneGoalOutside;
-            double t[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-            double dir = 0.0;
-            int mod = 0;
-            const int rc = opt_switch_times<false>(L.a_max, L.j_max, t_sample, qg, q0, v0, a0, L.v_max, t, dir, mod);
-            if (rc == kOptDefer) {
-                defer = true;
-                flags |= kLaneDeferred;
-            } else {
-                if (rc == kOptFalse) flags |= kStatusOptFailed;
-                store_opt_record(out, rj, t, dir, mod);
-            }
-            lane_flags[rj] = (signed char)flags;
-        }
-        block_push(defer, (unsigned long long)rj, queue, s_cnt);
-    }
-}
-
-__global__ void __launch_bounds__(64)
-k_opt_slow(int dof, double t_sample, Limits lim, Queries in, Records out, signed char* __restrict__ lane_flags, Queue queue)
-{
-    unsigned long long cnt[kQueueShards];
-    const unsigned long long count = queue_total(queue, cnt);
-    for (unsigned long long it = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; it < count;
-         it += (unsigned long long)gridDim.x * blockDim.x) {
-        const long long rj = (long long)queue_item(queue, cnt, it);
-        const long long q = rj / dof;
-        const int j = (int)(rj - q * dof);
-        const JointLimits L = load_limits(lim, j);
-        const long long ix = q * in.sq + (long long)j * in.sj;
-        double t[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-        double dir = 0.0;
-        int mod = 0;
-        const int rc = opt_switch_times<true>(L.a_max, L.j_max, t_sample, in.q_goal[ix], in.q_0[ix], in.v_0[ix], in.a_0[ix],
-                                              L.v_max, t, dir, mod);
-        store_opt_record(out, rj, t, dir, mod);
-        int flags = lane_flags[rj] & ~kLaneDeferred;
-        if (rc == kOptFalse) flags |= kStatusOptFailed;
-        lane_flags[rj] = (signed char)flags;
-    }
-}
-
-__global__ void __launch_bounds__(kQueriesPerBlock* kMaxJointSlots)
-k_reduce_scale(long long n, int dof, double t_sample, Limits lim, Queries in, Records out,
-               const signed char* __restrict__ lane_flags, Queue queue)
-{
-    __shared__ unsigned long long s_cnt[kMaxJointSlots + 1];
-    __shared__ double s_t[kMaxJointSlots][kQueriesPerBlock];
-    __shared__ int s_j[kMaxJointSlots][kQueriesPerBlock];
-    __shared__ int s_f[kMaxJointSlots][kQueriesPerBlock];
-
-    const int x = threadIdx.x, y = threadIdx.y, JB = blockDim.y;
-    const long long q = (long long)blockIdx.x * kQueriesPerBlock + x;
-    const bool live = q < n;
-
-    // cc:31-39: strict '>', first index wins, NaN never wins, init -1
-    double best_t = -1.0;
-    int best_j = -1, flags = 0;
-    if (live) {
-        for (int j = y; j < dof; j += JB) {
-            const long long rj = q * dof + j;
-            const double t6 = out.t_opt[rj * 7 + 6];
-            flags |= lane_flags[rj] & 0xff;
-            if (t6 > best_t) { best_t = t6; best_j = j; }
-        }
-    }
-    s_t[y][x] = best_t;
-    s_j[y][x] = best_j;
-    s_f[y][x] = flags;
-    __syncthreads();
-    double t_required = -1.0;
-    int slowest = -1;
-    flags = 0;
-    for (int yy = 0; yy < JB; ++yy) {
-        const double bt = s_t[yy][x];
-        const int bj = s_j[yy][x];
-        flags |= s_f[yy][x];
-        if (bj >= 0 && (bt > t_required || (bt == t_required && bj < slowest))) { t_required = bt; slowest = bj; }
-    }
-    if (slowest < 0) flags |= kStatusNoSlowest;
-    if (flags & kLaneGoalOutside) flags = (flags & ~kLaneGoalOutside) | kStatusGoalOutside;
-    if (live && y == 0) {
-        out.t_required[q] = t_required;
-        out.slowest[q] = slowest;
-        out.status[q] = flags;
-    }
-
-    // cc:43-55 with the closed-form candidates c1, c2 (cc:378-446)
-    int my_len = 0, nonfinite = 0;
-    for (int jb = 0; jb < dof; jb += JB) {   // same number of rounds in every wave: block_push() contains barriers
-        const int j = jb + y;
-        const bool active = live && j < dof;
-        const JointLimits L = load_limits(lim, j < dof ? j : dof - 1);
-        bool need_slow = false;
-        int lane_len = 0;
-        const long long rj = q * dof + j;
-        if (active) {
-            double ts[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-            double vd = L.v_max;
-            int mod = 0;   // failed query: zero record, never sampled
-            if (flags == 0) {
-                mod = out.mod[rj];
-                if (j != slowest) {
-                    const long long ix = q * in.sq + (long long)j * in.sj;
-                    const double qg = in.q_goal[ix], q0 = in.q_0[ix];
-                    double v0 = in.v_0[ix], a0 = in.a_0[ix];
-                    const double dir = out.dir[rj];
-                    if (dir < 0.0) { v0 = -v0; a0 = -a0; }
-                    vd = v_drive_candidate<1>(L.a_max, L.j_max, qg, q0, v0, a0, dir, t_required);
-                    int acc = try_v_drive<false>(L.a_max, L.j_max, t_sample, qg, q0, v0, a0, dir, t_required, vd, ts, mod);
-                    if (acc == kOptFalse) {
-                        vd = v_drive_candidate<2>(L.a_max, L.j_max, qg, q0, v0, a0, dir, t_required);
-                        acc = try_v_drive<false>(L.a_max, L.j_max, t_sample, qg, q0, v0, a0, dir, t_required, vd, ts, mod);
-                    }
-                    need_slow = (acc != kOptTrue);
-                }
-                if (!need_slow) {
-                    // cc:50-55: no scaled solution (or the slowest joint) -> optimal times
-                    double mx = ts[0];
-#pragma unroll
-                    for (int k = 1; k < 7; ++k) if (mx < ts[k]) mx = ts[k];
-                    if (mx <= 0.0) {
-#pragma unroll
-                        for (int k = 0; k < 7; ++k) ts[k] = out.t_opt[rj * 7 + k];
-                    }
-                }
-            }
-            if (!need_slow) {
-#pragma unroll
-                for (int k = 0; k < 7; ++k) out.t_scaled[rj * 7 + k] = ts[k];
-                out.v_drive[rj] = vd;
-                out.mod[rj] = (signed char)mod;
-                if (flags == 0) lane_len = joint_len(ts, t_sample);
-            }
-        }
-        block_push(need_slow, (unsigned long long)rj, queue, s_cnt);
-        if (lane_len < 0) nonfinite = 1;
-        else my_len = lane_len > my_len ? lane_len : my_len;
-    }
-    // traj_len (cc:716-719) over the joints finished here; queue-B lanes add theirs with atomicMax later
-    __syncthreads();
-    s_j[y][x] = my_len;
-    s_f[y][x] = nonfinite;
-    __syncthreads();
-    if (live && y == 0) {
-        int len = 0, bad = 0;
-        for (int yy = 0; yy < JB; ++yy) {
-            len = s_j[yy][x] > len ? s_j[yy][x] : len;
-            bad |= s_f[yy][x];
-        }
-        out.traj_len[q] = flags == 0 ? len : 0;
-        if (bad) out.status[q] = flags | kStatusNonFinite;
-    }
-}
-
-template <int C>
-LTP_DEV bool scaling_case(const JointLimits& L, double t_sample, double qg, double q0, double v0, double a0, double dir,
-                          double tr, double& vd, double (&ts)[7], int& mod)
-{
-    vd = v_drive_candidate<C>(L.a_max, L.j_max, qg, q0, v0, a0, dir, tr);
-    return try_v_drive<true>(L.a_max, L.j_max, t_sample, qg, q0, v0, a0, dir, tr, vd, ts, mod) == kOptTrue;
-}
-
-// cc:358-645 for one (query, joint): the eight candidates in the reference's order, then the reset
-LTP_DEV bool time_scaling_full(const JointLimits& L, double t_sample, double qg, double q0, double v0, double a0, double dir,
-                               double tr, double& vd, double (&ts)[7], int& mod, int& which)
-{
-    if (dir < 0.0) { v0 = -v0; a0 = -a0; }   // cc:372-375
-    which = 1;
-    if (scaling_case<1>(L, t_sample, qg, q0, v0, a0, dir, tr, vd, ts, mod)) return true;
-    which = 2;
-    if (scaling_case<2>(L, t_sample, qg, q0, v0, a0, dir, tr, vd, ts, mod)) return true;
-    which = 3;
-    if (scaling_case<3>(L, t_sample, qg, q0, v0, a0, dir, tr, vd, ts, mod)) return true;
-    which = 4;
-    if (scaling_case<4>(L, t_sample, qg, q0, v0, a0, dir, tr, vd, ts, mod)) return true;
-    which = 5;
-    if (scaling_case<5>(L, t_sample, qg, q0, v0, a0, dir, tr, vd, ts, mod)) return true;
-    which = 6;
-    if (scaling_case<6>(L, t_sample, qg, q0, v0, a0, dir, tr, vd, ts, mod)) return true;
-    which = 7;
-    if (scaling_case<7>(L, t_sample, qg, q0, v0, a0, dir, tr, vd, ts, mod)) return true;
-    which = 8;
-    if (scaling_case<8>(L, t_sample, qg, q0, v0, a0, dir, tr, vd, ts, mod)) return true;
-    which = 0;   // cc:640-644
-    mod = 0;
-    zero7(ts);
-    vd = L.v_max;
-    return false;
-}
-
-// Queue B. Block = 64 queued (query, joint) items x 8 waves; wave c evaluates candidate c+1 for all 64 items, so
-// the eight candidates of cc:378-638 (independent computations) run side by side and the kernel's latency is the
-// slowest candidate (the degree-6 solve) instead of their sum. The reference's "first accepted in order" is then a
-// lookup over eight flags in LDS.
-__global__ void __launch_bounds__(kQueriesPerBlock * 8)
-k_scaling_slow(int dof, double t_sample, Limits lim, Queries in, Records out, Queue queue)
-{
-    __shared__ int s_acc[8][kQueriesPerBlock];
-    const int x = threadIdx.x;
-    const int c = __builtin_amdgcn_readfirstlane(threadIdx.y);
-    unsigned long long cnt[kQueueShards];
-    const unsigned long long count = queue_total(queue, cnt);
-    for (unsigned long long base = (unsigned long long)blockIdx.x * kQueriesPerBlock; base < count;
-         base += (unsigned long long)gridDim.x * kQueriesPerBlock) {
-        const unsigned long long it = base + x;
-        const bool live = it < count;
-        bool acc = false;
-        double ts[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-        double vd = 0.0;
-        int mod = 0, j = 0;
-        long long rj = 0, q = 0;
-        JointLimits L = {0.0, 0.0, 0.0, 0.0, 0.0};
-        if (live) {
-            rj = (long long)queue_item(queue, cnt, it);
-            q = rj / dof;
-            j = (int)(rj - q * dof);
-            L = load_limits(lim, j);
-            const long long ix = q * in.sq + (long long)j * in.sj;
-            const double qg = in.q_goal[ix], q0 = in.q_0[ix];
-            double v0 = in.v_0[ix], a0 = in.a_0[ix];
-            const double dir = out.dir[rj], tr = out.t_required[q];
-            if (dir < 0.0) { v0 = -v0; a0 = -a0; }   // cc:372-375
-            switch (c) {
-            case 0: acc = scaling_case<1>(L, t_sample, qg, q0, v0, a0, dir, tr, vd, ts, mod); break;
-            case 1: acc = scaling_case<2>(L, t_sample, qg, q0, v0, a0, dir, tr, vd, ts, mod); break;
-            case 2: acc = scaling_case<3>(L, t_sample, qg, q0, v0, a0, dir, tr, vd, ts, mod); break;
-            case 3: acc = scaling_case<4>(L, t_sample, qg, q0, v0, a0, dir, tr, vd, ts, mod); break;
-            case 4: acc = scaling_case<5>(L, t_sample, qg, q0, v0, a0, dir, tr, vd, ts, mod); break;
-            case 5: acc = scaling_case<6>(L, t_sample, qg, q0, v0, a0, dir, tr, vd, ts, mod); break;
-            case 6: acc = scaling_case<7>(L, t_sample, qg, q0, v0, a0, dir, tr, vd, ts, mod); break;
-            default: acc = scaling_case<8>(L, t_sample, qg, q0, v0, a0, dir, tr, vd, ts, mod); break;
-            }
-        }
-        s_acc[c][x] = acc ? 1 : 0;
-        __syncthreads();
-        if (live) {
-            int first = -1;
-#pragma unroll
-            for (int cc = 7; cc >= 0; --cc) if (s_acc[cc][x]) first = cc;
-            const bool winner = (first == c);
-            const bool reset = (first < 0 && c == 0);   // cc:640-644
-            if (reset) {
-                mod = 0;
-                zero7(ts);
-                vd = L.v_max;
-            }
-            if (winner || reset) {
-                double mx = ts[0];
-#pragma unroll
-                for (int k = 1; k < 7; ++k) if (mx < ts[k]) mx = ts[k];
-                if (mx <= 0.0) {   // cc:50-55
-#pragma unroll
-                    for (int k = 0; k < 7; ++k) ts[k] = out.t_opt[rj * 7 + k];
-                }
-#pragma unroll
-                for (int k = 0; k < 7; ++k) out.t_scaled[rj * 7 + k] = ts[k];
-                out.v_drive[rj] = vd;
-                out.mod[rj] = (signed char)mod;
-                const int l = joint_len(ts, t_sample);
-                if (l < 0) atomicOr(&out.status[q], kStatusNonFinite);
-                else atomicMax(&out.traj_len[q], l);
-            }
-        }
-        __syncthreads();
-    }
-}
-
-// ---------------------------------------------------------------------------------------
-// traj_len (cc:716-719), per-plan packed size and the exclusive scan of sizes.
-// Packed layout of plan p at out + offsets[p]: [array q,v,a,j][joint][row_stride] doubles,
-// row_stride = round_up(traj_len, 16) so that every row starts 128-B aligned.
-// ---------------------------------------------------------------------------------------
-// Samples stored per row: every rows.stride-th sample (0, stride, 2*stride, ...), at most rows.max_samples of them.
-// {0, 1} stores whole trajectories, which is the reference's behaviour.
-LTP_HD int stored_len(int len, RowSpec rows)
-{
-    if (len <= 0) return 0;
-    const int st = rows.stride > 1 ? rows.stride : 1;
-    const int cnt = (len + st - 1) / st;
-    return (rows.max_samples > 0 && cnt > rows.max_samples) ? rows.max_samples : cnt;
-}
-
-LTP_DEV unsigned long long plan_size(int len, int dof)
-{
-    if (len <= 0) return 0ull;
-    const unsigned long long stride = ((unsigned long long)len + (kRowAlign - 1)) / kRowAlign * kRowAlign;
-    return 4ull * (unsigned long long)dof * stride;
-}
-
-__global__ void __launch_bounds__(256)
-k_finalize(long long n, int dof, double t_sample, RowSpec rows, Records rec, unsigned long long* __restrict__ block_sums)
-{
-    __shared__ unsigned long long s_part[256];
-    const long long base = (long long)blockIdx.x * kScanBlock;
-    unsigned long long local = 0ull;
-    for (int e = 0; e < kScanBlock / 256; ++e) {
-        const long long q = base + e * 256 + threadIdx.x;
-        if (q < n) {
-            int len = 0, st = rec.status[q];
-            if (st == 0) {
-                bool finite = true;
-                for (int j = 0; j < dof; ++j) {
-                    const double* t = rec.t_scaled + (q * dof + j) * 7;
-                    const double tj[7] = {t[0], t[1], t[2], t[3], t[4], t[5], t[6]};
-                    const int l = joint_len(tj, t_sample);
-                    finite = finite && l >= 0;
-                    len = l > len ? l : len;
-                }
-                if (!finite) { len = 0; st |= kStatusNonFinite; rec.status[q] = st; }
-            }
-            rec.traj_len[q] = len;
-            local += plan_size(stored_len(len, rows), dof);
-        }
-    }
-    s_part[threadIdx.x] = local;
-    __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-        if ((int)threadIdx.x < s) s_part[threadIdx.x] += s_part[threadIdx.x + s];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) block_sums[blockIdx.x] = s_part[0];
-}
-
-// batched path: traj_len/status were already reduced by k_reduce_scale / k_scaling_slow
-__global__ void __launch_bounds__(256)
-k_finalize_lens(long long n, int dof, RowSpec rows, Records rec, unsigned long long* __restrict__ block_sums)
-{
-    __shared__ unsigned long long s_part[256];
-    const long long base = (long long)blockIdx.x * kScanBlock;
-    unsigned long long local = 0ull;
-    for (int e = 0; e < kScanBlock / 256; ++e) {
-        const long long q = base + e * 256 + threadIdx.x;
-        if (q < n) {
-            int len = rec.traj_len[q];
-            if (rec.status[q] != 0) { len = 0; rec.traj_len[q] = 0; }   // failed or non-finite: nothing to sample
-            local += plan_size(stored_len(len, rows), dof);
-        }
-    }
-    s_part[threadIdx.x] = local;
-    __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-        if ((int)threadIdx.x < s) s_part[threadIdx.x] += s_part[threadIdx.x + s];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) block_sums[blockIdx.x] = s_part[0];
-}
-
-// exclusive scan of block_sums in place, single block
-__global__ void __launch_bounds__(1024)
-k_scan_top(long long nb, unsigned long long* __restrict__ block_sums)
-{
-    __shared__ unsigned long long s[1024];
-    __shared__ unsigned long long carry;
-    if (threadIdx.x == 0) carry = 0ull;
-    __syncthreads();
-    for (long long base = 0; base < nb; base += 1024) {
-        const long long i = base + threadIdx.x;
-        const unsigned long long v = i < nb ? block_sums[i] : 0ull;
-        s[threadIdx.x] = v;
-        __syncthreads();
-        for (int d = 1; d < 1024; d <<= 1) {
-            const unsigned long long add = (int)threadIdx.x >= d ? s[threadIdx.x - d] : 0ull;
-            __syncthreads();
-            s[threadIdx.x] += add;
-            __syncthreads();
-        }
-        if (i < nb) block_sums[i] = carry + s[threadIdx.x] - v;
-        __syncthreads();
-        if (threadIdx.x == 1023) carry += s[1023];
-        __syncthreads();
-    }
-}
-
-__global__ void __launch_bounds__(256)
-k_scan_apply(long long n, int dof, RowSpec rows, const int* __restrict__ traj_len,
-             const unsigned long long* __restrict__ block_sums, unsigned long long* __restrict__ offsets)
-{
-    __shared__ unsigned long long s[256];
-    const long long base = (long long)blockIdx.x * kScanBlock;
-    constexpr int E = kScanBlock / 256;
-    // thread owns E consecutive plans
-    unsigned long long sz[E], local = 0ull;
-#pragma unroll
-    for (int e = 0; e < E; ++e) {
-        const long long q = base + (long long)threadIdx.x * E + e;
-        sz[e] = q < n ? plan_size(stored_len(traj_len[q], rows), dof) : 0ull;
-        local += sz[e];
-    }
-    s[threadIdx.x] = local;
-    __syncthreads();
-    for (int d = 1; d < 256; d <<= 1) {
-        const unsigned long long add = (int)threadIdx.x >= d ? s[threadIdx.x - d] : 0ull;
-        __syncthreads();
-        s[threadIdx.x] += add;
-        __syncthreads();
-    }
-    unsigned long long run = block_sums[blockIdx.x] + s[threadIdx.x] - local;
-#pragma unroll
-    for (int e = 0; e < E; ++e) {
-        const long long q = base + (long long)threadIdx.x * E + e;
-        if (q < n) {
-            offsets[q] = run;
-            run += sz[e];
-            if (q == n - 1) offsets[n] = run;
-        }
-    }
-}
 
 // ---------------------------------------------------------------------------------------
 // The sampler: reference getTrajectory (cc:706-841).
@@ -1293,188 +755,8 @@ k_state_at(long long first, long long count, int dof, double t_sample, Limits li
 }
 
 // ---------------------------------------------------------------------------------------
-// Synthetic queries (distribution of reference tests/randomConfiguration.m:14-34
-// generalised to per-joint limits). Counter-based: value = f(seed, query, joint, field), so any
-// shard of any batch can be generated independently and the host reproduces it bit for bit.
-// ---------------------------------------------------------------------------------------
-LTP_DEV double unit_random(unsigned long long seed, unsigned long long query, unsigned int joint, unsigned int field)
-{
-    unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (((query * 64ull + joint) * 4ull + field) + 1ull);
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    z = z ^ (z >> 31);
-    return (double)(z >> 11) * 0x1.0p-53;
-}
-
-__global__ void __launch_bounds__(256)
-k_generate(long long n, int dof, Limits lim, unsigned long long seed, long long first_query,
-           double* __restrict__ q_goal, double* __restrict__ q_0, double* __restrict__ v_0, double* __restrict__ a_0,
-           long long sq, long long sj)
-{
-    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= n * dof) return;
-    const long long q = idx / dof;
-    const int j = (int)(idx - q * dof);
-    const JointLimits L = load_limits(lim, j);
-    const unsigned long long gq = (unsigned long long)(first_query + q);
-    const double eps = 1e-6;
-    const double u0 = unit_random(seed, gq, j, 0), u1 = unit_random(seed, gq, j, 1);
-    const double u2 = unit_random(seed, gq, j, 2), u3 = unit_random(seed, gq, j, 3);
-    const double q0 = L.q_min + u0 * (L.q_max - L.q_min);
-    const double qg = L.q_min + u1 * (L.q_max - L.q_min);
-    const double vm = L.v_max - eps;
-    const double v0 = -vm + u2 * (2.0 * vm);
-    double a_lb, a_ub;
-    if (v0 >= 0.0) {
-        a_lb = -(L.a_max - eps);
-        a_ub = dmin(L.a_max - eps, dsqrt(2.0 * L.j_max * (L.v_max - v0)));
-    } else {
-        a_lb = dmax(-(L.a_max - eps), -dsqrt(2.0 * L.j_max * (L.v_max - dabs(v0))));
-        a_ub = L.a_max;
-    }
-    const double a0 = a_lb + u3 * (a_ub - a_lb);
-    const long long ix = q * sq + (long long)j * sj;
-    q_goal[ix] = qg;
-    q_0[ix] = q0;
-    v_0[ix] = v0;
-    a_0[ix] = a0;
-}
-
-// ---------------------------------------------------------------------------------------
-// One-lane mirrors of the protected member functions (for the reference's KAT-style tests).
-// ---------------------------------------------------------------------------------------
-// LongTermPlanner::checkInputs (cc:68-77) for one query
-__global__ void k_check_inputs(int dof, Limits lim, const double* q_0, const double* v_0, const double* a_0, int* ok)
-{
-    int good = 1;
-    for (int j = 0; j < dof; ++j)
-        if (!check_inputs_joint(load_limits(lim, j), q_0[j], v_0[j], a_0[j])) good = 0;
-    *ok = good;
-}
-
-__global__ void k_single_opt_braking(int joint, double t_sample, Limits lim, double v_0, double a_0, double* out)
-{
-    const JointLimits L = load_limits(lim, joint);
-    double r[7] = {out[0], out[1], out[2], out[3], out[4], out[5], out[6]};
-    double q, dir;
-    opt_braking(L.a_max, L.j_max, t_sample, v_0, a_0, q, r, dir);
-#pragma unroll
-    for (int k = 0; k < 7; ++k) out[k] = r[k];
-    out[7] = q;
-    out[8] = dir;
-}
-
-__global__ void k_single_opt_switch(int joint, double t_sample, Limits lim, double q_goal, double q_0, double v_0, double a_0,
-                                    double v_drive, double* io)
-{
-    const JointLimits L = load_limits(lim, joint);
-    double t[7] = {io[0], io[1], io[2], io[3], io[4], io[5], io[6]};
-    double dir = 0.0;
-    int mod = 0;
-    const bool ok = opt_switch_times<true>(L.a_max, L.j_max, t_sample, q_goal, q_0, v_0, a_0, v_drive, t, dir, mod) == kOptTrue;
-#pragma unroll
-    for (int k = 0; k < 7; ++k) io[k] = t[k];
-    io[7] = dir;
-    io[8] = (double)mod;
-    io[9] = ok ? 1.0 : 0.0;
-}
-
-__global__ void k_single_time_scaling(int joint, double t_sample, Limits lim, double q_goal, double q_0, double v_0, double a_0,
-                                      double dir, double tr, double* io)
-{
-    const JointLimits L = load_limits(lim, joint);
-    double ts[7] = {io[0], io[1], io[2], io[3], io[4], io[5], io[6]};
-    double vd;
-    int mod = 0, which = 0;
-    const bool acc = time_scaling_full(L, t_sample, q_goal, q_0, v_0, a_0, dir, tr, vd, ts, mod, which);
-#pragma unroll
-    for (int k = 0; k < 7; ++k) io[k] = ts[k];
-    io[7] = vd;
-    io[8] = (double)mod;
-    io[9] = acc ? 1.0 : 0.0;
-    io[10] = (double)which;
-}
-
-// device arithmetic probes: tests compare these with the host's libm bit for bit
-__global__ void k_math_probe(long long n, const double* x, const double* y, double* out)
-{
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const double a = x[i], b = y[i];
-    double* o = out + i * 8;
-    o[0] = a / b;
-    o[1] = dsqrt(dabs(a));
-    o[2] = pw3(a);
-    o[3] = pw4(a);
-    o[4] = pw6(a);
-    o[5] = dfloor(a / b);
-    o[6] = dceil(a / b);
-    o[7] = a * b + a;
-}
-
-template <int N>
-LTP_DEV double probe_root(const double* c)
-{
-    double p[N + 1];
-#pragma unroll
-    for (int i = 0; i <= N; ++i) p[i] = c[i];
-    return smallest_positive_real_root<N>(p);
-}
-
-__global__ void k_roots_probe(long long n, int degree, const double* coef, double* root)
-{
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const double* c = coef + i * 7;
-    double r;
-    if (degree == 4) r = probe_root<4>(c);
-    else if (degree == 5) r = probe_root<5>(c);
-    else r = probe_root<6>(c);
-    root[i] = r;
-}
-
-// ---------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------
-long long queue_segment(long long n, int dof)
-{
-    const long long nblocks = (n + kQueriesPerBlock - 1) / kQueriesPerBlock;
-    return (nblocks + kQueueShards - 1) / kQueueShards * kQueriesPerBlock * (long long)dof;
-}
-
-void launch_switch_times(hipStream_t s, long long n, int dof, double t_sample, int goal_check, Limits lim, Queries in,
-                         Records out, signed char* lane_flags, unsigned long long* queue_items /* 2 * 8 * queue_segment(n, dof) */,
-                         unsigned long long* counts /* [16], zeroed by the caller on the same stream */)
-{
-    if (n <= 0) return;
-    const int jb = dof < kMaxJointSlots ? dof : kMaxJointSlots;
-    const dim3 block(kQueriesPerBlock, jb);
-    const dim3 grid((unsigned)((n + kQueriesPerBlock - 1) / kQueriesPerBlock));
-    const unsigned long long seg = (unsigned long long)queue_segment(n, dof);
-    const Queue qa{queue_items, counts, seg};
-    const Queue qb{queue_items + kQueueShards * seg, counts + kQueueShards, seg};
-    // queue lengths are only known on the device: fixed grids, grid-stride over the queues
-    long long a_blocks = (n * dof + 63) / 64;
-    if (a_blocks > 4096) a_blocks = 4096;
-    long long b_blocks = (n * dof + kQueriesPerBlock - 1) / kQueriesPerBlock;
-    if (b_blocks > 1024) b_blocks = 1024;
-    hipLaunchKernelGGL(k_opt_fast, grid, block, 0, s, n, dof, t_sample, goal_check, lim, in, out, lane_flags, qa);
-    hipLaunchKernelGGL(k_opt_slow, dim3((unsigned)a_blocks), dim3(64), 0, s, dof, t_sample, lim, in, out, lane_flags, qa);
-    hipLaunchKernelGGL(k_reduce_scale, grid, block, 0, s, n, dof, t_sample, lim, in, out, lane_flags, qb);
-    hipLaunchKernelGGL(k_scaling_slow, dim3((unsigned)b_blocks), dim3(kQueriesPerBlock, 8), 0, s, dof, t_sample, lim, in, out, qb);
-}
-
-void launch_offsets(hipStream_t s, long long n, int dof, double t_sample, Records rec,
-                    unsigned long long* block_sums, unsigned long long* offsets, bool lens_ready, RowSpec rows)
-{
-    if (n <= 0) return;
-    const long long nb = (n + kScanBlock - 1) / kScanBlock;
-    if (lens_ready) hipLaunchKernelGGL(k_finalize_lens, dim3((unsigned)nb), dim3(256), 0, s, n, dof, rows, rec, block_sums);
-    else hipLaunchKernelGGL(k_finalize, dim3((unsigned)nb), dim3(256), 0, s, n, dof, t_sample, rows, rec, block_sums);
-    hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, s, nb, block_sums);
-    hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nb), dim3(256), 0, s, n, dof, rows, rec.traj_len, block_sums, offsets);
-}
-
 // how many blocks of a persistent (work-queue) kernel the device holds at once: 0 = k_sample float64 rows,
 // 1 = k_sample float32 rows, 2 = k_envelope
 int sample_resident_blocks(int device, int which)
@@ -1561,45 +843,6 @@ void launch_state_at(hipStream_t s, long long first, long long count, int dof, d
     const long long total = count * dof;
     hipLaunchKernelGGL(k_state_at, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, first, count, dof, t_sample, lim, in, rec,
                        sample_index, uniform_index, q_0, v_0, a_0, sq, sj);
-}
-
-void launch_generate(hipStream_t s, long long n, int dof, Limits lim, unsigned long long seed, long long first_query,
-                     double* q_goal, double* q_0, double* v_0, double* a_0, long long sq, long long sj)
-{
-    if (n <= 0) return;
-    const long long total = n * dof;
-    hipLaunchKernelGGL(k_generate, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, n, dof, lim, seed, first_query,
-                       q_goal, q_0, v_0, a_0, sq, sj);
-}
-
-void launch_check_inputs(hipStream_t s, int dof, Limits lim, const double* q_0, const double* v_0, const double* a_0, int* ok)
-{
-    hipLaunchKernelGGL(k_check_inputs, dim3(1), dim3(1), 0, s, dof, lim, q_0, v_0, a_0, ok);
-}
-void launch_single_opt_braking(hipStream_t s, int joint, double t_sample, Limits lim, double v_0, double a_0, double* out10)
-{
-    hipLaunchKernelGGL(k_single_opt_braking, dim3(1), dim3(1), 0, s, joint, t_sample, lim, v_0, a_0, out10);
-}
-void launch_single_opt_switch(hipStream_t s, int joint, double t_sample, Limits lim, double q_goal, double q_0, double v_0,
-                              double a_0, double v_drive, double* io10)
-{
-    hipLaunchKernelGGL(k_single_opt_switch, dim3(1), dim3(1), 0, s, joint, t_sample, lim, q_goal, q_0, v_0, a_0, v_drive, io10);
-}
-void launch_single_time_scaling(hipStream_t s, int joint, double t_sample, Limits lim, double q_goal, double q_0, double v_0,
-                                double a_0, double dir, double t_required, double* out11)
-{
-    hipLaunchKernelGGL(k_single_time_scaling, dim3(1), dim3(1), 0, s, joint, t_sample, lim, q_goal, q_0, v_0, a_0, dir,
-                       t_required, out11);
-}
-void launch_math_probe(hipStream_t s, long long n, const double* x, const double* y, double* out)
-{
-    if (n <= 0) return;
-    hipLaunchKernelGGL(k_math_probe, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, x, y, out);
-}
-void launch_roots_probe(hipStream_t s, long long n, int degree, const double* coef, double* root)
-{
-    if (n <= 0) return;
-    hipLaunchKernelGGL(k_roots_probe, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, n, degree, coef, root);
 }
 
 }  // namespace ltp

@@ -2,7 +2,7 @@
 
 The distribution is the reference's tests/randomConfiguration.m:14-34 generalised to per-joint limits;
 the generator is counter-based (splitmix64 of (seed, query, joint, field)) so the HIP kernel
-``k_generate`` (csrc/ltp_kernels.hip) and this numpy mirror produce bit-identical batches and any
+``k_generate`` (csrc/ltp_aux_kernels.hip) and this numpy mirror produce bit-identical batches and any
 shard can be generated independently on any rank.
 """
 import numpy as np
@@ -30,7 +30,7 @@ _M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
 
 
 def unit_random(seed, query, joint, field):
-    """u in [0,1): same integer arithmetic as unit_random() in csrc/ltp_kernels.hip."""
+    """u in [0,1): same integer arithmetic as unit_random() in csrc/ltp_aux_kernels.hip."""
     with np.errstate(over="ignore"):
         query = np.asarray(query, dtype=np.uint64)
         joint = np.asarray(joint, dtype=np.uint64)
