@@ -12,6 +12,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <ctime>
 #include <vector>
 
 #include "ltp_hip.h"
@@ -206,6 +207,35 @@ int main()
         std::printf("hipGraph replay of plan + sample, %lld plans: %.3f ms per replay\n", n, ms / 20);
         HIP(hipGraphExecDestroy(exec));
         HIP(hipGraphDestroy(graph));
+    }
+
+    // ---- 5. latency of one planTrajectory-sized call through the host-pointer path (config 1 of BASELINE.json) ----
+    {
+        std::vector<double> t_o(dof * 7), t_s(dof * 7), d(dof), vd(dof);
+        std::vector<signed char> md(dof);
+        double treq;
+        int slow, ln, stt;
+        unsigned long long o2[2];
+        ltp_records hr{t_o.data(), t_s.data(), d.data(), vd.data(), md.data(), &treq, &slow, &ln, &stt};
+        for (int with_rows = 0; with_rows < 2; ++with_rows) {
+            float best = 1e30f, sum = 0;
+            const int reps = 200;
+            for (int i = 0; i < reps + 20; ++i) {
+                const long long pq = (i * 37) % n;
+                double* packed = nullptr;
+                timespec t0, t1;
+                clock_gettime(CLOCK_MONOTONIC, &t0);
+                int rc3 = ltp_plan_batch_host(h, 1, hq[0].data() + pq * dof, hq[1].data() + pq * dof, hq[2].data() + pq * dof,
+                                              hq[3].data() + pq * dof, &hr, o2, with_rows ? &packed : nullptr);
+                clock_gettime(CLOCK_MONOTONIC, &t1);
+                if (packed) ltp_free_host(packed);
+                CHECK(rc3 == LTP_OK);
+                const float us = (t1.tv_sec - t0.tv_sec) * 1e6f + (t1.tv_nsec - t0.tv_nsec) * 1e-3f;
+                if (i >= 20) { best = us < best ? us : best; sum += us; }
+            }
+            std::printf("one 7-DoF call through ltp_plan_batch_host, %s: mean %.1f us, best %.1f us\n",
+                        with_rows ? "switching times + sampled trajectory" : "switching times only", sum / reps, best);
+        }
     }
 
     ltp_destroy(h);
