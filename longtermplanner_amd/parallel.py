@@ -2,9 +2,10 @@
 
 Queries are independent — the only cross-lane step of the hot path, the slowest-joint reduction, is inside a
 query — so a batch shards as contiguous query ranges, one rank (process) per GPU, limits replicated, with NO
-collective on the data path. The only optional collective is a gather of the small switching-time records
-(RCCL when the tensors live on GPUs, gloo on CPU tensors); dense trajectories stay on the GPU that sampled
-them (a gather into one GPU is bounded by its 7 inbound xGMI links and by 288 GB of HBM).
+collective on the data path. Optional, both opt-in: an all_gather of the small switching-time records
+(gather_records) and point-to-point sends of trajectory tiles to one rank (gather_trajectories_to_root) — RCCL when
+the tensors live on GPUs, gloo on CPU tensors. By default dense trajectories stay on the GPU that sampled them (a
+gather into one GPU is bounded by its 7 inbound xGMI links and by 288 GB of HBM).
 """
 from typing import Dict, List, Tuple
 
@@ -45,3 +46,35 @@ def gather_records(local: Dict[str, "torch.Tensor"], n_total: int, group=None) -
         dist.all_gather(parts, pad, group=group)
         out[key] = torch.cat([p[:c] for p, c in zip(parts, counts)], dim=0)
     return out
+
+
+def gather_trajectories_to_root(tile: "torch.Tensor", elements: int, root: int = 0, group=None):
+    """OPT-IN: send the first `elements` elements of every rank's packed trajectory tile to `root`.
+
+    Point-to-point sends (RCCL send/recv over xGMI with the nccl backend, gloo on CPU tensors), one message per rank,
+    after an all_gather of the sizes. Returns, on `root`, a list with one 1-D tensor per rank (its own tile slice for
+    itself, not copied) and None elsewhere. The root must have room for the sum: 1 M x 7-DoF trajectories are 386 GB,
+    and a gather is bounded by the root's seven inbound xGMI links (~1 TB/s) — this is for small result sets, e.g.
+    the first-N-samples rows, not for whole batches.
+    """
+    import torch
+    import torch.distributed as dist
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    size = torch.tensor([int(elements)], dtype=torch.int64, device=tile.device)
+    sizes = [torch.zeros_like(size) for _ in range(world)]
+    dist.all_gather(sizes, size, group=group)
+    sizes = [int(s.item()) for s in sizes]
+    if rank != root:
+        if sizes[rank]:
+            dist.send(tile[: sizes[rank]].contiguous(), dst=root, group=group)
+        return None
+    parts = []
+    for r in range(world):
+        if r == root:
+            parts.append(tile[: sizes[r]])
+            continue
+        buf = torch.empty(sizes[r], dtype=tile.dtype, device=tile.device)
+        if sizes[r]:
+            dist.recv(buf, src=r, group=group)
+        parts.append(buf)
+    return parts

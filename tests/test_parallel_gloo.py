@@ -53,3 +53,33 @@ def test_two_rank_shard_and_gather(tmp_path, oracle_mod):
     ref = oracle_mod.Oracle(D, 0.001, **lim).plan_batch(qg, q0, v0, a0, sample=False)
     for k in ("t_scaled", "t_required", "slowest", "traj_len", "status"):
         assert np.array_equal(got[k], ref[k]), k
+
+
+def _traj_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from longtermplanner_amd.parallel import gather_trajectories_to_root
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        # ragged "tiles": rank r holds 1000 * (r + 1) + 7 valid elements of a larger buffer
+        n = 1000 * (rank + 1) + 7
+        tile = torch.full((5000,), -1.0, dtype=torch.float64)
+        tile[:n] = torch.arange(n, dtype=torch.float64) + 10000.0 * rank
+        parts = gather_trajectories_to_root(tile, n, root=0)
+        if rank == 0:
+            np.savez(os.path.join(out_dir, "traj.npz"), **{f"r{i}": p.numpy() for i, p in enumerate(parts)})
+        else:
+            assert parts is None
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_trajectory_gather_to_root(tmp_path):
+    import torch.multiprocessing as mp
+    world = 2
+    mp.spawn(_traj_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    got = np.load(os.path.join(tmp_path, "traj.npz"))
+    for r in range(world):
+        n = 1000 * (r + 1) + 7
+        assert np.array_equal(got[f"r{r}"], np.arange(n, dtype=np.float64) + 10000.0 * r)
