@@ -97,6 +97,10 @@ class LongTermPlanner {
   mutable ltp_planner* handle_ = nullptr;
   mutable bool dirty_ = true;
   int device_ = 0;
+  // NEW options (defaults = the reference's behaviour); kept here so that copies and re-created handles inherit them
+  int max_samples_ = 0;
+  int sample_stride_ = 1;
+  bool goal_check_ = false;
 
   static void raise(const ltp_planner* h, int rc, const char* what) {
     throw std::runtime_error(std::string("long_term_planner (MI355X): ") + what + " failed with code " + std::to_string(rc) +
@@ -115,6 +119,9 @@ class LongTermPlanner {
       if (rc != LTP_OK) raise(handle_, rc, "ltp_set_limits");
       if ((rc = ltp_set_sample_time(handle_, t_sample_)) != LTP_OK) raise(handle_, rc, "ltp_set_sample_time");
       if ((rc = ltp_set_dof(handle_, dof_)) != LTP_OK) raise(handle_, rc, "ltp_set_dof");
+      if ((rc = ltp_set_max_samples(handle_, max_samples_)) != LTP_OK) raise(handle_, rc, "ltp_set_max_samples");
+      if ((rc = ltp_set_sample_stride(handle_, sample_stride_)) != LTP_OK) raise(handle_, rc, "ltp_set_sample_stride");
+      if ((rc = ltp_set_goal_check(handle_, goal_check_ ? 1 : 0)) != LTP_OK) raise(handle_, rc, "ltp_set_goal_check");
       dirty_ = false;
     }
     return handle_;
@@ -136,11 +143,13 @@ class LongTermPlanner {
 
   LongTermPlanner(const LongTermPlanner& o)
       : dof_(o.dof_), t_sample_(o.t_sample_), q_min_(o.q_min_), q_max_(o.q_max_), v_max_(o.v_max_), a_max_(o.a_max_),
-        j_max_(o.j_max_), device_(o.device_) {}
+        j_max_(o.j_max_), device_(o.device_), max_samples_(o.max_samples_), sample_stride_(o.sample_stride_),
+        goal_check_(o.goal_check_) {}
   LongTermPlanner& operator=(const LongTermPlanner& o) {
     if (this != &o) {
       dof_ = o.dof_; t_sample_ = o.t_sample_; q_min_ = o.q_min_; q_max_ = o.q_max_; v_max_ = o.v_max_; a_max_ = o.a_max_;
-      j_max_ = o.j_max_; device_ = o.device_; dirty_ = true;
+      j_max_ = o.j_max_; device_ = o.device_; max_samples_ = o.max_samples_; sample_stride_ = o.sample_stride_;
+      goal_check_ = o.goal_check_; dirty_ = true;
     }
     return *this;
   }
@@ -216,22 +225,19 @@ class LongTermPlanner {
 
   /** @brief NEW: store only the first `max_samples` samples of each trajectory (0 = all, the reference's behaviour). */
   inline void setMaxSamples(int max_samples) {
-    const int rc = ltp_set_max_samples(handle(), max_samples);
-    if (rc != LTP_OK) raise(handle_, rc, "ltp_set_max_samples");
+    if (max_samples < 0) throw std::runtime_error("long_term_planner (MI355X): max_samples < 0");
+    max_samples_ = max_samples; dirty_ = true;
   }
 
   /** @brief NEW: store every `stride`-th sample of each trajectory (1 = every sample, the reference's behaviour). */
   inline void setSampleStride(int stride) {
-    const int rc = ltp_set_sample_stride(handle(), stride);
-    if (rc != LTP_OK) raise(handle_, rc, "ltp_set_sample_stride");
+    if (stride < 1) throw std::runtime_error("long_term_planner (MI355X): stride < 1");
+    sample_stride_ = stride; dirty_ = true;
   }
 
   /** @brief NEW, off by default: reject a q_goal outside [q_min, q_max] before planning (LTP_STATUS_GOAL_OUTSIDE;
    * planTrajectory then returns false with traj untouched). The reference leaves q_goal unchecked (cc:68-77). */
-  inline void setGoalCheck(bool enabled) {
-    const int rc = ltp_set_goal_check(handle(), enabled ? 1 : 0);
-    if (rc != LTP_OK) raise(handle_, rc, "ltp_set_goal_check");
-  }
+  inline void setGoalCheck(bool enabled) { goal_check_ = enabled; dirty_ = true; }
 
   /** @brief NEW: HIP device ordinal used by this planner (default 0). */
   inline void setDevice(int device) { if (device != device_) { release(); device_ = device; dirty_ = true; } }

@@ -189,6 +189,23 @@ static void testApiSurface()
   EXPECT_TRUE(n_ok == 2 && b.length[0] > 1 && b.length[1] > 1);
   EXPECT_NEAR(b.row(1, 0, 0)[b.length[1] - 1], 0.3, 0.02);
   EXPECT_TRUE(b.trajectory(0).length == b.length[0]);
+  // NEW options travel with copies and survive a handle that is created later
+  LongTermPlannerExposed opts(6, 0.001, std::vector<double>(6, -3.1), std::vector<double>(6, 3.1), std::vector<double>(6, 10.0),
+                              {2, 2, 2, 4, 4, 4}, {4, 4, 4, 4, 4, 2});
+  opts.setMaxSamples(100);      // before any device call: no handle exists yet
+  opts.setGoalCheck(true);
+  LongTermPlannerExposed opts2 = opts;
+  ltpn::BatchTrajectory bc;
+  std::vector<double> far = qg;
+  far[6] = 5.0;                 // query 1: goal outside [-3.1, 3.1]
+  opts2.planTrajectoryBatch(2, far.data(), z.data(), z.data(), z.data(), bc);
+  EXPECT_TRUE(bc.stored[0] == 100 && bc.length[0] == b.length[0]);
+  EXPECT_TRUE((bc.status[1] & LTP_STATUS_GOAL_OUTSIDE) != 0 && bc.length[1] == 0);
+  for (int k = 0; k < 100; k += 9) EXPECT_TRUE(bc.row(0, 0, 2)[k] == b.row(0, 0, 2)[k]);
+  opts2.setMaxSamples(0);
+  opts2.setGoalCheck(false);
+  opts2.planTrajectoryBatch(2, far.data(), z.data(), z.data(), z.data(), bc);
+  EXPECT_TRUE(bc.stored[0] == b.length[0] && bc.status[1] == LTP_STATUS_END_LIMIT);
 }
 
 int main()
