@@ -201,6 +201,35 @@ class LongTermPlanner {
     return ok;
   }
 
+  /**
+   * @brief NEW: plan n queries and reduce every trajectory on the device to per-joint position envelopes —
+   * env[((p*dof + joint)*n_windows + w)*2 + {0,1}] = {min, max} of the q samples w*window .. (w+1)*window-1; windows past
+   * the end hold the last position, plans without a trajectory NaN. The dense trajectories never exist, so this also
+   * works for batches whose trajectories would not fit in memory. `out` (optional) receives the records.
+   * @return number of queries for which planTrajectory would have returned true.
+   */
+  long long planEnvelopeBatch(long long n, const double* q_goal, const double* q_0, const double* v_0, const double* a_0,
+                              int window, int n_windows, std::vector<double>& env, BatchTrajectory* out = nullptr) {
+    ltp_planner* h = handle();
+    BatchTrajectory local;
+    BatchTrajectory& b = out ? *out : local;
+    const std::size_t nd = static_cast<std::size_t>(n) * dof_;
+    b.n = n; b.dof = dof_; b.t_sample = t_sample_;
+    b.t_opt.assign(nd * 7, 0.0); b.t_scaled.assign(nd * 7, 0.0); b.dir.assign(nd, 0.0); b.v_drive.assign(nd, 0.0);
+    b.mod.assign(nd, 0); b.t_required.assign(n, 0.0); b.slowest.assign(n, -1); b.length.assign(n, 0);
+    b.status.assign(n, 0); b.offsets.assign(n + 1, 0ull); b.packed.clear(); b.stored.assign(n, 0);
+    env.assign(nd * static_cast<std::size_t>(n_windows > 0 ? n_windows : 0) * 2, 0.0);
+    double dummy_d = 0; signed char dummy_c = 0;
+    ltp_records rec{nd ? b.t_opt.data() : &dummy_d, nd ? b.t_scaled.data() : &dummy_d, nd ? b.dir.data() : &dummy_d,
+                    nd ? b.v_drive.data() : &dummy_d, nd ? b.mod.data() : &dummy_c, b.t_required.data(), b.slowest.data(),
+                    b.length.data(), b.status.data()};
+    const int rc = ltp_plan_envelope_host(h, n, q_goal, q_0, v_0, a_0, window, n_windows, &rec, env.empty() ? &dummy_d : env.data());
+    if (rc != LTP_OK) raise(h, rc, "ltp_plan_envelope_host");
+    long long ok = 0;
+    for (long long p = 0; p < n; ++p) ok += b.status[p] == 0;
+    return ok;
+  }
+
   /** @brief reference long_term_planner.h:161-165, cc:68-77 */
   bool checkInputs(const std::vector<double>& q_0, const std::vector<double>& v_0, const std::vector<double>& a_0) {
     int ok = 0;

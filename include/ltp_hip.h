@@ -177,6 +177,13 @@ int ltp_plan_batch_host(ltp_planner* p, long long n, const double* q_goal, const
                         const double* a_0, const ltp_records* host_records, unsigned long long* offsets,
                         double** packed);
 
+/* planTrajectory stages 1-3 + the on-device envelope consumer (ltp_envelope_batch) for host arrays: a host caller
+ * cannot take in the dense trajectories of a large batch (32*dof*traj_len bytes per plan over PCIe), but it can take
+ * their position envelopes. env: host, n*dof*n_windows*2 doubles, layout as in ltp_envelope_batch. host_records
+ * (optional, members may be NULL) receives the records as ltp_plan_batch_host does; status includes END_LIMIT. */
+int ltp_plan_envelope_host(ltp_planner* p, long long n, const double* q_goal, const double* q_0, const double* v_0,
+                           const double* a_0, int window, int n_windows, const ltp_records* host_records, double* env);
+
 /* LongTermPlanner::getTrajectory (cc:706-841) for n host records ([n][dof][7] times etc.). */
 int ltp_get_trajectory_host(ltp_planner* p, long long n, const double* t, const double* dir, const signed char* mod,
                             const double* q_0, const double* v_0, const double* a_0, const double* v_drive,

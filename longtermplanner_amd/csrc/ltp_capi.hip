@@ -708,6 +708,38 @@ int ltp_plan_batch_host(ltp_planner* p, long long n, const double* q_goal, const
     return download_records(p, n, dof, dr.r, host_records);   // after sampling: status carries END_LIMIT
 }
 
+int ltp_plan_envelope_host(ltp_planner* p, long long n, const double* q_goal, const double* q_0, const double* v_0,
+                           const double* a_0, int window, int n_windows, const ltp_records* host_records, double* env)
+{
+    if (!p || n < 0 || !env) return fail(p, LTP_ERR_INVALID_ARGUMENT, "null argument");
+    if (window < 1 || n_windows < 1) return fail(p, LTP_ERR_INVALID_ARGUMENT, "window and n_windows must be >= 1");
+    if (n > 0 && p->dof > 0 && (!q_goal || !q_0 || !v_0 || !a_0)) return fail(p, LTP_ERR_INVALID_ARGUMENT, "null query array");
+    int rc;
+    { std::lock_guard<std::mutex> g(p->mu); rc = check_config(p); }
+    if (rc != LTP_OK) return rc;
+    LTP_HIP_TRY(p, hipSetDevice(p->device));
+    const int dof = p->dof;
+    const size_t nd = (size_t)n * dof;
+    const double* const h_in[4] = {q_goal, q_0, v_0, a_0};
+    DevRecords dr;
+    LTP_HIP_TRY(p, dr.alloc_all(n, dof));
+    double* d_in[4] = {nullptr, nullptr, nullptr, nullptr};
+    for (int k = 0; k < 4; ++k) {
+        LTP_HIP_TRY(p, dr.alloc(&d_in[k], nd));
+        if (nd) LTP_HIP_TRY(p, hipMemcpy(d_in[k], h_in[k], sizeof(double) * nd, hipMemcpyHostToDevice));
+    }
+    double* d_env = nullptr;
+    const size_t env_doubles = nd * (size_t)n_windows * 2;
+    LTP_HIP_TRY(p, dr.alloc(&d_env, env_doubles));
+    const ltp_queries dq{d_in[0], d_in[1], d_in[2], d_in[3], dof, 1};
+    rc = ltp_plan_switch_times_batch(p, n, &dq, &dr.r, nullptr, nullptr);
+    if (rc == LTP_OK) rc = ltp_envelope_batch(p, 0, n, &dq, &dr.r, window, n_windows, d_env, nullptr);
+    if (rc != LTP_OK) return rc;
+    if (env_doubles) LTP_HIP_TRY(p, hipMemcpy(env, d_env, sizeof(double) * env_doubles, hipMemcpyDeviceToHost));   // synchronises
+    else LTP_HIP_TRY(p, hipDeviceSynchronize());
+    return download_records(p, n, dof, dr.r, host_records);   // after the consumer: status carries END_LIMIT
+}
+
 int ltp_get_trajectory_host(ltp_planner* p, long long n, const double* t, const double* dir, const signed char* mod,
                             const double* q_0, const double* v_0, const double* a_0, const double* v_drive,
                             int* traj_len, int* status, unsigned long long* offsets, double** packed)

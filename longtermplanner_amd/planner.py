@@ -196,6 +196,20 @@ class LongTermPlanner:
             self._lib.ltp_free_host(packed)
         return r
 
+    def planEnvelopeHost(self, q_goal, q_0, v_0, a_0, window, n_windows):
+        """NEW: stages 1-3 + on-device envelope consumer for numpy arrays (ltp_plan_envelope_host). Returns (records dict,
+        env[n][dof][n_windows][2])."""
+        D = self.dof
+        ins = [np.ascontiguousarray(np.asarray(x, dtype=np.float64).reshape(-1, D)) for x in (q_goal, q_0, v_0, a_0)]
+        n = ins[0].shape[0]
+        r = dict(t_opt=np.zeros((n, D, 7)), t_scaled=np.zeros((n, D, 7)), dir=np.zeros((n, D)), v_drive=np.zeros((n, D)),
+                 mod=np.zeros((n, D), dtype=np.int8), t_required=np.zeros(n), slowest=np.zeros(n, dtype=np.int32),
+                 traj_len=np.zeros(n, dtype=np.int32), status=np.zeros(n, dtype=np.int32))
+        rec = _abi.Records(*[r[k].ctypes.data for k in ("t_opt", "t_scaled", "dir", "v_drive", "mod", "t_required", "slowest", "traj_len", "status")])
+        env = np.zeros((n, D, int(n_windows), 2))
+        self._check(self._lib.ltp_plan_envelope_host(self._h, n, *[_ptr(x) for x in ins], int(window), int(n_windows), C.byref(rec), _ptr(env)))
+        return r, env
+
     def getTrajectoryBatchHost(self, t, dir_, mod, q_0, v_0, a_0, v_drive):
         D = self.dof
         t = np.ascontiguousarray(np.asarray(t, dtype=np.float64).reshape(-1, D, 7))

@@ -5,6 +5,7 @@
 // :198-262, gridTestOneJoint :264-323 on a coarser grid) and reach the protected methods through a
 // `using`-exporting subclass exactly as tests/include/long_term_planner_fixture.h:34-39 does, so this file
 // also proves that the protected signatures are source-compatible. Runs on the GPU (no CPU path exists).
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <iostream>
@@ -189,6 +190,22 @@ static void testApiSurface()
   EXPECT_TRUE(n_ok == 2 && b.length[0] > 1 && b.length[1] > 1);
   EXPECT_NEAR(b.row(1, 0, 0)[b.length[1] - 1], 0.3, 0.02);
   EXPECT_TRUE(b.trajectory(0).length == b.length[0]);
+  // NEW: envelopes instead of dense trajectories through the host-pointer class API
+  {
+    std::vector<double> env;
+    ltpn::BatchTrajectory rec;
+    const int W = 64, K = 60;
+    const long long ok_env = six.planEnvelopeBatch(2, qg.data(), z.data(), z.data(), z.data(), W, K, env, &rec);
+    EXPECT_TRUE(ok_env == 2 && rec.length[0] == b.length[0] && (long long)env.size() == 2LL * 6 * K * 2);
+    for (int p = 0; p < 2; ++p)
+      for (int j = 0; j < 6; ++j)
+        for (int w = 0; w < K; ++w) {
+          const int L = b.length[p], lo_i = std::min(w * W, L - 1), hi_i = std::min(w * W + W, L);
+          double mn = b.row(p, 0, j)[lo_i], mx = mn;
+          for (int i = lo_i; i < std::max(hi_i, lo_i + 1); ++i) { mn = std::min(mn, b.row(p, 0, j)[i]); mx = std::max(mx, b.row(p, 0, j)[i]); }
+          EXPECT_TRUE(env[((p * 6 + j) * K + w) * 2] == mn && env[((p * 6 + j) * K + w) * 2 + 1] == mx);
+        }
+  }
   // NEW options travel with copies and survive a handle that is created later
   LongTermPlannerExposed opts(6, 0.001, std::vector<double>(6, -3.1), std::vector<double>(6, 3.1), std::vector<double>(6, 10.0),
                               {2, 2, 2, 4, 4, 4}, {4, 4, 4, 4, 4, 2});

@@ -547,3 +547,20 @@ def test_many_joints(amd, oracle_mod, dof):
     assert np.array_equal(r["slowest"], o["slowest"]) and np.array_equal(r["traj_len"], o["traj_len"])
     assert np.array_equal(r["mod"], o["mod"])
     _compare(amd, r, o, dof, q0, v0, a0, orc)
+
+
+def test_envelope_through_the_host_pointer_api(amd, ref7):
+    import torch
+    D, lim, ltp, _ = ref7
+    n, W, K = 500, 40, 50
+    qg, q0, v0, a0 = amd.generate_queries(n, lim, seed=55)
+    q0[9, 3] = -77.0
+    rec, env = ltp.planEnvelopeHost(qg, q0, v0, a0, W, K)
+    dev = [torch.from_numpy(x).cuda() for x in (qg, q0, v0, a0)]
+    b = ltp.planSwitchTimesBatch(*dev)
+    want = ltp.envelopeBatch(b, 0, n, W, K)
+    torch.cuda.synchronize()
+    assert np.array_equal(env, want.cpu().numpy(), equal_nan=True)
+    assert np.array_equal(rec["status"], b.status.cpu().numpy()) and np.array_equal(rec["traj_len"], b.traj_len.cpu().numpy())
+    assert np.array_equal(rec["t_scaled"], b.t_scaled.cpu().numpy(), equal_nan=True)
+    assert rec["status"][9] & amd.STATUS_INVALID_INPUT and np.all(np.isnan(env[9]))
