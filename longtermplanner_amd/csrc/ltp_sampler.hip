@@ -349,7 +349,8 @@ LTP_DEV void stream_rows(SegTable& tab, int j0, int nj, int dof, int slen, unsig
     const int nslots = (slen + N - 1) / N;
     const int sstride = rows.stride > 1 ? rows.stride : 1;
 
-    // Pass B, once per item: the slots that contain a run boundary. There are at most 19 per row, but in the
+    // Pass B, once per item: the slots that contain a run boundary (and the row's last slot if it is partly padding).
+    // There are at most 19 per row, but in the
     // row-by-row loop below most 64-slot wave steps contain one, and a wave that has one would execute the per-sample
     // path for all its lanes. So lane k of joint slot jl (the mapping of the table build) evaluates the slot of
     // boundary k, if that slot really straddles it and boundary k-1 has not claimed the same slot, and parks the four
@@ -359,9 +360,12 @@ LTP_DEV void stream_rows(SegTable& tab, int j0, int nj, int dof, int slen, unsig
     if constexpr (!DRY) {
         const int jl = threadIdx.x >> 5, k = threadIdx.x & 31;
         const int nruns = jl < nj ? tab.nseg[jl] : 0;
-        if (k >= 1 && k < nruns) {
+        if (k < nruns) {
             const int* st = tab.start[jl];
-            const int u = (st[k] + sstride - 1) / sstride;             // first stored sample at or after boundary k
+            // lane k >= 1: the slot of boundary k; lane 0: the last slot of the row if the row ends inside it (its
+            // tail is padding), so that the main loop never has to mask anything
+            const int u = k >= 1 ? (st[k] + sstride - 1) / sstride      // first stored sample at or after boundary k
+                                 : slen;
             bool mine = (u % N) != 0 && u < N * nslots;
             if (mine && k > 1) {
                 const int up = (st[k - 1] + sstride - 1) / sstride;
@@ -369,7 +373,7 @@ LTP_DEV void stream_rows(SegTable& tab, int j0, int nj, int dof, int slen, unsig
             }
             if (mine) {
                 const int i0 = u / N * N, t0 = i0 * sstride;
-                int kh = k - 1;
+                int kh = k >= 1 ? k - 1 : nruns - 1;
                 while (st[kh] > t0) --kh;                               // run of the slot's first sample (st[0] = 0)
                 int ch = st[kh], nh = kh + 1 < nruns ? st[kh + 1] : 0x7fffffff;
                 V o[4];
@@ -420,21 +424,23 @@ LTP_DEV void stream_rows(SegTable& tab, int j0, int nj, int dof, int slen, unsig
                     cur = nxt;
                     nxt = kr + 1 < nruns ? st[kr + 1] : 0x7fffffff;
                 }
-                if (t0 + (N - 1) * sstride >= nxt) {
-                    // run boundary kr+1 lies inside the slot: pass B has left the finished values in LDS
+                const bool straddles = t0 + (N - 1) * sstride >= nxt;
+                if (straddles || i0 + N > slen) {
+                    // run boundary kr+1 lies inside the slot, or the row ends inside it: pass B has left the finished
+                    // values in LDS (entry 0 is the row's last slot)
+                    const int e = straddles ? kr + 1 : 0;
 #pragma unroll
-                    for (int x = 0; x < 4; ++x) o[x] = *reinterpret_cast<const V*>(&tab.bnd[jl2][kr + 1][x]);
+                    for (int x = 0; x < 4; ++x) o[x] = *reinterpret_cast<const V*>(&tab.bnd[jl2][e][x]);
                 } else {
                     double c[kRunCoefs];
 #pragma unroll
                     for (int x = 0; x < kRunCoefs; ++x) c[x] = tab.c[jl2][kr][x];
 #pragma unroll
                     for (int h = 0; h < N; ++h) {
-                        const bool pad = i0 + h >= slen;
                         double x4[4];
                         run_eval(c, t0 + h * sstride - cur + 1, x4[0], x4[1], x4[2], x4[3]);
 #pragma unroll
-                        for (int x = 0; x < 4; ++x) o[x][h] = pad ? (T)0 : (T)x4[x];
+                        for (int x = 0; x < 4; ++x) o[x][h] = (T)x4[x];
                     }
                 }
             }
