@@ -7,17 +7,24 @@ offsets scan, and the dense q/v/a/j sampler for every plan of the batch. The sam
 1M x 7-DoF batch (~385 GB at 1 ms) exceeds HBM, so the sampler runs over resident chunks that reuse
 one output tile (SURVEY.md §7 hard part 5); every byte of every trajectory is still written.
 
-Contract: `python bench.py --gpus N --steps K --warmup W` (N>1 under torch.distributed.run, one rank
-per GPU, RCCL only for the barrier/timing reduction: query ranges shard with no data-path
-collective). Rank 0 prints ONE JSON line.
+Contract: `python bench.py --gpus N --steps K --warmup W`, one rank (process) per GPU; RCCL only for the
+barrier / timing reduction: query ranges shard with no data-path collective. Rank 0 prints ONE JSON line.
+Launched under torch.distributed.run the ranks come from the environment (RANK / LOCAL_RANK / WORLD_SIZE);
+launched plainly with --gpus N > 1, this process spawns the N rank processes itself BEFORE importing torch or
+touching a GPU, forwards their output, and exits non-zero if any of them fails — it never reports an
+n_gpus: 1 line under an N-GPU request.
+
+The line carries the headline workload (BASELINE.json configs[2]: 1 M x 7-DoF, 1 ms, full sampling) and, in
+"secondary", the other single-GPU configs run back to back in the same process (S-ref limits, configs[1]
+100 k switching times only, configs[4] 1 M x 30-DoF); with N > 1 the secondary entry is configs[3]
+(10 M queries sharded over the N GPUs, strong scaling).
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -25,8 +32,15 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
+def shard_range(n_total, rank, world):
+    """Contiguous query range of a rank (remainder to the lowest ranks); = ltp_shard_range, parallel.shard_range."""
+    base, rem = divmod(int(n_total), int(world))
+    return rank * base + min(rank, rem), base + (1 if rank < rem else 0)
+
+
 def chunk_bounds(offsets_host, capacity):
-    """Greedy [first, end) plan ranges whose packed size fits `capacity` doubles."""
+    """Greedy [first, end) plan ranges whose packed size fits `capacity` elements."""
+    import numpy as np
     n = offsets_host.size - 1
     bounds, first = [], 0
     while first < n:
@@ -84,12 +98,15 @@ def cpu_baseline(dof, lim, t_sample, seed, sample_switch_only):
                       f"{dt:.1f} s wall"}
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=1_000_000, help="queries per GPU per step")
+    ap.add_argument("--batch", type=int, default=1_000_000, help="queries per GPU per step (weak scaling)")
+    ap.add_argument("--global-batch", type=int, default=0,
+                    help="total queries per step over ALL GPUs, sharded as contiguous ranges (strong scaling; overrides --batch). "
+                         "BASELINE.json configs[3] is --gpus 8 --global-batch 10000000")
     ap.add_argument("--limits", default="panda", choices=["panda", "ref", "ref30"])
     ap.add_argument("--t-sample", type=float, default=0.001)
     ap.add_argument("--tile-gib", type=float, default=192.0, help="size of the reused trajectory output tile")
@@ -99,8 +116,9 @@ def main():
     ap.add_argument("--max-samples", type=int, default=0, help="store only the first N samples per row (0 = whole trajectories, the reference behaviour)")
     ap.add_argument("--sample-stride", type=int, default=1, help="store every N-th sample per row (1 = every sample, the reference behaviour)")
     ap.add_argument("--f32", action="store_true", help="store float32 rows (same binary64 results, rounded once); default float64 as the reference")
-    ap.add_argument("--switch-only", action="store_true", help="config[1]: stages 1-3 only, no sampling")
+    ap.add_argument("--switch-only", action="store_true", help="config[1]: stages 1-3 (+ the end-limit check) only, no sampling")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="only the primary workload (profiling runs)")
     ap.add_argument("--plain-stores", action="store_true", help="sampler uses plain instead of non-temporal stores")
     ap.add_argument("--window-gib", type=float, default=0.0, help="DIAGNOSTIC: chunk capacity; chunks rotate through windows of the tile")
     ap.add_argument("--spread", type=int, default=0, help="sampler block->plan interleave factor (0 = library default 64, 1 = plan order)")
@@ -115,87 +133,125 @@ def main():
                          "--max-samples samples, restart every query from stored sample K (ltp_replan_states_batch); value counts every replan")
     ap.add_argument("--sample-blocks", type=int, default=0, help="TUNING: size of the sampler's persistent grid (0 = library default)")
     ap.add_argument("--gather", action="store_true", help="also all_gather t_required over RCCL each step (optional path)")
-    args = ap.parse_args()
+    ap.add_argument("--checksum", action="store_true",
+                    help="add an order-independent checksum of all records of the batch (summed over ranks) to the line: equal for any sharding of one global batch")
+    return ap.parse_args(argv)
 
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as fresh child processes. This parent has not
+    imported torch and never touches a GPU; it only forwards the children's output and their verdict."""
+    import socket
+    if args.backend == "nccl" and args.device is not None:
+        print("bench.py: --backend nccl needs one GPU per rank (RCCL cannot run several ranks on one device); "
+              "use --backend gloo --device D to rehearse N ranks on one GPU", file=sys.stderr)
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    live = list(procs)
+    while live:
+        time.sleep(0.2)
+        for p in list(live):
+            code = p.poll()
+            if code is None:
+                continue
+            live.remove(p)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                print(f"bench.py: rank {procs.index(p)} exited with code {code}; stopping the other ranks", file=sys.stderr)
+                for q in live:      # exactly the processes started above
+                    q.terminate()
+    return rc
+
+
+class Workload:
+    """One measured configuration: limits, per-rank shard of the batch and the variant switches."""
+
+    def __init__(self, args, **over):
+        self.limits, self.t_sample, self.layout = args.limits, args.t_sample, args.layout
+        self.batch, self.global_batch = args.batch, args.global_batch
+        self.steps, self.warmup = args.steps, args.warmup
+        self.switch_only, self.f32 = args.switch_only, args.f32
+        self.max_samples, self.sample_stride = args.max_samples, args.sample_stride
+        self.envelope, self.receding = args.envelope, args.receding
+        self.plain_stores, self.dry, self.spread, self.window_gib = args.plain_stores, args.dry_sampler, args.spread, args.window_gib
+        self.sample_blocks, self.gather, self.checksum, self.seed = args.sample_blocks, args.gather, args.checksum, args.seed
+        self.name = "primary"
+        for k, v in over.items():
+            setattr(self, k, v)
+
+
+def run_workload(wl, ctx):
+    """Runs one workload on this rank; returns the JSON object (rank 0) or None."""
+    import numpy as np
     import torch
     import torch.distributed as dist
     from longtermplanner_amd import LongTermPlanner, limit_set
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.device is not None:
-        local_rank = args.device
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.backend == "nccl":      # "nccl" is RCCL on ROCm
-            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
-        else:
-            dist.init_process_group("gloo")
-    if world != args.gpus and rank == 0:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device(f"cuda:{local_rank}")
-    cdev = dev if args.backend == "nccl" else torch.device("cpu")     # where collective tensors live
-
-    dof, lim = limit_set(args.limits)
-    ltp = LongTermPlanner(dof, args.t_sample, device=local_rank, **lim)
-    n = args.batch
-    # this rank's shard of the global batch: query indices [rank*n, (rank+1)*n), generated on the device
-    qg, q0, v0, a0 = ltp.generateQueries(n, seed=args.seed, first_query=rank * n, layout=args.layout)
-    if args.max_samples:
-        ltp.setMaxSamples(args.max_samples)
-    if args.sample_stride > 1:
-        ltp.setSampleStride(args.sample_stride)
-    if args.sample_blocks:
-        ltp._check(ltp._lib.ltp_debug_set_sample_blocks(ltp._h, args.sample_blocks))
-    rec_spec = tuple(int(x) for x in args.receding.split(":")) if args.receding else None
-    rec_direct = bool(rec_spec) and not args.max_samples      # restart states straight from the records (ltp_state_at_batch)
-    env_spec = tuple(int(x) for x in args.envelope.split(":")) if args.envelope else None
+    world, rank, dev, cdev, local_rank = ctx["world"], ctx["rank"], ctx["dev"], ctx["cdev"], ctx["local_rank"]
+    dof, lim = limit_set(wl.limits)
+    ltp = LongTermPlanner(dof, wl.t_sample, device=local_rank, **lim)
+    if wl.global_batch:
+        first_query, n = shard_range(wl.global_batch, rank, world)
+        total_queries = wl.global_batch
+    else:
+        n = wl.batch
+        first_query, total_queries = rank * n, world * n
+    # this rank's shard of the global batch: query indices [first_query, first_query + n), generated on the device
+    qg, q0, v0, a0 = ltp.generateQueries(n, seed=wl.seed, first_query=first_query, layout=wl.layout)
+    if wl.max_samples:
+        ltp.setMaxSamples(wl.max_samples)
+    if wl.sample_stride > 1:
+        ltp.setSampleStride(wl.sample_stride)
+    if wl.sample_blocks:
+        ltp._check(ltp._lib.ltp_debug_set_sample_blocks(ltp._h, wl.sample_blocks))
+    rec_spec = tuple(int(x) for x in wl.receding.split(":")) if wl.receding else None
+    rec_direct = bool(rec_spec) and not wl.max_samples      # restart states straight from the records (ltp_state_at_batch)
+    env_spec = tuple(int(x) for x in wl.envelope.split(":")) if wl.envelope else None
     env_out = torch.empty((n, dof, env_spec[1], 2), dtype=torch.float64, device=dev) if env_spec else None
     tile = None
-    if not args.switch_only and not env_spec and not rec_direct:
-        # one big reused output tile; if this GPU cannot give 192 GiB right now, halve until it can
-        gib = args.tile_gib
-        while tile is None:
-            try:
-                tile = torch.empty(int(gib * (1 << 30)) // (4 if args.f32 else 8), dtype=torch.float32 if args.f32 else torch.float64, device=dev)
-            except torch.OutOfMemoryError:
-                if gib <= 8:
-                    raise
-                gib /= 2
-                torch.cuda.empty_cache()
-        args.tile_gib = gib
+    tile_gib = None
+    if not wl.switch_only and not env_spec and not rec_direct:
+        tile_bytes, tile_gib = ctx["tile"]()
+        tile = tile_bytes.view(torch.float32 if wl.f32 else torch.float64)
     offsets_pinned = torch.empty(n + 1, dtype=torch.int64, pin_memory=True)
     batch = None
-    gather_buf = [torch.empty(n, dtype=torch.float64, device=cdev) for _ in range(world)] if (args.gather and world > 1) else None
+    gather_buf = [torch.empty(n, dtype=torch.float64, device=cdev) for _ in range(world)] if (wl.gather and world > 1 and not wl.global_batch) else None
     ev_pairs = []
     n_chunks = 0
 
     def step(timed):
         nonlocal batch, n_chunks
         if rec_spec:
-            # every round: stages 1-3, first-N rows of all plans into the tile (they fit: N is small), new start states
+            # every round: stages 1-3 (+ end-limit verdict), first-N rows of all plans into the tile (they fit: N is small), new start states
             s0, s1, s2 = q0, v0, a0
             for _ in range(rec_spec[0]):
-                batch = ltp.planSwitchTimesBatch(qg, s0, s1, s2, layout=args.layout, batch=batch)
+                batch = ltp.planSwitchTimesBatch(qg, s0, s1, s2, layout=wl.layout, batch=batch, end_limit=rec_direct)
                 if rec_direct:
-                    s0, s1, s2 = ltp.stateAt(batch, 0, n, rec_spec[1], layout=args.layout)
+                    s0, s1, s2 = ltp.stateAt(batch, 0, n, rec_spec[1], layout=wl.layout)
                     continue
                 if timed:
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record()
-                ltp.sampleBatch(batch, 0, n, tile, streaming=not args.plain_stores, spread=args.spread)
+                ltp.sampleBatch(batch, 0, n, tile, streaming=not wl.plain_stores, spread=wl.spread)
                 if timed:
                     e1.record()
                     ev_pairs.append((e0, e1))
-                s0, s1, s2 = ltp.replanStates(batch, 0, n, tile, rec_spec[1], layout=args.layout)
+                s0, s1, s2 = ltp.replanStates(batch, 0, n, tile, rec_spec[1], layout=wl.layout)
             n_chunks = 1
             return
-        batch = ltp.planSwitchTimesBatch(qg, q0, v0, a0, layout=args.layout, batch=batch)
+        # switching times only: the end-limit check (cc:59-61) runs without the sampler, so status is planTrajectory's bool
+        batch = ltp.planSwitchTimesBatch(qg, q0, v0, a0, layout=wl.layout, batch=batch, end_limit=wl.switch_only)
         if gather_buf is not None:
             dist.all_gather(gather_buf, batch.t_required.to(cdev))
-        if args.switch_only:
+        if wl.switch_only:
             return
         if env_spec:
             if timed:
@@ -209,7 +265,7 @@ def main():
             return
         offsets_pinned.copy_(batch.offsets, non_blocking=True)
         torch.cuda.current_stream().synchronize()       # chunk boundaries depend on this batch's trajectory lengths
-        win = int(args.window_gib * (1 << 30)) // 8 if args.window_gib > 0 else tile.numel()
+        win = int(wl.window_gib * (1 << 30)) // 8 if wl.window_gib > 0 else tile.numel()
         nwin = max(1, tile.numel() // win)
         bounds = chunk_bounds(offsets_pinned.numpy().view(np.uint64), win)
         n_chunks = len(bounds)
@@ -218,12 +274,12 @@ def main():
             if timed:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-            ltp.sampleBatch(batch, first, end - first, view, streaming=not args.plain_stores, dry=args.dry_sampler, spread=args.spread)
+            ltp.sampleBatch(batch, first, end - first, view, streaming=not wl.plain_stores, dry=wl.dry, spread=wl.spread)
             if timed:
                 e1.record()
                 ev_pairs.append((e0, e1))
 
-    for _ in range(args.warmup):
+    for _ in range(wl.warmup):
         step(False)
 
     def sync_all():
@@ -234,7 +290,7 @@ def main():
 
     sync_all()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(wl.steps):
         step(True)
     sync_all()
     elapsed = time.perf_counter() - t0
@@ -246,69 +302,203 @@ def main():
     # bookkeeping outside the timed region
     status = batch.status.cpu().numpy()
     traj_len = batch.traj_len.cpu().numpy().astype(np.int64)
-    stored = -(-traj_len // args.sample_stride)
-    stored = np.minimum(stored, args.max_samples) if args.max_samples else stored
-    alg_bytes_per_step = int((16 if args.f32 else 32) * dof * stored.sum())   # 32*D*traj_len per plan (f64; stored samples)
+    stored = -(-traj_len // wl.sample_stride)
+    stored = np.minimum(stored, wl.max_samples) if wl.max_samples else stored
+    alg_bytes_per_step = int((16 if wl.f32 else 32) * dof * stored.sum())   # 32*D*traj_len per plan (f64; stored samples)
     if env_spec:
         alg_bytes_per_step = 16 * dof * env_spec[1] * n                         # what the consumer writes: [min, max] per window
+    checksum = None
+    if wl.checksum:
+        # order-independent: sums of the raw 64-bit patterns (mod 2^63) of every record array of this shard, summed over ranks
+        # (a wrapping int64 sum is the true sum mod 2^64, hence also mod 2^48; the small residues add up without overflow)
+        M = 1 << 48
+        acc = 0
+        for x in (batch.t_opt, batch.t_scaled, batch.dir, batch.v_drive, batch.t_required):
+            acc += int(x.contiguous().view(torch.int64).sum().item()) % M
+        for x in (batch.mod, batch.slowest, batch.traj_len, batch.status):
+            acc += int(x.to(torch.int64).sum().item()) % M
+        c = torch.tensor([acc % M], dtype=torch.int64, device=cdev)
+        if world > 1:
+            dist.all_reduce(c, op=dist.ReduceOp.SUM)
+        checksum = int(c.item()) % M
+    counts = torch.tensor([float((status == 0).sum()), float(traj_len.sum()), float(alg_bytes_per_step)], dtype=torch.float64, device=cdev)
+    if world > 1:
+        dist.all_reduce(counts, op=dist.ReduceOp.SUM)
+    ok_total, len_total, bytes_total = (float(x) for x in counts.tolist())
     roofline = None
     if ev_pairs:
         kern_ms = sum(a.elapsed_time(b) for a, b in ev_pairs)
         launches = len(ev_pairs)
         rounds = rec_spec[0] if rec_spec else 1    # receding variant: the lengths of the last round stand for all rounds
-        achieved = alg_bytes_per_step * rounds * args.steps / (kern_ms * 1e-3) / 1e9
-        traffic = None
+        achieved = alg_bytes_per_step * rounds * wl.steps / (kern_ms * 1e-3) / 1e9
+        roofline = {"kernel": "k_envelope" if env_spec else "k_sample", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 4),
+                    # HBM bytes per launch are a PMC measurement (rocprofv3 --pmc WRITE_SIZE, separate pass): not available inside
+                    # this process. The committed measurement of the same workload, if any, is quoted with its provenance.
+                    "traffic": None,
+                    "algorithmic_bytes_per_launch": alg_bytes_per_step // max(n_chunks, 1),
+                    "avg_launch_ms": round(kern_ms / launches, 4), "launches_timed": launches,
+                    "measured_on": f"rank 0 of {world}" if world > 1 else "rank 0"}
         pmc = os.path.join(ROOT, "profiles", "sampler_write_bytes.json")
-        if os.path.exists(pmc):
+        if os.path.exists(pmc) and not (env_spec or rec_spec or wl.f32 or wl.max_samples or wl.sample_stride > 1):
             try:
                 rec = json.load(open(pmc))
-                if rec.get("limits") == args.limits and rec.get("batch") == n and rec.get("tile_gib") == args.tile_gib:
-                    traffic = rec.get("write_bytes_per_launch")
+                if rec.get("limits") == wl.limits and rec.get("batch") == n and rec.get("tile_gib") == tile_gib:
+                    roofline["traffic_from_profile"] = {"write_bytes_per_launch": rec.get("write_bytes_per_launch"),
+                                                        "source": "profiles/sampler_write_bytes.json (committed rocprofv3 --pmc WRITE_SIZE pass of this workload; NOT measured in this run)",
+                                                        "collected": rec.get("collected", "round 1")}
             except Exception:
-                traffic = None
-        roofline = {"kernel": "k_envelope" if env_spec else "k_sample", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                    "algorithmic_bytes_per_launch": alg_bytes_per_step // max(n_chunks, 1),
-                    "avg_launch_ms": round(kern_ms / launches, 4), "launches_timed": launches}
+                pass
+
+    if rank != 0:
+        return None
+    replans = rec_spec[0] if rec_spec else 1
+    out = {
+        "metric": "7-DoF trajectory plans/sec (batch 1M)" if dof == 7 else f"{dof}-DoF trajectory plans/sec",
+        "value": round(total_queries * wl.steps * replans / elapsed, 1),
+        "unit": "plans/s",
+        "n_gpus": world,
+        "steps": wl.steps,
+        "warmup": wl.warmup,
+        "ms_per_step": round(elapsed / wl.steps * 1e3, 3),
+        "higher_is_better": True,
+        "scaling": "strong" if wl.global_batch else "weak",
+        "vs_baseline": None,
+        "dtype": "f64" if not wl.f32 else "f64 (rows stored as f32)",
+        "data": "synthetic" if not wl.dry else "DIAGNOSTIC dry sampler: NOT a valid result",
+        "config": {
+            "workload": ((f"{wl.global_batch} x {dof}-DoF queries per step sharded over {world} GPU(s) ({n} on rank 0)" if wl.global_batch else
+                          f"{n} x {dof}-DoF queries per GPU per step") + f", limits '{wl.limits}', Tsample {wl.t_sample} s, "
+                         + (f"{rec_spec[0]} receding-horizon cycles per step on the device (plan, " + ("state at sample" if rec_direct else f"first {wl.max_samples} samples, replan from stored sample") + f" {rec_spec[1]}); value counts replans; " if rec_spec else "")
+                         + ("switching times only (stages 1-3 + end-limit check, no rows)" if wl.switch_only else
+                            "no rows stored (ltp_state_at_batch)" if rec_direct else
+                            f"on-device envelope consumer: [min q, max q] over {env_spec[1]} windows of {env_spec[0]} samples per joint, no dense rows" if env_spec else
+                            ("full q/v/a/j sampling" if not (wl.max_samples or wl.sample_stride > 1) else
+                             f"q/v/a/j rows: every {wl.sample_stride}-th sample" + (f", first {wl.max_samples} stored" if wl.max_samples else ""))
+                            + f" into a reused {tile_gib} GiB tile ({n_chunks} chunks per step)")),
+            "batch_per_gpu": n if not wl.global_batch else None, "global_batch": total_queries, "dof": dof, "t_sample": wl.t_sample,
+            "limits": wl.limits, "input_layout": wl.layout,
+            "sharding": "contiguous query ranges per rank, no data-path collective" + (", RCCL all_gather of t_required" if gather_buf else ""),
+            "plans_ok_frac": round(ok_total / total_queries, 5),
+            "mean_traj_len": round(len_total / total_queries, 1),
+            "bytes_per_plan": round(bytes_total / total_queries, 1),
+        },
+    }
+    if checksum is not None:
+        out["config"]["records_checksum"] = checksum
+    if roofline:
+        out["roofline"] = roofline
+    return out
+
+
+def main():
+    args = parse_args()
+    if args.gpus < 1:
+        print("bench.py: --gpus must be >= 1", file=sys.stderr)
+        return 2
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        return spawn_ranks(args)            # no torch, no GPU in this process
+    world = int(env_world or "1")
+    rank = int(os.environ.get("RANK", "0"))
+    if world != args.gpus:
+        # never report a line for a different number of GPUs than was asked for
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE {world} rank(s)", file=sys.stderr)
+        return 2
+
+    import torch
+    import torch.distributed as dist
+
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.device is not None:
+        local_rank = args.device
+    if local_rank >= torch.cuda.device_count():
+        print(f"bench.py: rank {rank} wants HIP device {local_rank}, but only {torch.cuda.device_count()} device(s) are visible", file=sys.stderr)
+        return 3
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if args.backend == "nccl":      # "nccl" is RCCL on ROCm
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        else:
+            dist.init_process_group("gloo")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device(f"cuda:{local_rank}")
+    cdev = dev if args.backend == "nccl" else torch.device("cpu")     # where collective tensors live
+
+    # one big reused output tile for every workload of this process; if this GPU cannot give 192 GiB right now
+    # (e.g. several rehearsal ranks share it), halve until it can
+    tile_state = {}
+
+    def get_tile():
+        if "t" not in tile_state:
+            gib = args.tile_gib
+            share = world if args.device is not None else 1       # rehearsal: N ranks on one device share its memory
+            gib = gib / share
+            while True:
+                try:
+                    tile_state["t"] = torch.empty(int(gib * (1 << 30)), dtype=torch.uint8, device=dev)
+                    break
+                except torch.OutOfMemoryError:
+                    if gib <= 1:
+                        raise
+                    gib /= 2
+                    torch.cuda.empty_cache()
+            tile_state["gib"] = gib
+        return tile_state["t"], tile_state["gib"]
+
+    ctx = {"world": world, "rank": rank, "dev": dev, "cdev": cdev, "local_rank": local_rank, "tile": get_tile}
+    primary = Workload(args)
+    out = run_workload(primary, ctx)
+
+    variant = (args.switch_only or args.f32 or args.max_samples or args.sample_stride > 1 or args.envelope or args.receding or args.dry_sampler
+               or args.limits != "panda" or args.batch != 1_000_000 or args.global_batch or args.window_gib or args.layout != "query_major")
+    secondary = []
+    if not args.no_secondary and not variant:
+        few = max(1, min(args.steps, 2))
+        if world == 1:
+            plans = [
+                ("S-ref: the reference's own limits (README.md:129-131), 1 M x 7-DoF, full sampling",
+                 dict(limits="ref", steps=few, warmup=1)),
+                ("configs[1]: 100 k x 7-DoF, switching times only",
+                 dict(batch=100_000, switch_only=True, steps=max(args.steps, 20), warmup=2)),
+                ("configs[1] with the reference's limits",
+                 dict(limits="ref", batch=100_000, switch_only=True, steps=max(args.steps, 20), warmup=2)),
+                ("configs[4]: 1 M x 30-DoF (S-ref30), full sampling through the reused tile",
+                 dict(limits="ref30", steps=few, warmup=1)),
+            ]
+        else:
+            plans = [(f"configs[3]: 10 M x 7-DoF queries sharded over {world} GPUs, full sampling",
+                      dict(global_batch=10_000_000, steps=few, warmup=1))]
+        for name, over in plans:
+            try:
+                o = run_workload(Workload(args, name=name, **over), ctx)
+            except Exception as e:      # a secondary workload must not take the headline down
+                o = {"error": f"{type(e).__name__}: {e}"} if rank == 0 else None
+                if world > 1:
+                    raise
+            if o is not None:
+                keep = {k: o[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "scaling", "roofline") if k in o}
+                if "config" in o:
+                    keep["config"] = o["config"]
+                if "error" in o:
+                    keep["error"] = o["error"]
+                keep["name"] = name
+                secondary.append(keep)
 
     if rank == 0:
-        out = {
-            "metric": "7-DoF trajectory plans/sec (batch 1M)" if dof == 7 else f"{dof}-DoF trajectory plans/sec",
-            "value": round(world * n * args.steps * (rec_spec[0] if rec_spec else 1) / elapsed, 1),
-            "unit": "plans/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 3),
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "f64" if not args.f32 else "f64 (rows stored as f32)",
-            "data": "synthetic" if not args.dry_sampler else "DIAGNOSTIC dry sampler: NOT a valid result",
-            "config": {
-                "workload": (f"{n} x {dof}-DoF queries per GPU per step, limits '{args.limits}', Tsample {args.t_sample} s, "
-                             + (f"{rec_spec[0]} receding-horizon cycles per step on the device (plan, " + ("state at sample" if rec_direct else f"first {args.max_samples} samples, replan from stored sample") + f" {rec_spec[1]}); value counts replans; " if rec_spec else "")
-                             + ("switching times only (stages 1-3)" if args.switch_only else
-                                "no rows stored (ltp_state_at_batch)" if rec_direct else
-                                f"on-device envelope consumer: [min q, max q] over {env_spec[1]} windows of {env_spec[0]} samples per joint, no dense rows" if env_spec else
-                                (f"full q/v/a/j sampling" if not (args.max_samples or args.sample_stride > 1) else
-                                 f"q/v/a/j rows: every {args.sample_stride}-th sample" + (f", first {args.max_samples} stored" if args.max_samples else ""))
-                                + f" into a reused {args.tile_gib} GiB tile ({n_chunks} chunks per step)")),
-                "batch_per_gpu": n, "dof": dof, "t_sample": args.t_sample, "limits": args.limits, "input_layout": args.layout,
-                "sharding": "contiguous query ranges per rank, no data-path collective" + (", RCCL all_gather of t_required" if gather_buf else ""),
-                "plans_ok_frac": round(float((status == 0).mean()), 5),
-                "mean_traj_len": round(float(traj_len.mean()), 1),
-                "bytes_per_plan": round(alg_bytes_per_step / n, 1),
-            },
-        }
-        if roofline:
-            out["roofline"] = roofline
+        if secondary:
+            out["secondary"] = secondary
         if world == 1 and not args.no_cpu_baseline:
+            from longtermplanner_amd import limit_set
+            dof, lim = limit_set(args.limits)
             out["cpu_baseline"] = cpu_baseline(dof, lim, args.t_sample, args.seed, args.switch_only)
         print(json.dumps(out), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

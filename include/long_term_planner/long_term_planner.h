@@ -13,7 +13,10 @@
 //   * the reference's std::cerr diagnostic at cc:343 is not printed;
 //   * corners the reference leaves undefined (out-of-range writes of the sampler,
 //     non-finite switching times) are defined: dropped writes / `false`;
-//   * NEW: planTrajectoryBatch(), the batched overload this library exists for.
+//   * NEW: planTrajectoryBatch(), the batched overload this library exists for, and planTrajectoryBatchSharded(),
+//     the same over several devices from one process (contiguous query ranges, no collective).
+// Threading: as with the reference, concurrent planTrajectory / planTrajectoryBatch calls on one object are allowed as
+// long as no setter runs at the same time (the lazily created device handle is guarded by a mutex).
 #ifndef long_term_planner_H
 #define long_term_planner_H
 
@@ -23,6 +26,7 @@
 #include <cstddef>
 #include <functional>
 #include <math.h>
+#include <mutex>
 #include <numeric>
 #include <stdexcept>
 #include <string>
@@ -93,9 +97,18 @@ class LongTermPlanner {
   std::vector<double> a_max_;
   std::vector<double> j_max_;
 
-  // device-side twin of the members above; created lazily, never shared between copies
-  mutable ltp_planner* handle_ = nullptr;
-  mutable bool dirty_ = true;
+  // device-side twins of the members above; created lazily, never shared between copies. handle_ serves the
+  // single-device calls, shards_[i] the i-th shard of planTrajectoryBatchSharded. mu_ guards creation/configuration:
+  // the reference allows concurrent planTrajectory calls on one object (it mutates no members), so two threads'
+  // first calls must not race here either.
+  struct DeviceTwin {
+    ltp_planner* h = nullptr;
+    int device = 0;
+    bool dirty = true;
+  };
+  mutable DeviceTwin handle_;
+  mutable std::vector<DeviceTwin> shards_;
+  mutable std::mutex mu_;
   int device_ = 0;
   // NEW options (defaults = the reference's behaviour); kept here so that copies and re-created handles inherit them
   int max_samples_ = 0;
@@ -107,29 +120,71 @@ class LongTermPlanner {
                              (h ? std::string(": ") + ltp_last_error(h) : std::string(" (no HIP device? there is no CPU fallback)")));
   }
 
-  ltp_planner* handle() const {
-    const int n = static_cast<int>(std::min({q_min_.size(), q_max_.size(), v_max_.size(), a_max_.size(), j_max_.size()}));
-    if (!handle_) {
-      const int rc = ltp_create(0, t_sample_, nullptr, nullptr, nullptr, nullptr, nullptr, device_, &handle_);
+  void markDirty() {
+    handle_.dirty = true;
+    for (auto& s : shards_) s.dirty = true;
+  }
+
+  // caller holds mu_
+  ltp_planner* ready(DeviceTwin& t, int device) const {
+    if (t.h && t.device != device) { ltp_destroy(t.h); t.h = nullptr; }
+    if (!t.h) {
+      const int rc = ltp_create(0, t_sample_, nullptr, nullptr, nullptr, nullptr, nullptr, device, &t.h);
       if (rc != LTP_OK) raise(nullptr, rc, "ltp_create");
-      dirty_ = true;
+      t.device = device;
+      t.dirty = true;
     }
-    if (dirty_) {
-      int rc = ltp_set_limits(handle_, n, q_min_.data(), q_max_.data(), v_max_.data(), a_max_.data(), j_max_.data());
-      if (rc != LTP_OK) raise(handle_, rc, "ltp_set_limits");
-      if ((rc = ltp_set_sample_time(handle_, t_sample_)) != LTP_OK) raise(handle_, rc, "ltp_set_sample_time");
-      if ((rc = ltp_set_dof(handle_, dof_)) != LTP_OK) raise(handle_, rc, "ltp_set_dof");
-      if ((rc = ltp_set_max_samples(handle_, max_samples_)) != LTP_OK) raise(handle_, rc, "ltp_set_max_samples");
-      if ((rc = ltp_set_sample_stride(handle_, sample_stride_)) != LTP_OK) raise(handle_, rc, "ltp_set_sample_stride");
-      if ((rc = ltp_set_goal_check(handle_, goal_check_ ? 1 : 0)) != LTP_OK) raise(handle_, rc, "ltp_set_goal_check");
-      dirty_ = false;
+    if (t.dirty) {
+      const int n = static_cast<int>(std::min({q_min_.size(), q_max_.size(), v_max_.size(), a_max_.size(), j_max_.size()}));
+      int rc = ltp_set_limits(t.h, n, q_min_.data(), q_max_.data(), v_max_.data(), a_max_.data(), j_max_.data());
+      if (rc != LTP_OK) raise(t.h, rc, "ltp_set_limits");
+      if ((rc = ltp_set_sample_time(t.h, t_sample_)) != LTP_OK) raise(t.h, rc, "ltp_set_sample_time");
+      if ((rc = ltp_set_dof(t.h, dof_)) != LTP_OK) raise(t.h, rc, "ltp_set_dof");
+      if ((rc = ltp_set_max_samples(t.h, max_samples_)) != LTP_OK) raise(t.h, rc, "ltp_set_max_samples");
+      if ((rc = ltp_set_sample_stride(t.h, sample_stride_)) != LTP_OK) raise(t.h, rc, "ltp_set_sample_stride");
+      if ((rc = ltp_set_goal_check(t.h, goal_check_ ? 1 : 0)) != LTP_OK) raise(t.h, rc, "ltp_set_goal_check");
+      t.dirty = false;
     }
-    return handle_;
+    return t.h;
+  }
+
+  ltp_planner* handle() const {
+    std::lock_guard<std::mutex> g(mu_);
+    return ready(handle_, device_);
   }
 
   void release() {
-    if (handle_) ltp_destroy(handle_);
-    handle_ = nullptr;
+    if (handle_.h) ltp_destroy(handle_.h);
+    handle_.h = nullptr;
+    for (auto& s : shards_)
+      if (s.h) ltp_destroy(s.h);
+    shards_.clear();
+  }
+
+  // sizes `out` for n queries and returns the record pointers the C ABI fills
+  ltp_records prepare(long long n, BatchTrajectory& out, double& dummy_d, signed char& dummy_c) const {
+    const std::size_t nd = static_cast<std::size_t>(n) * dof_;
+    out.n = n; out.dof = dof_; out.t_sample = t_sample_;
+    out.t_opt.assign(nd * 7, 0.0); out.t_scaled.assign(nd * 7, 0.0); out.dir.assign(nd, 0.0); out.v_drive.assign(nd, 0.0);
+    out.mod.assign(nd, 0); out.t_required.assign(n, 0.0); out.slowest.assign(n, -1); out.length.assign(n, 0);
+    out.status.assign(n, 0); out.offsets.assign(n + 1, 0ull); out.packed.clear(); out.stored.assign(n, 0);
+    // zero-sized vectors have a null data(); the C ABI wants non-null record pointers
+    return ltp_records{nd ? out.t_opt.data() : &dummy_d, nd ? out.t_scaled.data() : &dummy_d, nd ? out.dir.data() : &dummy_d,
+                       nd ? out.v_drive.data() : &dummy_d, nd ? out.mod.data() : &dummy_c, out.t_required.data(),
+                       out.slowest.data(), out.length.data(), out.status.data()};
+  }
+
+  long long finish(ltp_planner* h, long long n, double* packed, BatchTrajectory& out) const {
+    if (packed) {
+      out.packed.assign(packed, packed + out.offsets[n]);
+      ltp_free_host(packed);
+    }
+    long long ok = 0;
+    for (long long p = 0; p < n; ++p) {
+      ok += out.status[p] == 0;
+      out.stored[p] = ltp_stored_samples(h, out.length[p]);
+    }
+    return ok;
   }
 
  public:
@@ -149,7 +204,7 @@ class LongTermPlanner {
     if (this != &o) {
       dof_ = o.dof_; t_sample_ = o.t_sample_; q_min_ = o.q_min_; q_max_ = o.q_max_; v_max_ = o.v_max_; a_max_ = o.a_max_;
       j_max_ = o.j_max_; device_ = o.device_; max_samples_ = o.max_samples_; sample_stride_ = o.sample_stride_;
-      goal_check_ = o.goal_check_; dirty_ = true;
+      goal_check_ = o.goal_check_; markDirty();
     }
     return *this;
   }
@@ -175,30 +230,37 @@ class LongTermPlanner {
   long long planTrajectoryBatch(long long n, const double* q_goal, const double* q_0, const double* v_0, const double* a_0,
                                 BatchTrajectory& out, bool sample = true) {
     ltp_planner* h = handle();
-    const std::size_t nd = static_cast<std::size_t>(n) * dof_;
-    out.n = n; out.dof = dof_; out.t_sample = t_sample_;
-    out.t_opt.assign(nd * 7, 0.0); out.t_scaled.assign(nd * 7, 0.0); out.dir.assign(nd, 0.0); out.v_drive.assign(nd, 0.0);
-    out.mod.assign(nd, 0); out.t_required.assign(n, 0.0); out.slowest.assign(n, -1); out.length.assign(n, 0);
-    out.status.assign(n, 0); out.offsets.assign(n + 1, 0ull); out.packed.clear();
-    // zero-sized vectors have a null data(); the C ABI wants non-null record pointers
     double dummy_d = 0; signed char dummy_c = 0;
-    ltp_records rec{nd ? out.t_opt.data() : &dummy_d, nd ? out.t_scaled.data() : &dummy_d, nd ? out.dir.data() : &dummy_d,
-                    nd ? out.v_drive.data() : &dummy_d, nd ? out.mod.data() : &dummy_c, out.t_required.data(),
-                    out.slowest.data(), out.length.data(), out.status.data()};
+    const ltp_records rec = prepare(n, out, dummy_d, dummy_c);
     double* packed = nullptr;
     const int rc = ltp_plan_batch_host(h, n, q_goal, q_0, v_0, a_0, &rec, out.offsets.data(), sample ? &packed : nullptr);
     if (rc != LTP_OK) raise(h, rc, "ltp_plan_batch_host");
-    if (packed) {
-      out.packed.assign(packed, packed + out.offsets[n]);
-      ltp_free_host(packed);
+    return finish(h, n, packed, out);
+  }
+
+  /**
+   * @brief NEW: planTrajectoryBatch over several devices from ONE process. Shard g — the contiguous
+   * query range ltp_shard_range(n, g, devices.size()) — is planned on HIP device devices[g] by its own handle and host
+   * thread; limits are replicated, nothing is exchanged between devices (queries are independent). `out` is
+   * bit-identical to planTrajectoryBatch over all n queries. A device may be listed more than once (virtual shards).
+   * @return number of queries for which planTrajectory would have returned true.
+   */
+  long long planTrajectoryBatchSharded(long long n, const double* q_goal, const double* q_0, const double* v_0, const double* a_0,
+                                       BatchTrajectory& out, const std::vector<int>& devices, bool sample = true) {
+    if (devices.empty()) throw std::runtime_error("long_term_planner (MI355X): planTrajectoryBatchSharded needs at least one device");
+    std::vector<ltp_planner*> hs(devices.size());
+    {
+      std::lock_guard<std::mutex> g(mu_);
+      if (shards_.size() < devices.size()) shards_.resize(devices.size());
+      for (std::size_t i = 0; i < devices.size(); ++i) hs[i] = ready(shards_[i], devices[i]);
     }
-    long long ok = 0;
-    out.stored.resize(n);
-    for (long long p = 0; p < n; ++p) {
-      ok += out.status[p] == 0;
-      out.stored[p] = ltp_stored_samples(h, out.length[p]);
-    }
-    return ok;
+    double dummy_d = 0; signed char dummy_c = 0;
+    const ltp_records rec = prepare(n, out, dummy_d, dummy_c);
+    double* packed = nullptr;
+    const int rc = ltp_plan_batch_multi(hs.data(), static_cast<int>(hs.size()), n, q_goal, q_0, v_0, a_0, &rec, out.offsets.data(),
+                                        sample ? &packed : nullptr);
+    if (rc != LTP_OK) raise(hs[0], rc, "ltp_plan_batch_multi");
+    return finish(hs[0], n, packed, out);
   }
 
   /**
@@ -243,33 +305,33 @@ class LongTermPlanner {
   inline void setLimits(std::vector<double> q_min, std::vector<double> q_max, std::vector<double> v_max,
                         std::vector<double> a_max, std::vector<double> j_max) {
     q_min_ = q_min; q_max_ = q_max; v_max_ = v_max; a_max_ = a_max; j_max_ = j_max;
-    dirty_ = true;
+    markDirty();
   }
 
   /** @brief reference long_term_planner.h:194-196 */
-  inline void setSampleTime(double t_sample) { t_sample_ = t_sample; dirty_ = true; }
+  inline void setSampleTime(double t_sample) { t_sample_ = t_sample; markDirty(); }
 
   /** @brief reference long_term_planner.h:203-205 (takes a double there as well) */
-  inline void setDoF(double dof) { dof_ = dof; dirty_ = true; }
+  inline void setDoF(double dof) { dof_ = dof; markDirty(); }
 
   /** @brief NEW: store only the first `max_samples` samples of each trajectory (0 = all, the reference's behaviour). */
   inline void setMaxSamples(int max_samples) {
     if (max_samples < 0) throw std::runtime_error("long_term_planner (MI355X): max_samples < 0");
-    max_samples_ = max_samples; dirty_ = true;
+    max_samples_ = max_samples; markDirty();
   }
 
   /** @brief NEW: store every `stride`-th sample of each trajectory (1 = every sample, the reference's behaviour). */
   inline void setSampleStride(int stride) {
     if (stride < 1) throw std::runtime_error("long_term_planner (MI355X): stride < 1");
-    sample_stride_ = stride; dirty_ = true;
+    sample_stride_ = stride; markDirty();
   }
 
   /** @brief NEW, off by default: reject a q_goal outside [q_min, q_max] before planning (LTP_STATUS_GOAL_OUTSIDE;
    * planTrajectory then returns false with traj untouched). The reference leaves q_goal unchecked (cc:68-77). */
-  inline void setGoalCheck(bool enabled) { goal_check_ = enabled; dirty_ = true; }
+  inline void setGoalCheck(bool enabled) { goal_check_ = enabled; markDirty(); }
 
   /** @brief NEW: HIP device ordinal used by this planner (default 0). */
-  inline void setDevice(int device) { if (device != device_) { release(); device_ = device; dirty_ = true; } }
+  inline void setDevice(int device) { if (device != device_) { device_ = device; markDirty(); } }
 
   /** @brief NEW: the C-ABI handle, for callers that drive the device-pointer entry points of ltp_hip.h directly. */
   ltp_planner* nativeHandle() { return handle(); }

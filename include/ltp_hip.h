@@ -15,6 +15,19 @@
  * stream). Functions ending in _batch take DEVICE pointers and only enqueue
  * work; functions ending in _host take host pointers and are synchronous.
  * All arithmetic is IEEE binary64, as in the reference.
+ *
+ * Streams. A handle owns ONE device workspace (compaction queues, lane flags, scan scratch) that
+ * ltp_plan_switch_times_batch uses. Calls on one stream are ordered by the stream. When a call arrives on a
+ * different stream than the handle's previous workspace user, the library inserts the dependency itself (an event
+ * recorded after the previous call, waited for by the new stream), so two streams of one handle — e.g. a
+ * double-buffered pipeline — serialise on the workspace instead of racing. For concurrency use one handle per
+ * stream (handles are cheap: ~1 MB plus the workspace). A stream that is being captured into a hipGraph is exempt
+ * (events cannot cross a capture): do not replay such a graph concurrently with other work of the same handle.
+ *
+ * Batch geometry. dof, t_sample, max_samples and sample_stride are captured when a batch is planned
+ * (ltp_plan_switch_times_batch) and define its records, offsets and row strides. The calls that consume a planned
+ * batch (ltp_sample_batch*, ltp_envelope_batch, ltp_replan_states*_batch, ltp_state_at_batch, ltp_end_limit_batch)
+ * return LTP_ERR_INVALID_ARGUMENT if one of them was changed on the handle in between.
  */
 #ifndef LTP_HIP_H
 #define LTP_HIP_H
@@ -121,6 +134,15 @@ int ltp_reserve_batch(ltp_planner* p, long long n);
 int ltp_plan_switch_times_batch(ltp_planner* p, long long n, const ltp_queries* in, const ltp_records* out,
                                 unsigned long long* offsets, void* stream);
 
+/* The end-limit check of planTrajectory (cc:59-61) WITHOUT sampling: for plans [first, first+count) of a planned
+ * batch, walks every joint's runs to the last trajectory sample (the value ltp_sample_batch would store at
+ * traj_len-1, bit for bit) and sets LTP_STATUS_END_LIMIT where it lies outside [q_min, q_max]. After this call
+ * status == 0 is exactly planTrajectory's return value. ltp_sample_batch* and ltp_envelope_batch apply the same
+ * check themselves; ltp_plan_switch_times_batch alone does not (status then holds the pre-sampling verdict
+ * cc:14-39 only). The _host calls that do not sample run it for the caller. */
+int ltp_end_limit_batch(ltp_planner* p, long long first, long long count, const ltp_queries* in, const ltp_records* rec,
+                        void* stream);
+
 /* getTrajectory (cc:706-841) + the end-limit check (cc:59-61) for plans [first, first+count):
  * plan p is written at out + (offsets[p] - offsets[first]); plans that would end beyond
  * `capacity` doubles get LTP_STATUS_OVERFLOW and are skipped.
@@ -146,13 +168,16 @@ int ltp_envelope_batch(ltp_planner* p, long long first, long long count, const l
 
 /* SURVEY.md §8(f).1 receding horizon (reference README.md:10-13): start states of the next plans = sample k of the
  * trajectories sampled into `tile` by ltp_sample_batch(first, count, ...). sample_index: device int[count] or NULL
- * (then uniform_index for all); k is clamped to the stored samples; plans that were not sampled keep the start
- * state they had in `in`. Output element (local plan i, joint j) at ptr[i*query_stride + j*joint_stride]. */
+ * (then uniform_index for all); k is clamped to the stored samples; plans that were not sampled — traj_len 0,
+ * LTP_STATUS_OVERFLOW, or rows that would end beyond `capacity` elements of `tile` (the capacity given to
+ * ltp_sample_batch) — keep the start state they had in `in`; nothing outside the tile is read. Output element (local plan i, joint j) at ptr[i*query_stride + j*joint_stride]. */
 int ltp_replan_states_batch(ltp_planner* p, long long first, long long count, const ltp_queries* in, const ltp_records* rec,
-                            const unsigned long long* offsets, const double* tile, const int* sample_index, int uniform_index,
+                            const unsigned long long* offsets, const double* tile, unsigned long long capacity,
+                            const int* sample_index, int uniform_index,
                             double* q_0, double* v_0, double* a_0, long long query_stride, long long joint_stride, void* stream);
 int ltp_replan_states_f32_batch(ltp_planner* p, long long first, long long count, const ltp_queries* in, const ltp_records* rec,
-                                const unsigned long long* offsets, const float* tile, const int* sample_index, int uniform_index,
+                                const unsigned long long* offsets, const float* tile, unsigned long long capacity,
+                                const int* sample_index, int uniform_index,
                                 double* q_0, double* v_0, double* a_0, long long query_stride, long long joint_stride, void* stream);
 /* The same without any sampled rows: the state at TRAJECTORY sample k (0 .. traj_len-1, clamped; not a stored-sample
  * index) of plans [first, first+count), computed from the switching-time records alone with the sampler's own run
@@ -172,10 +197,29 @@ int ltp_generate_queries_batch(ltp_planner* p, long long n, unsigned long long s
 
 /* Full planTrajectory (cc:7-63) for n row-major [n][dof] host queries. Any record pointer may be NULL.
  * If packed != NULL, *packed receives a malloc'ed buffer of offsets[n] doubles (free with ltp_free_host)
- * and offsets ([n+1], host) must be non-NULL. */
+ * and offsets ([n+1], host) must be non-NULL. With packed == NULL nothing is sampled, but status still carries
+ * LTP_STATUS_END_LIMIT (ltp_end_limit_batch runs instead of the sampler): status == 0 is planTrajectory's bool. */
 int ltp_plan_batch_host(ltp_planner* p, long long n, const double* q_goal, const double* q_0, const double* v_0,
                         const double* a_0, const ltp_records* host_records, unsigned long long* offsets,
                         double** packed);
+
+/* ---- one process, several devices: contiguous query ranges, no collective ---------------- */
+
+/* Range of shard `rank` of `world` over n queries: [*first, *first + *count), remainder to the lowest ranks. The same
+ * rule as longtermplanner_amd/parallel.py::shard_range, bench.py and planTrajectoryBatchSharded. */
+void ltp_shard_range(long long n, int rank, int world, long long* first, long long* count);
+
+/* ltp_plan_batch_host over k planners, normally one per device (ltp_create(..., device = g, ...)), all configured
+ * identically (else LTP_ERR_INVALID_ARGUMENT): shard g plans queries ltp_shard_range(n, g, k) on its own device from
+ * its own host thread, all shards concurrently; there is no exchange between devices (queries are independent; the
+ * only cross-lane step of planTrajectory, the slowest-joint reduction cc:31-39, is inside a query). Results are
+ * written as ONE batch: records at their global query index, offsets rebased to the concatenated `*packed` buffer —
+ * bit-identical to a single ltp_plan_batch_host call over all n queries. Several planners may name the same device
+ * ("virtual shards", how the tests check this on one GPU). On error the first failing shard's code is returned
+ * and ltp_last_error(planners[0]) names the shard. */
+int ltp_plan_batch_multi(ltp_planner* const* planners, int k, long long n, const double* q_goal, const double* q_0,
+                         const double* v_0, const double* a_0, const ltp_records* host_records, unsigned long long* offsets,
+                         double** packed);
 
 /* planTrajectory stages 1-3 + the on-device envelope consumer (ltp_envelope_batch) for host arrays: a host caller
  * cannot take in the dense trajectories of a large batch (32*dof*traj_len bytes per plan over PCIe), but it can take

@@ -81,7 +81,7 @@ _SIGNATURES = {
     "ltp_set_goal_check": (C.c_int, [C.c_void_p, C.c_int]),
     "ltp_get_goal_check": (C.c_int, [C.c_void_p]),
     "ltp_replan_states_batch": (C.c_int, [C.c_void_p, C.c_longlong, C.c_longlong, C.POINTER(Queries), C.POINTER(Records), C.c_void_p,
-                                          C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong,
+                                          C.c_void_p, C.c_ulonglong, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong,
                                           C.c_longlong, C.c_void_p]),
     "ltp_plan_switch_times_batch": (C.c_int, [C.c_void_p, C.c_longlong, C.POINTER(Queries), C.POINTER(Records), C.c_void_p, C.c_void_p]),
     "ltp_sample_batch": (C.c_int, [C.c_void_p, C.c_longlong, C.c_longlong, C.POINTER(Queries), C.POINTER(Records), C.c_void_p,
@@ -89,8 +89,12 @@ _SIGNATURES = {
     "ltp_sample_batch_f32": (C.c_int, [C.c_void_p, C.c_longlong, C.c_longlong, C.POINTER(Queries), C.POINTER(Records), C.c_void_p,
                                        C.c_void_p, C.c_ulonglong, C.c_int, C.c_void_p]),
     "ltp_replan_states_f32_batch": (C.c_int, [C.c_void_p, C.c_longlong, C.c_longlong, C.POINTER(Queries), C.POINTER(Records), C.c_void_p,
-                                              C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong,
+                                              C.c_void_p, C.c_ulonglong, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong,
                                               C.c_longlong, C.c_void_p]),
+    "ltp_end_limit_batch": (C.c_int, [C.c_void_p, C.c_longlong, C.c_longlong, C.POINTER(Queries), C.POINTER(Records), C.c_void_p]),
+    "ltp_shard_range": (None, [C.c_longlong, C.c_int, C.c_int, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
+    "ltp_plan_batch_multi": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_longlong, _dp, _dp, _dp, _dp, C.POINTER(Records), _up,
+                                       C.POINTER(_dp)]),
     "ltp_generate_queries_batch": (C.c_int, [C.c_void_p, C.c_longlong, C.c_ulonglong, C.c_longlong, C.c_void_p, C.c_void_p,
                                              C.c_void_p, C.c_void_p, C.c_longlong, C.c_longlong, C.c_void_p]),
     "ltp_plan_batch_host": (C.c_int, [C.c_void_p, C.c_longlong, _dp, _dp, _dp, _dp, C.POINTER(Records), _up, C.POINTER(_dp)]),

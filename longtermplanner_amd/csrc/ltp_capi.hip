@@ -8,6 +8,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 struct ltp_planner {
@@ -42,6 +43,13 @@ struct ltp_planner {
     double* d_traj = nullptr;
     double* h_traj = nullptr;              // pinned
     size_t traj_doubles = 0;
+    // the workspace above has one user at a time: the stream of the latest ltp_plan_switch_times_batch and an event
+    // recorded behind its work; a call on another stream waits for that event first (include/ltp_hip.h, "Streams")
+    hipStream_t ws_stream = nullptr;
+    hipEvent_t ws_event = nullptr;
+    bool ws_used = false;
+    // geometry of the batches planned by this handle (include/ltp_hip.h, "Batch geometry")
+    struct Geometry { bool valid = false; int dof = 0; double t_sample = 0.0; int max_samples = 0; int stride = 1; } planned;
     std::mutex mu;
     std::string err;
 };
@@ -165,6 +173,48 @@ bool records_complete(const ltp_records* r)
     return r && r->t_opt && r->t_scaled && r->dir && r->v_drive && r->mod && r->t_required && r->slowest && r->traj_len && r->status;
 }
 
+// Called with p->mu held, before a call on stream `s` touches the handle's workspace: if the previous user was another
+// stream, `s` waits for the event recorded behind that user's work.
+int workspace_acquire(ltp_planner* p, hipStream_t s, bool& capturing)
+{
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    capturing = false;
+    if (s != nullptr && hipStreamIsCapturing(s, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) capturing = true;
+    (void)hipGetLastError();   // legacy-stream queries may leave a sticky "not supported" behind
+    if (capturing) return LTP_OK;
+    if (!p->ws_event) LTP_HIP_TRY(p, hipEventCreateWithFlags(&p->ws_event, hipEventDisableTiming));
+    if (p->ws_used && p->ws_stream != s) LTP_HIP_TRY(p, hipStreamWaitEvent(s, p->ws_event, 0));
+    return LTP_OK;
+}
+
+int workspace_release(ltp_planner* p, hipStream_t s, bool capturing)
+{
+    if (capturing) return LTP_OK;
+    LTP_HIP_TRY(p, hipEventRecord(p->ws_event, s));
+    p->ws_stream = s;
+    p->ws_used = true;
+    return LTP_OK;
+}
+
+void capture_geometry(ltp_planner* p)
+{
+    p->planned.valid = true;
+    p->planned.dof = p->dof;
+    p->planned.t_sample = p->t_sample;
+    p->planned.max_samples = p->max_samples;
+    p->planned.stride = p->sample_stride;
+}
+
+// consumers of a planned batch: the handle must still have the geometry the batch was planned with
+int check_geometry(ltp_planner* p)
+{
+    const auto& g = p->planned;
+    if (g.valid && (g.dof != p->dof || g.t_sample != p->t_sample || g.max_samples != p->max_samples || g.stride != p->sample_stride))
+        return fail(p, LTP_ERR_INVALID_ARGUMENT,
+                    "dof, t_sample, max_samples or sample_stride changed since the batch was planned; plan it again");
+    return LTP_OK;
+}
+
 // device-side record arrays owned for the duration of a *_host call
 struct DevRecords {
     ltp_records r{};
@@ -236,6 +286,7 @@ void ltp_destroy(ltp_planner* p)
     if (p->h_arena) (void)hipHostFree(p->h_arena);
     if (p->d_traj) (void)hipFree(p->d_traj);
     if (p->h_traj) (void)hipHostFree(p->h_traj);
+    if (p->ws_event) (void)hipEventDestroy(p->ws_event);
     delete p;
 }
 
@@ -326,6 +377,7 @@ int ltp_plan_switch_times_batch(ltp_planner* p, long long n, const ltp_queries* 
     hipStream_t s = (hipStream_t)stream;
     LTP_HIP_TRY(p, hipSetDevice(p->device));
     if (n == 0 || p->dof == 0) {
+        capture_geometry(p);
         // dof == 0: every query fails with slowest_joint == -1 (cc:39); nothing to launch per joint
         if (offsets) LTP_HIP_TRY(p, hipMemsetAsync(offsets, 0, sizeof(unsigned long long) * (size_t)(n + 1), s));
         if (n > 0) {
@@ -341,12 +393,28 @@ int ltp_plan_switch_times_batch(ltp_planner* p, long long n, const ltp_queries* 
     }
     rc = reserve(p, n);
     if (rc != LTP_OK) return rc;
+    bool capturing = false;
+    if ((rc = workspace_acquire(p, s, capturing)) != LTP_OK) return rc;
+    capture_geometry(p);
     const ltp::Limits L = dev_limits(p);
     const ltp::Queries q = to_dev(in);
     const ltp::Records r = to_dev(out);
     LTP_HIP_TRY(p, hipMemsetAsync(p->d_queue_count, 0, 16 * sizeof(unsigned long long), s));
     ltp::launch_switch_times(s, n, p->dof, p->t_sample, p->goal_check, L, q, r, p->d_lane_flags, p->d_queue, p->d_queue_count);
     ltp::launch_offsets(s, n, p->dof, p->t_sample, r, p->d_block_sums, offsets ? offsets : p->d_offsets_scratch, true, ltp::RowSpec{p->max_samples, p->sample_stride});
+    LTP_HIP_TRY(p, hipGetLastError());
+    return workspace_release(p, s, capturing);
+}
+
+int ltp_end_limit_batch(ltp_planner* p, long long first, long long count, const ltp_queries* in, const ltp_records* rec, void* stream)
+{
+    if (!p || first < 0 || count < 0 || !in || !records_complete(rec)) return fail(p, LTP_ERR_INVALID_ARGUMENT, "null argument");
+    std::lock_guard<std::mutex> g(p->mu);
+    int rc = check_config(p);
+    if (rc == LTP_OK) rc = check_geometry(p);
+    if (rc != LTP_OK) return rc;
+    LTP_HIP_TRY(p, hipSetDevice(p->device));
+    ltp::launch_end_limit((hipStream_t)stream, first, count, p->dof, p->t_sample, dev_limits(p), to_dev(in), to_dev(rec));
     LTP_HIP_TRY(p, hipGetLastError());
     return LTP_OK;
 }
@@ -360,6 +428,7 @@ static int sample_batch_any(ltp_planner* p, long long first, long long count, co
     if (((uintptr_t)out & 15u) != 0) return fail(p, LTP_ERR_INVALID_ARGUMENT, "trajectory buffer must be 16-byte aligned");
     std::lock_guard<std::mutex> g(p->mu);
     int rc = check_config(p);
+    if (rc == LTP_OK) rc = check_geometry(p);
     if (rc != LTP_OK) return rc;
     if (count == 0 || p->dof == 0) return LTP_OK;
     if ((rc = reserve(p, 0)) != LTP_OK) return rc;   // work-queue heads, resident block counts (no-op after the first call)
@@ -393,6 +462,7 @@ int ltp_envelope_batch(ltp_planner* p, long long first, long long count, const l
     if (((uintptr_t)env & 15u) != 0) return fail(p, LTP_ERR_INVALID_ARGUMENT, "envelope buffer must be 16-byte aligned");
     std::lock_guard<std::mutex> g(p->mu);
     int rc = check_config(p);
+    if (rc == LTP_OK) rc = check_geometry(p);
     if (rc != LTP_OK) return rc;
     if (count == 0 || p->dof == 0) return LTP_OK;
     if ((rc = reserve(p, 0)) != LTP_OK) return rc;
@@ -406,18 +476,19 @@ int ltp_envelope_batch(ltp_planner* p, long long first, long long count, const l
 }
 
 static int replan_states_any(ltp_planner* p, long long first, long long count, const ltp_queries* in, const ltp_records* rec,
-                             const unsigned long long* offsets, const void* tile, bool f32, const int* sample_index,
-                             int uniform_index, double* q_0, double* v_0, double* a_0, long long query_stride,
-                             long long joint_stride, void* stream)
+                             const unsigned long long* offsets, const void* tile, bool f32, unsigned long long capacity,
+                             const int* sample_index, int uniform_index, double* q_0, double* v_0, double* a_0,
+                             long long query_stride, long long joint_stride, void* stream)
 {
-    if (!p || first < 0 || count < 0 || !in || !records_complete(rec) || !offsets || !tile || !q_0 || !v_0 || !a_0)
+    if (!p || first < 0 || count < 0 || !in || !records_complete(rec) || !offsets || (!tile && capacity > 0) || !q_0 || !v_0 || !a_0)
         return fail(p, LTP_ERR_INVALID_ARGUMENT, "null argument");
     std::lock_guard<std::mutex> g(p->mu);
     int rc = check_config(p);
+    if (rc == LTP_OK) rc = check_geometry(p);
     if (rc != LTP_OK) return rc;
     LTP_HIP_TRY(p, hipSetDevice(p->device));
     ltp::launch_replan_states((hipStream_t)stream, first, count, p->dof, ltp::RowSpec{p->max_samples, p->sample_stride}, to_dev(in), to_dev(rec), offsets, tile, f32,
-                              sample_index, uniform_index, q_0, v_0, a_0, query_stride, joint_stride);
+                              capacity, sample_index, uniform_index, q_0, v_0, a_0, query_stride, joint_stride);
     LTP_HIP_TRY(p, hipGetLastError());
     return LTP_OK;
 }
@@ -430,6 +501,7 @@ int ltp_state_at_batch(ltp_planner* p, long long first, long long count, const l
         return fail(p, LTP_ERR_INVALID_ARGUMENT, "null argument");
     std::lock_guard<std::mutex> g(p->mu);
     int rc = check_config(p);
+    if (rc == LTP_OK) rc = check_geometry(p);
     if (rc != LTP_OK) return rc;
     LTP_HIP_TRY(p, hipSetDevice(p->device));
     ltp::launch_state_at((hipStream_t)stream, first, count, p->dof, p->t_sample, dev_limits(p), to_dev(in), to_dev(rec), sample_index,
@@ -439,18 +511,20 @@ int ltp_state_at_batch(ltp_planner* p, long long first, long long count, const l
 }
 
 int ltp_replan_states_batch(ltp_planner* p, long long first, long long count, const ltp_queries* in, const ltp_records* rec,
-                            const unsigned long long* offsets, const double* tile, const int* sample_index, int uniform_index,
+                            const unsigned long long* offsets, const double* tile, unsigned long long capacity,
+                            const int* sample_index, int uniform_index,
                             double* q_0, double* v_0, double* a_0, long long query_stride, long long joint_stride, void* stream)
 {
-    return replan_states_any(p, first, count, in, rec, offsets, tile, false, sample_index, uniform_index, q_0, v_0, a_0,
+    return replan_states_any(p, first, count, in, rec, offsets, tile, false, capacity, sample_index, uniform_index, q_0, v_0, a_0,
                              query_stride, joint_stride, stream);
 }
 
 int ltp_replan_states_f32_batch(ltp_planner* p, long long first, long long count, const ltp_queries* in, const ltp_records* rec,
-                                const unsigned long long* offsets, const float* tile, const int* sample_index, int uniform_index,
+                                const unsigned long long* offsets, const float* tile, unsigned long long capacity,
+                                const int* sample_index, int uniform_index,
                                 double* q_0, double* v_0, double* a_0, long long query_stride, long long joint_stride, void* stream)
 {
-    return replan_states_any(p, first, count, in, rec, offsets, tile, true, sample_index, uniform_index, q_0, v_0, a_0,
+    return replan_states_any(p, first, count, in, rec, offsets, tile, true, capacity, sample_index, uniform_index, q_0, v_0, a_0,
                              query_stride, joint_stride, stream);
 }
 
@@ -479,7 +553,8 @@ static int run_sample_to_host(ltp_planner* p, long long n, const ltp_queries& dq
     const unsigned long long total = offsets[n];
     double* d_out = nullptr;
     LTP_HIP_TRY(p, hipMalloc((void**)&d_out, sizeof(double) * (size_t)(total ? total : 2)));
-    // padding between rows is never written by the sampler: make the host copy deterministic
+    // row padding beyond a row's last 16-byte slot is never written by the sampler (the tail of that slot is
+    // zero-filled): make the host copy deterministic
     hipError_t e = hipMemset(d_out, 0, sizeof(double) * (size_t)(total ? total : 2));
     int rc = LTP_OK;
     if (e != hipSuccess) rc = hip_fail(p, e, "hipMemset");
@@ -591,7 +666,8 @@ int sample_to_host_small(ltp_planner* p, long long n, const ArenaLayout& L, cons
 {
     int rc = ensure_traj(p, (size_t)(total ? total : 2));
     if (rc != LTP_OK) return rc;
-    // padding between rows is never written by the sampler: make the host copy deterministic
+    // row padding beyond a row's last 16-byte slot is never written by the sampler (the tail of that slot is
+    // zero-filled): make the host copy deterministic
     LTP_HIP_TRY(p, hipMemsetAsync(p->d_traj, 0, sizeof(double) * (size_t)(total ? total : 2), nullptr));
     rc = ltp_sample_batch(p, 0, n, &dq, &dr, d_off, p->d_traj, total, 0, nullptr);
     if (rc != LTP_OK) return rc;
@@ -624,6 +700,7 @@ int plan_batch_host_small(ltp_planner* p, long long n, const double* const (&h_i
     const ltp_records dr = arena_records(p->d_arena, L);
     unsigned long long* d_off = (unsigned long long*)(p->d_arena + L.offsets);
     rc = ltp_plan_switch_times_batch(p, n, &dq, &dr, d_off, nullptr);
+    if (rc == LTP_OK && !packed) rc = ltp_end_limit_batch(p, 0, n, &dq, &dr, nullptr);   // cc:59-61 without the sampler
     if (rc != LTP_OK) return rc;
     LTP_HIP_TRY(p, hipMemcpyAsync(p->h_arena + L.rec_begin, p->d_arena + L.rec_begin, L.end - L.rec_begin, hipMemcpyDeviceToHost, nullptr));
     LTP_HIP_TRY(p, hipStreamSynchronize(nullptr));
@@ -697,6 +774,7 @@ int ltp_plan_batch_host(ltp_planner* p, long long n, const double* q_goal, const
     LTP_HIP_TRY(p, dr.alloc(&d_off, (size_t)n + 1));
     ltp_queries dq{d_in[0], d_in[1], d_in[2], d_in[3], dof, 1};
     rc = ltp_plan_switch_times_batch(p, n, &dq, &dr.r, d_off, nullptr);
+    if (rc == LTP_OK && !packed) rc = ltp_end_limit_batch(p, 0, n, &dq, &dr.r, nullptr);   // cc:59-61 without the sampler
     if (rc != LTP_OK) return rc;
     LTP_HIP_TRY(p, hipDeviceSynchronize());
     if (packed) {
@@ -706,6 +784,101 @@ int ltp_plan_batch_host(ltp_planner* p, long long n, const double* q_goal, const
         LTP_HIP_TRY(p, hipMemcpy(offsets, d_off, sizeof(unsigned long long) * (size_t)(n + 1), hipMemcpyDeviceToHost));
     }
     return download_records(p, n, dof, dr.r, host_records);   // after sampling: status carries END_LIMIT
+}
+
+void ltp_shard_range(long long n, int rank, int world, long long* first, long long* count)
+{
+    long long f = 0, c = 0;
+    if (n > 0 && world > 0 && rank >= 0 && rank < world) {
+        const long long base = n / world, rem = n % world;
+        c = base + (rank < rem ? 1 : 0);
+        f = rank * base + (rank < rem ? rank : rem);
+    }
+    if (first) *first = f;
+    if (count) *count = c;
+}
+
+int ltp_plan_batch_multi(ltp_planner* const* planners, int k, long long n, const double* q_goal, const double* q_0,
+                         const double* v_0, const double* a_0, const ltp_records* host_records, unsigned long long* offsets,
+                         double** packed)
+{
+    if (!planners || k < 1 || !planners[0]) return LTP_ERR_INVALID_ARGUMENT;
+    ltp_planner* p0 = planners[0];
+    if (n < 0 || (packed && !offsets)) return fail(p0, LTP_ERR_INVALID_ARGUMENT, "null argument");
+    if (packed) *packed = nullptr;
+    for (int g = 1; g < k; ++g) {
+        const ltp_planner* pg = planners[g];
+        bool same = pg && pg->dof == p0->dof && pg->t_sample == p0->t_sample && pg->max_samples == p0->max_samples &&
+                    pg->sample_stride == p0->sample_stride && pg->goal_check == p0->goal_check;
+        for (int l = 0; same && l < 5; ++l) {
+            same = (int)pg->h_lim[l].size() >= p0->dof && (int)p0->h_lim[l].size() >= p0->dof;
+            for (int j = 0; same && j < p0->dof; ++j) same = pg->h_lim[l][j] == p0->h_lim[l][j];
+        }
+        if (!same) return fail(p0, LTP_ERR_INVALID_ARGUMENT, "planner " + std::to_string(g) + " is not configured like planner 0");
+        for (int h = 0; h < g; ++h)
+            if (planners[h] == pg) return fail(p0, LTP_ERR_INVALID_ARGUMENT, "the same planner handle is listed twice");
+    }
+    const int dof = p0->dof;
+    std::vector<long long> first((size_t)k), count((size_t)k);
+    for (int g = 0; g < k; ++g) ltp_shard_range(n, g, k, &first[g], &count[g]);
+    std::vector<int> rcs((size_t)k, LTP_OK);
+    std::vector<double*> parts((size_t)k, nullptr);
+    std::vector<std::vector<unsigned long long>> offs((size_t)k);
+    auto run = [&](int g) {
+        const long long f = first[g], c = count[g];
+        const size_t fd = (size_t)f * dof;
+        ltp_records r{};
+        if (host_records) {
+            r = *host_records;
+            if (r.t_opt) r.t_opt += fd * 7;
+            if (r.t_scaled) r.t_scaled += fd * 7;
+            if (r.dir) r.dir += fd;
+            if (r.v_drive) r.v_drive += fd;
+            if (r.mod) r.mod += fd;
+            if (r.t_required) r.t_required += f;
+            if (r.slowest) r.slowest += f;
+            if (r.traj_len) r.traj_len += f;
+            if (r.status) r.status += f;
+        }
+        offs[g].assign((size_t)c + 1, 0ull);
+        rcs[g] = ltp_plan_batch_host(planners[g], c, q_goal ? q_goal + fd : nullptr, q_0 ? q_0 + fd : nullptr, v_0 ? v_0 + fd : nullptr,
+                                     a_0 ? a_0 + fd : nullptr, host_records ? &r : nullptr, offsets ? offs[g].data() : nullptr,
+                                     packed ? &parts[g] : nullptr);
+    };
+    {
+        // one host thread per shard: the _host calls are synchronous, and each thread binds its own device
+        std::vector<std::thread> th;
+        for (int g = 1; g < k; ++g) th.emplace_back(run, g);
+        run(0);
+        for (auto& t : th) t.join();
+    }
+    int rc = LTP_OK;
+    for (int g = 0; g < k && rc == LTP_OK; ++g)
+        if (rcs[g] != LTP_OK)
+            rc = fail(p0, rcs[g], "shard " + std::to_string(g) + " (device " + std::to_string(planners[g]->device) + "): " + planners[g]->err);
+    if (rc == LTP_OK && offsets) {
+        unsigned long long base = 0ull;
+        for (int g = 0; g < k; ++g) {
+            for (long long i = 0; i < count[g]; ++i) offsets[first[g] + i] = base + offs[g][(size_t)i];
+            base += offs[g][(size_t)count[g]];
+        }
+        offsets[n] = base;
+        if (packed) {
+            double* all = (double*)malloc(sizeof(double) * (size_t)(base ? base : 1));
+            if (!all) rc = fail(p0, LTP_ERR_OUT_OF_MEMORY, "malloc");
+            else {
+                unsigned long long at = 0ull;
+                for (int g = 0; g < k; ++g) {
+                    const unsigned long long sz = offs[g][(size_t)count[g]];
+                    if (sz) memcpy(all + at, parts[g], sizeof(double) * (size_t)sz);
+                    at += sz;
+                }
+                *packed = all;
+            }
+        }
+    }
+    for (int g = 0; g < k; ++g) free(parts[g]);
+    return rc;
 }
 
 int ltp_plan_envelope_host(ltp_planner* p, long long n, const double* q_goal, const double* q_0, const double* v_0,
@@ -774,6 +947,7 @@ int ltp_get_trajectory_host(ltp_planner* p, long long n, const double* t, const 
         unsigned long long* d_off = (unsigned long long*)(p->d_arena + L.offsets);
         {
             std::lock_guard<std::mutex> g(p->mu);
+            capture_geometry(p);
             ltp::launch_offsets(nullptr, n, dof, p->t_sample, to_dev(&dr), p->d_block_sums, d_off, false,
                                 ltp::RowSpec{p->max_samples, p->sample_stride});
             LTP_HIP_TRY(p, hipGetLastError());
@@ -809,6 +983,7 @@ int ltp_get_trajectory_host(ltp_planner* p, long long n, const double* t, const 
     ltp_queries dq{d_in[0], d_in[0], d_in[1], d_in[2], dof, 1};   // q_goal is not used by the sampler
     if (n > 0 && dof > 0) {
         std::lock_guard<std::mutex> g(p->mu);
+        capture_geometry(p);
         ltp::launch_offsets(nullptr, n, dof, p->t_sample, to_dev(&dr.r), p->d_block_sums, d_off, false, ltp::RowSpec{p->max_samples, p->sample_stride});
         LTP_HIP_TRY(p, hipGetLastError());
     }

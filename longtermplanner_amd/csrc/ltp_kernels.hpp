@@ -89,8 +89,10 @@ void launch_envelope(hipStream_t s, long long first, long long count, int dof, d
                      Records rec, int window, int n_windows, double* env, unsigned long long* next_item /* zeroed on the same stream */,
                      int resident_blocks, unsigned long long* probe = nullptr /* diagnostic: 16 stamps per item */);
 void launch_replan_states(hipStream_t s, long long first, long long count, int dof, RowSpec rows, Queries in, Records rec,
-                          const unsigned long long* offsets, const void* tile, bool f32, const int* sample_index, int uniform_index,
+                          const unsigned long long* offsets, const void* tile, bool f32, unsigned long long capacity,
+                          const int* sample_index, int uniform_index,
                           double* q_0, double* v_0, double* a_0, long long sq, long long sj);
+void launch_end_limit(hipStream_t s, long long first, long long count, int dof, double t_sample, Limits lim, Queries in, Records rec);
 void launch_state_at(hipStream_t s, long long first, long long count, int dof, double t_sample, Limits lim, Queries in,
                      Records rec, const int* sample_index, int uniform_index, double* q_0, double* v_0, double* a_0,
                      long long sq, long long sj);

@@ -675,7 +675,7 @@ k_envelope(long long first, long long count, int dof, double t_sample, Limits li
 template <typename T>
 __global__ void __launch_bounds__(256)
 k_replan_states(long long first, long long count, int dof, RowSpec rows, Queries in, Records rec,
-                const unsigned long long* __restrict__ offsets, const T* __restrict__ tile,
+                const unsigned long long* __restrict__ offsets, const T* __restrict__ tile, unsigned long long capacity,
                 const int* __restrict__ sample_index, int uniform_index,
                 double* __restrict__ q_0, double* __restrict__ v_0, double* __restrict__ a_0, long long sq, long long sj)
 {
@@ -686,7 +686,11 @@ k_replan_states(long long first, long long count, int dof, RowSpec rows, Queries
     const long long p = first + local;
     const long long dst = local * sq + (long long)j * sj;
     const int slen = stored_len(rec.traj_len[p], rows);
-    if (slen <= 0) {   // plan was not sampled: carry its start state over unchanged
+    const unsigned long long stride = ((unsigned long long)slen + (kRowAlign - 1)) / kRowAlign * kRowAlign;
+    const unsigned long long rel = offsets[p] - offsets[first];
+    // not sampled: no trajectory, flagged by the sampler as not fitting its tile, or (the same test k_sample applies)
+    // rows that would end beyond the tile -> carry the start state over unchanged, read nothing outside the tile
+    if (slen <= 0 || (rec.status[p] & kStatusOverflow) || rel + 4ull * dof * stride > capacity) {
         const long long ix = p * in.sq + (long long)j * in.sj;
         q_0[dst] = in.q_0[ix];
         v_0[dst] = in.v_0[ix];
@@ -695,8 +699,7 @@ k_replan_states(long long first, long long count, int dof, RowSpec rows, Queries
     }
     int k = sample_index ? sample_index[local] : uniform_index;
     k = k < 0 ? 0 : (k >= slen ? slen - 1 : k);   // beyond the stored samples: the last stored state
-    const unsigned long long stride = ((unsigned long long)slen + (kRowAlign - 1)) / kRowAlign * kRowAlign;
-    const T* row = tile + (offsets[p] - offsets[first]) + (unsigned long long)j * stride + k;
+    const T* row = tile + rel + (unsigned long long)j * stride + k;
     const unsigned long long arr = (unsigned long long)dof * stride;
     q_0[dst] = (double)row[0];
     v_0[dst] = (double)row[arr];
@@ -789,6 +792,25 @@ k_state_at(long long first, long long count, int dof, double t_sample, Limits li
     a_0[dst] = a;
 }
 
+// planTrajectory's end-limit check (cc:59-61) without sampled rows: lane = (plan, joint) walks its runs to the last
+// trajectory sample — the bits k_sample would have stored at traj_len-1, which is also what build_run_tables step (5)
+// tests — and flags the plan if that position lies outside the joint range.
+__global__ void __launch_bounds__(256)
+k_end_limit(long long first, long long count, int dof, double t_sample, Limits lim, Queries in, Records rec)
+{
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= count * dof) return;
+    const long long local = idx / dof;
+    const int j = (int)(idx - local * dof);
+    const long long p = first + local;
+    const int len = rec.traj_len[p];
+    if (len <= 0) return;                                     // failed before sampling: the reference never gets to cc:59
+    const long long ix = p * in.sq + (long long)j * in.sj;
+    double q = in.q_0[ix], v = in.v_0[ix], a = in.a_0[ix];
+    for_each_run(lim, rec, p * dof + j, j, len, t_sample, q, v, a, [](int, int, const RunCoef&) { return false; });
+    if (q < lim.q_min[j] || q > lim.q_max[j]) atomicOr(&rec.status[p], kStatusEndLimit);
+}
+
 // ---------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------
@@ -856,7 +878,8 @@ void launch_envelope(hipStream_t s, long long first, long long count, int dof, d
 }
 
 void launch_replan_states(hipStream_t s, long long first, long long count, int dof, RowSpec rows, Queries in, Records rec,
-                          const unsigned long long* offsets, const void* tile, bool f32, const int* sample_index, int uniform_index,
+                          const unsigned long long* offsets, const void* tile, bool f32, unsigned long long capacity,
+                          const int* sample_index, int uniform_index,
                           double* q_0, double* v_0, double* a_0, long long sq, long long sj)
 {
     if (count <= 0 || dof <= 0) return;
@@ -864,10 +887,17 @@ void launch_replan_states(hipStream_t s, long long first, long long count, int d
     const dim3 grid((unsigned)((total + 255) / 256)), block(256);
     if (f32)
         hipLaunchKernelGGL(k_replan_states<float>, grid, block, 0, s, first, count, dof, rows, in, rec, offsets,
-                           (const float*)tile, sample_index, uniform_index, q_0, v_0, a_0, sq, sj);
+                           (const float*)tile, capacity, sample_index, uniform_index, q_0, v_0, a_0, sq, sj);
     else
         hipLaunchKernelGGL(k_replan_states<double>, grid, block, 0, s, first, count, dof, rows, in, rec, offsets,
-                           (const double*)tile, sample_index, uniform_index, q_0, v_0, a_0, sq, sj);
+                           (const double*)tile, capacity, sample_index, uniform_index, q_0, v_0, a_0, sq, sj);
+}
+
+void launch_end_limit(hipStream_t s, long long first, long long count, int dof, double t_sample, Limits lim, Queries in, Records rec)
+{
+    if (count <= 0 || dof <= 0) return;
+    const long long total = count * dof;
+    hipLaunchKernelGGL(k_end_limit, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, first, count, dof, t_sample, lim, in, rec);
 }
 
 void launch_state_at(hipStream_t s, long long first, long long count, int dof, double t_sample, Limits lim, Queries in,

@@ -228,6 +228,32 @@ class LongTermPlanner:
         self._lib.ltp_free_host(packed)
         return dict(traj_len=traj_len, status=status, offsets=offsets, packed=out)
 
+    @staticmethod
+    def planBatchSharded(planners, q_goal, q_0, v_0, a_0, sample=True):
+        """NEW: one process, several devices. `planners`: identically configured LongTermPlanner objects,
+        normally one per device; shard g plans the contiguous query range shard_range(n, g, len(planners)) on its own
+        device and host thread (ltp_plan_batch_multi); the result dict is that of ONE planBatchHost call over all queries."""
+        lib = planners[0]._lib
+        D = planners[0].dof
+        ins = [np.ascontiguousarray(np.asarray(x, dtype=np.float64).reshape(-1, D)) for x in (q_goal, q_0, v_0, a_0)]
+        n = ins[0].shape[0]
+        r = dict(t_opt=np.zeros((n, D, 7)), t_scaled=np.zeros((n, D, 7)), dir=np.zeros((n, D)), v_drive=np.zeros((n, D)),
+                 mod=np.zeros((n, D), dtype=np.int8), t_required=np.zeros(n), slowest=np.zeros(n, dtype=np.int32),
+                 traj_len=np.zeros(n, dtype=np.int32), status=np.zeros(n, dtype=np.int32))
+        rec = _abi.Records(*[r[k].ctypes.data for k in ("t_opt", "t_scaled", "dir", "v_drive", "mod", "t_required", "slowest", "traj_len", "status")])
+        offsets = np.zeros(n + 1, dtype=np.uint64)
+        packed = _dp()
+        handles = (C.c_void_p * len(planners))(*[pl._h for pl in planners])
+        rc = lib.ltp_plan_batch_multi(handles, len(planners), n, *[_ptr(x) for x in ins], C.byref(rec),
+                                      offsets.ctypes.data_as(C.POINTER(C.c_ulonglong)), C.byref(packed) if sample else None)
+        planners[0]._check(rc)
+        r["offsets"] = offsets
+        if sample:
+            total = int(offsets[n])
+            r["packed"] = np.ctypeslib.as_array(packed, shape=(max(total, 1),))[:total].copy()
+            lib.ltp_free_host(packed)
+        return r
+
     # ---- batched device calls (torch CUDA tensors, asynchronous on torch's current stream) ----
     def _stream(self):
         import torch
@@ -251,8 +277,11 @@ class LongTermPlanner:
         self._check(self._lib.ltp_generate_queries_batch(self._h, n, seed, first_query, *[x.data_ptr() for x in out], sq, sj, self._stream()))
         return out
 
-    def planSwitchTimesBatch(self, q_goal, q_0, v_0, a_0, layout="query_major", batch: Optional[DeviceBatch] = None):
-        """Stages 1-3 + traj_len + packed offsets for a device batch (ltp_plan_switch_times_batch)."""
+    def planSwitchTimesBatch(self, q_goal, q_0, v_0, a_0, layout="query_major", batch: Optional[DeviceBatch] = None,
+                             end_limit=False):
+        """Stages 1-3 + traj_len + packed offsets for a device batch (ltp_plan_switch_times_batch). end_limit=True also
+        runs planTrajectory's end-limit check (cc:59-61) without sampling (ltp_end_limit_batch), so that status == 0 is
+        exactly planTrajectory's bool; sampleBatch / envelopeBatch apply that check themselves."""
         n, q = self._queries(q_goal, q_0, v_0, a_0, layout)
         if batch is None or batch.n != n or batch.dof != self.dof:
             batch = DeviceBatch(n, self.dof, q_0.device)
@@ -260,7 +289,14 @@ class LongTermPlanner:
         batch.inputs = (q_goal, q_0, v_0, a_0)   # the sampler reads q_0/v_0/a_0 again: keep the tensors alive with the batch
         rec = batch.c_records()
         self._check(self._lib.ltp_plan_switch_times_batch(self._h, n, C.byref(q), C.byref(rec), batch.offsets.data_ptr(), self._stream()))
+        if end_limit:
+            self.endLimit(batch, 0, n)
         return batch
+
+    def endLimit(self, batch: DeviceBatch, first, count):
+        """planTrajectory's end-limit check (cc:59-61) for plans [first, first+count) without sampling (ltp_end_limit_batch)."""
+        rec = batch.c_records()
+        self._check(self._lib.ltp_end_limit_batch(self._h, first, count, C.byref(batch.queries), C.byref(rec), self._stream()))
 
     def sampleBatch(self, batch: DeviceBatch, first, count, out, streaming=True, dry=False, spread=0):
         """getTrajectory for plans [first, first+count) into the float64 CUDA tensor `out` (ltp_sample_batch).
@@ -296,7 +332,7 @@ class LongTermPlanner:
         per_plan = None if isinstance(sample_index, int) else sample_index
         fn = self._lib.ltp_replan_states_f32_batch if tile.dtype == torch.float32 else self._lib.ltp_replan_states_batch
         self._check(fn(self._h, first, count, C.byref(batch.queries), C.byref(rec), batch.offsets.data_ptr(),
-                       tile.data_ptr(), per_plan.data_ptr() if per_plan is not None else None,
+                       tile.data_ptr(), tile.numel(), per_plan.data_ptr() if per_plan is not None else None,
                        sample_index if per_plan is None else 0, *[x.data_ptr() for x in out], sq, sj, self._stream()))
         return out
 

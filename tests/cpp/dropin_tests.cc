@@ -8,7 +8,9 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstring>
 #include <iostream>
+#include <thread>
 #include <vector>
 
 #include "long_term_planner/long_term_planner.h"
@@ -225,6 +227,64 @@ static void testApiSurface()
   EXPECT_TRUE(bc.stored[0] == b.length[0] && bc.status[1] == LTP_STATUS_END_LIMIT);
 }
 
+// Two threads issue the FIRST call on one object at the same time (the reference allows concurrent planTrajectory on
+// one object, SURVEY §8(b) "Threading"): the lazily created device handle must be created once, and both get results.
+static void testConcurrentFirstCall()
+{
+  for (int round = 0; round < 4; ++round) {
+    LongTermPlannerExposed ltp(6, 0.001, std::vector<double>(6, -3.1), std::vector<double>(6, 3.1), std::vector<double>(6, 10.0),
+                               {2, 2, 2, 4, 4, 4}, {4, 4, 4, 4, 4, 2});
+    ltpn::Trajectory t[2];
+    bool ok[2] = {false, false};
+    std::string err[2];
+    auto work = [&](int w) {
+      try {
+        ok[w] = ltp.planTrajectory({1, -1, 0.5, 2, -2, 0}, {0, 0, 0, 0, 0, 0}, {0.1, 0, -0.1, 0, 0.2, 0}, {0, 0.1, 0, -0.1, 0, 0}, t[w]);
+      } catch (const std::exception& e) { err[w] = e.what(); }
+    };
+    std::thread a(work, 0), b(work, 1);
+    a.join(); b.join();
+    EXPECT_TRUE(err[0].empty() && err[1].empty());
+    EXPECT_TRUE(ok[0] && ok[1] && t[0].length == t[1].length && t[0].length > 1);
+    if (ok[0] && ok[1] && t[0].length == t[1].length)
+      for (int i = 0; i < 6; ++i) EXPECT_TRUE(std::memcmp(t[0].q[i].data(), t[1].q[i].data(), sizeof(double) * t[0].length) == 0);
+  }
+}
+
+// NEW: one process, one handle per shard; here three virtual shards on device 0 (and an odd batch size, so the
+// shards differ in length). Everything must have the bits of the unsharded call.
+static void testShardedBatch()
+{
+  LongTermPlannerExposed ltp(6, 0.004, std::vector<double>(6, -3.1), std::vector<double>(6, 3.1), std::vector<double>(6, 1.0),
+                             {2, 2, 2, 4, 4, 4}, {15, 15, 15, 15, 15, 8});
+  const long long n = 101;
+  std::vector<double> qg(n * 6), q0(n * 6), v0(n * 6), a0(n * 6);
+  unsigned long long z = 88172645463325252ull;
+  auto u = [&]() { z ^= z << 13; z ^= z >> 7; z ^= z << 17; return (double)(z >> 11) * (1.0 / 9007199254740992.0); };
+  for (long long i = 0; i < n * 6; ++i) { qg[i] = -3.0 + 6.0 * u(); q0[i] = -3.0 + 6.0 * u(); v0[i] = -0.5 + u(); a0[i] = -0.5 + u(); }
+  q0[5 * 6 + 2] = 7.0;          // one invalid query (checkInputs false) inside shard 0
+  ltpn::BatchTrajectory one, many, none;
+  const long long ok1 = ltp.planTrajectoryBatch(n, qg.data(), q0.data(), v0.data(), a0.data(), one);
+  const long long ok3 = ltp.planTrajectoryBatchSharded(n, qg.data(), q0.data(), v0.data(), a0.data(), many, {0, 0, 0});
+  EXPECT_TRUE(ok1 == ok3 && ok1 > 0 && ok1 < n);
+  EXPECT_TRUE(one.status == many.status && one.length == many.length && one.stored == many.stored && one.slowest == many.slowest);
+  EXPECT_TRUE(one.offsets == many.offsets && one.mod == many.mod);
+  auto same = [](const std::vector<double>& a, const std::vector<double>& b) {
+    return a.size() == b.size() && (a.empty() || std::memcmp(a.data(), b.data(), sizeof(double) * a.size()) == 0);
+  };
+  EXPECT_TRUE(same(one.t_opt, many.t_opt) && same(one.t_scaled, many.t_scaled) && same(one.dir, many.dir));
+  EXPECT_TRUE(same(one.v_drive, many.v_drive) && same(one.t_required, many.t_required));
+  EXPECT_TRUE(same(one.packed, many.packed) && !one.packed.empty());
+  // switching times only: status still is planTrajectory's verdict (end-limit check without sampling, cc:59-61)
+  const long long ok0 = ltp.planTrajectoryBatchSharded(n, qg.data(), q0.data(), v0.data(), a0.data(), none, {0, 0}, false);
+  EXPECT_TRUE(ok0 == ok1 && none.status == one.status && none.packed.empty() && none.offsets == one.offsets);
+  // more shards than queries: the tail shards are empty
+  ltpn::BatchTrajectory tiny, tiny1;
+  ltp.planTrajectoryBatchSharded(2, qg.data(), q0.data(), v0.data(), a0.data(), tiny, {0, 0, 0, 0});
+  ltp.planTrajectoryBatch(2, qg.data(), q0.data(), v0.data(), a0.data(), tiny1);
+  EXPECT_TRUE(tiny.status == tiny1.status && same(tiny.packed, tiny1.packed) && tiny.offsets == tiny1.offsets);
+}
+
 int main()
 {
   try {
@@ -234,6 +294,8 @@ int main()
     testTimeScaling();
     testGridOneJointCoarse();
     testApiSurface();
+    testConcurrentFirstCall();
+    testShardedBatch();
   } catch (const std::exception& e) {
     std::printf("EXCEPTION: %s\n", e.what());
     return 2;

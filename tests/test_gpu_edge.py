@@ -564,3 +564,122 @@ def test_envelope_through_the_host_pointer_api(amd, ref7):
     assert np.array_equal(rec["status"], b.status.cpu().numpy()) and np.array_equal(rec["traj_len"], b.traj_len.cpu().numpy())
     assert np.array_equal(rec["t_scaled"], b.t_scaled.cpu().numpy(), equal_nan=True)
     assert rec["status"][9] & amd.STATUS_INVALID_INPUT and np.all(np.isnan(env[9]))
+
+
+def test_replan_states_skips_plans_the_sampler_skipped(amd, ref7):
+    """plans flagged LTP_STATUS_OVERFLOW (or whose rows would end beyond the tile) were never written, so the
+    receding-horizon gather must carry their start state over and must not read outside the tile."""
+    import torch
+    D, lim, ltp, _ = ref7
+    n = 400
+    qm = ltp.generateQueries(n, seed=21)
+    b = ltp.planSwitchTimesBatch(*qm)
+    torch.cuda.synchronize()
+    off = b.offsets.cpu().numpy().view(np.uint64)
+    cap = int(off[150] - off[0]) + 8                     # deliberately small tile: plans >= 150 do not fit
+    big = torch.full((int(off[-1]) + 64,), float("nan"), dtype=torch.float64, device="cuda")
+    tile = big[:cap]
+    ltp.sampleBatch(b, 0, n, tile)
+    st = b.status.cpu().numpy()
+    lens = b.traj_len.cpu().numpy()
+    over = (st & amd.STATUS_OVERFLOW) != 0
+    assert over[150:][lens[150:] > 0].all() and not over[:150].any()
+    q1, v1, a1 = ltp.replanStates(b, 0, n, tile, 50)
+    torch.cuda.synchronize()
+    for p in range(n):
+        if over[p] or lens[p] <= 0:
+            assert torch.equal(q1[p], qm[1][p]) and torch.equal(v1[p], qm[2][p]) and torch.equal(a1[p], qm[3][p]), p
+        else:
+            q, v, a, _ = amd.unpack_trajectory(tile.cpu().numpy(), int(off[p] - off[0]), D, int(lens[p]))
+            kk = min(50, int(lens[p]) - 1)
+            assert np.array_equal(q1[p].cpu().numpy(), q[:, kk]) and np.array_equal(a1[p].cpu().numpy(), a[:, kk])
+    assert not torch.isnan(q1).any()                     # nothing came from beyond the tile (NaN there)
+    # the capacity test alone protects too: clear the flag, the gather still refuses rows beyond `capacity`
+    b.status &= ~amd.STATUS_OVERFLOW
+    q2, _, _ = ltp.replanStates(b, 0, n, tile, 50)
+    torch.cuda.synchronize()
+    assert torch.equal(q1, q2)
+
+
+def test_one_handle_on_two_streams_serialises_on_its_workspace(amd, ref7):
+    """the compaction queues / lane flags / scan scratch are per handle. Two streams that use ONE handle (a
+    double-buffered pipeline) must get the results of serial runs: the library orders them with an event."""
+    import torch
+    D, lim, _, _ = ref7
+    ltp = amd.LongTermPlanner(D, 0.001, device=0, **lim)       # reference limits: 6.5 % of lanes go through queue A
+    streams = [torch.cuda.Stream() for _ in range(2)]
+    n = 200000
+    queries = [ltp.generateQueries(n, seed=300 + i) for i in range(2)]
+    serial = []
+    for i in range(2):
+        b = ltp.planSwitchTimesBatch(*queries[i])
+        torch.cuda.synchronize()
+        serial.append({k: getattr(b, k).clone() for k in ("t_opt", "t_scaled", "v_drive", "mod", "traj_len", "status", "offsets")})
+    batches = [None, None]
+    for rep in range(6):
+        for i in range(2):
+            with torch.cuda.stream(streams[i]):
+                batches[i] = ltp.planSwitchTimesBatch(*queries[i], batch=batches[i])
+    torch.cuda.synchronize()
+    for i in range(2):
+        for k, want in serial[i].items():
+            assert torch.equal(getattr(batches[i], k).nan_to_num(7.0) if want.is_floating_point() else getattr(batches[i], k),
+                               want.nan_to_num(7.0) if want.is_floating_point() else want), (i, k)
+
+
+def test_end_limit_verdict_without_sampling(amd, ref7, oracle_mod):
+    """status == 0 must mean planTrajectory's `true` also when nothing is sampled (cc:59-61 needs the last sample)."""
+    import torch
+    D, lim, _, _ = ref7
+    ltp4 = amd.LongTermPlanner(D, 0.004, device=0, **lim)      # 4 ms: ~0.5 % of random plans overshoot a joint limit
+    orc4 = oracle_mod.Oracle(D, 0.004, **lim)
+    n = 20000
+    qg, q0, v0, a0 = amd.generate_queries(n, lim, seed=77)
+    o = orc4.plan_batch(qg, q0, v0, a0, sample=True)
+    want_true = o["status"] == 1                               # oracle: 1 = true, 2 = end-limit false, 0 = early false
+    assert (o["status"] == 2).sum() >= 3
+    r0 = ltp4.planBatchHost(qg, q0, v0, a0, sample=False)
+    assert np.array_equal(r0["status"] == 0, want_true)
+    assert np.array_equal((r0["status"] & amd.STATUS_END_LIMIT) != 0, o["status"] == 2)
+    # device path: plan alone carries the pre-sampling verdict, end_limit=True the full one, the sampler the same bits
+    qm = [torch.from_numpy(x).cuda() for x in (qg, q0, v0, a0)]
+    b = ltp4.planSwitchTimesBatch(*qm)
+    torch.cuda.synchronize()
+    assert not (b.status.cpu().numpy() & amd.STATUS_END_LIMIT).any()
+    b1 = ltp4.planSwitchTimesBatch(*qm, end_limit=True)
+    torch.cuda.synchronize()
+    st1 = b1.status.cpu().numpy().copy()
+    tile = torch.zeros(int(b.offsets[-1].item()), dtype=torch.float64, device="cuda")
+    ltp4.sampleBatch(b, 0, n, tile)
+    torch.cuda.synchronize()
+    assert np.array_equal(st1, b.status.cpu().numpy()) and np.array_equal(st1, r0["status"])
+    # sub-range form
+    b2 = ltp4.planSwitchTimesBatch(*qm)
+    ltp4.endLimit(b2, 5000, 10000)
+    torch.cuda.synchronize()
+    st2 = b2.status.cpu().numpy()
+    assert np.array_equal(st2[5000:15000], st1[5000:15000]) and not (st2[:5000] & amd.STATUS_END_LIMIT).any()
+
+
+def test_changed_geometry_between_plan_and_sample_is_rejected(amd, ref7):
+    """ADVICE r1: dof / t_sample / max_samples / sample_stride define a planned batch's records, offsets and row strides;
+    changing one of them on the handle before a consumer call is an error, not overlapping rows."""
+    import torch
+    D, lim, _, _ = ref7
+    ltp = amd.LongTermPlanner(D, 0.001, device=0, **lim)
+    qm = ltp.generateQueries(300, seed=2)
+    b = ltp.planSwitchTimesBatch(*qm)
+    tile = torch.zeros(int(b.offsets[-1].item()), dtype=torch.float64, device="cuda")
+    for change, undo in ((lambda: ltp.setMaxSamples(64), lambda: ltp.setMaxSamples(0)),
+                         (lambda: ltp.setSampleStride(2), lambda: ltp.setSampleStride(1)),
+                         (lambda: ltp.setSampleTime(0.002), lambda: ltp.setSampleTime(0.001)),
+                         (lambda: ltp.setDoF(D - 1), lambda: ltp.setDoF(D))):
+        change()
+        for call in (lambda: ltp.sampleBatch(b, 0, 300, tile), lambda: ltp.envelopeBatch(b, 0, 300, 32, 8),
+                     lambda: ltp.replanStates(b, 0, 300, tile, 3), lambda: ltp.stateAt(b, 0, 300, 3), lambda: ltp.endLimit(b, 0, 300)):
+            with pytest.raises(amd.LtpError) as e:
+                call()
+            assert e.value.code == 1 and "plan it again" in str(e.value)
+        undo()
+        ltp.sampleBatch(b, 0, 300, tile)                      # restored: accepted again
+    torch.cuda.synchronize()
