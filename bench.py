@@ -437,7 +437,7 @@ def main():
             gib = gib / share
             while True:
                 try:
-                    tile_state["t"] = torch.empty(int(gib * (1 << 30)), dtype=torch.uint8, device=dev)
+                    tile_state["t"] = torch.empty(int(gib * (1 << 30)) // 4096 * 4096, dtype=torch.uint8, device=dev)
                     break
                 except torch.OutOfMemoryError:
                     if gib <= 1:
