@@ -83,8 +83,10 @@ long ltpo_kat_grid_one_joint(long *n_checks, double *worst_err)
     return fails;
 }
 
-/* case_hist[0..8]: how often timeScaling ended in "none" (0) or case 1..8 */
-long ltpo_kat_grid_time_scaling(long *n_checks, double *worst_err, long *case_hist)
+/* case_hist[0..8]: how often timeScaling ended in "none" (0) or case 1..8; mod_hist[0..1]: the calls accepted in case 1 or 2
+ * split by the mod_jerk_profile flag they return (standard / modified profile); *sum_err / *n_err: sum and count of the goal
+ * errors |q_end - q_goal| (README.md:128-136 quotes their mean and maximum) */
+long ltpo_kat_grid_time_scaling_stats(long *n_checks, double *worst_err, long *case_hist, long *mod_hist, double *sum_err, long *n_err)
 {
     const double eps = 1e-6, tol_q = 0.02, tol_t = 0.1, step = 0.1;
     const double q_min[1] = {-6}, q_max[1] = {7}, v_max[1] = {1.0}, a_max[1] = {2.0}, j_max[1] = {15.0};
@@ -96,6 +98,9 @@ long ltpo_kat_grid_time_scaling(long *n_checks, double *worst_err, long *case_hi
     *n_checks = 0;
     *worst_err = 0;
     for (c = 0; c < 9; c++) case_hist[c] = 0;
+    mod_hist[0] = mod_hist[1] = 0;
+    *sum_err = 0;
+    *n_err = 0;
     for (i = (int)q_min[0] / step; i <= (int)q_max[0] / step; i++) {
         double q_goal = i * step;
         for (j = (int)-v_max[0] / step; j < (int)v_max[0] / step; j++) {
@@ -126,12 +131,15 @@ long ltpo_kat_grid_time_scaling(long *n_checks, double *worst_err, long *case_hi
                     if (t_ltp[6] < tol_q) break;
                     okts = ltpo_time_scaling_ex(&P, 0, q_goal, q_0, v_0, a_0, dir, t_ltp[6] + incr[l], t_scaled, &v_drive, &mod2, &cs);
                     case_hist[cs]++;
+                    if (cs == 1 || cs == 2) mod_hist[mod2 ? 1 : 0]++;
                     if (!okts) for (m = 0; m < 7; m++) t_scaled[m] = t_ltp[m];
                     if (!final_state(&P, t_scaled, dir, mod2, q_0, v_0, a_0, v_drive, &qe, &ve, &ae)) { fails++; continue; }
                     err = fabs(qe - q_goal);
                     (*n_checks)++;
                     if (!(err <= tol_q)) fails++;
                     if (err > *worst_err) *worst_err = err;
+                    *sum_err += err;
+                    (*n_err)++;
                     if (fabs(t_ltp[6] + incr[l] - t_scaled[6]) > tol_t) {
                         (*n_checks) += 3;
                         if (!(fabs(ve) <= tol_q)) fails++;
@@ -143,4 +151,11 @@ long ltpo_kat_grid_time_scaling(long *n_checks, double *worst_err, long *case_hi
         }
     }
     return fails;
+}
+
+long ltpo_kat_grid_time_scaling(long *n_checks, double *worst_err, long *case_hist)
+{
+    long mod_hist[2], n_err;
+    double sum_err;
+    return ltpo_kat_grid_time_scaling_stats(n_checks, worst_err, case_hist, mod_hist, &sum_err, &n_err);
 }

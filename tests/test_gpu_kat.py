@@ -80,6 +80,51 @@ def test_plan_trajectory_endpoint_kat(amd, oracle_mod, kat, name):
             assert np.max(np.abs(np.asarray(got) - ref)) <= TOL
 
 
+def test_matlab_twin_full_tables_on_the_device(amd, kat):
+    """tests/unittests/testOptSwitchTimes.m:36 / testTimeScaling.m:44 compare ALL seven switching times (the C++ tests only the
+    first three): the HIP path against the stricter form, without any oracle code."""
+    m = kat["matlab_twins"]
+    for name in ("opt_switch_times", "time_scaling"):
+        mm = m[name]
+        t_all = np.cumsum(np.array(mm["t_rel_rows"]).T, axis=1)
+        for i in range(len(mm["q_goal"])):
+            ltp = amd.LongTermPlanner(1, 0.001, [-3.1], [3.1], [mm["v_max"][i]], [mm["a_max"][i]], [mm["j_max"][i]], device=0)
+            for sgn in ((1, -1) if i else (1,)):
+                if name == "opt_switch_times":
+                    ok, t, _, _ = ltp.optSwitchTimes(0, sgn * mm["q_goal"][i], sgn * mm["q_0"], sgn * mm["v_0"][i], sgn * mm["a_0"][i], mm["v_max"][i])
+                else:
+                    ok, t, _, _, _ = ltp.timeScaling(0, sgn * mm["q_goal"][i], sgn * mm["q_0"], sgn * mm["v_0"][i], sgn * mm["a_0"][i],
+                                                     sgn * mm["dir"][i], t_all[i, -1])
+                assert ok and np.all(np.abs(t - t_all[i]) < mm["eps"]), (name, i, sgn, t)
+
+
+def test_six_dof_fixture_multi_joint_plan(amd, oracle_mod, kat):
+    """The reference's unused 6-DoF fixture (long_term_planner_fixture.h:97-109) as a multi-DoF planTrajectory case: the
+    slowest-joint reduction and time scaling with dof > 1 (cc:31-55) on the device vs the oracle, and the end-point checks."""
+    f = kat["fixture_6dof"]
+    lim = {k: f[k] for k in ("q_min", "q_max", "v_max", "a_max", "j_max")}
+    ltp = amd.LongTermPlanner(6, f["t_sample"], device=0, **lim)
+    orc = oracle_mod.Oracle(6, f["t_sample"], **lim)
+    rng = np.random.default_rng(6)
+    n = 40
+    qg = rng.uniform(-3.0, 3.0, (n, 6)); q0 = rng.uniform(-3.0, 3.0, (n, 6))
+    v0 = rng.uniform(-1.0, 1.0, (n, 6)); a0 = rng.uniform(-1.0, 1.0, (n, 6))
+    r = ltp.planBatchHost(qg, q0, v0, a0, sample=True)
+    assert np.all(r["status"] == 0)
+    for p in range(n):
+        o = orc.plan_trajectory(qg[p], q0[p], v0[p], a0[p])
+        assert o["status"] == 1 and o["length"] == r["traj_len"][p] and o["slowest"] == r["slowest"][p]
+        assert np.array_equal(o["mod"], r["mod"][p]) and np.array_equal(o["dir"], r["dir"][p])
+        assert np.max(np.abs(o["t_scaled"] - r["t_scaled"][p])) <= TOL and np.max(np.abs(o["v_drive"] - r["v_drive"][p])) <= TOL
+        got = amd.unpack_trajectory(r["packed"], int(r["offsets"][p]), 6, int(r["traj_len"][p]))
+        for g, w in zip(got, (o["q"], o["v"], o["a"], o["j"])):
+            assert np.max(np.abs(g - w)) <= TOL
+        assert np.all(np.abs(got[0][:, -1] - qg[p]) <= 1e-2) and np.all(got[1][:, -1] == 0.0) and np.all(got[2][:, -1] == 0.0)
+    # the same through the single-call API, as the reference's end-point tests call it
+    traj = amd.Trajectory()
+    assert ltp.planTrajectory(qg[0], q0[0], v0[0], a0[0], traj) is True and traj.dof == 6 and traj.length == r["traj_len"][0]
+
+
 def _grid_inputs(kat_grid):
     """The (q_goal, v_0, a_0) grid of gridTestOneJoint (long_term_planner_tests.cc:279-298)."""
     g = kat_grid

@@ -117,17 +117,108 @@ def test_grid_one_joint(oracle_mod):
     assert fails == 0 and n.value > 50000 and worst.value < 0.02
 
 
-def test_grid_time_scaling(oracle_mod):
+def test_grid_time_scaling(oracle_mod, kat):
     # long_term_planner_tests.cc:325-407; 594 984 timeScaling calls, as SURVEY.md App. B counted
     L = oracle_mod.lib()
-    L.ltpo_kat_grid_time_scaling.restype = C.c_long
-    n = C.c_long(); worst = C.c_double(); hist = (C.c_long * 9)()
-    fails = L.ltpo_kat_grid_time_scaling(C.byref(n), C.byref(worst), hist)
+    L.ltpo_kat_grid_time_scaling_stats.restype = C.c_long
+    n = C.c_long(); worst = C.c_double(); hist = (C.c_long * 9)(); mod = (C.c_long * 2)(); sum_err = C.c_double(); n_err = C.c_long()
+    fails = L.ltpo_kat_grid_time_scaling_stats(C.byref(n), C.byref(worst), hist, mod, C.byref(sum_err), C.byref(n_err))
     h = list(hist)
+    g = kat["grid_time_scaling_histogram"]
     assert fails == 0 and worst.value < 0.02
-    assert sum(h) == 594984
-    # accepted-case histogram of the compiled reference TU: c3 422, c4 60, c5 13, c6 0, c7 4, c8 0, none 351
-    assert h[3:] == [422, 60, 13, 0, 4, 0] and h[0] == 351 and h[1] + h[2] == 594134
+    assert sum(h) == g["calls"] == 594984
+    # accepted-case histogram of the compiled reference TU, reproduced exactly: the polynomial cases ...
+    assert h[3:] == [g["c3"], g["c4"], g["c5"], g["c6"], g["c7"], g["c8"]] and h[0] == g["none"]
+    # ... and the closed-form acceptances split by the jerk profile they end in (the survey's "c1 539 718 / c2 54 416")
+    assert list(mod) == [g["standard_profile"], g["modified_profile"]] == [539718, 54416]
+    assert h[1] + h[2] == mod[0] + mod[1]
+    # README.md:128-136: "average absolute error at the goal position 0.003 rad, worst case below 0.015 rad" on this grid
+    # (the README figures come from the MATLAB twin, whose sampler differs in the last samples: App. C; the C++ restatement
+    # must be at least as good as the published figures)
+    acc = kat["readme_accuracy"]
+    mean = sum_err.value / n_err.value
+    assert n_err.value == 594984
+    assert worst.value < acc["worst_goal_error_below"]
+    assert 0.5 * acc["mean_goal_error"] < mean <= acc["mean_goal_error"], mean
+    # README.md:117-120: the fallback to the optimal times is needed in "less than 1 out of 1000 cases"
+    assert h[0] / sum(h) < acc["fallback_rate_below"]
+
+
+def test_matlab_twin_tables_equal_the_cpp_tables(kat):
+    """The reference holds every unit table twice: in tests/src/long_term_planner_tests.cc and in tests/unittests/*.m.
+    Both transcriptions must be the same data (a typo in either would show here)."""
+    m = kat["matlab_twins"]
+    k = kat["opt_braking"]; mm = m["opt_braking"]
+    assert np.array_equal(np.array(mm["t_rel_rows"]).T, np.array(k["t_rel"]))
+    for key in ("v_0", "a_0", "a_max", "j_max"):
+        assert np.array_equal(np.array(mm[key], dtype=float), np.array(k[key], dtype=float)), key
+    assert np.array_equal(np.array(mm["q_goal"]), np.array(k["q"])) and mm["eps"] == k["eps"] and set(k["v_max"]) == {mm["v_max"]}
+    k = kat["opt_switch_times"]; mm = m["opt_switch_times"]
+    assert np.array_equal(np.array(mm["t_rel_rows"]).T, np.array(k["t_rel"]))
+    assert np.allclose(np.cumsum(np.array(mm["t_rel_rows"]).T, axis=1), np.array(k["t"]), rtol=0, atol=1e-12)
+    for key in ("v_max", "a_max", "j_max", "q_goal", "v_0", "a_0"):
+        assert np.array_equal(np.array(mm[key], dtype=float), np.array(k[key], dtype=float)), key
+    assert set(k["q_0"]) == {mm["q_0"]} and mm["eps"] == k["eps"]
+    k = kat["time_scaling"]; mm = m["time_scaling"]
+    t = np.cumsum(np.array(mm["t_rel_rows"]).T, axis=1)
+    assert np.allclose(t, np.array(k["t"]), rtol=0, atol=1e-12) and np.allclose(t[:, -1], np.array(k["t_required"]), rtol=0, atol=1e-12)
+    for key in ("v_max", "a_max", "j_max", "q_goal", "v_0", "a_0", "dir"):
+        assert np.array_equal(np.array(mm[key], dtype=float), np.array(k[key], dtype=float)), key
+    assert mm["eps"] == k["eps"]
+
+
+def test_oracle_against_the_matlab_twins_full_tables(oracle_mod, kat):
+    """The MATLAB twins compare ALL seven switching times at eps (testOptSwitchTimes.m:36, testTimeScaling.m:44), the C++ tests
+    only the first three: pin the oracle to the stricter form."""
+    m = kat["matlab_twins"]
+    mm = m["opt_switch_times"]
+    t_all = np.cumsum(np.array(mm["t_rel_rows"]).T, axis=1)
+    for i in range(len(mm["q_goal"])):
+        o = oracle_mod.Oracle(1, 0.001, [-3.1], [3.1], [mm["v_max"][i]], [mm["a_max"][i]], [mm["j_max"][i]])
+        for sgn in ((1, -1) if i else (1,)):
+            ok, t, d, mod = o.opt_switch_times(0, sgn * mm["q_goal"][i], sgn * mm["q_0"], sgn * mm["v_0"][i], sgn * mm["a_0"][i], mm["v_max"][i])
+            assert ok and np.all(np.abs(t - t_all[i]) < mm["eps"]), (i, sgn, t)
+    mm = m["time_scaling"]
+    t_all = np.cumsum(np.array(mm["t_rel_rows"]).T, axis=1)
+    for i in range(len(mm["q_goal"])):
+        o = oracle_mod.Oracle(1, 0.001, [-3.1], [3.1], [mm["v_max"][i]], [mm["a_max"][i]], [mm["j_max"][i]])
+        for sgn in ((1, -1) if i else (1,)):
+            ok, t, vd, mod, case = o.time_scaling(0, sgn * mm["q_goal"][i], sgn * mm["q_0"], sgn * mm["v_0"][i], sgn * mm["a_0"][i],
+                                                  sgn * mm["dir"][i], t_all[i, -1])
+            assert ok and np.all(np.abs(t - t_all[i]) < mm["eps"]), (i, sgn, t)
+    mm = m["opt_braking"]
+    for i in range(len(mm["v_0"])):
+        o = oracle_mod.Oracle(1, 0.001, [-3.1], [3.1], [mm["v_max"]], [mm["a_max"][i]], [mm["j_max"][i]])
+        for sgn in ((1, -1) if i else (1,)):
+            q, t, d = o.opt_braking(0, sgn * mm["v_0"][i], sgn * mm["a_0"][i])
+            assert np.all(np.abs(t[:3] - np.array(mm["t_rel_rows"])[:, i]) < mm["eps"]) and abs(q - sgn * mm["q_goal"][i]) < mm["eps"]
+
+
+def test_six_dof_fixture_runs_a_multi_joint_plan(oracle_mod, kat):
+    """tests/include/long_term_planner_fixture.h:97-109 defines a 6-DoF planner that no reference test uses. It is the only
+    reference-held multi-joint limit set: run planTrajectory on it (slowest-joint reduction + time scaling with dof > 1,
+    cc:31-55) and check what the reference's end-point tests check per joint (goal within 1e-2, cc:59-61 passed), plus the
+    synchronisation the README promises (all joints end with the slowest one, within timeScaling's window cc:370)."""
+    f = kat["fixture_6dof"]
+    o = oracle_mod.Oracle(6, f["t_sample"], f["q_min"], f["q_max"], f["v_max"], f["a_max"], f["j_max"])
+    rng = np.random.default_rng(6)
+    n_sync = 0
+    for trial in range(40):
+        qg = rng.uniform(-3.0, 3.0, 6); q0 = rng.uniform(-3.0, 3.0, 6)
+        v0 = rng.uniform(-1.0, 1.0, 6); a0 = rng.uniform(-1.0, 1.0, 6)
+        r = o.plan_trajectory(qg, q0, v0, a0)
+        assert r["status"] == 1, trial
+        L = r["length"]
+        assert np.all(np.abs(r["q"][:, L - 1] - qg) <= 1e-2), (trial, r["q"][:, L - 1] - qg)
+        assert np.all(r["v"][:, L - 1] == 0.0) and np.all(r["a"][:, L - 1] == 0.0)
+        s = int(r["slowest"])
+        assert r["t_required"] == r["t_opt"][s, 6] == np.max(r["t_opt"][:, 6])
+        end = r["t_scaled"][:, 6]
+        scaled = np.array([not np.array_equal(r["t_scaled"][j], r["t_opt"][j]) for j in range(6)])
+        # every joint that timeScaling re-timed ends inside its acceptance window around t_required (cc:402: -tol/10 .. tol)
+        assert np.all((r["t_required"] - end[scaled] < 0.1) & (r["t_required"] - end[scaled] > -0.01))
+        n_sync += int(scaled.sum())
+    assert n_sync >= 150          # 5 of 6 joints are re-timed in nearly every plan
 
 
 def test_check_inputs(oracle_mod, kat):
