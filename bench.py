@@ -131,6 +131,9 @@ def parse_args(argv=None):
     ap.add_argument("--receding", default="", metavar="ROUNDS:K",
                     help="VARIANT (SURVEY §8(f).1): per step ROUNDS receding-horizon cycles on the device — plan, sample the first "
                          "--max-samples samples, restart every query from stored sample K (ltp_replan_states_batch); value counts every replan")
+    ap.add_argument("--table-pass", default="auto", choices=["auto", "on", "off"],
+                    help="where the sampler's run tables are built: by the table pass (a kernel of its own) or inside the sampler kernel (ltp_set_table_pass)")
+    ap.add_argument("--table-gib", type=float, default=0.0, help="upper bound of the table-pass workspace (default: library default, 4 GiB)")
     ap.add_argument("--sample-blocks", type=int, default=0, help="TUNING: size of the sampler's persistent grid (0 = library default)")
     ap.add_argument("--gather", action="store_true", help="also all_gather t_required over RCCL each step (optional path)")
     ap.add_argument("--checksum", action="store_true",
@@ -183,6 +186,7 @@ class Workload:
         self.envelope, self.receding = args.envelope, args.receding
         self.plain_stores, self.dry, self.spread, self.window_gib = args.plain_stores, args.dry_sampler, args.spread, args.window_gib
         self.sample_blocks, self.gather, self.checksum, self.seed = args.sample_blocks, args.gather, args.checksum, args.seed
+        self.table_pass, self.table_gib = args.table_pass, args.table_gib
         self.name = "primary"
         for k, v in over.items():
             setattr(self, k, v)
@@ -212,6 +216,8 @@ def run_workload(wl, ctx):
         ltp.setSampleStride(wl.sample_stride)
     if wl.sample_blocks:
         ltp._check(ltp._lib.ltp_debug_set_sample_blocks(ltp._h, wl.sample_blocks))
+    if wl.table_pass != "auto" or wl.table_gib:
+        ltp.setTablePass({"auto": 0, "on": 1, "off": -1}[wl.table_pass], int(wl.table_gib * (1 << 30)) if wl.table_gib else None)
     rec_spec = tuple(int(x) for x in wl.receding.split(":")) if wl.receding else None
     rec_direct = bool(rec_spec) and not wl.max_samples      # restart states straight from the records (ltp_state_at_batch)
     env_spec = tuple(int(x) for x in wl.envelope.split(":")) if wl.envelope else None
@@ -377,7 +383,7 @@ def run_workload(wl, ctx):
                              f"q/v/a/j rows: every {wl.sample_stride}-th sample" + (f", first {wl.max_samples} stored" if wl.max_samples else ""))
                             + f" into a reused {tile_gib} GiB tile ({n_chunks} chunks per step)")),
             "batch_per_gpu": n if not wl.global_batch else None, "global_batch": total_queries, "dof": dof, "t_sample": wl.t_sample,
-            "limits": wl.limits, "input_layout": wl.layout,
+            "limits": wl.limits, "input_layout": wl.layout, "table_pass": wl.table_pass,
             "sharding": "contiguous query ranges per rank, no data-path collective" + (", RCCL all_gather of t_required" if gather_buf else ""),
             "plans_ok_frac": round(ok_total / total_queries, 5),
             "mean_traj_len": round(len_total / total_queries, 1),
@@ -452,7 +458,7 @@ def main():
     out = run_workload(primary, ctx)
 
     variant = (args.switch_only or args.f32 or args.max_samples or args.sample_stride > 1 or args.envelope or args.receding or args.dry_sampler
-               or args.limits != "panda" or args.batch != 1_000_000 or args.global_batch or args.window_gib or args.layout != "query_major")
+               or args.table_pass != "auto" or args.limits != "panda" or args.batch != 1_000_000 or args.global_batch or args.window_gib or args.layout != "query_major")
     secondary = []
     if not args.no_secondary and not variant:
         few = max(1, min(args.steps, 2))

@@ -118,6 +118,18 @@ int ltp_get_sample_stride(const ltp_planner* p);
 int ltp_set_goal_check(ltp_planner* p, int enabled);
 int ltp_get_goal_check(const ltp_planner* p);
 
+/* Table pass. A sampler / envelope item (one plan x <= 8 joints) needs the joint's run tables (<= 20 runs of constant jerk
+ * with 10 closed-form coefficients each). They are either built inside the sampler kernel by the item's block (no extra
+ * memory traffic, ~8 us of latency per item: right for long rows, which hide it) or by a kernel of their own before the
+ * sampler (lane = (plan, joint); 1 696 bytes per joint written and read back through the handle's workspace; an item then
+ * costs one prefetched read: right for short rows — first-N-samples rows, receding-horizon rows, envelopes). Both give
+ * bit-identical rows. mode 0 = automatic (the pass for ltp_envelope_batch and when max_samples caps a joint's four rows at
+ * <= 8 KiB), 1 = always, -1 = never. ltp_sample_batch's flags bits 2 / 3 force the pass / the fused build per call. */
+int ltp_set_table_pass(ltp_planner* p, int mode);
+int ltp_get_table_pass(const ltp_planner* p);
+/* Upper bound (bytes, default 4 GiB) of the table workspace; ranges whose tables do not fit are processed in pieces. */
+int ltp_set_table_workspace(ltp_planner* p, unsigned long long bytes);
+
 /* ---- batched hot path (device pointers, asynchronous on `stream`) -------------------------- */
 
 /* Allocates the handle's device workspace for batches of up to n queries now. The batched calls below grow it on
@@ -147,6 +159,7 @@ int ltp_end_limit_batch(ltp_planner* p, long long first, long long count, const 
  * plan p is written at out + (offsets[p] - offsets[first]); plans that would end beyond
  * `capacity` doubles get LTP_STATUS_OVERFLOW and are skipped.
  * flags: bit 0 = non-temporal stores (recommended); bit 1 = diagnostic dry run (stores without arithmetic);
+ * bit 2 = force the table pass, bit 3 = force the fused table build (default: ltp_set_table_pass);
  * bits 8..23 = block interleave factor (0 = default 64, 1 = blocks in plan order). Large tiles (>= 64 GiB)
  * written with the default interleave reach the HBM fill ceiling; see DESIGN.md. */
 int ltp_sample_batch(ltp_planner* p, long long first, long long count, const ltp_queries* in, const ltp_records* rec,

@@ -80,6 +80,9 @@ _SIGNATURES = {
                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_longlong, C.c_void_p]),
     "ltp_set_goal_check": (C.c_int, [C.c_void_p, C.c_int]),
     "ltp_get_goal_check": (C.c_int, [C.c_void_p]),
+    "ltp_set_table_pass": (C.c_int, [C.c_void_p, C.c_int]),
+    "ltp_get_table_pass": (C.c_int, [C.c_void_p]),
+    "ltp_set_table_workspace": (C.c_int, [C.c_void_p, C.c_ulonglong]),
     "ltp_replan_states_batch": (C.c_int, [C.c_void_p, C.c_longlong, C.c_longlong, C.POINTER(Queries), C.POINTER(Records), C.c_void_p,
                                           C.c_void_p, C.c_ulonglong, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong,
                                           C.c_longlong, C.c_void_p]),

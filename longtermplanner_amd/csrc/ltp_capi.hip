@@ -18,7 +18,7 @@ struct ltp_planner {
     int max_samples = 0;                   // 0 = store whole trajectories (reference behaviour)
     int sample_stride = 1;                 // store every sample_stride-th sample
     int goal_check = 0;                    // 1 = reject q_goal outside [q_min,q_max] up front (reference: unchecked)
-    int sample_blocks[3] = {0, 0, 0};      // resident blocks of k_sample f64 / k_sample f32 / k_envelope (work-queue grids)
+    int sample_blocks[5] = {0, 0, 0, 0, 0};   // resident blocks of k_sample f64 / f32, k_envelope, k_sample_tab f64 / f32 (work-queue grids)
     int sample_blocks_override = 0;        // tuning aid (ltp_debug_set_sample_blocks)
     unsigned long long* d_sample_next = nullptr;   // ring of work-queue heads, one per in-flight sampler launch
     unsigned sample_next_slot = 0;
@@ -33,6 +33,10 @@ struct ltp_planner {
     long long ws_items = 0;                // capacity of d_lane_flags in (query, joint) items
     long long ws_queue_entries = 0;        // capacity of d_queue in u64 entries
     long long ws_queries = 0;
+    int table_pass = 0;                    // 0 = automatic, 1 = always, -1 = never (ltp_set_table_pass)
+    unsigned long long* d_tables = nullptr;   // run tables of the table pass (k_build_tables); part of the workspace
+    unsigned long long tables_bytes = 0;      // allocated
+    unsigned long long tables_cap = 4ull << 30;   // upper bound for d_tables; longer ranges are processed in pieces
     double* d_small = nullptr;             // 16 doubles for the one-lane entry points
     unsigned long long* dbg_stamps = nullptr; // diagnostic: per-block start/end stamps of k_sample (caller-owned)
     // persistent buffers of the small synchronous host-pointer calls (no hipMalloc per call)
@@ -55,6 +59,8 @@ struct ltp_planner {
 };
 
 namespace {
+
+constexpr bool kEnvelopeTablePassByDefault = true;   // measured: see DESIGN.md "Table pass"
 
 int fail(ltp_planner* p, int code, const std::string& msg)
 {
@@ -125,6 +131,8 @@ int reserve(ltp_planner* p, long long n)
     if (!p->d_sample_next) LTP_HIP_TRY(p, hipMalloc((void**)&p->d_sample_next, sizeof(unsigned long long) * 64));
     for (int w = 0; w < 3; ++w)
         if (p->sample_blocks[w] == 0) p->sample_blocks[w] = ltp::sample_resident_blocks(p->device, w);
+    for (int w = 0; w < 2; ++w)
+        if (p->sample_blocks[3 + w] == 0) p->sample_blocks[3 + w] = ltp::sample_tab_resident_blocks(p->device, w == 1);
     const long long queue_entries = 16 * ltp::queue_segment(n, p->dof > 0 ? p->dof : 1);
     if (queue_entries > p->ws_queue_entries) {
         if (p->d_queue) LTP_HIP_TRY(p, hipFree(p->d_queue));
@@ -215,6 +223,37 @@ int check_geometry(ltp_planner* p)
     return LTP_OK;
 }
 
+// Table pass or fused build? (DESIGN.md "Table pass".) The pass writes and re-reads up to 1 696 bytes per joint and runs
+// the sampler with streaming waves that never wait; the fused build costs every item ~8 us of latency, three barriers and
+// a drain of its own stores: the pass pays when a joint's rows are short (measured crossover: ~8 KiB per joint, i.e. a cap
+// of 256 float64 / 512 float32 samples). `row_bytes` = bytes of one joint's four rows under the cap (0 = no cap).
+bool want_table_pass(const ltp_planner* p, unsigned long long row_bytes)
+{
+    if (p->table_pass != 0) return p->table_pass > 0;
+    return row_bytes > 0 && row_bytes <= 8192ull;
+}
+
+// plans per piece so that the tables of a piece fit the workspace; grows the workspace (up to tables_cap) if needed
+int ensure_tables(ltp_planner* p, long long count, long long* plans_per_piece)
+{
+    const long long dof = p->dof;
+    const unsigned long long per_tile = ltp::table_bytes(64);
+    unsigned long long want = ltp::table_bytes(count * dof);
+    const unsigned long long cap = p->tables_cap < per_tile * (unsigned long long)dof ? per_tile * (unsigned long long)dof : p->tables_cap;
+    if (want > cap) want = cap / per_tile * per_tile;
+    if (want > p->tables_bytes) {
+        if (p->d_tables) LTP_HIP_TRY(p, hipFree(p->d_tables));
+        p->d_tables = nullptr;
+        p->tables_bytes = 0;
+        LTP_HIP_TRY(p, hipMalloc((void**)&p->d_tables, (size_t)want));
+        p->tables_bytes = want;
+    }
+    long long plans = (long long)(p->tables_bytes / per_tile) * 64 / dof;
+    if (plans < 1) return fail(p, LTP_ERR_OUT_OF_MEMORY, "table workspace too small for one plan");
+    *plans_per_piece = plans < count ? plans : count;
+    return LTP_OK;
+}
+
 // device-side record arrays owned for the duration of a *_host call
 struct DevRecords {
     ltp_records r{};
@@ -281,6 +320,7 @@ void ltp_destroy(ltp_planner* p)
     if (p->d_block_sums) (void)hipFree(p->d_block_sums);
     if (p->d_offsets_scratch) (void)hipFree(p->d_offsets_scratch);
     if (p->d_small) (void)hipFree(p->d_small);
+    if (p->d_tables) (void)hipFree(p->d_tables);
     if (p->d_sample_next) (void)hipFree(p->d_sample_next);
     if (p->d_arena) (void)hipFree(p->d_arena);
     if (p->h_arena) (void)hipHostFree(p->h_arena);
@@ -342,6 +382,21 @@ int ltp_set_goal_check(ltp_planner* p, int enabled)
     return LTP_OK;
 }
 int ltp_get_goal_check(const ltp_planner* p) { return p ? p->goal_check : -1; }
+int ltp_set_table_pass(ltp_planner* p, int mode)
+{
+    if (!p || mode < -1 || mode > 1) return fail(p, LTP_ERR_INVALID_ARGUMENT, "table pass mode must be -1, 0 or 1");
+    std::lock_guard<std::mutex> g(p->mu);
+    p->table_pass = mode;
+    return LTP_OK;
+}
+int ltp_get_table_pass(const ltp_planner* p) { return p ? p->table_pass : -2; }
+int ltp_set_table_workspace(ltp_planner* p, unsigned long long bytes)
+{
+    if (!p || bytes == 0) return fail(p, LTP_ERR_INVALID_ARGUMENT, "table workspace must be > 0 bytes");
+    std::lock_guard<std::mutex> g(p->mu);
+    p->tables_cap = bytes;
+    return LTP_OK;
+}
 int ltp_stored_samples(const ltp_planner* p, int traj_len)
 {
     if (!p || traj_len <= 0) return 0;
@@ -432,12 +487,33 @@ static int sample_batch_any(ltp_planner* p, long long first, long long count, co
     if (rc != LTP_OK) return rc;
     if (count == 0 || p->dof == 0) return LTP_OK;
     if ((rc = reserve(p, 0)) != LTP_OK) return rc;   // work-queue heads, resident block counts (no-op after the first call)
+    const hipStream_t s = (hipStream_t)stream;
+    const ltp::RowSpec rows{p->max_samples, p->sample_stride};
+    const int blocks = p->sample_blocks_override > 0 ? p->sample_blocks_override : p->sample_blocks[f32 ? 1 : 0];
+    // bytes of one joint's four rows when the cap applies (a cap is the only way rows are known to be short up front)
+    const unsigned long long row_bytes = p->max_samples > 0 ? 4ull * (f32 ? 4 : 8) * (unsigned long long)p->max_samples : 0ull;
+    if (!(flags & 2) && (!p->dbg_stamps || (flags & 4)) && ((flags & 4) || (!(flags & 8) && want_table_pass(p, row_bytes)))) {
+        // table pass: per piece of the range, k_build_tables then the sampler variant that reads the tables
+        bool capturing = false;
+        if ((rc = workspace_acquire(p, s, capturing)) != LTP_OK) return rc;
+        long long piece = 0;
+        if ((rc = ensure_tables(p, count, &piece)) != LTP_OK) return rc;
+        for (long long f = first; f < first + count; f += piece) {
+            const long long c = first + count - f < piece ? first + count - f : piece;
+            unsigned long long* head = p->d_sample_next + (p->sample_next_slot++ & 63u);
+            LTP_HIP_TRY(p, hipMemsetAsync(head, 0, sizeof(unsigned long long), s));
+            ltp::launch_build_tables(s, f, c, p->dof, p->t_sample, dev_limits(p), to_dev(in), to_dev(rec), rows, false, p->d_tables);
+            ltp::launch_sample_tab(s, f, c, first, p->dof, to_dev(rec), offsets, out, f32, capacity, flags, rows, head,
+                                   p->sample_blocks_override > 0 ? p->sample_blocks_override : p->sample_blocks[f32 ? 4 : 3], p->d_tables, p->dbg_stamps);
+        }
+        LTP_HIP_TRY(p, hipGetLastError());
+        return workspace_release(p, s, capturing);
+    }
     // each launch gets its own work-queue head from a ring of 64, zeroed in stream order just before the kernel
     unsigned long long* head = p->d_sample_next + (p->sample_next_slot++ & 63u);
-    LTP_HIP_TRY(p, hipMemsetAsync(head, 0, sizeof(unsigned long long), (hipStream_t)stream));
-    ltp::launch_sample((hipStream_t)stream, first, count, p->dof, p->t_sample, dev_limits(p), to_dev(in), to_dev(rec), offsets,
-                       out, f32, capacity, flags, ltp::RowSpec{p->max_samples, p->sample_stride}, head,
-                       p->sample_blocks_override > 0 ? p->sample_blocks_override : p->sample_blocks[f32 ? 1 : 0], p->dbg_stamps);
+    LTP_HIP_TRY(p, hipMemsetAsync(head, 0, sizeof(unsigned long long), s));
+    ltp::launch_sample(s, first, count, p->dof, p->t_sample, dev_limits(p), to_dev(in), to_dev(rec), offsets,
+                       out, f32, capacity, flags, rows, head, blocks, p->dbg_stamps);
     LTP_HIP_TRY(p, hipGetLastError());
     return LTP_OK;
 }
@@ -466,11 +542,28 @@ int ltp_envelope_batch(ltp_planner* p, long long first, long long count, const l
     if (rc != LTP_OK) return rc;
     if (count == 0 || p->dof == 0) return LTP_OK;
     if ((rc = reserve(p, 0)) != LTP_OK) return rc;
+    const hipStream_t s = (hipStream_t)stream;
+    const int blocks = p->sample_blocks_override > 0 ? p->sample_blocks_override : p->sample_blocks[2];
+    if (!p->dbg_stamps && (p->table_pass > 0 || (p->table_pass == 0 && kEnvelopeTablePassByDefault))) {
+        bool capturing = false;
+        if ((rc = workspace_acquire(p, s, capturing)) != LTP_OK) return rc;
+        long long piece = 0;
+        if ((rc = ensure_tables(p, count, &piece)) != LTP_OK) return rc;
+        for (long long f = first; f < first + count; f += piece) {
+            const long long c = first + count - f < piece ? first + count - f : piece;
+            unsigned long long* head = p->d_sample_next + (p->sample_next_slot++ & 63u);
+            LTP_HIP_TRY(p, hipMemsetAsync(head, 0, sizeof(unsigned long long), s));
+            ltp::launch_build_tables(s, f, c, p->dof, p->t_sample, dev_limits(p), to_dev(in), to_dev(rec), ltp::RowSpec{0, 1}, true, p->d_tables);
+            ltp::launch_envelope(s, f, c, first, p->dof, p->t_sample, dev_limits(p), to_dev(in), to_dev(rec), window, n_windows, env, head,
+                                 blocks, nullptr, p->d_tables);
+        }
+        LTP_HIP_TRY(p, hipGetLastError());
+        return workspace_release(p, s, capturing);
+    }
     unsigned long long* head = p->d_sample_next + (p->sample_next_slot++ & 63u);
-    LTP_HIP_TRY(p, hipMemsetAsync(head, 0, sizeof(unsigned long long), (hipStream_t)stream));
-    ltp::launch_envelope((hipStream_t)stream, first, count, p->dof, p->t_sample, dev_limits(p), to_dev(in), to_dev(rec), window,
-                         n_windows, env, head, p->sample_blocks_override > 0 ? p->sample_blocks_override : p->sample_blocks[2],
-                         p->dbg_stamps);
+    LTP_HIP_TRY(p, hipMemsetAsync(head, 0, sizeof(unsigned long long), s));
+    ltp::launch_envelope(s, first, count, first, p->dof, p->t_sample, dev_limits(p), to_dev(in), to_dev(rec), window,
+                         n_windows, env, head, blocks, p->dbg_stamps);
     LTP_HIP_TRY(p, hipGetLastError());
     return LTP_OK;
 }

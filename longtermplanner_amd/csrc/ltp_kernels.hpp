@@ -80,14 +80,27 @@ void launch_switch_times(hipStream_t s, long long n, int dof, double t_sample, i
                          Records out, signed char* lane_flags, unsigned long long* queue_items, unsigned long long* counts);
 void launch_offsets(hipStream_t s, long long n, int dof, double t_sample, Records rec,
                     unsigned long long* block_sums, unsigned long long* offsets, bool lens_ready, RowSpec rows);
+// Run tables: built inside the sampler / envelope kernel by the item's block, or by the table pass —
+// launch_build_tables(first, count, ...) leaves table_bytes(count * dof) bytes in `tables` for launch_sample_tab /
+// launch_envelope(tables != nullptr). base_first: the plan whose offset is the origin of out / env (== first unless a
+// range is processed in pieces that share one table buffer).
+unsigned long long table_bytes(long long lanes /* plans * dof */);
+void launch_build_tables(hipStream_t s, long long first, long long count, int dof, double t_sample, Limits lim, Queries in, Records rec,
+                         RowSpec rows, bool whole_trajectory /* false: only the runs capped rows touch */, unsigned long long* tables);
 void launch_sample(hipStream_t s, long long first, long long count, int dof, double t_sample, Limits lim, Queries in,
                    Records rec, const unsigned long long* offsets, void* out, bool f32, unsigned long long capacity,
                    int flags, RowSpec rows, unsigned long long* next_item /* zeroed on the same stream */,
                    int resident_blocks, unsigned long long* stamps = nullptr);
+void launch_sample_tab(hipStream_t s, long long first, long long count, long long base_first, int dof, Records rec,
+                       const unsigned long long* offsets, void* out, bool f32, unsigned long long capacity, int flags, RowSpec rows,
+                       unsigned long long* next_item /* zeroed on the same stream */, int resident_blocks, const unsigned long long* tables,
+                       unsigned long long* stamps = nullptr /* diagnostic: 8 per (plan, joint group) item */);
+int sample_tab_resident_blocks(int device, bool f32);
 int sample_resident_blocks(int device, int which /* 0 k_sample f64, 1 k_sample f32, 2 k_envelope */);
-void launch_envelope(hipStream_t s, long long first, long long count, int dof, double t_sample, Limits lim, Queries in,
+void launch_envelope(hipStream_t s, long long first, long long count, long long base_first, int dof, double t_sample, Limits lim, Queries in,
                      Records rec, int window, int n_windows, double* env, unsigned long long* next_item /* zeroed on the same stream */,
-                     int resident_blocks, unsigned long long* probe = nullptr /* diagnostic: 16 stamps per item */);
+                     int resident_blocks, unsigned long long* probe = nullptr /* diagnostic: 16 stamps per item */,
+                     const unsigned long long* tables = nullptr);
 void launch_replan_states(hipStream_t s, long long first, long long count, int dof, RowSpec rows, Queries in, Records rec,
                           const unsigned long long* offsets, const void* tile, bool f32, unsigned long long capacity,
                           const int* sample_index, int uniform_index,

@@ -48,10 +48,18 @@ struct SegScratch {              // scratch of the cooperative table build, dead
     int runMode[kSampleJointGroup][kMaxSegments];
     double state[kSampleJointGroup][kMaxSegments][3];
 };
+// The run table of one joint: kTableWords 8-byte words. This is the layout in LDS and, word for word, what the table
+// pass (k_build_tables) writes to global memory for the sampler variants that do not build tables themselves.
+struct JointTable {
+    int nseg;                               // word 0 (low half)
+    int reserved;
+    int start[kMaxSegments + 2];            // words 1..11: first sample of run k; start[nseg] = traj_len
+    double c[kMaxSegments][kRunCoefs];      // words 12..211
+};
+constexpr int kTableWords = 1 + (kMaxSegments + 2) / 2 + kMaxSegments * kRunCoefs;
+static_assert(sizeof(JointTable) == kTableWords * 8, "JointTable must be kTableWords 8-byte words");
 struct SegTable {
-    int start[kSampleJointGroup][kMaxSegments + 1];
-    double c[kSampleJointGroup][kMaxSegments][kRunCoefs];
-    int nseg[kSampleJointGroup];
+    JointTable jt[kSampleJointGroup];
     union {
         SegScratch w;
         // the sampler reuses the space for the finished 16-byte slots that contain run boundary k: [q, v, a, j]
@@ -144,21 +152,58 @@ LTP_DEV void wave_sync()
 // What one lane contributes to the table build of a (plan, joint group) item, fetched ahead of time: lane k < 7 of a
 // joint slot holds one switching time, lanes 7..12 the per-joint scalars; len / off are the plan's traj_len and packed
 // offset (the same in every lane).
+// With the table pass (k_build_tables) the lane instead holds up to kTableLoads 8-byte words of the finished tables:
+// word (threadIdx.x >> 3) + 32 r of joint slot threadIdx.x & 7.
+constexpr int kTableLoads = (kTableWords + 31) / 32;
+template <bool TABLES>
 struct ItemRegs {
+    int len;
+    unsigned long long off;
+    double pa, pb;
+    unsigned long long w[kTableLoads];
+};
+template <>
+struct ItemRegs<false> {
     int len;
     unsigned long long off;
     double pa, pb;
 };
 
-// Issues the loads of an item (nothing here waits for them). p < 0: no item.
-LTP_DEV ItemRegs fetch_item(long long p, int j0, int nj, int dof, const Limits& lim, const Queries& in, const Records& rec,
-                            const unsigned long long* __restrict__ offsets)
+// global-memory form of the tables: lane index i = local plan * dof + joint; tiles of 64 lanes, word-major inside a tile,
+// so that the table pass stores 512 contiguous bytes per wave instruction and the 8 joints of an item are read as 64-byte runs
+LTP_DEV unsigned long long table_word_index(unsigned long long lane, int word)
 {
-    ItemRegs r;
+    return (lane >> 6) * (unsigned long long)(kTableWords * 64) + (unsigned long long)word * 64ull + (lane & 63ull);
+}
+
+// Issues the loads of an item (nothing here waits for them). p < 0: no item. tables != nullptr (TABLES): plan p is local
+// plan p - tab_first of the table pass.
+template <bool TABLES>
+LTP_DEV ItemRegs<TABLES> fetch_item(long long p, int j0, int nj, int dof, const Limits& lim, const Queries& in, const Records& rec,
+                                    const unsigned long long* __restrict__ offsets,
+                                    const unsigned long long* __restrict__ tables = nullptr, long long tab_first = 0)
+{
+    ItemRegs<TABLES> r;
     r.len = 0; r.off = 0ull; r.pa = 0.0; r.pb = 0.0;
+    if constexpr (TABLES) {
+#pragma unroll
+        for (int x = 0; x < kTableLoads; ++x) r.w[x] = 0ull;
+    }
     if (p < 0) return r;
     r.len = rec.traj_len[p];
     if (offsets) r.off = offsets[p];
+    if constexpr (TABLES) {
+        const int jt = threadIdx.x & 7, wb = threadIdx.x >> 3;
+        if (jt < nj) {
+            const unsigned long long lane = (unsigned long long)(p - tab_first) * dof + j0 + jt;
+#pragma unroll
+            for (int x = 0; x < kTableLoads; ++x) {
+                const int w = wb + 32 * x;
+                if (w < kTableWords) r.w[x] = tables[table_word_index(lane, w)];
+            }
+        }
+        return r;
+    }
     const int jl = threadIdx.x >> 5, k = threadIdx.x & 31;
     if (jl < nj) {
         const int j = j0 + jl;
@@ -248,16 +293,16 @@ LTP_DEV void build_run_tables(SegTable& tab, long long p, int j0, int nj, int le
             const int cm = tab.w.runMode[jl][m];
             if (cm >= 0) { ++distinct; if (cm < cval) ++pos; }
         }
-        if (mine) tab.start[jl][pos] = cval;
-        if (k == 0) { tab.start[jl][distinct] = len; tab.nseg[jl] = distinct; }
+        if (mine) tab.jt[jl].start[pos] = cval;
+        if (k == 0) { tab.jt[jl].start[distinct] = len; tab.jt[jl].nseg = distinct; }
     }
     wave_sync();
     if constexpr (PROBE) { if (threadIdx.x == 0) probe[6] = wall_clock64(); }
     // (4) lane k < ns: mode and jerk of run k, and everything of the run's end-state update that does not depend
-    //     on the state (parked in tab.c[.][k][0..5] until step (6) overwrites it with the coefficients)
-    const int ns = jact ? tab.nseg[jl] : 0;
+    //     on the state (parked in tab.jt[.].c[k][0..5] until step (6) overwrites it with the coefficients)
+    const int ns = jact ? tab.jt[jl].nseg : 0;
     if (k < ns) {
-        const int b = tab.start[jl][k];
+        const int b = tab.jt[jl].start[k];
         const int* sj = tab.w.s[jl];
         const bool phase4 = sj[3] - sj[2] > 2;                                         // cc:813
         int mode = 0;
@@ -266,10 +311,10 @@ LTP_DEV void build_run_tables(SegTable& tab, long long p, int j0, int nj, int le
         const double J = jerk_at(sj, tab.w.Jp[jl], tab.w.corr[jl], b);
         tab.w.runMode[jl][k] = mode;
         tab.w.runJ[jl][k] = J;
-        const double md = (double)(tab.start[jl][k + 1] - b);     // samples in the run
+        const double md = (double)(tab.jt[jl].start[k + 1] - b);     // samples in the run
         const double s1 = 0.5 * (md * (md + 1.0));
         const double tj = Ts * J;
-        double* pre = tab.c[jl][k];
+        double* pre = tab.jt[jl].c[k];
         pre[0] = md;
         pre[1] = s1;
         pre[2] = s1 * (md + 2.0) * (1.0 / 3.0);
@@ -287,12 +332,12 @@ LTP_DEV void build_run_tables(SegTable& tab, long long p, int j0, int nj, int le
         double q = tab.w.misc[jl][2], v = tab.w.misc[jl][3], a = tab.w.misc[jl][4];   // state "before sample 0" (cc:810-812)
         // software-pipelined by hand: the state-independent factors of run m+1 are fetched from LDS while the
         // dependent chain of run m executes (the chain is ~5 binary64 operations, an LDS round trip is longer)
-        const double* pre = tab.c[jl][0];
+        const double* pre = tab.jt[jl].c[0];
         double md = pre[0], s1 = pre[1], s2 = pre[2], p3 = pre[3], p4 = pre[4], p5 = pre[5];
         int mode = tab.w.runMode[jl][0];
         for (int m = 0; m < ns; ++m) {
             const int mn = m + 1 < ns ? m + 1 : m;
-            const double* nx = tab.c[jl][mn];
+            const double* nx = tab.jt[jl].c[mn];
             const double md_n = nx[0], s1_n = nx[1], s2_n = nx[2], p3_n = nx[3], p4_n = nx[4], p5_n = nx[5];
             const int mode_n = tab.w.runMode[jl][mn];
             tab.w.state[jl][m][0] = a; tab.w.state[jl][m][1] = v; tab.w.state[jl][m][2] = q;
@@ -321,12 +366,176 @@ LTP_DEV void build_run_tables(SegTable& tab, long long p, int j0, int nj, int le
         const RunCoef rc = run_coef(tab.w.runMode[jl][k], tab.w.runJ[jl][k], tab.w.state[jl][k][0], tab.w.state[jl][k][1],
                                     tab.w.state[jl][k][2], tab.w.misc[jl][1], Ts);
 #pragma unroll
-        for (int x = 0; x < kRunCoefs; ++x) tab.c[jl][k][x] = rc.c[x];
+        for (int x = 0; x < kRunCoefs; ++x) tab.jt[jl].c[k][x] = rc.c[x];
     }
     __builtin_amdgcn_s_setprio(0);
 }
 
+// Table-pass form of build_run_tables: the finished tables arrive in registers (fetch_item<true>) and only have to be
+// placed in LDS. The caller must pass a block barrier before any wave reads them.
+LTP_DEV void install_run_tables(SegTable& tab, int nj, const unsigned long long (&w)[kTableLoads])
+{
+    const int jt = threadIdx.x & 7, wb = threadIdx.x >> 3;
+    if (jt < nj) {
+        unsigned long long* dst = reinterpret_cast<unsigned long long*>(&tab.jt[jt]);
+#pragma unroll
+        for (int x = 0; x < kTableLoads; ++x) {
+            const int word = wb + 32 * x;
+            if (word < kTableWords) dst[word] = w[x];
+        }
+    }
+}
+
+// Pass B of an item, one (joint, boundary) task: the 16-byte slot that contains run boundary k (k >= 1) — or, for
+// k == 0, the last slot of the row if the row ends inside it — evaluated sample by sample and parked in bnd[k][0..3]
+// ([q, v, a, j]), if that slot really straddles the boundary and boundary k-1 has not claimed the same slot.
+// There are at most 19 such slots per row, but in the row-by-row loop of pass A most 64-slot wave steps contain one, and a
+// wave that has one would execute the per-sample path for all its lanes; with the finished values waiting in LDS pass A
+// still writes every row as full contiguous wave stores (leaving holes for scattered 16-byte stores costs 13 % of the
+// float64 bandwidth).
+template <typename T>
+LTP_DEV void boundary_slot(const JointTable& jt, double2_t (*bnd)[4], int k, int slen, int sstride)
+{
+    typedef typename OutVec<T>::type V;
+    constexpr int N = OutVec<T>::N;
+    const int nslots = (slen + N - 1) / N;
+    const int nruns = jt.nseg;
+    if (k >= nruns) return;
+    const int* st = jt.start;
+    // k >= 1: the slot of boundary k; k == 0: the last slot of the row if the row ends inside it (its tail is padding), so
+    // that pass A never has to mask anything
+    const int u = k >= 1 ? (st[k] + sstride - 1) / sstride      // first stored sample at or after boundary k
+                         : slen;
+    bool mine = (u % N) != 0 && u < N * nslots;
+    if (mine && k > 1) {
+        const int up = (st[k - 1] + sstride - 1) / sstride;
+        if ((up % N) != 0 && up / N == u / N) mine = false;     // boundary k-1 owns this slot
+    }
+    if (!mine) return;
+    const int i0 = u / N * N, t0 = i0 * sstride;
+    int kh = k >= 1 ? k - 1 : nruns - 1;
+    while (st[kh] > t0) --kh;                                   // run of the slot's first sample (st[0] = 0)
+    int ch = st[kh], nh = kh + 1 < nruns ? st[kh + 1] : 0x7fffffff;
+    V o[4];
+#pragma unroll
+    for (int h = 0; h < N; ++h) {
+        const int i = t0 + h * sstride;
+        while (nh <= i) {
+            ++kh;
+            ch = nh;
+            nh = kh + 1 < nruns ? st[kh + 1] : 0x7fffffff;
+        }
+        const bool pad = i0 + h >= slen;                        // the tail of the last slot is row padding
+        double x4[4];
+        run_eval(jt.c[kh], i - ch + 1, x4[0], x4[1], x4[2], x4[3]);
+#pragma unroll
+        for (int x = 0; x < 4; ++x) o[x][h] = pad ? (T)0 : (T)x4[x];
+    }
+#pragma unroll
+    for (int x = 0; x < 4; ++x) *reinterpret_cast<V*>(&bnd[k][x]) = o[x];
+}
+
+// Pass A of an item: row by row; the N samples of every slot that pass B did not take lie in one run, whose coefficients
+// are read once. Called by the four streaming waves of a block (wave = 0..3).
+template <bool STREAMING, bool DRY, typename T>
+LTP_DEV void stream_pass_a(const JointTable* jt, double2_t (*bnd)[kMaxSegments][4], int j0, int nj, int dof, int slen,
+                           unsigned long long stride, T* __restrict__ plan_base, int sstride, int wave, int lane)
+{
+    // Per joint, every lane produces q, v, a and j of N consecutive samples (a "slot": N = 2 doubles or 4 floats)
+    // and issues four 16-B stores, i.e. four 1 KiB wave stores into the four rows of that joint. (Measured on
+    // MI355X: for float64 rows this runs at the same rate as the identical store pattern without any arithmetic;
+    // deeper unrolling, writing the rows one after the other, and walking the (joint, slot) space as one flat sequence
+    // so that no step has idle lanes are all slower, the last one by 15 %.) float rows hold the binary64 results
+    // rounded once.
+    typedef typename OutVec<T>::type V;
+    constexpr int N = OutVec<T>::N;
+    const unsigned long long arr_stride = (unsigned long long)dof * stride;   // distance between q, v, a, j blocks
+    const int nslots = (slen + N - 1) / N;
+    // Rows shorter than the block (first-N-samples rows) are shared out so that no wave idles: wpr waves per row,
+    // 4 / wpr rows at a time. Long rows: wpr = 4, i.e. all 256 lanes on one row after the other.
+    const int lw = nslots <= 64 ? 0 : (nslots <= 128 ? 1 : 2);                      // wpr = 1 << lw
+    // Streaming float64 rows: buffer stores through descriptors of the four rows being written (base and size in SGPRs,
+    // one 32-bit lane offset for all four stores, anything beyond the row dropped by the hardware's range check),
+    // non-temporal at agent scope ("sc1 nt"; only the buffer builtins take the cache-policy bits). Measured on MI355X
+    // against the compiler's non-temporal global store, same box: +0.5-0.9 % for float64 rows (7.06 -> 7.09, 6.97 -> 7.02
+    // TB/s), but -3 % for float32 rows, which therefore keep the global store. A descriptor spans at most 1 GiB, so a
+    // longer row — 64 M float64 samples — is written window by window; any realistic row is one window.
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    constexpr int kWindowSlots = 1 << 26;
+    constexpr bool kBufferStores = STREAMING && sizeof(T) == 8;
+    for (int jl2 = wave >> lw; jl2 < nj; jl2 += 4 >> lw) {
+        T* const row = plan_base + (unsigned long long)(j0 + jl2) * stride;
+        const int* st = jt[jl2].start;
+        const int nruns = jt[jl2].nseg;
+        // run cursor of this lane: samples [cur, nxt) belong to run kr (nxt = INT_MAX for the last run)
+        int kr = 0, cur = 0, nxt = nruns > 1 ? st[1] : 0x7fffffff;
+        for (int wbase = 0; wbase < nslots; wbase += kWindowSlots) {
+            const int wend = nslots - wbase < kWindowSlots ? nslots : wbase + kWindowSlots;
+            __amdgpu_buffer_rsrc_t rsrc[4];
+            if constexpr (kBufferStores) {
+#pragma unroll
+                for (int x = 0; x < 4; ++x) {
+                    // (plan_base and everything else in this address is wave-uniform: scalar arithmetic)
+                    rsrc[x] = __builtin_amdgcn_make_buffer_rsrc(row + x * arr_stride + (unsigned long long)wbase * N, 0,
+                                                                (wend - wbase) * (int)sizeof(V), 0x00020000);
+                }
+            }
+            for (int slot = wbase + ((wave & ((1 << lw) - 1)) << 6) + lane; slot < wend; slot += 64 << lw) {
+                const int i0 = N * slot;              // first stored sample of this slot; it is sample i0*sstride of the trajectory
+                V o[4];
+                if constexpr (DRY) {
+#pragma unroll
+                    for (int x = 0; x < 4; ++x)
+#pragma unroll
+                        for (int h = 0; h < N; ++h) o[x][h] = (T)(i0 + h);
+                } else {
+                    const int t0 = i0 * sstride;
+                    while (nxt <= t0) {
+                        ++kr;
+                        cur = nxt;
+                        nxt = kr + 1 < nruns ? st[kr + 1] : 0x7fffffff;
+                    }
+                    const bool straddles = t0 + (N - 1) * sstride >= nxt;
+                    if (straddles || i0 + N > slen) {
+                        // run boundary kr+1 lies inside the slot, or the row ends inside it: pass B has left the
+                        // finished values in LDS (entry 0 is the row's last slot)
+                        const int e = straddles ? kr + 1 : 0;
+#pragma unroll
+                        for (int x = 0; x < 4; ++x) o[x] = *reinterpret_cast<const V*>(&bnd[jl2][e][x]);
+                    } else {
+                        double c[kRunCoefs];
+#pragma unroll
+                        for (int x = 0; x < kRunCoefs; ++x) c[x] = jt[jl2].c[kr][x];
+#pragma unroll
+                        for (int h = 0; h < N; ++h) {
+                            double x4[4];
+                            run_eval(c, t0 + h * sstride - cur + 1, x4[0], x4[1], x4[2], x4[3]);
+#pragma unroll
+                            for (int x = 0; x < 4; ++x) o[x][h] = (T)x4[x];
+                        }
+                    }
+                }
+                if constexpr (kBufferStores) {
+                    const unsigned voff = (unsigned)(slot - wbase) * (unsigned)sizeof(V);
+#pragma unroll
+                    for (int x = 0; x < 4; ++x)
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o[x]), rsrc[x], voff, 0, /*nt | sc1*/ 2 | 16);
+                } else if constexpr (STREAMING) {
+#pragma unroll
+                    for (int x = 0; x < 4; ++x) __builtin_nontemporal_store(o[x], reinterpret_cast<V*>(row + x * arr_stride + i0));
+                } else {
+#pragma unroll
+                    for (int x = 0; x < 4; ++x) *reinterpret_cast<V*>(row + x * arr_stride + i0) = o[x];
+                }
+            }
+        }
+    }
+}
+
 // Streams the rows of one item (plan x joint group) from the run tables in LDS. Every thread of the block calls this.
+// (Pass B and pass A are boundary_slot() and stream_pass_a() above, written out in place: composed from those two
+// functions k_sample needs 96 instead of 89 VGPRs — one more than its budget of 5 blocks per CU allows — and the spill
+// reload sits behind the look-ahead loads. Keep the three in step; tests/test_gpu_edge.py compares their rows bit for bit.)
 template <bool STREAMING, bool DRY, typename T>
 LTP_DEV void stream_rows(SegTable& tab, int j0, int nj, int dof, int slen, unsigned long long stride, T* __restrict__ plan_base,
                          RowSpec rows)
@@ -353,9 +562,9 @@ LTP_DEV void stream_rows(SegTable& tab, int j0, int nj, int dof, int slen, unsig
     // float64 bandwidth).
     if constexpr (!DRY) {
         const int jl = threadIdx.x >> 5, k = threadIdx.x & 31;
-        const int nruns = jl < nj ? tab.nseg[jl] : 0;
+        const int nruns = jl < nj ? tab.jt[jl].nseg : 0;
         if (k < nruns) {
-            const int* st = tab.start[jl];
+            const int* st = tab.jt[jl].start;
             // lane k >= 1: the slot of boundary k; lane 0: the last slot of the row if the row ends inside it (its
             // tail is padding), so that the main loop never has to mask anything
             const int u = k >= 1 ? (st[k] + sstride - 1) / sstride      // first stored sample at or after boundary k
@@ -381,7 +590,7 @@ LTP_DEV void stream_rows(SegTable& tab, int j0, int nj, int dof, int slen, unsig
                     }
                     const bool pad = i0 + h >= slen;                    // the tail of the last slot is row padding
                     double x4[4];
-                    run_eval(tab.c[jl][kh], i - ch + 1, x4[0], x4[1], x4[2], x4[3]);
+                    run_eval(tab.jt[jl].c[kh], i - ch + 1, x4[0], x4[1], x4[2], x4[3]);
 #pragma unroll
                     for (int x = 0; x < 4; ++x) o[x][h] = pad ? (T)0 : (T)x4[x];
                 }
@@ -408,8 +617,8 @@ LTP_DEV void stream_rows(SegTable& tab, int j0, int nj, int dof, int slen, unsig
     constexpr bool kBufferStores = STREAMING && sizeof(T) == 8;
     for (int jl2 = wave >> lw; jl2 < nj; jl2 += 4 >> lw) {
         T* const row = plan_base + (unsigned long long)(j0 + jl2) * stride;
-        const int* st = tab.start[jl2];
-        const int nruns = tab.nseg[jl2];
+        const int* st = tab.jt[jl2].start;
+        const int nruns = tab.jt[jl2].nseg;
         // run cursor of this lane: samples [cur, nxt) belong to run kr (nxt = INT_MAX for the last run)
         int kr = 0, cur = 0, nxt = nruns > 1 ? st[1] : 0x7fffffff;
         for (int wbase = 0; wbase < nslots; wbase += kWindowSlots) {
@@ -448,7 +657,7 @@ LTP_DEV void stream_rows(SegTable& tab, int j0, int nj, int dof, int slen, unsig
                     } else {
                         double c[kRunCoefs];
 #pragma unroll
-                        for (int x = 0; x < kRunCoefs; ++x) c[x] = tab.c[jl2][kr][x];
+                        for (int x = 0; x < kRunCoefs; ++x) c[x] = tab.jt[jl2].c[kr][x];
 #pragma unroll
                         for (int h = 0; h < N; ++h) {
                             double x4[4];
@@ -494,7 +703,8 @@ template <bool STREAMING, bool DRY, typename T>
 __global__ void __launch_bounds__(kSampleThreads, (sizeof(T) == 4 ? kSampleBlocksPerCU - 1 : kSampleBlocksPerCU))
 k_sample(long long first, long long count, int dof, double t_sample, Limits lim, Queries in, Records rec,
          const unsigned long long* __restrict__ offsets, T* __restrict__ out, unsigned long long capacity,
-         unsigned long long* __restrict__ stamps, int spread, RowSpec rows, unsigned long long* __restrict__ next_item)
+         unsigned long long* __restrict__ stamps, int spread, RowSpec rows, unsigned long long* __restrict__ next_item,
+         int draw_chunk /* items per queue draw, a power of two */)
 {
     __shared__ SegTable tab;
     __shared__ unsigned long long s_item;
@@ -502,6 +712,15 @@ k_sample(long long first, long long count, int dof, double t_sample, Limits lim,
     const long long per = (count + spread - 1) / spread;
     const unsigned long long total = (unsigned long long)per * spread * ngroups;
     const unsigned long long off0 = offsets[first];
+    // Queue draws. One device-scope counter sustains ~90 atomics/us; items of short (capped) rows are drawn faster than
+    // that, so a draw takes draw_chunk consecutive items (1 for whole trajectories: a long item at the end of a launch is
+    // a long tail). Thread 0 keeps the chunk; chunk_i is the same in every thread.
+    unsigned long long chunk_base = 0ull;
+    int chunk_i = 0;
+    auto draw = [&]() -> unsigned long long {      // thread 0 only
+        if (chunk_i == 0) chunk_base = atomicAdd(next_item, (unsigned long long)draw_chunk);
+        return chunk_base + (unsigned long long)chunk_i;
+    };
 
     // item -> (local plan, joint group); local >= count are the holes of the interleave
     auto decode = [&](unsigned long long item, long long& local, int& j0, int& nj) {
@@ -515,13 +734,14 @@ k_sample(long long first, long long count, int dof, double t_sample, Limits lim,
         long long local; int j0, nj;
         decode(item, local, j0, nj);
         const bool some = item < total && local < count;
-        return fetch_item(some ? first + local : -1, j0, nj, dof, lim, in, rec, offsets);
+        return fetch_item<false>(some ? first + local : -1, j0, nj, dof, lim, in, rec, offsets);
     };
 
-    if (threadIdx.x == 0) s_item = atomicAdd(next_item, 1ull);
+    if (threadIdx.x == 0) s_item = draw();
+    chunk_i = (chunk_i + 1) & (draw_chunk - 1);
     __syncthreads();
     unsigned long long item = s_item;
-    ItemRegs cur = fetch(item);
+    ItemRegs<false> cur = fetch(item);
     __syncthreads();   // s_item may be rewritten
     while (item < total) {
         long long local; int j0, nj;
@@ -544,12 +764,13 @@ k_sample(long long first, long long count, int dof, double t_sample, Limits lim,
             ok = false;
         }
         unsigned long long drawn = 0ull;
-        if (threadIdx.x == 0) drawn = atomicAdd(next_item, 1ull);      // returns while the tables are built
+        if (threadIdx.x == 0) drawn = draw();                          // an atomic returns while the tables are built
+        chunk_i = (chunk_i + 1) & (draw_chunk - 1);
         if (ok) build_run_tables(tab, p, j0, nj, len, t_sample, lim, rec, cur.pa, cur.pb);
         if (threadIdx.x == 0) s_item = drawn;
         __syncthreads();                                               // tables complete, next item known
         const unsigned long long nitem = s_item;
-        const ItemRegs nxt = fetch(nitem);                             // in flight while this item streams
+        const ItemRegs<false> nxt = fetch(nitem);                      // in flight while this item streams
         if (ok) {
             if (stamps && lead) stamps[3 * local + 1] = wall_clock64();   // run tables ready
             stream_rows<STREAMING, DRY, T>(tab, j0, nj, dof, slen, stride, out + rel, rows);
@@ -560,6 +781,308 @@ k_sample(long long first, long long count, int dof, double t_sample, Limits lim,
         cur = nxt;
     }
 }
+
+// ---------------------------------------------------------------------------------------
+// The sampler for rows that are short compared with an item's fixed costs (first-N-samples rows, receding-horizon rows).
+// k_sample pays per item: a table build of ~8 us of latency, three block barriers, and — because a wave's loads and stores
+// share one in-order counter on gfx950 — one complete drain of the wave's own row stores before it can consume the next
+// item's prefetched records. For 1.7 k-sample rows other blocks of the CU cover that; for a few hundred samples per row it
+// is most of the item (measured: 3.6-3.8 TB/s for 256-sample rows, the same with and without the table build).
+// Here the roles are split between the waves of a block:
+//   * the run tables come from the table pass (k_build_tables), compact: only the runs the stored samples touch;
+//   * the last wave, the loader, draws the coming items and copies the next item's tables into the OTHER of two LDS
+//     buffers; it issues loads but never row stores;
+//   * the other waves, the streaming waves, each own one joint of the current item: boundary slots (pass B), then the
+//     joint's rows (pass A) from the current buffer; they issue stores but never loads, so nothing they execute ever waits
+//     for a store to complete;
+//   * one block barrier per item hands the buffers over (s_barrier does not wait for outstanding stores).
+// Rows are bit-identical to k_sample's: same tables (for_each_run == the cooperative build), same boundary_slot / pass A.
+// ---------------------------------------------------------------------------------------
+constexpr int kTabStreamWaves = 7;                              // streaming waves per block; wave kTabStreamWaves is the loader
+constexpr int kTabThreads = (kTabStreamWaves + 1) * 64;          // 8 waves: two per SIMD
+constexpr int kTabJointGroup = 7;                                // joints per item: one row set per streaming wave
+struct TabItem {
+    unsigned long long rel;               // element offset of the plan inside `out`
+    int slen;                             // stored samples per row; 0 = nothing to stream (hole, failed plan, does not fit)
+    int j0, nj;
+    int done;                             // 1 = the queue is exhausted
+    unsigned long long item;              // queue position (diagnostic stamps only)
+};
+struct TabBuffer {
+    JointTable jt[kTabJointGroup];
+    TabItem hdr;
+};
+
+// What a streaming wave does with an item: wave w owns joint w (nj <= 3: several waves share a joint) and writes the
+// joint's four rows, 64 slots = 1 KiB per row and step. Same slot arithmetic as stream_pass_a, except that a slot which
+// contains a run boundary (or the end of the row) is evaluated sample by sample in place, by exactly boundary_slot()'s
+// steps, instead of being picked up from a pass B: rows this kernel is meant for are one or two wave steps long, and a
+// pass B costs the wave ~2 us per item in which it issues no store.
+template <bool STREAMING, typename T>
+LTP_DEV void tab_stream(const TabBuffer& B, int dof, T* __restrict__ out, int sstride, int wave)
+{
+    typedef typename OutVec<T>::type V;
+    constexpr int N = OutVec<T>::N;
+    // the lane id is recomputed per item: kept in a register across the kernel it ends up spilled (the loader branch needs
+    // the registers), and a scratch reload here would wait for every row store the wave has in flight
+    const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const int slen = B.hdr.slen, j0 = B.hdr.j0, nj = B.hdr.nj;
+    if (slen <= 0) return;
+    const int wpr = nj >= 4 ? 1 : (nj == 3 ? 2 : (nj == 2 ? 3 : 7));     // waves per joint
+    const int jl2 = wave / wpr, sub = wave - jl2 * wpr;
+    if (jl2 >= nj) return;
+    const unsigned long long stride = ((unsigned long long)slen + (kRowAlign - 1)) / kRowAlign * kRowAlign;
+    const unsigned long long arr_stride = (unsigned long long)dof * stride;
+    const int nslots = (slen + N - 1) / N;
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    constexpr int kWindowSlots = 1 << 26;
+    constexpr bool kBufferStores = STREAMING && sizeof(T) == 8;
+    T* const row = out + B.hdr.rel + (unsigned long long)(j0 + jl2) * stride;
+    const int* st = B.jt[jl2].start;
+    const int nruns = B.jt[jl2].nseg;
+    int kr = 0, cur = 0, nxt = nruns > 1 ? st[1] : 0x7fffffff;
+    for (int wbase = 0; wbase < nslots; wbase += kWindowSlots) {
+        const int wend = nslots - wbase < kWindowSlots ? nslots : wbase + kWindowSlots;
+        __amdgpu_buffer_rsrc_t rsrc[4];
+        if constexpr (kBufferStores) {
+#pragma unroll
+            for (int x = 0; x < 4; ++x)
+                rsrc[x] = __builtin_amdgcn_make_buffer_rsrc(row + x * arr_stride + (unsigned long long)wbase * N, 0,
+                                                            (wend - wbase) * (int)sizeof(V), 0x00020000);
+        }
+        for (int slot = wbase + sub * 64 + lane; slot < wend; slot += 64 * wpr) {
+            const int i0 = N * slot;
+            V o[4];
+            const int t0 = i0 * sstride;
+            while (nxt <= t0) {
+                ++kr;
+                cur = nxt;
+                nxt = kr + 1 < nruns ? st[kr + 1] : 0x7fffffff;
+            }
+            const bool straddles = t0 + (N - 1) * sstride >= nxt;
+            if (straddles || i0 + N > slen) {
+                // a run boundary or the end of the row inside the slot: sample by sample (the tail of the last slot is
+                // row padding and stays zero)
+                int kh = kr, ch = cur, nh = nxt;
+#pragma unroll
+                for (int h = 0; h < N; ++h) {
+                    const int i = t0 + h * sstride;
+                    while (nh <= i) {
+                        ++kh;
+                        ch = nh;
+                        nh = kh + 1 < nruns ? st[kh + 1] : 0x7fffffff;
+                    }
+                    const bool pad = i0 + h >= slen;
+                    double x4[4];
+                    run_eval(B.jt[jl2].c[kh], i - ch + 1, x4[0], x4[1], x4[2], x4[3]);
+#pragma unroll
+                    for (int x = 0; x < 4; ++x) o[x][h] = pad ? (T)0 : (T)x4[x];
+                }
+            } else {
+                double c[kRunCoefs];
+#pragma unroll
+                for (int x = 0; x < kRunCoefs; ++x) c[x] = B.jt[jl2].c[kr][x];
+#pragma unroll
+                for (int h = 0; h < N; ++h) {
+                    double x4[4];
+                    run_eval(c, t0 + h * sstride - cur + 1, x4[0], x4[1], x4[2], x4[3]);
+#pragma unroll
+                    for (int x = 0; x < 4; ++x) o[x][h] = (T)x4[x];
+                }
+            }
+            if constexpr (kBufferStores) {
+                const unsigned voff = (unsigned)(slot - wbase) * (unsigned)sizeof(V);
+#pragma unroll
+                for (int x = 0; x < 4; ++x)
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o[x]), rsrc[x], voff, 0, /*nt | sc1*/ 2 | 16);
+            } else if constexpr (STREAMING) {
+#pragma unroll
+                for (int x = 0; x < 4; ++x) __builtin_nontemporal_store(o[x], reinterpret_cast<V*>(row + x * arr_stride + i0));
+            } else {
+#pragma unroll
+                for (int x = 0; x < 4; ++x) *reinterpret_cast<V*>(row + x * arr_stride + i0) = o[x];
+            }
+        }
+    }
+}
+
+// What the loader wave holds about one item from the iteration that requests its data to the one (two iterations later)
+// that installs it: the item's place in the batch (wave-uniform) and, per lane, the loads in flight — traj_len and offset
+// of the plan, and word ws + 8 r (r < kTabBatch) of the run table of joint slot jl, where ws = lane >> 3, jl = lane & 7.
+constexpr int kTabBatch = 10;      // covers tables of up to 6 runs (12 + 6 x 10 <= 80 words): the usual case of capped rows
+struct TabSlot {
+    unsigned long long item;       // queue position (>= total: none)
+    long long local;               // plan index inside [first, first + count), or -1 for a hole of the interleave
+    int j0, nj;
+    int len;
+    unsigned long long off;
+    unsigned long long v[kTabBatch];
+};
+
+template <bool STREAMING, typename T>
+LTP_DEV void sample_tab_body(long long first, long long count, long long base_first, int dof, Records rec,
+                             const unsigned long long* __restrict__ offsets, T* __restrict__ out, unsigned long long capacity, int spread,
+                             RowSpec rows, unsigned long long* __restrict__ next_item, const unsigned long long* __restrict__ tables,
+                             int draw_chunk, unsigned long long* __restrict__ stamps /* diagnostic: 8 per item, nullptr in product calls */)
+{
+    __shared__ TabBuffer buf[2];
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int sstride = rows.stride > 1 ? rows.stride : 1;
+    if (wave < kTabStreamWaves) {
+        // ---- streaming waves: stores only ----
+        __syncthreads();
+        for (int b = 0;; b ^= 1) {
+            if (buf[b].hdr.done) break;
+            const bool stamp = stamps && wave == 0 && (threadIdx.x & 63) == 0;
+            const unsigned long long it = buf[b].hdr.item;
+            if (stamp) stamps[8 * it + 4] = wall_clock64();
+            tab_stream<STREAMING, T>(buf[b], dof, out, sstride, wave);
+            if (stamp) stamps[8 * it + 5] = wall_clock64();
+            __syncthreads();
+            if (stamp) stamps[8 * it + 6] = wall_clock64();
+        }
+        return;
+    }
+    // ---- loader wave: loads only. Under the sampler's own write traffic a global read takes ~8 us, several times an
+    // item's streaming time, so every load is issued TWO iterations before its result is used: two items' requests are
+    // always in flight (slots A and B, alternating), queue positions come in chunks drawn one chunk ahead, and the table
+    // request does not depend on the header (a fixed kTabBatch words per lane; tables with more runs fetch the rest when
+    // they are installed — such rows are long enough to hide that). An iteration then costs the LDS copy and pass B. ----
+    // The loader shares its SIMD with five streaming waves that keep the vector ALU busy: it runs at raised issue priority.
+    __builtin_amdgcn_s_setprio(3);
+    const int lane = threadIdx.x & 63;
+    const int ngroups = (dof + kTabJointGroup - 1) / kTabJointGroup;
+    const long long per = (count + spread - 1) / spread;
+    const unsigned long long total = (unsigned long long)per * spread * ngroups;
+    const unsigned long long off0 = offsets[base_first];
+    const int jl = lane & 7, ws = lane >> 3;
+    auto uniform64 = [](unsigned long long x) -> unsigned long long {
+        return ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(x >> 32)) << 32) |
+               (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)x);
+    };
+    // Queue positions: a draw takes draw_chunk consecutive items (one device-scope counter sustains ~90 atomics/us; short
+    // items are drawn faster than that), and the atomic for the next chunk is issued when the current one is opened.
+    unsigned long long chunk_next = 0ull, chunk_cur = 0ull;
+    int chunk_i = draw_chunk;
+    if (lane == 0) chunk_next = atomicAdd(next_item, (unsigned long long)draw_chunk);
+    auto next_item_id = [&]() __attribute__((always_inline)) -> unsigned long long {
+        if (chunk_i == draw_chunk) {
+            chunk_cur = uniform64(chunk_next);
+            if (lane == 0) chunk_next = atomicAdd(next_item, (unsigned long long)draw_chunk);
+            chunk_i = 0;
+        }
+        return chunk_cur + (unsigned long long)(chunk_i++);
+    };
+    auto table_ptr = [&](const TabSlot& h) __attribute__((always_inline)) -> const unsigned long long* {
+        const bool act = h.item < total && h.local >= 0 && jl < h.nj;
+        return tables + table_word_index((unsigned long long)(act ? h.local : 0) * dof + (act ? h.j0 + jl : 0), 0);
+    };
+    auto request = [&](TabSlot& h, unsigned long long item) __attribute__((always_inline)) {   // issues every load of the item; nothing here waits
+        h.item = item; h.local = -1; h.j0 = 0; h.nj = 0; h.len = 0; h.off = 0ull;
+        if (item >= total) return;
+        const int group = (int)(item % ngroups);
+        const long long slot = (long long)(item / ngroups);
+        const long long local = (slot % spread) * per + slot / spread;
+        h.j0 = group * kTabJointGroup;
+        h.nj = (dof - h.j0) < kTabJointGroup ? (dof - h.j0) : kTabJointGroup;
+        if (local >= count) return;
+        h.local = local;
+        h.len = rec.traj_len[first + local];
+        h.off = offsets[first + local];
+        const unsigned long long* tp = table_ptr(h);
+#pragma unroll
+        for (int r = 0; r < kTabBatch; ++r) h.v[r] = tp[(unsigned)(ws + 8 * r) * 64u];
+    };
+    auto install = [&](TabBuffer& B, TabSlot& h) __attribute__((always_inline)) {
+        if (h.item >= total) {
+            if (lane == 0) B.hdr.done = 1;
+            return;
+        }
+        int slen = 0;
+        unsigned long long rel = 0ull;
+        if (h.local >= 0) {
+            const int len = __builtin_amdgcn_readfirstlane(h.len);
+            slen = stored_len(len, rows);
+            rel = uniform64(h.off) - off0;
+            const unsigned long long stride = ((unsigned long long)slen + (kRowAlign - 1)) / kRowAlign * kRowAlign;
+            if (slen > 0 && rel + 4ull * dof * stride > capacity) {
+                if (lane == 0 && h.j0 == 0) atomicOr(&rec.status[first + h.local], kStatusOverflow);
+                slen = 0;
+            }
+        }
+        if (lane == 0) { B.hdr.rel = rel; B.hdr.slen = slen; B.hdr.j0 = h.j0; B.hdr.nj = h.nj; B.hdr.done = 0; B.hdr.item = h.item; }
+        if (stamps && lane == 0) stamps[8 * h.item + 0] = wall_clock64();
+        if (slen <= 0) return;
+        // word 0 of joint slot x (its run count) sits in lane x (ws == 0, r == 0)
+        const bool act = jl < h.nj;
+        const int nseg_lane = (int)(unsigned)h.v[0];
+        int nseg_max = 0;
+#pragma unroll
+        for (int x = 0; x < kTabJointGroup; ++x) {
+            const int nx = x < h.nj ? __builtin_amdgcn_readlane(nseg_lane, x) : 0;
+            nseg_max = nx > nseg_max ? nx : nseg_max;
+        }
+        const int nwords_max = 1 + (kMaxSegments + 2) / 2 + nseg_max * kRunCoefs;
+        unsigned long long* dst = reinterpret_cast<unsigned long long*>(&B.jt[act ? jl : 0]);
+        // the LDS copy is written for every word of the batch: entries past a joint's run count are never read
+#pragma unroll
+        for (int r = 0; r < kTabBatch; ++r)
+            if (act) dst[ws + 8 * r] = h.v[r];
+        for (int base = 8 * kTabBatch; base < nwords_max; base += 8 * kTabBatch) {   // longer tables: the rest, now
+            const unsigned long long* tp = table_ptr(h);
+#pragma unroll
+            for (int r = 0; r < kTabBatch; ++r) {
+                const int w = base + ws + 8 * r;
+                h.v[r] = tp[(unsigned)(w < kTableWords ? w : 0) * 64u];
+            }
+#pragma unroll
+            for (int r = 0; r < kTabBatch; ++r) {
+                const int w = base + ws + 8 * r;
+                if (act && w < kTableWords) dst[w] = h.v[r];
+            }
+        }
+        if (stamps && lane == 0) { stamps[8 * h.item + 1] = wall_clock64(); stamps[8 * h.item + 2] = stamps[8 * h.item + 1]; }
+    };
+    // one loader iteration: install the item of slot h into B, then reuse the slot for the item two places further on
+    auto iterate = [&](TabBuffer& B, TabSlot& h) __attribute__((always_inline)) -> bool {
+        install(B, h);
+        const unsigned long long installed = h.item;
+        __builtin_amdgcn_sched_barrier(0);
+        request(h, next_item_id());
+        if (stamps && lane == 0 && installed < total) stamps[8 * installed + 3] = wall_clock64();
+        __syncthreads();
+        if (stamps && lane == 0 && installed < total) stamps[8 * installed + 7] = wall_clock64();
+        return installed >= total;                     // the buffer just published says done: everyone leaves after using it
+    };
+
+    TabSlot A, Bs;
+    request(A, next_item_id());                        // item 0
+    request(Bs, next_item_id());                       // item 1
+    // item 0 -> buf[0]; its barrier releases the streaming waves' first iteration
+    bool done = iterate(buf[0], A);
+    while (!done) {
+        // streaming waves are on buf[0]: fill buf[1]; then the other way round
+        done = iterate(buf[1], Bs);
+        if (done) break;
+        done = iterate(buf[0], A);
+    }
+}
+
+// The register budget decides how many streaming waves a CU holds, and attributes cannot depend on template parameters:
+// one kernel per row type. 3 blocks of 8 waves per CU (21 streaming waves, 6 waves per SIMD, <= 80 VGPRs, LDS 125 KB).
+#define LTP_TAB_KERNEL(NAME, ST, TY, WAVES)                                                                                          \
+    __global__ void __launch_bounds__(kTabThreads) __attribute__((amdgpu_waves_per_eu(WAVES, 8)))                                    \
+    NAME(long long first, long long count, long long base_first, int dof, Records rec, const unsigned long long* __restrict__ offsets, \
+         TY* __restrict__ out, unsigned long long capacity, int spread, RowSpec rows, unsigned long long* __restrict__ next_item,     \
+         const unsigned long long* __restrict__ tables, int draw_chunk, unsigned long long* __restrict__ stamps)                      \
+    {                                                                                                                                 \
+        sample_tab_body<ST, TY>(first, count, base_first, dof, rec, offsets, out, capacity, spread, rows, next_item, tables, draw_chunk, stamps); \
+    }
+LTP_TAB_KERNEL(k_sample_tab_f64, false, double, 6)
+LTP_TAB_KERNEL(k_sample_tab_f64_nt, true, double, 6)
+LTP_TAB_KERNEL(k_sample_tab_f32, false, float, 4)
+LTP_TAB_KERNEL(k_sample_tab_f32_nt, true, float, 4)
+#undef LTP_TAB_KERNEL
 
 // ---------------------------------------------------------------------------------------
 // On-device consumer: position envelopes instead of dense rows. A caller that only needs to
@@ -579,21 +1102,29 @@ LTP_DEV double run_eval_q(const double* c, int m)
     return c[0] + (c[1] * md + (c[2] * s1 + c[3] * s2));   // the q line of run_eval
 }
 
-template <bool PROBE>
+template <bool PROBE, bool TABLES>
 __global__ void __launch_bounds__(kSampleThreads, kSampleBlocksPerCU)
-k_envelope(long long first, long long count, int dof, double t_sample, Limits lim, Queries in, Records rec, int window,
+k_envelope(long long first, long long count, long long base_first, int dof, double t_sample, Limits lim, Queries in, Records rec, int window,
            int n_windows, int lg, double* __restrict__ env, unsigned long long* __restrict__ next_item,
-           unsigned long long* __restrict__ probe_buf /* diagnostic, PROBE only: 16 stamps per item */)
+           unsigned long long* __restrict__ probe_buf /* diagnostic, PROBE only: 16 stamps per item */,
+           const unsigned long long* __restrict__ tables)
 {
     __shared__ SegTable tab;
     __shared__ unsigned long long s_item;
     const int ngroups = (dof + kSampleJointGroup - 1) / kSampleJointGroup;
     const unsigned long long total = (unsigned long long)count * ngroups;
+    constexpr int kChunk = 4;                      // items per queue draw (see k_sample)
+    unsigned long long chunk_base = 0ull;
+    int chunk_i = 0;
     for (;;) {
         __syncthreads();
         unsigned long long t_top = 0ull;
         if constexpr (PROBE) t_top = wall_clock64();
-        if (threadIdx.x == 0) s_item = atomicAdd(next_item, 1ull);
+        if (threadIdx.x == 0) {
+            if (chunk_i == 0) chunk_base = atomicAdd(next_item, (unsigned long long)kChunk);
+            s_item = chunk_base + (unsigned long long)chunk_i;
+        }
+        chunk_i = (chunk_i + 1) & (kChunk - 1);
         __syncthreads();
         const unsigned long long item = s_item;
         if (item >= total) break;
@@ -609,15 +1140,16 @@ k_envelope(long long first, long long count, int dof, double t_sample, Limits li
         const int nj = (dof - j0) < kSampleJointGroup ? (dof - j0) : kSampleJointGroup;
         const int len = rec.traj_len[p];
         const int tasks = nj * n_windows;
-        double2_t* const dst = reinterpret_cast<double2_t*>(env) + ((unsigned long long)local * dof + j0) * n_windows;
+        double2_t* const dst = reinterpret_cast<double2_t*>(env) + ((unsigned long long)(p - base_first) * dof + j0) * n_windows;
         if (len <= 0) {
             const double nan = __builtin_nan("");
             for (int task = threadIdx.x; task < tasks; task += kSampleThreads) dst[task] = double2_t{nan, nan};
             continue;
         }
         if constexpr (PROBE) { if (threadIdx.x == 0) probe[2] = wall_clock64(); }
-        const ItemRegs regs = fetch_item(p, j0, nj, dof, lim, in, rec, nullptr);
-        build_run_tables<PROBE>(tab, p, j0, nj, len, t_sample, lim, rec, regs.pa, regs.pb, probe);
+        const ItemRegs<TABLES> regs = fetch_item<TABLES>(p, j0, nj, dof, lim, in, rec, nullptr, tables, first);
+        if constexpr (TABLES) install_run_tables(tab, nj, regs.w);
+        else build_run_tables<PROBE>(tab, p, j0, nj, len, t_sample, lim, rec, regs.pa, regs.pb, probe);
         __syncthreads();
         if constexpr (PROBE) { if (threadIdx.x == 0) probe[9] = wall_clock64(); }
         // g lanes share one (joint, window) task (g = 2^lg divides 64, chosen by the host so that the block has
@@ -631,15 +1163,15 @@ k_envelope(long long first, long long count, int dof, double t_sample, Limits li
             double lo = __builtin_huge_val(), hi = -__builtin_huge_val();
             if (live) {
                 const int jl = task / n_windows, w = task - jl * n_windows;
-                const int* st = tab.start[jl];
-                const int nruns = tab.nseg[jl];
+                const int* st = tab.jt[jl].start;
+                const int nruns = tab.jt[jl].nseg;
                 const long long b = (long long)w * window;
                 const bool past = b >= (long long)len;                            // past the end: the last sample only
                 int i = past ? len - 1 + r : (int)b + r;
                 const int e = (b + window < (long long)len) ? (int)(b + window) : len;
                 int kr = 0, cur = 0, nxt = nruns > 1 ? st[1] : 0x7fffffff;
                 // the four q coefficients of the current run stay in registers; they are re-read at a run boundary only
-                double c4[4] = {tab.c[jl][0][0], tab.c[jl][0][1], tab.c[jl][0][2], tab.c[jl][0][3]};
+                double c4[4] = {tab.jt[jl].c[0][0], tab.jt[jl].c[0][1], tab.jt[jl].c[0][2], tab.jt[jl].c[0][3]};
                 for (; i < e; i += g) {
                     if (nxt <= i) {
                         do {
@@ -648,7 +1180,7 @@ k_envelope(long long first, long long count, int dof, double t_sample, Limits li
                             nxt = kr + 1 < nruns ? st[kr + 1] : 0x7fffffff;
                         } while (nxt <= i);
 #pragma unroll
-                        for (int x = 0; x < 4; ++x) c4[x] = tab.c[jl][kr][x];
+                        for (int x = 0; x < 4; ++x) c4[x] = tab.jt[jl].c[kr][x];
                     }
                     const double q = run_eval_q(c4, i - cur + 1);
                     lo = __builtin_fmin(lo, q);
@@ -811,21 +1343,120 @@ k_end_limit(long long first, long long count, int dof, double t_sample, Limits l
     if (q < lim.q_min[j] || q > lim.q_max[j]) atomicOr(&rec.status[p], kStatusEndLimit);
 }
 
+// The table pass: the run tables of plans [first, first + count) as a kernel of its own, lane = (plan, joint), everything
+// in registers (the walk of k_state_at), written word for word in the JointTable layout. A sampler item then costs one
+// (prefetched) table read instead of a cooperative build of ~8 us of latency — what short rows, the envelope consumer and
+// receding-horizon rows are bound by. 1 696 bytes per joint: worth it when a plan's rows are not much longer than that.
+// Also applies the end-limit check of cc:59-61 (the sampler variants that read tables no longer do).
+__global__ void __launch_bounds__(256)
+k_build_tables(long long first, long long count, int dof, double t_sample, Limits lim, Queries in, Records rec,
+               int needed_end /* runs that start at or after this sample are not stored (capped rows) */,
+               unsigned long long* __restrict__ tables)
+{
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= count * dof) return;
+    const long long local = idx / dof;
+    const int j = (int)(idx - local * dof);
+    const long long p = first + local;
+    unsigned long long* const T = tables + table_word_index((unsigned long long)idx, 0);
+    const int len = rec.traj_len[p];
+    if (len <= 0) { T[0] = 0ull; return; }                     // nseg 0: the sampler skips such plans anyway
+    const long long ix = p * in.sq + (long long)j * in.sj;
+    double q = in.q_0[ix], v = in.v_0[ix], a = in.a_0[ix];
+    int run = 0;
+    int last_b = len;
+    for_each_run(lim, rec, p * dof + j, j, len, t_sample, q, v, a, [&](int b, int, const RunCoef& rc) {
+        if (b < needed_end) {
+            reinterpret_cast<int*>(T + (1 + (run >> 1)) * 64)[run & 1] = b;
+#pragma unroll
+            for (int x = 0; x < kRunCoefs; ++x) T[(1 + (kMaxSegments + 2) / 2 + run * kRunCoefs + x) * 64] = __builtin_bit_cast(unsigned long long, rc.c[x]);
+            ++run;
+        } else if (last_b == len) {
+            last_b = b;                                        // first run that is not stored: it ends the last stored one
+        }
+        return false;                                          // the walk still goes to the last sample: end-limit check
+    });
+    reinterpret_cast<int*>(T + (1 + (run >> 1)) * 64)[run & 1] = last_b;
+    T[0] = (unsigned long long)(unsigned)run;
+    if (q < lim.q_min[j] || q > lim.q_max[j]) atomicOr(&rec.status[p], kStatusEndLimit);   // cc:59-61: q is sample len-1
+}
+
 // ---------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------
 // how many blocks of a persistent (work-queue) kernel the device holds at once: 0 = k_sample float64 rows,
 // 1 = k_sample float32 rows, 2 = k_envelope
+// items per queue draw: 1 for whole trajectories; for capped rows as many as keep a draw at >= ~256 KB of rows, at most 8
+static int queue_draw_chunk(RowSpec rows, bool f32, int joints_per_item)
+{
+    if (rows.max_samples <= 0) return 1;
+    const long long item_bytes = 4ll * (f32 ? 4 : 8) * rows.max_samples * joints_per_item;
+    int k = 1;
+    while (k < 8 && item_bytes * (2 * k) <= 262144) k *= 2;
+    return k;
+}
+
 int sample_resident_blocks(int device, int which)
 {
     int cus = 0, per_cu = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus <= 0) cus = 256;
     hipError_t e;
     if (which == 1) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_sample<true, false, float>, kSampleThreads, 0);
-    else if (which == 2) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_envelope<false>, kSampleThreads, 0);
+    else if (which == 2) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_envelope<false, false>, kSampleThreads, 0);
     else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_sample<true, false, double>, kSampleThreads, 0);
     if (e != hipSuccess || per_cu <= 0) per_cu = 4;
     return cus * per_cu;
+}
+
+unsigned long long table_bytes(long long lanes)
+{
+    return (unsigned long long)((lanes + 63) / 64) * (unsigned long long)kTableWords * 64ull * 8ull;
+}
+
+void launch_build_tables(hipStream_t s, long long first, long long count, int dof, double t_sample, Limits lim, Queries in, Records rec,
+                         RowSpec rows, bool whole_trajectory, unsigned long long* tables)
+{
+    if (count <= 0 || dof <= 0) return;
+    const long long total = count * dof;
+    // capped rows only touch the samples before max_samples * stride
+    long long needed = 0x7fffffffll;
+    if (!whole_trajectory && rows.max_samples > 0) needed = (long long)rows.max_samples * (rows.stride > 1 ? rows.stride : 1);
+    if (needed > 0x7fffffffll) needed = 0x7fffffffll;
+    hipLaunchKernelGGL(k_build_tables, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, first, count, dof, t_sample, lim, in, rec,
+                       (int)needed, tables);
+}
+
+int sample_tab_resident_blocks(int device, bool f32)
+{
+    int cus = 0, per_cu = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus <= 0) cus = 256;
+    hipError_t e = f32 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_sample_tab_f32_nt, kTabThreads, 0)
+                       : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_sample_tab_f64_nt, kTabThreads, 0);
+    if (e != hipSuccess || per_cu <= 0) per_cu = f32 ? 2 : 3;
+    return cus * per_cu;
+}
+
+void launch_sample_tab(hipStream_t s, long long first, long long count, long long base_first, int dof, Records rec,
+                       const unsigned long long* offsets, void* out, bool f32, unsigned long long capacity, int flags, RowSpec rows,
+                       unsigned long long* next_item, int resident_blocks, const unsigned long long* tables, unsigned long long* stamps)
+{
+    if (count <= 0) return;
+    int spread = (flags >> 8) & 0xFFFF;
+    if (spread == 0) spread = kSampleSpread;
+    if ((long long)spread > count) spread = (int)count;
+    const int ngroups = (dof + kTabJointGroup - 1) / kTabJointGroup;
+    long long blocks = resident_blocks > 0 ? resident_blocks : 768;
+    if (blocks > count * ngroups) blocks = count * ngroups;
+    const dim3 grid((unsigned)blocks), block(kTabThreads);
+    const int draw_chunk = queue_draw_chunk(rows, f32, dof < kTabJointGroup ? dof : kTabJointGroup);
+#define LTP_TAB_CASE(K, TY) hipLaunchKernelGGL(K, grid, block, 0, s, first, count, base_first, dof, rec, offsets, (TY*)out, capacity, spread, rows, next_item, tables, draw_chunk, stamps)
+    switch ((flags & 1) | (f32 ? 2 : 0)) {
+    case 0: LTP_TAB_CASE(k_sample_tab_f64, double); break;
+    case 1: LTP_TAB_CASE(k_sample_tab_f64_nt, double); break;
+    case 2: LTP_TAB_CASE(k_sample_tab_f32, float); break;
+    default: LTP_TAB_CASE(k_sample_tab_f32_nt, float); break;
+    }
+#undef LTP_TAB_CASE
 }
 
 void launch_sample(hipStream_t s, long long first, long long count, int dof, double t_sample, Limits lim, Queries in,
@@ -843,7 +1474,8 @@ void launch_sample(hipStream_t s, long long first, long long count, int dof, dou
     const dim3 block(kSampleThreads);
     // flags bit 0: non-temporal stores; bit 1 (diagnostic): skip the arithmetic and store sample indices, which
     // measures the ceiling of this store pattern; bits 8..23: block interleave factor (0 = default 64, 1 = plan order)
-#define LTP_SAMPLE_CASE(ST, DR, TY) hipLaunchKernelGGL((k_sample<ST, DR, TY>), grid, block, 0, s, first, count, dof, t_sample, lim, in, rec, offsets, (TY*)out, capacity, stamps, spread, rows, next_item)
+    const int draw_chunk = queue_draw_chunk(rows, f32, dof < kSampleJointGroup ? dof : kSampleJointGroup);
+#define LTP_SAMPLE_CASE(ST, DR, TY) hipLaunchKernelGGL((k_sample<ST, DR, TY>), grid, block, 0, s, first, count, dof, t_sample, lim, in, rec, offsets, (TY*)out, capacity, stamps, spread, rows, next_item, draw_chunk)
     switch ((flags & 3) | (f32 ? 4 : 0)) {
     case 0: LTP_SAMPLE_CASE(false, false, double); break;
     case 1: LTP_SAMPLE_CASE(true, false, double); break;
@@ -857,9 +1489,9 @@ void launch_sample(hipStream_t s, long long first, long long count, int dof, dou
 #undef LTP_SAMPLE_CASE
 }
 
-void launch_envelope(hipStream_t s, long long first, long long count, int dof, double t_sample, Limits lim, Queries in,
+void launch_envelope(hipStream_t s, long long first, long long count, long long base_first, int dof, double t_sample, Limits lim, Queries in,
                      Records rec, int window, int n_windows, double* env, unsigned long long* next_item, int resident_blocks,
-                     unsigned long long* probe)
+                     unsigned long long* probe, const unsigned long long* tables)
 {
     if (count <= 0 || n_windows <= 0) return;
     const int ngroups = (dof + kSampleJointGroup - 1) / kSampleJointGroup;
@@ -870,11 +1502,14 @@ void launch_envelope(hipStream_t s, long long first, long long count, int dof, d
     int lg = 0;
     while (lg < 6 && (tasks << (lg + 1)) <= kSampleThreads && (2 << lg) <= window) ++lg;
     if (probe)
-        hipLaunchKernelGGL(k_envelope<true>, dim3((unsigned)blocks), dim3(kSampleThreads), 0, s, first, count, dof, t_sample, lim, in,
-                           rec, window, n_windows, lg, env, next_item, probe);
+        hipLaunchKernelGGL((k_envelope<true, false>), dim3((unsigned)blocks), dim3(kSampleThreads), 0, s, first, count, base_first, dof, t_sample, lim, in,
+                           rec, window, n_windows, lg, env, next_item, probe, tables);
+    else if (tables)
+        hipLaunchKernelGGL((k_envelope<false, true>), dim3((unsigned)blocks), dim3(kSampleThreads), 0, s, first, count, base_first, dof, t_sample, lim, in,
+                           rec, window, n_windows, lg, env, next_item, probe, tables);
     else
-        hipLaunchKernelGGL(k_envelope<false>, dim3((unsigned)blocks), dim3(kSampleThreads), 0, s, first, count, dof, t_sample, lim, in,
-                           rec, window, n_windows, lg, env, next_item, probe);
+        hipLaunchKernelGGL((k_envelope<false, false>), dim3((unsigned)blocks), dim3(kSampleThreads), 0, s, first, count, base_first, dof, t_sample, lim, in,
+                           rec, window, n_windows, lg, env, next_item, probe, tables);
 }
 
 void launch_replan_states(hipStream_t s, long long first, long long count, int dof, RowSpec rows, Queries in, Records rec,

@@ -117,6 +117,13 @@ class LongTermPlanner:
         LTP_STATUS_GOAL_OUTSIDE (64) instead of planning them and failing the end-limit check (cc:59-61)."""
         self._check(self._lib.ltp_set_goal_check(self._h, 1 if enabled else 0))
 
+    def setTablePass(self, mode, workspace_bytes=None):
+        """NEW: where the sampler's run tables are built — 0 automatic, 1 always by the table pass (a kernel of its own,
+        1 696 B per joint through the workspace), -1 always inside the sampler kernel. Rows are bit-identical either way."""
+        self._check(self._lib.ltp_set_table_pass(self._h, int(mode)))
+        if workspace_bytes is not None:
+            self._check(self._lib.ltp_set_table_workspace(self._h, int(workspace_bytes)))
+
     def storedSamples(self, traj_len):
         return self._lib.ltp_stored_samples(self._h, int(traj_len))
 
@@ -298,7 +305,7 @@ class LongTermPlanner:
         rec = batch.c_records()
         self._check(self._lib.ltp_end_limit_batch(self._h, first, count, C.byref(batch.queries), C.byref(rec), self._stream()))
 
-    def sampleBatch(self, batch: DeviceBatch, first, count, out, streaming=True, dry=False, spread=0):
+    def sampleBatch(self, batch: DeviceBatch, first, count, out, streaming=True, dry=False, spread=0, tables=None):
         """getTrajectory for plans [first, first+count) into the float64 CUDA tensor `out` (ltp_sample_batch).
         dry=True is a diagnostic: same stores, no arithmetic (ceiling of the store pattern)."""
         import torch
@@ -306,7 +313,8 @@ class LongTermPlanner:
         fn = self._lib.ltp_sample_batch_f32 if out.dtype == torch.float32 else self._lib.ltp_sample_batch   # float32 tile -> float rows
         assert out.dtype in (torch.float32, torch.float64)
         self._check(fn(self._h, first, count, C.byref(batch.queries), C.byref(rec), batch.offsets.data_ptr(),
-                       out.data_ptr(), out.numel(), (1 if streaming else 0) | (2 if dry else 0) | (int(spread) << 8), self._stream()))
+                       out.data_ptr(), out.numel(), (1 if streaming else 0) | (2 if dry else 0) | (int(spread) << 8)
+                       | (0 if tables is None else (4 if tables else 8)), self._stream()))
 
     def envelopeBatch(self, batch: DeviceBatch, first, count, window, n_windows, out=None):
         """NEW (on-device consumer): [count, dof, n_windows, 2] = min / max of q over windows of `window`

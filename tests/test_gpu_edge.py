@@ -683,3 +683,44 @@ def test_changed_geometry_between_plan_and_sample_is_rejected(amd, ref7):
         undo()
         ltp.sampleBatch(b, 0, 300, tile)                      # restored: accepted again
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("limits,n", [("ref", 700), ("panda", 1500), ("ref30", 130)])
+def test_table_pass_gives_the_bits_of_the_fused_build(amd, limits, n):
+    """The sampler's run tables come either from the cooperative build inside k_sample or from the table pass
+    (k_build_tables, lane = (plan, joint)): rows of every format, envelopes and the end-limit verdict must be bit-identical,
+    also when the table workspace is so small that the range is processed in many pieces."""
+    import torch
+    D, lim = amd.limit_set(limits)
+    ltp = amd.LongTermPlanner(D, 0.001, device=0, **lim)
+    qm = ltp.generateQueries(n, seed=77)
+    qm[1][11, 0] = 99.0                                         # a rejected plan in the middle
+    for cap, stride in ((0, 1), (200, 1), (0, 3), (64, 2)):
+        ltp.setMaxSamples(cap); ltp.setSampleStride(stride)
+        res = {}
+        for mode in ("fused", "tables", "tables_small_workspace"):
+            ltp.setTablePass(0, (1 << 32) if mode != "tables_small_workspace" else 40 * D * 1696)
+            b = ltp.planSwitchTimesBatch(*qm)
+            total = int(b.offsets[-1].item())
+            t64 = torch.full((total,), 3.0, dtype=torch.float64, device="cuda")
+            t32 = torch.full((total,), 3.0, dtype=torch.float32, device="cuda")
+            ltp.sampleBatch(b, 0, n, t64, tables=(mode != "fused"))
+            ltp.sampleBatch(b, 0, n, t32, tables=(mode != "fused"), streaming=False)
+            # a sub-range into its own tile: offsets are relative to the first plan of the call
+            sub = torch.full((int((b.offsets[n - 3] - b.offsets[40]).item()) + 8,), 3.0, dtype=torch.float64, device="cuda")
+            ltp.sampleBatch(b, 40, n - 43, sub, tables=(mode != "fused"))
+            torch.cuda.synchronize()
+            res[mode] = (t64, t32, sub, b.status.clone(), b.traj_len.clone())
+        for mode in ("tables", "tables_small_workspace"):
+            for got, want in zip(res[mode], res["fused"]):
+                assert torch.equal(got, want), (cap, stride, mode)
+    ltp.setMaxSamples(0); ltp.setSampleStride(1)
+    b = ltp.planSwitchTimesBatch(*qm)
+    env = {}
+    for mode, flag in (("fused", -1), ("tables", 1), ("pieces", 1)):
+        ltp.setTablePass(flag, (1 << 32) if mode != "pieces" else 40 * D * 1696)
+        env[mode] = (ltp.envelopeBatch(b, 0, n, 48, 24).clone(), ltp.envelopeBatch(b, 30, n - 60, 100, 7).clone())
+    torch.cuda.synchronize()
+    for mode in ("tables", "pieces"):
+        for got, want in zip(env[mode], env["fused"]):
+            assert torch.equal(got.nan_to_num(7.0), want.nan_to_num(7.0)), mode

@@ -1,0 +1,41 @@
+"""Diagnostic: where the time of an item goes in the table-pass sampler (k_sample_tab_*): loader and streaming-wave stamps.
+usage: python tools/tab_probe.py [n] [max_samples] [f32]"""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from longtermplanner_amd import LongTermPlanner, limit_set
+dof, lim = limit_set("panda")
+ltp = LongTermPlanner(dof, 0.001, device=0, **lim)
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 400000
+cap = int(sys.argv[2]) if len(sys.argv) > 2 else 256
+f32 = len(sys.argv) > 3
+ltp.setMaxSamples(cap)
+ltp.setTablePass(1, 16 << 30)
+qg, q0, v0, a0 = ltp.generateQueries(n)
+b = ltp.planSwitchTimesBatch(qg, q0, v0, a0)
+torch.cuda.synchronize()
+total = int(b.offsets[-1].item())
+tile = torch.empty(total, dtype=torch.float32 if f32 else torch.float64, device="cuda")
+ngroups = (dof + 6) // 7
+per = (n + 63) // 64
+items = per * 64 * ngroups
+stamps = torch.zeros(8 * items, dtype=torch.int64, device="cuda")
+ltp.sampleBatch(b, 0, n, tile, tables=True)
+torch.cuda.synchronize()
+ltp._lib.ltp_debug_set_sample_stamps(ltp._h, stamps.data_ptr())
+for rep in range(2):
+    stamps.zero_()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); ltp.sampleBatch(b, 0, n, tile, tables=True); e1.record()
+    torch.cuda.synchronize()
+    s = stamps.cpu().numpy().reshape(items, 8).astype(np.float64) / 100.0     # us
+    ok = (s[:, 0] > 0) & (s[:, 2] > 0) & (s[:, 4] > 0) & (s[:, 6] > 0) & (s[:, 3] > 0) & (s[:, 7] > 0)
+    s = s[ok]
+    print(f"rep {rep}: {e0.elapsed_time(e1):.2f} ms (build + sample), {ok.sum()} items stamped; per item, mean us:")
+    print(f"   loader: wait+copy tables {np.mean(s[:,1]-s[:,0]):.2f}  pass B {np.mean(s[:,2]-s[:,1]):.2f}  "
+          f"streams: issue rows {np.mean(s[:,5]-s[:,4]):.2f}  barrier wait {np.mean(s[:,6]-s[:,5]):.2f}  "
+          f"install->stream start {np.mean(s[:,4]-s[:,2]):.2f}")
+    print(f"   loader: requests {np.mean(s[:,3]-s[:,2]):.2f}  loader barrier wait {np.mean(s[:,7]-s[:,3]):.2f}  loader barrier exit -> stream start of that item {np.mean(s[:,4]-s[:,7]):.2f}")
+    order = np.argsort(s[:, 4])
+    print(f"   span {(s[:,6].max()-s[:,0].min())/1e3:.2f} ms")
+ltp._lib.ltp_debug_set_sample_stamps(ltp._h, None)
