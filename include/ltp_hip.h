@@ -123,8 +123,8 @@ int ltp_get_goal_check(const ltp_planner* p);
  * memory traffic, ~8 us of latency per item: right for long rows, which hide it) or by a kernel of their own before the
  * sampler (lane = (plan, joint); 1 696 bytes per joint written and read back through the handle's workspace; an item then
  * costs one prefetched read: right for short rows — first-N-samples rows, receding-horizon rows, envelopes). Both give
- * bit-identical rows. mode 0 = automatic (the pass for ltp_envelope_batch and when max_samples caps a joint's four rows at
- * <= 8 KiB), 1 = always, -1 = never. ltp_sample_batch's flags bits 2 / 3 force the pass / the fused build per call. */
+ * bit-identical rows. mode 0 = automatic (the pass for ltp_envelope_batch and when max_samples is at most 256 for float64 /
+ * 1024 for float32 rows), 1 = always, -1 = never. ltp_sample_batch's flags bits 2 / 3 force the pass / the fused build per call. */
 int ltp_set_table_pass(ltp_planner* p, int mode);
 int ltp_get_table_pass(const ltp_planner* p);
 /* Upper bound (bytes, default 4 GiB) of the table workspace; ranges whose tables do not fit are processed in pieces. */

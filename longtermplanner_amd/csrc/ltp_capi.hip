@@ -225,12 +225,12 @@ int check_geometry(ltp_planner* p)
 
 // Table pass or fused build? (DESIGN.md "Table pass".) The pass writes and re-reads up to 1 696 bytes per joint and runs
 // the sampler with streaming waves that never wait; the fused build costs every item ~8 us of latency, three barriers and
-// a drain of its own stores: the pass pays when a joint's rows are short (measured crossover: ~8 KiB per joint, i.e. a cap
-// of 256 float64 / 512 float32 samples). `row_bytes` = bytes of one joint's four rows under the cap (0 = no cap).
-bool want_table_pass(const ltp_planner* p, unsigned long long row_bytes)
+// a drain of its own stores: the pass pays when a joint's rows are short (measured crossover: a cap between 256 and 512
+// float64 samples, and beyond 1024 float32 samples, whose fused kernel only holds 16 waves per CU). `row_bytes` = bytes of one joint's four rows under the cap (0 = no cap).
+bool want_table_pass(const ltp_planner* p, unsigned long long row_bytes, bool f32)
 {
     if (p->table_pass != 0) return p->table_pass > 0;
-    return row_bytes > 0 && row_bytes <= 8192ull;
+    return row_bytes > 0 && row_bytes <= (f32 ? 16384ull : 8192ull);
 }
 
 // plans per piece so that the tables of a piece fit the workspace; grows the workspace (up to tables_cap) if needed
@@ -492,7 +492,7 @@ static int sample_batch_any(ltp_planner* p, long long first, long long count, co
     const int blocks = p->sample_blocks_override > 0 ? p->sample_blocks_override : p->sample_blocks[f32 ? 1 : 0];
     // bytes of one joint's four rows when the cap applies (a cap is the only way rows are known to be short up front)
     const unsigned long long row_bytes = p->max_samples > 0 ? 4ull * (f32 ? 4 : 8) * (unsigned long long)p->max_samples : 0ull;
-    if (!(flags & 2) && (!p->dbg_stamps || (flags & 4)) && ((flags & 4) || (!(flags & 8) && want_table_pass(p, row_bytes)))) {
+    if (!(flags & 2) && (!p->dbg_stamps || (flags & 4)) && ((flags & 4) || (!(flags & 8) && want_table_pass(p, row_bytes, f32)))) {
         // table pass: per piece of the range, k_build_tables then the sampler variant that reads the tables
         bool capturing = false;
         if ((rc = workspace_acquire(p, s, capturing)) != LTP_OK) return rc;

@@ -1069,7 +1069,8 @@ LTP_DEV void sample_tab_body(long long first, long long count, long long base_fi
 }
 
 // The register budget decides how many streaming waves a CU holds, and attributes cannot depend on template parameters:
-// one kernel per row type. 3 blocks of 8 waves per CU (21 streaming waves, 6 waves per SIMD, <= 80 VGPRs, LDS 125 KB).
+// one kernel per row type. float64: 3 blocks of 8 waves per CU (21 streaming waves, 6 waves per SIMD, <= 80 VGPRs);
+// float32 (4 samples per lane in flight, 116 VGPRs; at 80 it spills inside the store loop): 2 blocks (14 streaming waves).
 #define LTP_TAB_KERNEL(NAME, ST, TY, WAVES)                                                                                          \
     __global__ void __launch_bounds__(kTabThreads) __attribute__((amdgpu_waves_per_eu(WAVES, 8)))                                    \
     NAME(long long first, long long count, long long base_first, int dof, Records rec, const unsigned long long* __restrict__ offsets, \
