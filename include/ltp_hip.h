@@ -258,6 +258,15 @@ int ltp_opt_switch_times_host(ltp_planner* p, int joint, double q_goal, double q
 int ltp_time_scaling_host(ltp_planner* p, int joint, double q_goal, double q_0, double v_0, double a_0, double dir,
                           double t_required, double* scaled_t, double* v_drive, char* mod, int* ok, int* accepted_case);
 
+/* roots<T>() of the reference's long_term_planner/roots.h:22-34 (the one third-party computation of the hot path: Eigen 3.4's
+ * EigenSolver on the monic companion matrix) for n polynomials of degree 1..8: ALL eigenvalues, in Eigen's output order and
+ * conjugate-pair convention ((re, +im) first), real eigenvalues with an exactly zero imaginary part — what
+ * getSmallestPositiveNonComplexRoot (roots.h:43-50) selects from. coef: [n][degree+1], highest coefficient first; re, im:
+ * [n][degree]. A non-finite companion matrix or a non-converged iteration gives NaN (the reference: uninitialised).
+ * The float form exists because the reference's own known-answer test is in float (tests/src/roots_tests.cc:9-32). */
+int ltp_roots_f64_host(ltp_planner* p, long long n, int degree, const double* coef, double* re, double* im);
+int ltp_roots_f32_host(ltp_planner* p, long long n, int degree, const float* coef, float* re, float* im);
+
 /* ---- diagnostics used by the parity tests ---------------------------------------------------- */
 /* device_buffer (3 x count u64, or NULL to switch off): k_sample block start / run tables ready / end on the
  * 100 MHz wall clock; ltp_envelope_batch writes 16 u64 per (plan, joint group) item instead: loop top, item drawn,

@@ -147,9 +147,50 @@ __global__ void k_roots_probe(long long n, int degree, const double* coef, doubl
     root[i] = r;
 }
 
+// roots<T>() of the reference's long_term_planner/roots.h:22-34 for polynomial i: all eigenvalues of the companion matrix,
+// in Eigen's output order (companion_eigenvalues). coef: [n][degree + 1] highest coefficient first; re, im: [n][degree].
+template <int N, typename R>
+LTP_DEV void roots_all_one(const R* c, R* re, R* im)
+{
+    R p[N + 1], r[N], m[N];
+#pragma unroll
+    for (int i = 0; i <= N; ++i) p[i] = c[i];
+    companion_eigenvalues<N, R>(p, r, m);
+#pragma unroll
+    for (int i = 0; i < N; ++i) { re[i] = r[i]; im[i] = m[i]; }
+}
+
+template <typename R>
+__global__ void k_roots_all(long long n, int degree, const R* coef, R* re, R* im)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const R* c = coef + i * (degree + 1);
+    R* r = re + i * degree;
+    R* m = im + i * degree;
+    switch (degree) {
+    case 1: roots_all_one<1, R>(c, r, m); break;
+    case 2: roots_all_one<2, R>(c, r, m); break;
+    case 3: roots_all_one<3, R>(c, r, m); break;
+    case 4: roots_all_one<4, R>(c, r, m); break;
+    case 5: roots_all_one<5, R>(c, r, m); break;
+    case 6: roots_all_one<6, R>(c, r, m); break;
+    case 7: roots_all_one<7, R>(c, r, m); break;
+    default: roots_all_one<8, R>(c, r, m); break;
+    }
+}
+
 // ---------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------
+void launch_roots_all(hipStream_t s, long long n, int degree, bool f32, const void* coef, void* re, void* im)
+{
+    if (n <= 0) return;
+    const dim3 grid((unsigned)((n + 63) / 64)), block(64);
+    if (f32) hipLaunchKernelGGL(k_roots_all<float>, grid, block, 0, s, n, degree, (const float*)coef, (float*)re, (float*)im);
+    else hipLaunchKernelGGL(k_roots_all<double>, grid, block, 0, s, n, degree, (const double*)coef, (double*)re, (double*)im);
+}
+
 void launch_generate(hipStream_t s, long long n, int dof, Limits lim, unsigned long long seed, long long first_query,
                      double* q_goal, double* q_0, double* v_0, double* a_0, long long sq, long long sj)
 {

@@ -1170,6 +1170,34 @@ int ltp_time_scaling_host(ltp_planner* p, int joint, double q_goal, double q_0, 
     return LTP_OK;
 }
 
+static int roots_host_any(ltp_planner* p, long long n, int degree, bool f32, const void* coef, void* re, void* im)
+{
+    if (!p || n < 0 || degree < 1 || degree > 8 || !coef || !re || !im) return fail(p, LTP_ERR_INVALID_ARGUMENT, "bad argument (degree 1..8)");
+    LTP_HIP_TRY(p, hipSetDevice(p->device));
+    const size_t es = f32 ? sizeof(float) : sizeof(double);
+    void *dc = nullptr, *dr = nullptr, *di = nullptr;
+    DevRecords holder;
+    LTP_HIP_TRY(p, holder.alloc((char**)&dc, (size_t)n * (degree + 1) * es));
+    LTP_HIP_TRY(p, holder.alloc((char**)&dr, (size_t)n * degree * es));
+    LTP_HIP_TRY(p, holder.alloc((char**)&di, (size_t)n * degree * es));
+    LTP_HIP_TRY(p, hipMemcpy(dc, coef, (size_t)n * (degree + 1) * es, hipMemcpyHostToDevice));
+    ltp::launch_roots_all(nullptr, n, degree, f32, dc, dr, di);
+    LTP_HIP_TRY(p, hipGetLastError());
+    LTP_HIP_TRY(p, hipMemcpy(re, dr, (size_t)n * degree * es, hipMemcpyDeviceToHost));
+    LTP_HIP_TRY(p, hipMemcpy(im, di, (size_t)n * degree * es, hipMemcpyDeviceToHost));
+    return LTP_OK;
+}
+
+int ltp_roots_f64_host(ltp_planner* p, long long n, int degree, const double* coef, double* re, double* im)
+{
+    return roots_host_any(p, n, degree, false, coef, re, im);
+}
+
+int ltp_roots_f32_host(ltp_planner* p, long long n, int degree, const float* coef, float* re, float* im)
+{
+    return roots_host_any(p, n, degree, true, coef, re, im);
+}
+
 int ltp_debug_set_sample_stamps(ltp_planner* p, unsigned long long* device_buffer)
 {
     if (!p) return LTP_ERR_INVALID_ARGUMENT;

@@ -121,5 +121,6 @@ void launch_single_time_scaling(hipStream_t s, int joint, double t_sample, Limit
                                 double a_0, double dir, double t_required, double* out11);
 void launch_math_probe(hipStream_t s, long long n, const double* x, const double* y, double* out);
 void launch_roots_probe(hipStream_t s, long long n, int degree, const double* coef, double* root);
+void launch_roots_all(hipStream_t s, long long n, int degree, bool f32, const void* coef, void* re, void* im);
 
 }  // namespace ltp

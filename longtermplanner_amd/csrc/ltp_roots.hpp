@@ -25,15 +25,36 @@ namespace ltp {
 constexpr double kDblMin = 2.2250738585072014e-308;
 constexpr double kDblEps = 2.220446049250313e-16;
 
+// scalar traits of the iteration: binary64 for the planner, binary32 only for the reference's float known-answer test
+// (tests/src/roots_tests.cc:9-32, through long_term_planner/roots.h)
+template <typename R> struct RealTraits;
+template <> struct RealTraits<double> {
+    static LTP_DEV double min() { return kDblMin; }
+    static LTP_DEV double eps() { return kDblEps; }
+    static LTP_DEV double sqrt(double x) { return __builtin_sqrt(x); }
+    static LTP_DEV double inf() { return __builtin_huge_val(); }
+};
+template <> struct RealTraits<float> {
+    static LTP_DEV float min() { return 1.17549435e-38f; }
+    static LTP_DEV float eps() { return 1.1920929e-07f; }
+    static LTP_DEV float sqrt(float x) { return __builtin_sqrtf(x); }
+    static LTP_DEV float inf() { return __builtin_huge_valf(); }
+};
+template <typename R> LTP_DEV R rabs(R x) { return x < R(0) ? -x : x; }
+template <> LTP_DEV double rabs<double>(double x) { return __builtin_fabs(x); }
+template <typename R> LTP_DEV R rmax(R a, R b) { return a < b ? b : a; }
+template <typename R> LTP_DEV bool rfinite(R x) { return rabs(x) < RealTraits<R>::inf(); }
+
 // Eigen MatrixBase::makeHouseholder on (w0; w1, w2)
-LTP_DEV void householder3(double w0, double w1, double w2, double& e0, double& e1, double& tau, double& beta)
+template <typename R>
+LTP_DEV void householder3(R w0, R w1, R w2, R& e0, R& e1, R& tau, R& beta)
 {
-    double tail_sq = w1 * w1 + w2 * w2;
-    if (tail_sq <= kDblMin) {
-        tau = 0.0; beta = w0; e0 = 0.0; e1 = 0.0;
+    R tail_sq = w1 * w1 + w2 * w2;
+    if (tail_sq <= RealTraits<R>::min()) {
+        tau = R(0); beta = w0; e0 = R(0); e1 = R(0);
     } else {
-        double b = dsqrt(w0 * w0 + tail_sq);
-        if (w0 >= 0.0) b = -b;
+        R b = RealTraits<R>::sqrt(w0 * w0 + tail_sq);
+        if (w0 >= R(0)) b = -b;
         e0 = w1 / (w0 - b);
         e1 = w2 / (w0 - b);
         tau = (b - w0) / b;
@@ -41,14 +62,15 @@ LTP_DEV void householder3(double w0, double w1, double w2, double& e0, double& e
     }
 }
 
-LTP_DEV void householder2(double w0, double w1, double& e0, double& tau, double& beta)
+template <typename R>
+LTP_DEV void householder2(R w0, R w1, R& e0, R& tau, R& beta)
 {
-    double tail_sq = w1 * w1;
-    if (tail_sq <= kDblMin) {
-        tau = 0.0; beta = w0; e0 = 0.0;
+    R tail_sq = w1 * w1;
+    if (tail_sq <= RealTraits<R>::min()) {
+        tau = R(0); beta = w0; e0 = R(0);
     } else {
-        double b = dsqrt(w0 * w0 + tail_sq);
-        if (w0 >= 0.0) b = -b;
+        R b = RealTraits<R>::sqrt(w0 * w0 + tail_sq);
+        if (w0 >= R(0)) b = -b;
         e0 = w1 / (w0 - b);
         tau = (b - w0) / b;
         beta = b;
@@ -56,75 +78,76 @@ LTP_DEV void householder2(double w0, double w1, double& e0, double& tau, double&
 }
 
 // Eigen JacobiRotation::makeGivens, real case
-LTP_DEV void givens(double p, double q, double& c, double& s)
+template <typename R>
+LTP_DEV void givens(R p, R q, R& c, R& s)
 {
-    if (q == 0.0) {
-        c = p < 0.0 ? -1.0 : 1.0;
-        s = 0.0;
-    } else if (p == 0.0) {
-        c = 0.0;
-        s = q < 0.0 ? 1.0 : -1.0;
-    } else if (dabs(p) > dabs(q)) {
-        double t = q / p;
-        double u = dsqrt(1.0 + t * t);
-        if (p < 0.0) u = -u;
-        c = 1.0 / u;
+    if (q == R(0)) {
+        c = p < R(0) ? R(-1) : R(1);
+        s = R(0);
+    } else if (p == R(0)) {
+        c = R(0);
+        s = q < R(0) ? R(1) : R(-1);
+    } else if (rabs(p) > rabs(q)) {
+        R t = q / p;
+        R u = RealTraits<R>::sqrt(R(1) + t * t);
+        if (p < R(0)) u = -u;
+        c = R(1) / u;
         s = -t * c;
     } else {
-        double t = p / q;
-        double u = dsqrt(1.0 + t * t);
-        if (q < 0.0) u = -u;
-        s = -1.0 / u;
+        R t = p / q;
+        R u = RealTraits<R>::sqrt(R(1) + t * t);
+        if (q < R(0)) u = -u;
+        s = R(-1) / u;
         c = -t * s;
     }
 }
 
-// Smallest admissible root of p[0] x^N + ... + p[N] (highest coefficient first).
-template <int N>
-__device__ double smallest_positive_real_root(const double (&p)[N + 1])
+// RealSchur::compute on the monic companion matrix of p (highest coefficient first): T is left quasi-triangular, in the
+// scaled units (multiply by scale_out). false: non-finite matrix or no convergence within 40 N iterations.
+template <int N, typename R>
+__device__ bool real_schur_companion(const R (&p)[N + 1], R (&T)[N][N], R& scale_out)
 {
-    static_assert(N >= 3 && N <= 8, "degree out of range");
-    double T[N][N];
+    static_assert(N >= 1 && N <= 8, "degree out of range");
 #pragma unroll
     for (int i = 0; i < N; ++i)
 #pragma unroll
-        for (int j = 0; j < N; ++j) T[i][j] = 0.0;
+        for (int j = 0; j < N; ++j) T[i][j] = R(0);
 #pragma unroll
-    for (int i = 1; i < N; ++i) T[i][i - 1] = 1.0;
+    for (int i = 1; i < N; ++i) T[i][i - 1] = R(1);
     bool finite = true;
 #pragma unroll
     for (int i = 0; i < N; ++i) {
-        double c = (-1.0 * p[N - i]) / p[0];
+        R c = (R(-1) * p[N - i]) / p[0];
         T[i][N - 1] = c;
-        finite = finite && dfinite(c);
+        finite = finite && rfinite(c);
     }
-    if (!finite) return kInf;
+    if (!finite) return false;
 
     // RealSchur::compute: scale to max|a_ij| == 1 (the sub-diagonal ones make scale >= 1)
-    double scale = 0.0;
+    R scale = R(0);
 #pragma unroll
     for (int i = 0; i < N; ++i)
 #pragma unroll
-        for (int j = 0; j < N; ++j) scale = dmax(scale, dabs(T[i][j]));
+        for (int j = 0; j < N; ++j) scale = rmax(scale, rabs(T[i][j]));
 #pragma unroll
     for (int i = 0; i < N; ++i)
 #pragma unroll
         for (int j = 0; j < N; ++j) T[i][j] = T[i][j] / scale;
 
-    double norm = 0.0;
+    R norm = R(0);
 #pragma unroll
     for (int j = 0; j < N; ++j) {
-        double colsum = 0.0;
+        R colsum = R(0);
 #pragma unroll
         for (int i = 0; i < N; ++i)
-            if (i < j + 2) colsum += dabs(T[i][j]);
+            if (i < j + 2) colsum += rabs(T[i][j]);
         norm += colsum;
     }
-    const double consider_zero = dmax(norm * (kDblEps * kDblEps), kDblMin);
+    const R consider_zero = rmax(norm * (RealTraits<R>::eps() * RealTraits<R>::eps()), RealTraits<R>::min());
 
     int iu = N - 1, iter = 0, total_iter = 0;
     const int max_iters = 40 * N;
-    double exshift = 0.0;
+    R exshift = R(0);
     bool converged = true;
 
     while (iu >= 0) {
@@ -135,9 +158,9 @@ __device__ double smallest_positive_real_root(const double (&p)[N + 1])
 #pragma unroll
             for (int r = N - 1; r >= 1; --r) {
                 if (r <= iu && !stop) {
-                    double s = dabs(T[r - 1][r - 1]) + dabs(T[r][r]);
-                    s = dmax(s * kDblEps, consider_zero);
-                    if (dabs(T[r][r - 1]) <= s) stop = true;
+                    R s = rabs(T[r - 1][r - 1]) + rabs(T[r][r]);
+                    s = rmax(s * RealTraits<R>::eps(), consider_zero);
+                    if (rabs(T[r][r - 1]) <= s) stop = true;
                     else il = r - 1;
                 }
             }
@@ -148,7 +171,7 @@ __device__ double smallest_positive_real_root(const double (&p)[N + 1])
             for (int u = 0; u < N; ++u) {
                 if (u == iu) {
                     T[u][u] = T[u][u] + exshift;
-                    if (u > 0) T[u][u > 0 ? u - 1 : 0] = 0.0;
+                    if (u > 0) T[u][u > 0 ? u - 1 : 0] = R(0);
                 }
             }
             iu -= 1;
@@ -158,37 +181,37 @@ __device__ double smallest_positive_real_root(const double (&p)[N + 1])
 #pragma unroll
             for (int u = 1; u < N; ++u) {
                 if (u == iu) {
-                    double pp = 0.5 * (T[u - 1][u - 1] - T[u][u]);
-                    double qq = pp * pp + T[u][u - 1] * T[u - 1][u];
+                    R pp = R(0.5) * (T[u - 1][u - 1] - T[u][u]);
+                    R qq = pp * pp + T[u][u - 1] * T[u - 1][u];
                     T[u][u] += exshift;
                     T[u - 1][u - 1] += exshift;
-                    if (qq >= 0.0) {
-                        double z = dsqrt(dabs(qq));
-                        double c, s;
-                        if (pp >= 0.0) givens(pp + z, T[u][u - 1], c, s);
+                    if (qq >= R(0)) {
+                        R z = RealTraits<R>::sqrt(rabs(qq));
+                        R c, s;
+                        if (pp >= R(0)) givens(pp + z, T[u][u - 1], c, s);
                         else givens(pp - z, T[u][u - 1], c, s);
 #pragma unroll
                         for (int k = u - 1; k < N; ++k) {
-                            double x = T[u - 1][k], y = T[u][k];
+                            R x = T[u - 1][k], y = T[u][k];
                             T[u - 1][k] = c * x + (-s) * y;
                             T[u][k] = s * x + c * y;
                         }
 #pragma unroll
                         for (int k = 0; k <= u; ++k) {
-                            double x = T[k][u - 1], y = T[k][u];
+                            R x = T[k][u - 1], y = T[k][u];
                             T[k][u - 1] = c * x + (-s) * y;
                             T[k][u] = s * x + c * y;
                         }
-                        T[u][u - 1] = 0.0;
+                        T[u][u - 1] = R(0);
                     }
-                    if (u > 1) T[u - 1][u > 1 ? u - 2 : 0] = 0.0;
+                    if (u > 1) T[u - 1][u > 1 ? u - 2 : 0] = R(0);
                 }
             }
             iu -= 2;
             iter = 0;
         } else {
             // one Francis double-shift step on the window [il, iu], iu >= il + 2
-            double sh0 = 0.0, sh1 = 0.0, sh2 = 0.0, sub0 = 0.0, sub1 = 0.0;
+            R sh0 = R(0), sh1 = R(0), sh2 = R(0), sub0 = R(0), sub1 = R(0);
 #pragma unroll
             for (int u = 2; u < N; ++u) {
                 if (u == iu) {
@@ -204,24 +227,24 @@ __device__ double smallest_positive_real_root(const double (&p)[N + 1])
 #pragma unroll
                 for (int i = 0; i < N; ++i)
                     if (i <= iu) T[i][i] -= sh0;
-                double s = dabs(sub0) + dabs(sub1);
-                sh0 = 0.75 * s;
-                sh1 = 0.75 * s;
-                sh2 = -0.4375 * s * s;
+                R s = rabs(sub0) + rabs(sub1);
+                sh0 = R(0.75) * s;
+                sh1 = R(0.75) * s;
+                sh2 = R(-0.4375) * s * s;
             }
             if (iter == 30) {
-                double s = (sh1 - sh0) / 2.0;
+                R s = (sh1 - sh0) / R(2);
                 s = s * s + sh2;
-                if (s > 0.0) {
-                    s = dsqrt(s);
+                if (s > R(0)) {
+                    s = RealTraits<R>::sqrt(s);
                     if (sh1 < sh0) s = -s;
-                    s = s + (sh1 - sh0) / 2.0;
+                    s = s + (sh1 - sh0) / R(2);
                     s = sh0 - sh2 / s;
                     exshift += s;
 #pragma unroll
                     for (int i = 0; i < N; ++i)
                         if (i <= iu) T[i][i] -= s;
-                    sh0 = sh1 = sh2 = 0.964;
+                    sh0 = sh1 = sh2 = R(0.964);
                 }
             }
             iter += 1;
@@ -230,15 +253,15 @@ __device__ double smallest_positive_real_root(const double (&p)[N + 1])
 
             // initFrancisQRStep
             int im = il;
-            double v0 = 0.0, v1 = 0.0, v2 = 0.0;
+            R v0 = R(0), v1 = R(0), v2 = R(0);
             {
                 bool found = false;
 #pragma unroll
                 for (int m = N - 3; m >= 0; --m) {
                     if (m <= iu - 2 && m >= il && !found) {
-                        const double Tmm = T[m][m];
-                        const double r = sh0 - Tmm;
-                        const double s = sh1 - Tmm;
+                        const R Tmm = T[m][m];
+                        const R r = sh0 - Tmm;
+                        const R s = sh1 - Tmm;
                         v0 = (r * s - sh2) / T[m + 1][m] + T[m][m + 1];
                         v1 = T[m + 1][m + 1] - Tmm - r - s;
                         v2 = T[m + 2][m + 1];
@@ -247,9 +270,9 @@ __device__ double smallest_positive_real_root(const double (&p)[N + 1])
                             found = true;
                         } else {
                             const int mm1 = m > 0 ? m - 1 : 0;
-                            const double lhs = T[m][mm1] * (dabs(v1) + dabs(v2));
-                            const double rhs = v0 * (dabs(T[mm1][mm1]) + dabs(Tmm) + dabs(T[m + 1][m + 1]));
-                            if (dabs(lhs) < kDblEps * rhs) found = true;
+                            const R lhs = T[m][mm1] * (rabs(v1) + rabs(v2));
+                            const R rhs = v0 * (rabs(T[mm1][mm1]) + rabs(Tmm) + rabs(T[m + 1][m + 1]));
+                            if (rabs(lhs) < RealTraits<R>::eps() * rhs) found = true;
                         }
                     }
                 }
@@ -260,18 +283,18 @@ __device__ double smallest_positive_real_root(const double (&p)[N + 1])
                 if (k >= im && k <= iu - 2) {
                     const bool first = (k == im);
                     const int km1 = k > 0 ? k - 1 : 0;
-                    double w0, w1, w2;
+                    R w0, w1, w2;
                     if (first) { w0 = v0; w1 = v1; w2 = v2; }
                     else { w0 = T[k][km1]; w1 = T[k + 1][km1]; w2 = T[k + 2][km1]; }
-                    double e0, e1, tau, beta;
+                    R e0, e1, tau, beta;
                     householder3(w0, w1, w2, e0, e1, tau, beta);
-                    if (beta != 0.0) {
+                    if (beta != R(0)) {
                         if (first && k > il) T[k][km1] = -T[k][km1];
                         else if (!first) T[k][km1] = beta;
-                        if (tau != 0.0) {
+                        if (tau != R(0)) {
 #pragma unroll
                             for (int j = k; j < N; ++j) {
-                                double tmp = e0 * T[k + 1][j] + e1 * T[k + 2][j];
+                                R tmp = e0 * T[k + 1][j] + e1 * T[k + 2][j];
                                 tmp += T[k][j];
                                 T[k][j] -= tau * tmp;
                                 T[k + 1][j] -= (tau * e0) * tmp;
@@ -281,7 +304,7 @@ __device__ double smallest_positive_real_root(const double (&p)[N + 1])
 #pragma unroll
                             for (int i = 0; i < N; ++i) {
                                 if (i <= k + 3 && i <= rmax) {
-                                    double tmp = T[i][k + 1] * e0 + T[i][k + 2] * e1;
+                                    R tmp = T[i][k + 1] * e0 + T[i][k + 2] * e1;
                                     tmp += T[i][k];
                                     T[i][k] -= tau * tmp;
                                     T[i][k + 1] -= (tau * tmp) * e0;
@@ -296,21 +319,21 @@ __device__ double smallest_positive_real_root(const double (&p)[N + 1])
 #pragma unroll
             for (int u = 2; u < N; ++u) {
                 if (u == iu) {
-                    double e0, tau, beta;
+                    R e0, tau, beta;
                     householder2(T[u - 1][u - 2], T[u][u - 2], e0, tau, beta);
-                    if (beta != 0.0) {
+                    if (beta != R(0)) {
                         T[u - 1][u - 2] = beta;
-                        if (tau != 0.0) {
+                        if (tau != R(0)) {
 #pragma unroll
                             for (int j = u - 1; j < N; ++j) {
-                                double tmp = e0 * T[u][j];
+                                R tmp = e0 * T[u][j];
                                 tmp += T[u - 1][j];
                                 T[u - 1][j] -= tau * tmp;
                                 T[u][j] -= (tau * e0) * tmp;
                             }
 #pragma unroll
                             for (int i = 0; i <= u; ++i) {
-                                double tmp = T[i][u] * e0;
+                                R tmp = T[i][u] * e0;
                                 tmp += T[i][u - 1];
                                 T[i][u - 1] -= tau * tmp;
                                 T[i][u] -= (tau * tmp) * e0;
@@ -323,12 +346,24 @@ __device__ double smallest_positive_real_root(const double (&p)[N + 1])
 #pragma unroll
             for (int i = 2; i < N; ++i) {
                 if (i >= im + 2 && i <= iu) {
-                    T[i][i - 2] = 0.0;
-                    if (i > im + 2) T[i][i >= 3 ? i - 3 : 0] = 0.0;
+                    T[i][i - 2] = R(0);
+                    if (i > im + 2) T[i][i >= 3 ? i - 3 : 0] = R(0);
                 }
             }
         }
     }
+    scale_out = scale;
+    return converged;
+}
+
+// Smallest admissible root of p[0] x^N + ... + p[N] (highest coefficient first).
+template <int N>
+__device__ double smallest_positive_real_root(const double (&p)[N + 1])
+{
+    static_assert(N >= 3 && N <= 8, "degree out of range");
+    double T[N][N];
+    double scale;
+    const bool converged = real_schur_companion<N, double>(p, T, scale);
     if (!converged) return kInf;
 
     // EigenSolver::compute: eigenvalues off the quasi-triangular T (after T *= scale),
@@ -366,6 +401,53 @@ __device__ double smallest_positive_real_root(const double (&p)[N + 1])
         }
     }
     return best;
+}
+
+// All eigenvalues of the companion matrix, in the order and with the conjugate-pair convention of Eigen 3.4's
+// EigenSolver::compute (roots.h:32-33): read off the quasi-triangular T top to bottom; a 1x1 block is a real eigenvalue
+// (imaginary part exactly zero), a 2x2 block that splitOffTwoRows could not split a pair (re, +im), (re, -im).
+// A non-finite matrix or a non-converged iteration yields NaN everywhere (Eigen leaves the vector uninitialised).
+template <int N, typename R>
+__device__ void companion_eigenvalues(const R (&p)[N + 1], R (&re)[N], R (&im)[N])
+{
+    R T[N][N];
+    R scale;
+    const bool ok = real_schur_companion<N, R>(p, T, scale);
+    const R nan = RealTraits<R>::inf() - RealTraits<R>::inf();
+    if (!ok) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) { re[i] = nan; im[i] = nan; }
+        return;
+    }
+    bool skip = false;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        if (skip) { skip = false; continue; }
+        const R tii = T[i][i] * scale;
+        bool is_real = true;
+        R sub = R(0);
+        if (i < N - 1) {
+            sub = T[i + 1 < N ? i + 1 : i][i] * scale;
+            is_real = (sub == R(0));
+        }
+        if (is_real) {
+            re[i] = tii;
+            im[i] = R(0);
+        } else {
+            const int ip = i + 1 < N ? i + 1 : i;
+            const R tpp = T[ip][ip] * scale;
+            const R pp = R(0.5) * (tii - tpp);
+            R t0 = sub, t1 = T[i][ip] * scale;
+            const R maxval = rmax(rabs(pp), rmax(rabs(t0), rabs(t1)));
+            t0 /= maxval;
+            t1 /= maxval;
+            const R p0 = pp / maxval;
+            const R z = maxval * RealTraits<R>::sqrt(rabs(p0 * p0 + t0 * t1));
+            re[i] = tpp + pp; im[i] = z;
+            re[ip] = tpp + pp; im[ip] = -z;
+            skip = true;
+        }
+    }
 }
 
 }  // namespace ltp

@@ -359,6 +359,20 @@ class LongTermPlanner:
                                                  sample_index if per_plan is None else 0, *[x.data_ptr() for x in out], sq, sj, self._stream()))
         return out
 
+    def roots(self, poly, dtype=np.float64):
+        """roots<T>() of the reference's roots.h:22-34 on the device: all eigenvalues of the companion matrix of each
+        polynomial (rows of `poly`, highest coefficient first), as a complex array in Eigen's output order."""
+        dt = np.dtype(dtype)
+        poly = np.ascontiguousarray(np.atleast_2d(np.asarray(poly, dtype=dt)))
+        n, deg = poly.shape[0], poly.shape[1] - 1
+        re = np.zeros((n, deg), dtype=dt); im = np.zeros((n, deg), dtype=dt)
+        if dt == np.float32:
+            fp = C.POINTER(C.c_float)
+            self._check(self._lib.ltp_roots_f32_host(self._h, n, deg, poly.ctypes.data_as(fp), re.ctypes.data_as(fp), im.ctypes.data_as(fp)))
+        else:
+            self._check(self._lib.ltp_roots_f64_host(self._h, n, deg, _ptr(poly), _ptr(re), _ptr(im)))
+        return re + 1j * im
+
     # ---- diagnostics for the parity tests ----
     def debugMathProbe(self, x, y):
         x, y = _vec(x), _vec(y)

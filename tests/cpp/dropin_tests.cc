@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "long_term_planner/long_term_planner.h"
+#include "long_term_planner/roots.h"
 
 namespace ltpn = long_term_planner;
 
@@ -227,6 +228,24 @@ static void testApiSurface()
   EXPECT_TRUE(bc.stored[0] == b.length[0] && bc.status[1] == LTP_STATUS_END_LIMIT);
 }
 
+// The reference's root-finder test (tests/src/roots_tests.cc:9-32) on the device path: float, degree 6, the six eigenvalues
+// in Eigen's output order at the reference's tolerances.
+static void testRootsHeader()
+{
+  const std::vector<float> poly = {144.f, -1008.f, 2448.f, 3024.01920000000f, -15768.1344000000f, 0.f, 22752.4032012800f};
+  const std::vector<std::complex<float>> r = ltpn::roots<float>(poly);
+  EXPECT_TRUE(r.size() == 6);
+  const double re[6] = {-1.67276, -1.35687, 2.00001, 2.09261, 2.9685, 2.9685}, im[6] = {0, 0, 0, 0, 2.79663, -2.79663};
+  for (int i = 0; i < 6 && r.size() == 6; ++i) {
+    EXPECT_NEAR(r[i].real(), re[i], 1e-5);
+    EXPECT_NEAR(r[i].imag(), im[i], i < 4 ? 1e-9 : 1e-5);
+  }
+  EXPECT_NEAR(ltpn::getSmallestPositiveNonComplexRoot<float>(r), 2.00001, 1e-5);
+  // double: (x - 1)(x - 2)(x^2 + 1) -> smallest admissible root 1; x^4 + 1 -> none
+  EXPECT_NEAR(ltpn::getSmallestPositiveNonComplexRoot<double>(ltpn::roots<double>({1, -3, 3, -3, 2})), 1.0, 1e-12);
+  EXPECT_TRUE(std::isinf(ltpn::getSmallestPositiveNonComplexRoot<double>(ltpn::roots<double>({1, 0, 0, 0, 1}))));
+}
+
 // Two threads issue the FIRST call on one object at the same time (the reference allows concurrent planTrajectory on
 // one object, SURVEY §8(b) "Threading"): the lazily created device handle must be created once, and both get results.
 static void testConcurrentFirstCall()
@@ -294,6 +313,7 @@ int main()
     testTimeScaling();
     testGridOneJointCoarse();
     testApiSurface();
+    testRootsHeader();
     testConcurrentFirstCall();
     testShardedBatch();
   } catch (const std::exception& e) {

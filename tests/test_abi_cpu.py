@@ -76,3 +76,27 @@ def test_cpp_dropin_builds_with_plain_gxx_and_fails_loudly_without_gpu(abi):
     if not _has_gpu():
         r = subprocess.run([exe], capture_output=True, text=True)
         assert r.returncode == 2 and "no CPU fallback" in r.stdout
+
+
+def _build_cmake_consumer(tmp_path):
+    import shutil
+    if shutil.which("cmake") is None:
+        pytest.skip("cmake not installed")
+    build = tmp_path / "build"
+    subprocess.check_call(["cmake", "-S", os.path.join(ROOT, "tests", "cmake_consumer"), "-B", str(build),
+                           f"-Dlong_term_planner_DIR={os.path.join(ROOT, 'cmake')}"], stdout=subprocess.DEVNULL)
+    subprocess.check_call(["cmake", "--build", str(build)], stdout=subprocess.DEVNULL)
+    return str(build / "consumer")
+
+
+def test_cmake_package_resolves_like_the_reference(abi, tmp_path):
+    """find_package(long_term_planner) + target long_term_planner::long_term_planner, version 1.0.0
+    (/root/reference/CMakeLists.txt:17-57): an unchanged consumer project configures, builds and links against the
+    drop-in; without a GPU the program reports the missing device instead of computing on the CPU."""
+    exe = _build_cmake_consumer(tmp_path)
+    p = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    import torch
+    if torch.cuda.device_count() == 0:
+        assert p.returncode == 3 and "no device" in p.stdout
+    else:
+        assert p.returncode == 0 and "planTrajectory: true" in p.stdout

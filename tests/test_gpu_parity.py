@@ -186,3 +186,29 @@ def test_fuzzed_limit_sets(amd, oracle_mod):
                 worst_x = max(worst_x, float(np.max(np.abs(got - ref))))
     print(f"fuzz: worst |dt| {worst_t:.3e}, worst |d(q,v,a,j)| {worst_x:.3e}")
     assert worst_t <= TOL and worst_x <= TOL
+
+
+def test_device_roots_all_eigenvalues_in_eigen_order(amd, oracle_mod, kat):
+    """long_term_planner/roots.h on the device (ltp_roots_f32_host / _f64_host): every eigenvalue of the companion matrix in
+    Eigen's output order. The reference's float degree-6 known-answer test (roots_tests.cc:9-32) at its own tolerances, and
+    bit-level agreement in order / classification with the oracle's restated EigenSolver on random polynomials."""
+    D, lim = amd.limit_set("ref")
+    ltp = amd.LongTermPlanner(D, 0.001, device=0, **lim)
+    k = kat["roots_f32_deg6"]
+    r = ltp.roots(k["poly"], dtype=np.float32)[0]
+    for i in range(6):
+        assert abs(float(r[i].real) - k["re"][i]) <= k["tol"] and abs(float(r[i].imag) - k["im"][i]) <= (k["tol_imag_real_roots"] if k["im"][i] == 0 else k["tol"])
+    assert all(float(r[i].imag) == 0.0 for i in range(4)) and r[4].imag > 0 > r[5].imag
+    ore, oim, st = oracle_mod.roots_f32(k["poly"])
+    assert st == 0 and np.allclose(r.real, ore, rtol=0, atol=2e-6) and np.allclose(r.imag, oim, rtol=0, atol=2e-6)
+    rng = np.random.default_rng(11)
+    for deg in range(1, 9):
+        polys = rng.normal(size=(400, deg + 1)) * 10.0 ** rng.integers(-2, 3, size=(400, deg + 1))
+        got = ltp.roots(polys)
+        for p, g in zip(polys, got):
+            ore, oim, st = oracle_mod.roots_f64(p)
+            assert st == 0
+            assert np.array_equal(g.imag == 0.0, oim == 0.0), (deg, p)
+            assert np.allclose(g.real, ore, rtol=1e-9, atol=1e-11) and np.allclose(g.imag, oim, rtol=1e-9, atol=1e-11), (deg, p, g, ore, oim)
+    # leading zero coefficient / non-finite companion matrix: NaN everywhere (defined here; the reference: uninitialised)
+    assert np.all(np.isnan(ltp.roots([0.0, 1.0, 2.0, 3.0, 4.0])[0].real))
