@@ -127,7 +127,10 @@ int reserve(ltp_planner* p, long long n)
     const long long items = n * (long long)(p->dof > 0 ? p->dof : 1);
     LTP_HIP_TRY(p, hipSetDevice(p->device));
     if (!p->d_queue_count) LTP_HIP_TRY(p, hipMalloc((void**)&p->d_queue_count, 16 * sizeof(unsigned long long)));
-    if (!p->d_small) LTP_HIP_TRY(p, hipMalloc((void**)&p->d_small, sizeof(double) * 16));
+    if (!p->d_small) {
+        LTP_HIP_TRY(p, hipMalloc((void**)&p->d_small, sizeof(double) * 16));
+        LTP_HIP_TRY(p, hipMemset(p->d_small, 0, sizeof(double) * 16));   // word 0: arrival counter of k_plan_small
+    }
     if (!p->d_sample_next) LTP_HIP_TRY(p, hipMalloc((void**)&p->d_sample_next, sizeof(unsigned long long) * 64));
     for (int w = 0; w < 3; ++w)
         if (p->sample_blocks[w] == 0) p->sample_blocks[w] = ltp::sample_resident_blocks(p->device, w);
@@ -685,6 +688,63 @@ static int download_records(ltp_planner* p, long long n, int dof, const ltp_reco
     return LTP_OK;
 }
 
+// ---- pinned result buffers: what ltp_plan_batch_host / ltp_get_trajectory_host hand out as *packed for small batches.
+// The fused small-batch kernel writes the rows straight into such a buffer (host memory the device can address), so the
+// caller gets them without any copy; ltp_free_host returns the buffer here instead of to the heap. ----
+namespace {
+
+struct PinnedPool {
+    struct Buf { void* ptr; size_t bytes; bool used; };
+    std::mutex mu;
+    std::vector<Buf> bufs;
+    static constexpr size_t kKeep = 16;           // buffers kept for reuse
+
+    void* acquire(size_t bytes)
+    {
+        std::lock_guard<std::mutex> g(mu);
+        for (auto& b : bufs)
+            if (!b.used && b.bytes >= bytes) { b.used = true; return b.ptr; }
+        void* ptr = nullptr;
+        if (hipHostMalloc(&ptr, bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        bufs.push_back(Buf{ptr, bytes, true});
+        return ptr;
+    }
+    // true if ptr is one of ours
+    bool release(void* ptr)
+    {
+        std::lock_guard<std::mutex> g(mu);
+        size_t idle = 0;
+        for (auto& b : bufs) idle += !b.used;
+        for (size_t i = 0; i < bufs.size(); ++i)
+            if (bufs[i].ptr == ptr) {
+                if (idle >= kKeep) { (void)hipHostFree(ptr); bufs.erase(bufs.begin() + (long)i); }
+                else bufs[i].used = false;
+                return true;
+            }
+        return false;
+    }
+};
+PinnedPool g_pinned;
+
+constexpr size_t kFusedRowsBytes = 8u << 20;      // rows of a fused small-batch call: up to 1 Mi doubles (7-DoF, 1 ms: 48 k)
+
+// waits for the kernel's completion word in pinned memory (a few microseconds sooner than a stream synchronisation)
+int wait_done(ltp_planner* p, volatile int* done)
+{
+    for (long spins = 0; *done == 0; ++spins) {
+        if (spins > 2000000) {                      // ~ a second without news: ask the runtime (reports a faulted kernel)
+            LTP_HIP_TRY(p, hipStreamSynchronize(nullptr));
+            if (*done == 0) return fail(p, LTP_ERR_HIP, "small-batch kernel finished without reporting");
+        }
+#if defined(__x86_64__)
+        __builtin_ia32_pause();
+#endif
+    }
+    return LTP_OK;
+}
+
+}  // namespace
+
 // ---- small-batch host path: one persistent device arena + pinned mirror, one H2D and one D2H per call ----
 namespace {
 
@@ -776,6 +836,78 @@ int sample_to_host_small(ltp_planner* p, long long n, const ArenaLayout& L, cons
     return LTP_OK;
 }
 
+// The fused path of ltp_plan_batch_host / ltp_get_trajectory_host for n * dof <= small_batch_pairs(): one launch of one
+// block that reads the queries from and writes records and rows to pinned host memory (k_plan_small), one wait. Caller holds
+// host_mu. Returns LTP_OK with *handled = false when the rows do not fit the pinned result buffer (caller takes the staged path).
+int plan_batch_host_fused(ltp_planner* p, long long n, const double* const (&h_in)[4], const ltp_records* host_records,
+                          const ltp_records* given /* getTrajectory: t_scaled, dir, mod, v_drive are inputs */,
+                          unsigned long long* offsets, double** packed, bool* handled)
+{
+    *handled = false;
+    const int dof = p->dof;
+    const size_t nd = (size_t)n * dof;
+    const ArenaLayout L = arena_layout(n, dof);
+    const size_t flag_at = (L.end + 63) & ~(size_t)63;
+    const int blocks = ltp::small_batch_blocks(dof, packed != nullptr);
+    const size_t ends_at = flag_at + 64;                         // [blocks][n] end-limit bits
+    int rc = ensure_arena(p, ends_at + sizeof(int) * (size_t)blocks * (size_t)n);
+    if (rc != LTP_OK) return rc;
+    for (int k = 0; k < 4; ++k)
+        if (h_in[k]) memcpy(p->h_arena + L.in[k], h_in[k], sizeof(double) * nd);
+    const ltp_records hr = arena_records(p->h_arena, L);
+    if (given) {
+        memcpy(hr.t_scaled, given->t_scaled, sizeof(double) * nd * 7);
+        memcpy(hr.dir, given->dir, sizeof(double) * nd);
+        memcpy(hr.v_drive, given->v_drive, sizeof(double) * nd);
+        memcpy(hr.mod, given->mod, nd);
+    }
+    double* rows = nullptr;
+    if (packed) {
+        rows = (double*)g_pinned.acquire(kFusedRowsBytes);
+        if (!rows) return LTP_OK;                                // no pinned memory to be had: staged path
+    }
+    volatile int* done = (volatile int*)(p->h_arena + flag_at);
+    *done = 0;
+    const double* in[4] = {(const double*)(p->h_arena + L.in[0]), (const double*)(p->h_arena + L.in[1]),
+                           (const double*)(p->h_arena + L.in[2]), (const double*)(p->h_arena + L.in[3])};
+    {
+        std::lock_guard<std::mutex> g(p->mu);
+        capture_geometry(p);
+        ltp::launch_plan_small(nullptr, (int)n, dof, p->t_sample, p->goal_check, ltp::RowSpec{p->max_samples, p->sample_stride}, dev_limits(p), in,
+                               to_dev(&hr), (unsigned long long*)(p->h_arena + L.offsets), rows, kFusedRowsBytes / sizeof(double),
+                               (int*)(p->h_arena + ends_at), (unsigned int*)p->d_small, done, given != nullptr);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) { if (rows) g_pinned.release(rows); return hip_fail(p, e, "k_plan_small"); }
+    }
+    rc = wait_done(p, done);
+    if (rc != LTP_OK) { if (rows) g_pinned.release(rows); return rc; }
+    if (*done == 2) {                                            // rows larger than the pinned buffer
+        g_pinned.release(rows);
+        return LTP_OK;
+    }
+    if (packed) {                                                // end-limit bits of the blocks that sampled (cc:59-61)
+        const int* ends = (const int*)(p->h_arena + ends_at);
+        for (int b = 0; b < blocks; ++b)
+            for (long long i = 0; i < n; ++i) hr.status[i] |= ends[(size_t)b * n + i];
+    }
+    const unsigned long long* h_off = (const unsigned long long*)(p->h_arena + L.offsets);
+    if (offsets) memcpy(offsets, h_off, sizeof(unsigned long long) * ((size_t)n + 1));
+    if (host_records) {
+        if (host_records->t_opt && !given) memcpy(host_records->t_opt, hr.t_opt, sizeof(double) * nd * 7);
+        if (host_records->t_scaled && !given) memcpy(host_records->t_scaled, hr.t_scaled, sizeof(double) * nd * 7);
+        if (host_records->dir && !given) memcpy(host_records->dir, hr.dir, sizeof(double) * nd);
+        if (host_records->v_drive && !given) memcpy(host_records->v_drive, hr.v_drive, sizeof(double) * nd);
+        if (host_records->mod && !given) memcpy(host_records->mod, hr.mod, nd);
+        if (host_records->t_required && !given) memcpy(host_records->t_required, hr.t_required, sizeof(double) * (size_t)n);
+        if (host_records->slowest && !given) memcpy(host_records->slowest, hr.slowest, sizeof(int) * (size_t)n);
+        if (host_records->traj_len) memcpy(host_records->traj_len, hr.traj_len, sizeof(int) * (size_t)n);
+        if (host_records->status) memcpy(host_records->status, hr.status, sizeof(int) * (size_t)n);
+    }
+    if (packed) *packed = rows;
+    *handled = true;
+    return LTP_OK;
+}
+
 // the staged path of ltp_plan_batch_host; caller holds host_mu
 int plan_batch_host_small(ltp_planner* p, long long n, const double* const (&h_in)[4], const ltp_records* host_records,
                           unsigned long long* offsets, double** packed)
@@ -818,7 +950,8 @@ int plan_batch_host_small(ltp_planner* p, long long n, const double* const (&h_i
     return LTP_OK;
 }
 
-// one-lane entry points: 16 doubles up, kernel, 16 doubles down, through the pinned arena
+// one-lane entry points: the kernel reads its 16 doubles from, and writes them back to, the pinned arena (host memory the
+// device addresses directly): one launch, one synchronisation, no copy engine
 extern "C++" {
 template <class Launch>
 int run_one_lane(ltp_planner* p, double (&buf)[16], Launch launch)
@@ -827,10 +960,8 @@ int run_one_lane(ltp_planner* p, double (&buf)[16], Launch launch)
     int rc = ensure_arena(p, sizeof(buf));
     if (rc != LTP_OK) return rc;
     memcpy(p->h_arena, buf, sizeof(buf));
-    LTP_HIP_TRY(p, hipMemcpyAsync(p->d_small, p->h_arena, sizeof(buf), hipMemcpyHostToDevice, nullptr));
-    launch();
+    launch((double*)p->h_arena);
     LTP_HIP_TRY(p, hipGetLastError());
-    LTP_HIP_TRY(p, hipMemcpyAsync(p->h_arena, p->d_small, sizeof(buf), hipMemcpyDeviceToHost, nullptr));
     LTP_HIP_TRY(p, hipStreamSynchronize(nullptr));
     memcpy(buf, p->h_arena, sizeof(buf));
     return LTP_OK;
@@ -854,6 +985,11 @@ int ltp_plan_batch_host(ltp_planner* p, long long n, const double* q_goal, const
     const double* const h_in[4] = {q_goal, q_0, v_0, a_0};
     if (n > 0 && dof > 0 && arena_layout(n, dof).end <= kSmallHostBytes) {
         std::lock_guard<std::mutex> hg(p->host_mu);
+        if (nd <= (size_t)ltp::small_batch_pairs()) {
+            bool handled = false;
+            rc = plan_batch_host_fused(p, n, h_in, host_records, nullptr, offsets, packed, &handled);
+            if (rc != LTP_OK || handled) return rc;
+        }
         return plan_batch_host_small(p, n, h_in, host_records, offsets, packed);
     }
     DevRecords dr;
@@ -970,7 +1106,7 @@ int ltp_plan_batch_multi(ltp_planner* const* planners, int k, long long n, const
             }
         }
     }
-    for (int g = 0; g < k; ++g) free(parts[g]);
+    for (int g = 0; g < k; ++g) ltp_free_host(parts[g]);   // small shards come from the pinned result pool
     return rc;
 }
 
@@ -1022,6 +1158,16 @@ int ltp_get_trajectory_host(ltp_planner* p, long long n, const double* t, const 
     if (n > 0 && dof > 0 && arena_layout(n, dof).end <= kSmallHostBytes) {
         // staged path: persistent arena + pinned mirror, one upload, one download
         std::lock_guard<std::mutex> hg(p->host_mu);
+        if (nd <= (size_t)ltp::small_batch_pairs()) {
+            // fused path: one launch, rows written straight into the pinned result buffer
+            const double* const h_in[4] = {nullptr, q_0, v_0, a_0};
+            const ltp_records given{nullptr, const_cast<double*>(t), const_cast<double*>(dir), const_cast<double*>(v_drive),
+                                    const_cast<signed char*>(mod), nullptr, nullptr, nullptr, nullptr};
+            const ltp_records outr{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, traj_len, status};
+            bool handled = false;
+            rc = plan_batch_host_fused(p, n, h_in, &outr, &given, offsets, packed, &handled);
+            if (rc != LTP_OK || handled) return rc;
+        }
         const ArenaLayout L = arena_layout(n, dof);
         rc = ensure_arena(p, L.end);
         if (rc != LTP_OK) return rc;
@@ -1088,7 +1234,10 @@ int ltp_get_trajectory_host(ltp_planner* p, long long n, const double* t, const 
     return LTP_OK;
 }
 
-void ltp_free_host(void* ptr) { free(ptr); }
+void ltp_free_host(void* ptr)
+{
+    if (ptr && !g_pinned.release(ptr)) free(ptr);
+}
 
 int ltp_check_inputs_host(ltp_planner* p, const double* q_0, const double* v_0, const double* a_0, int* ok)
 {
@@ -1107,11 +1256,9 @@ int ltp_check_inputs_host(ltp_planner* p, const double* q_0, const double* v_0, 
     memcpy(p->h_arena, q_0, sizeof(double) * dof);
     memcpy(p->h_arena + row, v_0, sizeof(double) * dof);
     memcpy(p->h_arena + 2 * row, a_0, sizeof(double) * dof);
-    LTP_HIP_TRY(p, hipMemcpyAsync(p->d_arena, p->h_arena, 3 * row, hipMemcpyHostToDevice, nullptr));
-    ltp::launch_check_inputs(nullptr, dof, dev_limits(p), (const double*)p->d_arena, (const double*)(p->d_arena + row),
-                             (const double*)(p->d_arena + 2 * row), (int*)(p->d_arena + 3 * row));
+    ltp::launch_check_inputs(nullptr, dof, dev_limits(p), (const double*)p->h_arena, (const double*)(p->h_arena + row),
+                             (const double*)(p->h_arena + 2 * row), (int*)(p->h_arena + 3 * row));   // pinned: no copies
     LTP_HIP_TRY(p, hipGetLastError());
-    LTP_HIP_TRY(p, hipMemcpyAsync(p->h_arena + 3 * row, p->d_arena + 3 * row, sizeof(int), hipMemcpyDeviceToHost, nullptr));
     LTP_HIP_TRY(p, hipStreamSynchronize(nullptr));
     *ok = *(const int*)(p->h_arena + 3 * row);
     return LTP_OK;
@@ -1125,7 +1272,7 @@ int ltp_opt_braking_host(ltp_planner* p, int joint, double v_0, double a_0, doub
     LTP_HIP_TRY(p, hipSetDevice(p->device));
     double buf[16] = {0};
     memcpy(buf, t_rel, sizeof(double) * 7);
-    const int rc = run_one_lane(p, buf, [&] { ltp::launch_single_opt_braking(nullptr, joint, p->t_sample, dev_limits(p), v_0, a_0, p->d_small); });
+    const int rc = run_one_lane(p, buf, [&](double* io) { ltp::launch_single_opt_braking(nullptr, joint, p->t_sample, dev_limits(p), v_0, a_0, io); });
     if (rc != LTP_OK) return rc;
     memcpy(t_rel, buf, sizeof(double) * 7);
     *q = buf[7];
@@ -1142,7 +1289,7 @@ int ltp_opt_switch_times_host(ltp_planner* p, int joint, double q_goal, double q
     LTP_HIP_TRY(p, hipSetDevice(p->device));
     double buf[16] = {0};
     memcpy(buf, t, sizeof(double) * 7);
-    const int rc = run_one_lane(p, buf, [&] { ltp::launch_single_opt_switch(nullptr, joint, p->t_sample, dev_limits(p), q_goal, q_0, v_0, a_0, v_drive, p->d_small); });
+    const int rc = run_one_lane(p, buf, [&](double* io) { ltp::launch_single_opt_switch(nullptr, joint, p->t_sample, dev_limits(p), q_goal, q_0, v_0, a_0, v_drive, io); });
     if (rc != LTP_OK) return rc;
     memcpy(t, buf, sizeof(double) * 7);
     *dir = buf[7];
@@ -1160,7 +1307,7 @@ int ltp_time_scaling_host(ltp_planner* p, int joint, double q_goal, double q_0, 
     LTP_HIP_TRY(p, hipSetDevice(p->device));
     double buf[16] = {0};
     memcpy(buf, scaled_t, sizeof(double) * 7);
-    const int rc = run_one_lane(p, buf, [&] { ltp::launch_single_time_scaling(nullptr, joint, p->t_sample, dev_limits(p), q_goal, q_0, v_0, a_0, dir, t_required, p->d_small); });
+    const int rc = run_one_lane(p, buf, [&](double* io) { ltp::launch_single_time_scaling(nullptr, joint, p->t_sample, dev_limits(p), q_goal, q_0, v_0, a_0, dir, t_required, io); });
     if (rc != LTP_OK) return rc;
     memcpy(scaled_t, buf, sizeof(double) * 7);
     *v_drive = buf[7];

@@ -109,6 +109,17 @@ void launch_end_limit(hipStream_t s, long long first, long long count, int dof, 
 void launch_state_at(hipStream_t s, long long first, long long count, int dof, double t_sample, Limits lim, Queries in,
                      Records rec, const int* sample_index, int uniform_index, double* q_0, double* v_0, double* a_0,
                      long long sq, long long sj);
+// planTrajectory for n queries with n * dof <= small_batch_pairs() in one launch of one block; every pointer may be host
+// memory the device can address (pinned). rows == nullptr: no sampling (status still carries the end-limit verdict).
+// *done becomes 1 when all results are visible to the host, 2 if the rows did not fit `capacity` (then nothing was sampled).
+// The grid has small_batch_blocks() blocks (one per joint when rows are written); end_flags: [blocks][n] ints the host ORs into
+// status; arrivals: one zeroed device word.
+int small_batch_pairs();
+int small_batch_blocks(int dof, bool with_rows);
+void launch_plan_small(hipStream_t s, int n, int dof, double t_sample, int goal_check, RowSpec rows, Limits lim, const double* const in[4],
+                       Records rec, unsigned long long* offsets, double* out_rows, unsigned long long capacity, int* end_flags,
+                       unsigned int* arrivals, volatile int* done,
+                       bool records_given = false /* getTrajectory: t_scaled, dir, mod, v_drive of `rec` are inputs */);
 void launch_generate(hipStream_t s, long long n, int dof, Limits lim, unsigned long long seed, long long first_query,
                      double* q_goal, double* q_0, double* v_0, double* a_0, long long sq, long long sj);
 

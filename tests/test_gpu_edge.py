@@ -724,3 +724,47 @@ def test_table_pass_gives_the_bits_of_the_fused_build(amd, limits, n):
     for mode in ("tables", "pieces"):
         for got, want in zip(env[mode], env["fused"]):
             assert torch.equal(got.nan_to_num(7.0), want.nan_to_num(7.0)), mode
+
+
+@pytest.mark.parametrize("limits,ts", [("ref", 0.004), ("panda", 0.001), ("ref30", 0.002)])
+def test_fused_small_batch_path_has_the_bits_of_the_batched_path(amd, limits, ts):
+    """A call with n * dof <= 128 (a single planTrajectory above all) runs as ONE launch of one block writing into pinned
+    host memory (k_plan_small). Records, offsets-relative rows, statuses and the one-joint getTrajectory entry must be
+    bit-identical to what the batched kernels give for the same queries inside a large batch."""
+    D, lim = amd.limit_set(limits)
+    ltp = amd.LongTermPlanner(D, ts, device=0, **lim)
+    n_big = 300
+    qg, q0, v0, a0 = amd.generate_queries(n_big, lim, seed=5)
+    q0[3, 0] = 99.0                                             # rejected by checkInputs
+    qg[4] = q0[4]; v0[4] = 0.0; a0[4] = 0.0                     # the all-zero plan (traj_len 1)
+    big = ltp.planBatchHost(qg, q0, v0, a0, sample=True)        # staged path: batched kernels
+    small_n = max(1, min(128 // D, 9))
+    for first in (0, 3, 50):
+        for cnt in sorted({1, min(2, small_n), small_n}):
+            sl = slice(first, first + cnt)
+            r = ltp.planBatchHost(qg[sl], q0[sl], v0[sl], a0[sl], sample=True)
+            r0 = ltp.planBatchHost(qg[sl], q0[sl], v0[sl], a0[sl], sample=False)
+            for key in ("t_opt", "t_scaled", "dir", "v_drive", "mod", "t_required", "slowest", "traj_len", "status"):
+                assert r[key].tobytes() == big[key][sl].tobytes(), (first, cnt, key)
+                assert r0[key].tobytes() == big[key][sl].tobytes(), (first, cnt, key, "no rows")
+            lo, hi = int(big["offsets"][first]), int(big["offsets"][first + cnt])
+            assert np.array_equal(r["offsets"], big["offsets"][first:first + cnt + 1] - big["offsets"][first])
+            assert r["packed"].tobytes() == big["packed"][lo:hi].tobytes(), (first, cnt)
+            g = ltp.getTrajectoryBatchHost(big["t_scaled"][sl], big["dir"][sl], big["mod"][sl], q0[sl], v0[sl], a0[sl], big["v_drive"][sl])
+            ran = (big["status"][sl] & 0x37) == 0
+            assert np.array_equal(g["traj_len"][ran], big["traj_len"][sl][ran])
+            if ran.all():
+                assert g["packed"].tobytes() == big["packed"][lo:hi].tobytes()
+    # capped and strided rows go through the same kernel
+    ltp.setMaxSamples(100); ltp.setSampleStride(3)
+    big2 = ltp.planBatchHost(qg, q0, v0, a0, sample=True)
+    r = ltp.planBatchHost(qg[10:12], q0[10:12], v0[10:12], a0[10:12], sample=True)
+    lo, hi = int(big2["offsets"][10]), int(big2["offsets"][12])
+    assert r["packed"].tobytes() == big2["packed"][lo:hi].tobytes() and np.array_equal(r["status"], big2["status"][10:12])
+    # a result larger than the pinned buffer (8 MiB) falls back to the staged path
+    ltp.setMaxSamples(0); ltp.setSampleStride(1)
+    if D == 30:
+        slow = amd.LongTermPlanner(D, 0.0002, device=0, **lim)  # 5x the samples: > 1 Mi doubles per plan
+        a = slow.planBatchHost(qg[:1], q0[:1], v0[:1], a0[:1], sample=True)
+        b = slow.planBatchHost(qg[:40], q0[:40], v0[:40], a0[:40], sample=True)
+        assert a["packed"].size * 8 > (8 << 20) and a["packed"].tobytes() == b["packed"][: int(b["offsets"][1])].tobytes()
