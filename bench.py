@@ -116,7 +116,10 @@ def parse_args(argv=None):
     ap.add_argument("--max-samples", type=int, default=0, help="store only the first N samples per row (0 = whole trajectories, the reference behaviour)")
     ap.add_argument("--sample-stride", type=int, default=1, help="store every N-th sample per row (1 = every sample, the reference behaviour)")
     ap.add_argument("--f32", action="store_true", help="store float32 rows (same binary64 results, rounded once); default float64 as the reference")
-    ap.add_argument("--switch-only", action="store_true", help="config[1]: stages 1-3 (+ the end-limit check) only, no sampling")
+    ap.add_argument("--switch-only", action="store_true", help="config[1]: stages 1-3 only, no sampling (status = the pre-sampling verdict cc:14-39)")
+    ap.add_argument("--end-limit", action="store_true",
+                    help="with --switch-only / --receding without rows: also run planTrajectory's end-limit check (cc:59-61) without sampling "
+                         "(ltp_end_limit_batch), so that status == 0 is exactly planTrajectory's bool")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="only the primary workload (profiling runs)")
     ap.add_argument("--plain-stores", action="store_true", help="sampler uses plain instead of non-temporal stores")
@@ -187,6 +190,7 @@ class Workload:
         self.plain_stores, self.dry, self.spread, self.window_gib = args.plain_stores, args.dry_sampler, args.spread, args.window_gib
         self.sample_blocks, self.gather, self.checksum, self.seed = args.sample_blocks, args.gather, args.checksum, args.seed
         self.table_pass, self.table_gib = args.table_pass, args.table_gib
+        self.end_limit = args.end_limit
         self.name = "primary"
         for k, v in over.items():
             setattr(self, k, v)
@@ -239,7 +243,7 @@ def run_workload(wl, ctx):
             # every round: stages 1-3 (+ end-limit verdict), first-N rows of all plans into the tile (they fit: N is small), new start states
             s0, s1, s2 = q0, v0, a0
             for _ in range(rec_spec[0]):
-                batch = ltp.planSwitchTimesBatch(qg, s0, s1, s2, layout=wl.layout, batch=batch, end_limit=rec_direct)
+                batch = ltp.planSwitchTimesBatch(qg, s0, s1, s2, layout=wl.layout, batch=batch, end_limit=rec_direct and wl.end_limit)
                 if rec_direct:
                     s0, s1, s2 = ltp.stateAt(batch, 0, n, rec_spec[1], layout=wl.layout)
                     continue
@@ -253,8 +257,8 @@ def run_workload(wl, ctx):
                 s0, s1, s2 = ltp.replanStates(batch, 0, n, tile, rec_spec[1], layout=wl.layout)
             n_chunks = 1
             return
-        # switching times only: the end-limit check (cc:59-61) runs without the sampler, so status is planTrajectory's bool
-        batch = ltp.planSwitchTimesBatch(qg, q0, v0, a0, layout=wl.layout, batch=batch, end_limit=wl.switch_only)
+        # switching times only: with --end-limit the check of cc:59-61 runs without the sampler and status is planTrajectory's bool
+        batch = ltp.planSwitchTimesBatch(qg, q0, v0, a0, layout=wl.layout, batch=batch, end_limit=wl.switch_only and wl.end_limit)
         if gather_buf is not None:
             dist.all_gather(gather_buf, batch.t_required.to(cdev))
         if wl.switch_only:
@@ -376,7 +380,7 @@ def run_workload(wl, ctx):
             "workload": ((f"{wl.global_batch} x {dof}-DoF queries per step sharded over {world} GPU(s) ({n} on rank 0)" if wl.global_batch else
                           f"{n} x {dof}-DoF queries per GPU per step") + f", limits '{wl.limits}', Tsample {wl.t_sample} s, "
                          + (f"{rec_spec[0]} receding-horizon cycles per step on the device (plan, " + ("state at sample" if rec_direct else f"first {wl.max_samples} samples, replan from stored sample") + f" {rec_spec[1]}); value counts replans; " if rec_spec else "")
-                         + ("switching times only (stages 1-3 + end-limit check, no rows)" if wl.switch_only else
+                         + (("switching times only (stages 1-3" + (" + end-limit check" if wl.end_limit else "; status = pre-sampling verdict") + ", no rows)") if wl.switch_only else
                             "no rows stored (ltp_state_at_batch)" if rec_direct else
                             f"on-device envelope consumer: [min q, max q] over {env_spec[1]} windows of {env_spec[0]} samples per joint, no dense rows" if env_spec else
                             ("full q/v/a/j sampling" if not (wl.max_samples or wl.sample_stride > 1) else
@@ -386,6 +390,8 @@ def run_workload(wl, ctx):
             "limits": wl.limits, "input_layout": wl.layout, "table_pass": wl.table_pass,
             "sharding": "contiguous query ranges per rank, no data-path collective" + (", RCCL all_gather of t_required" if gather_buf else ""),
             "plans_ok_frac": round(ok_total / total_queries, 5),
+            "plans_ok_is": ("planTrajectory's bool" if (wl.end_limit or not (wl.switch_only or rec_direct)) else
+                            "the pre-sampling verdict (cc:14-39); the end-limit check cc:59-61 was not run"),
             "mean_traj_len": round(len_total / total_queries, 1),
             "bytes_per_plan": round(bytes_total / total_queries, 1),
         },
@@ -457,7 +463,7 @@ def main():
     primary = Workload(args)
     out = run_workload(primary, ctx)
 
-    variant = (args.switch_only or args.f32 or args.max_samples or args.sample_stride > 1 or args.envelope or args.receding or args.dry_sampler
+    variant = (args.switch_only or args.end_limit or args.f32 or args.max_samples or args.sample_stride > 1 or args.envelope or args.receding or args.dry_sampler
                or args.table_pass != "auto" or args.limits != "panda" or args.batch != 1_000_000 or args.global_batch or args.window_gib or args.layout != "query_major")
     secondary = []
     if not args.no_secondary and not variant:
@@ -468,8 +474,12 @@ def main():
                  dict(limits="ref", steps=few, warmup=1)),
                 ("configs[1]: 100 k x 7-DoF, switching times only",
                  dict(batch=100_000, switch_only=True, steps=max(args.steps, 20), warmup=2)),
+                ("configs[1] + planTrajectory's end-limit verdict without sampling (ltp_end_limit_batch)",
+                 dict(batch=100_000, switch_only=True, end_limit=True, steps=max(args.steps, 20), warmup=2)),
                 ("configs[1] with the reference's limits",
                  dict(limits="ref", batch=100_000, switch_only=True, steps=max(args.steps, 20), warmup=2)),
+                ("switching times only, 1 M x 7-DoF",
+                 dict(switch_only=True, steps=max(args.steps, 10), warmup=2)),
                 ("configs[4]: 1 M x 30-DoF (S-ref30), full sampling through the reused tile",
                  dict(limits="ref30", steps=few, warmup=1)),
             ]

@@ -1,26 +1,42 @@
 #!/bin/bash
-# Runs on the GPU box (gpurun -- bash tools/refresh_profiles.sh): headline bench, workload variants and the rocprofv3
+# Runs on the GPU box (gpurun -- bash tools/refresh_profiles.sh [tag]): headline bench, workload variants and the rocprofv3
 # passes whose summaries are kept under profiles/. Everything lands in gpurun_out/; profiles/summarize.py condenses it.
 set -o pipefail
+TAG=${1:-r02}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$R/gpurun_out
-mkdir -p $O && rm -rf $O/prof_stats $O/prof_write $O/prof_fetch
+mkdir -p $O && rm -rf $O/prof_stats $O/prof_write $O/prof_fetch $O/prof_tab_stats
 cd $R
 timeout -k 10 400 python bench.py > $O/bench_default.json 2> $O/bench_default.err || exit 1
-echo "default done"; cat $O/bench_default.json
+echo "default done"; cut -c1-300 $O/bench_default.json
 : > $O/bench_variants.jsonl
-for a in "--limits ref" "--limits ref30 --batch 200000" "--switch-only --batch 100000" "--switch-only" "--switch-only --limits ref" \
-         "--max-samples 256" "--sample-stride 4" "--f32" "--f32 --limits ref" "--f32 --max-samples 256" "--envelope 64:32" \
-         "--envelope 64:32 --limits ref" "--receding 10:100" "--receding 10:100 --max-samples 128" "--tile-gib 64" "--layout joint_major"; do
+for a in "--limits ref" "--limits ref30 --batch 200000" "--switch-only --batch 100000" "--switch-only --batch 100000 --end-limit" "--switch-only" \
+         "--switch-only --end-limit" "--switch-only --limits ref" \
+         "--max-samples 256" "--max-samples 256 --table-pass off" "--max-samples 64" "--sample-stride 4" "--f32" "--f32 --limits ref" \
+         "--f32 --max-samples 256" "--f32 --max-samples 256 --table-pass off" "--f32 --max-samples 1024" "--envelope 64:32" \
+         "--envelope 64:32 --table-pass off" "--envelope 64:32 --limits ref" "--receding 10:100" "--receding 10:100 --end-limit" \
+         "--receding 10:100 --max-samples 128" "--receding 10:100 --max-samples 128 --table-pass off" "--tile-gib 64" "--layout joint_major"; do
   timeout -k 10 300 python bench.py --no-cpu-baseline $a >> $O/bench_variants.jsonl 2>> $O/bench_variants.err || exit 1
   echo "variant $a done"
 done
+# ceilings of the store pattern alone (DIAGNOSTIC: stores without arithmetic; not results)
+: > $O/bench_dry.jsonl
+for a in "" "--f32" "--max-samples 256 --table-pass off" "--limits ref"; do
+  timeout -k 10 300 python bench.py --no-cpu-baseline --no-secondary --dry-sampler $a >> $O/bench_dry.jsonl 2>> $O/bench_variants.err || exit 1
+  echo "dry $a done"
+done
+# N ranks rehearsed on this one GPU (gloo for the barrier; every rank on device 0): the launch path the 8-GPU node uses
+timeout -k 10 300 python bench.py --gpus 2 --backend gloo --device 0 --no-cpu-baseline --steps 3 > $O/bench_2ranks_gloo.json 2>> $O/bench_variants.err || exit 1
+timeout -k 10 300 python bench.py --gpus 4 --backend gloo --device 0 --no-cpu-baseline --no-secondary --global-batch 1000000 --steps 3 > $O/bench_4ranks_gloo_global.json 2>> $O/bench_variants.err || exit 1
+echo "rank rehearsal done"
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_stats -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/prof_stats.log 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_stats -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary > $O/prof_stats.log 2>&1 || exit 1
 echo "stats pass done"
-timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/prof_write -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $O/prof_write.log 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/prof_write -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-secondary > $O/prof_write.log 2>&1 || exit 1
 echo "WRITE_SIZE pass done"
-timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/prof_fetch -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $O/prof_fetch.log 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/prof_fetch -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-secondary > $O/prof_fetch.log 2>&1 || exit 1
 echo "FETCH_SIZE pass done"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_tab_stats -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary --max-samples 256 > $O/prof_tab_stats.log 2>&1 || exit 1
+echo "table-pass stats pass done"
 # keep only the small CSVs
-find $O/prof_stats $O/prof_write $O/prof_fetch -type f ! -name "*_kernel_stats.csv" ! -name "*_counter_collection.csv" -delete
+find $O/prof_stats $O/prof_write $O/prof_fetch $O/prof_tab_stats -type f ! -name "*_kernel_stats.csv" ! -name "*_counter_collection.csv" -delete
