@@ -274,6 +274,8 @@ int ltp_roots_f32_host(ltp_planner* p, long long n, int degree, const float* coe
 int ltp_debug_set_sample_stamps(ltp_planner* p, unsigned long long* device_buffer);
 /* tuning aid: size of the persistent k_sample / k_envelope grid (0 = what the device holds at once, the default) */
 int ltp_debug_set_sample_blocks(ltp_planner* p, int blocks);
+/* resident blocks of the persistent grids: which = 0 k_sample float64, 1 k_sample float32, 2 k_envelope, 3 / 4 k_sample_tab float64 / float32 */
+int ltp_debug_get_sample_blocks(ltp_planner* p, int which);
 /* out[i*8 + {0..7}] = x/y, sqrt|x|, x^3, x^4, x^6, floor(x/y), ceil(x/y), x*y+x computed on the device */
 int ltp_debug_math_probe_host(ltp_planner* p, long long n, const double* x, const double* y, double* out);
 /* root[i] = smallest positive exactly-real root of the degree-`degree` polynomial coef[i*7 .. i*7+degree]

@@ -74,6 +74,7 @@ _SIGNATURES = {
     "ltp_envelope_batch": (C.c_int, [C.c_void_p, C.c_longlong, C.c_longlong, C.POINTER(Queries), C.POINTER(Records), C.c_int, C.c_int,
                                      C.c_void_p, C.c_void_p]),
     "ltp_debug_set_sample_blocks": (C.c_int, [C.c_void_p, C.c_int]),
+    "ltp_debug_get_sample_blocks": (C.c_int, [C.c_void_p, C.c_int]),
     "ltp_reserve_batch": (C.c_int, [C.c_void_p, C.c_longlong]),
     "ltp_plan_envelope_host": (C.c_int, [C.c_void_p, C.c_longlong, _dp, _dp, _dp, _dp, C.c_int, C.c_int, C.POINTER(Records), _dp]),
     "ltp_state_at_batch": (C.c_int, [C.c_void_p, C.c_longlong, C.c_longlong, C.POINTER(Queries), C.POINTER(Records), C.c_void_p, C.c_int,

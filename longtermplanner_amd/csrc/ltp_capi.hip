@@ -1353,6 +1353,14 @@ int ltp_debug_set_sample_stamps(ltp_planner* p, unsigned long long* device_buffe
     return LTP_OK;
 }
 
+int ltp_debug_get_sample_blocks(ltp_planner* p, int which)
+{
+    if (!p || which < 0 || which > 4) return -1;
+    std::lock_guard<std::mutex> g(p->mu);
+    if (reserve(p, 0) != LTP_OK) return -1;
+    return p->sample_blocks[which];
+}
+
 int ltp_debug_set_sample_blocks(ltp_planner* p, int blocks)
 {
     if (!p || blocks < 0) return LTP_ERR_INVALID_ARGUMENT;

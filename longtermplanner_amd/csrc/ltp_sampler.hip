@@ -58,6 +58,7 @@ struct JointTable {
 };
 constexpr int kTableWords = 1 + (kMaxSegments + 2) / 2 + kMaxSegments * kRunCoefs;
 static_assert(sizeof(JointTable) == kTableWords * 8, "JointTable must be kTableWords 8-byte words");
+static_assert(kTableWords % 2 == 0, "the table pass stores word pairs");
 struct SegTable {
     JointTable jt[kSampleJointGroup];
     union {
@@ -169,11 +170,13 @@ struct ItemRegs<false> {
     double pa, pb;
 };
 
-// global-memory form of the tables: lane index i = local plan * dof + joint; tiles of 64 lanes, word-major inside a tile,
-// so that the table pass stores 512 contiguous bytes per wave instruction and the 8 joints of an item are read as 64-byte runs
+// global-memory form of the tables: lane index i = local plan * dof + joint; tiles of 64 lanes; inside a tile the 16-byte
+// word PAIR (2k, 2k+1) of lane l sits at pair k, lane l — the table pass stores whole 1 KiB lines per wave, the joints of an
+// item are neighbours, and a 16-byte-per-lane LDS-direct load (k_sample_tab's loader) fetches 64 consecutive pairs of one
+// joint's table straight into the JointTable layout
 LTP_DEV unsigned long long table_word_index(unsigned long long lane, int word)
 {
-    return (lane >> 6) * (unsigned long long)(kTableWords * 64) + (unsigned long long)word * 64ull + (lane & 63ull);
+    return (lane >> 6) * (unsigned long long)(kTableWords * 64) + ((unsigned long long)(word >> 1) * 64ull + (lane & 63ull)) * 2ull + (unsigned long long)(word & 1);
 }
 
 // Issues the loads of an item (nothing here waits for them). p < 0: no item. tables != nullptr (TABLES): plan p is local
@@ -801,6 +804,7 @@ k_sample(long long first, long long count, int dof, double t_sample, Limits lim,
 constexpr int kTabStreamWaves = 7;                              // streaming waves per block; wave kTabStreamWaves is the loader
 constexpr int kTabThreads = (kTabStreamWaves + 1) * 64;          // 8 waves: two per SIMD
 constexpr int kTabJointGroup = 7;                                // joints per item: one row set per streaming wave
+constexpr int kTabBuffers = 4;                                   // LDS table buffers per block (11.9 KB each)
 struct TabItem {
     unsigned long long rel;               // element offset of the plan inside `out`
     int slen;                             // stored samples per row; 0 = nothing to stream (hole, failed plan, does not fit)
@@ -808,10 +812,13 @@ struct TabItem {
     int done;                             // 1 = the queue is exhausted
     unsigned long long item;              // queue position (diagnostic stamps only)
 };
-struct TabBuffer {
-    JointTable jt[kTabJointGroup];
-    TabItem hdr;
+struct alignas(16) TabBuffer {
+    JointTable jt[kTabJointGroup];        // filled by LDS-direct loads (16 bytes per lane) from the table pass's output
+    unsigned long long raw_off[2];        // offsets[plan], offsets[plan + 1]: landing zone of an LDS-direct load
+    int raw_len[4];                       // traj_len[plan] (one dword lands here)
+    TabItem hdr;                          // what the streaming waves read, written by the loader when the loads are in
 };
+static_assert(sizeof(JointTable) % 16 == 0, "LDS-direct loads land 16 bytes per lane");
 
 // What a streaming wave does with an item: wave w owns joint w (nj <= 3: several waves share a joint) and writes the
 // joint's four rows, 64 slots = 1 KiB per row and step. Same slot arithmetic as stream_pass_a, except that a slot which
@@ -906,18 +913,38 @@ LTP_DEV void tab_stream(const TabBuffer& B, int dof, T* __restrict__ out, int ss
     }
 }
 
-// What the loader wave holds about one item from the iteration that requests its data to the one (two iterations later)
-// that installs it: the item's place in the batch (wave-uniform) and, per lane, the loads in flight — traj_len and offset
-// of the plan, and word ws + 8 r (r < kTabBatch) of the run table of joint slot jl, where ws = lane >> 3, jl = lane & 7.
-constexpr int kTabBatch = 10;      // covers tables of up to 6 runs (12 + 6 x 10 <= 80 words): the usual case of capped rows
-struct TabSlot {
-    unsigned long long item;       // queue position (>= total: none)
-    long long local;               // plan index inside [first, first + count), or -1 for a hole of the interleave
-    int j0, nj;
-    int len;
-    unsigned long long off;
-    unsigned long long v[kTabBatch];
-};
+// The lane id, recomputed (two instructions) and opaque to common-subexpression elimination: kept live across the loader's
+// loop it gets spilled, and a scratch reload in that loop waits for the table loads in flight (~8 us each time).
+LTP_DEV int fresh_lane()
+{
+    int l = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    asm volatile("" : "+v"(l));
+    return l;
+}
+
+// s_waitcnt with only the vector-memory counter set (gfx9 encoding: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt[5:4] << 14)
+#define LTP_WAIT_VMCNT(N) __builtin_amdgcn_s_waitcnt((((N) & 15) | (((N) >> 4) << 14)) | (7 << 4) | (15 << 8))
+
+// LDS accesses of the loader wave, as instructions the compiler does not model. Once a wave has LDS-direct loads in flight
+// the compiler puts "wait for ALL vector-memory operations" in front of every LDS access it knows of (it cannot tell that the
+// loads land elsewhere), which would drain the prefetches at every flag poll and header write. These are plain ds_read /
+// ds_write: LDS serves a wave's requests in order, reads wait for their own data, and the loader orders them against the
+// LDS-direct loads itself (LTP_WAIT_VMCNT). Untracked LDS operations can only make the compiler's own lgkmcnt waits stricter.
+LTP_DEV unsigned lds_offset(const void* p) { return (unsigned)(unsigned long long)(__attribute__((address_space(3))) const char*)p; }
+LTP_DEV int lds_peek32(unsigned a)
+{
+    int v;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(a) : "memory");
+    return v;
+}
+LTP_DEV unsigned long long lds_peek64(unsigned a)
+{
+    unsigned long long v;
+    asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(a) : "memory");
+    return v;
+}
+LTP_DEV void lds_poke32(unsigned a, int v) { asm volatile("ds_write_b32 %0, %1" : : "v"(a), "v"(v) : "memory"); }
+LTP_DEV void lds_poke64(unsigned a, unsigned long long v) { asm volatile("ds_write_b64 %0, %1" : : "v"(a), "v"(v) : "memory"); }
 
 template <bool STREAMING, typename T>
 LTP_DEV void sample_tab_body(long long first, long long count, long long base_first, int dof, Records rec,
@@ -925,147 +952,239 @@ LTP_DEV void sample_tab_body(long long first, long long count, long long base_fi
                              RowSpec rows, unsigned long long* __restrict__ next_item, const unsigned long long* __restrict__ tables,
                              int draw_chunk, unsigned long long* __restrict__ stamps /* diagnostic: 8 per item, nullptr in product calls */)
 {
-    __shared__ TabBuffer buf[2];
+    // Hand-over of the table buffers without block barriers: buffer s % kTabBuffers holds the block's s-th item once the
+    // loader has set s_ready[s % kTabBuffers] = s + 1; streaming wave w has finished s_consumed[w] items. The loader reuses
+    // a buffer when every wave is past the item that was in it; a fast wave may thus run kTabBuffers - 1 items ahead of a
+    // slow one (with one barrier per item every wave waited for the slowest: 3.1 of 8.8 us at 256-sample rows). All eight
+    // waves of a block are resident together, the loader waits only for the streaming waves and they only for the loader, the
+    // loader publishes a final "done" item and every wave leaves on reading it: no wait can last forever.
+    __shared__ TabBuffer buf[kTabBuffers];
+    __shared__ int s_ready[kTabBuffers];
+    __shared__ int s_consumed[kTabStreamWaves];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int sstride = rows.stride > 1 ? rows.stride : 1;
+    if (threadIdx.x < kTabBuffers) s_ready[threadIdx.x] = 0;
+    if (threadIdx.x < kTabStreamWaves) s_consumed[threadIdx.x] = 0;
+    __syncthreads();
     if (wave < kTabStreamWaves) {
-        // ---- streaming waves: stores only ----
-        __syncthreads();
-        for (int b = 0;; b ^= 1) {
+        // ---- streaming waves: LDS reads and row stores only ----
+        for (int seq = 0;; ++seq) {
+            const int b = seq % kTabBuffers;
+            while (__hip_atomic_load(&s_ready[b], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != seq + 1) __builtin_amdgcn_s_sleep(1);
             if (buf[b].hdr.done) break;
             const bool stamp = stamps && wave == 0 && (threadIdx.x & 63) == 0;
             const unsigned long long it = buf[b].hdr.item;
             if (stamp) stamps[8 * it + 4] = wall_clock64();
             tab_stream<STREAMING, T>(buf[b], dof, out, sstride, wave);
             if (stamp) stamps[8 * it + 5] = wall_clock64();
-            __syncthreads();
-            if (stamp) stamps[8 * it + 6] = wall_clock64();
+            // the wave's reads of buf[b] are complete (release orders its LDS traffic; row stores need not be: they carry
+            // their data in registers)
+            if ((threadIdx.x & 63) == 0) __hip_atomic_store(&s_consumed[wave], seq + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         return;
     }
-    // ---- loader wave: loads only. Under the sampler's own write traffic a global read takes ~8 us, several times an
-    // item's streaming time, so every load is issued TWO iterations before its result is used: two items' requests are
-    // always in flight (slots A and B, alternating), queue positions come in chunks drawn one chunk ahead, and the table
-    // request does not depend on the header (a fixed kTabBatch words per lane; tables with more runs fetch the rest when
-    // they are installed — such rows are long enough to hide that). An iteration then costs the LDS copy and pass B. ----
-    // The loader shares its SIMD with five streaming waves that keep the vector ALU busy: it runs at raised issue priority.
+    // ---- loader wave: loads only. Under the sampler's own write traffic a global read takes ~8 us, longer than an item
+    // streams, so an item's data is requested kTabAhead items before it is published — and it is requested with LDS-DIRECT
+    // loads (buffer_load ... lds, 16 bytes per lane straight into the JointTable of the item's buffer): no registers are held,
+    // and because such a load has no register result the compiler inserts no wait of its own for it; the one wait is written
+    // here. Loads complete in order, and every item issues exactly kPerItem of them (holes and the items after the end of the
+    // queue re-read item 0's tables into a buffer nobody streams), so "item seq is in" is "at most kTabAhead * kPerItem
+    // vector-memory operations outstanding" — a constant. Anything else the loader issues in between (queue draws, status
+    // bits, stamps) only makes that wait stricter. The loader shares its SIMD with five streaming waves that keep the vector
+    // ALU busy: it runs at raised issue priority. ----
     __builtin_amdgcn_s_setprio(3);
-    const int lane = threadIdx.x & 63;
+    constexpr int kTabAhead = 2;
+    static_assert(kTabAhead + 2 <= kTabBuffers, "buffers: one being streamed, one being published, kTabAhead in flight");
     const int ngroups = (dof + kTabJointGroup - 1) / kTabJointGroup;
     const long long per = (count + spread - 1) / spread;
     const unsigned long long total = (unsigned long long)per * spread * ngroups;
     const unsigned long long off0 = offsets[base_first];
-    const int jl = lane & 7, ws = lane >> 3;
+    constexpr unsigned kTileBytes = (unsigned)kTableWords * 64u * 8u;
+    // capped rows only touch the first runs: 40 word pairs (80 words, 6 runs) per joint; whole tables are 106 pairs
+    const bool whole_tables = rows.max_samples <= 0;
+    typedef __attribute__((address_space(3))) void* lds_ptr;
     auto uniform64 = [](unsigned long long x) -> unsigned long long {
         return ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(x >> 32)) << 32) |
                (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)x);
     };
     // Queue positions: a draw takes draw_chunk consecutive items (one device-scope counter sustains ~90 atomics/us; short
-    // items are drawn faster than that), and the atomic for the next chunk is issued when the current one is opened.
-    unsigned long long chunk_next = 0ull, chunk_cur = 0ull;
-    int chunk_i = draw_chunk;
-    if (lane == 0) chunk_next = atomicAdd(next_item, (unsigned long long)draw_chunk);
-    auto next_item_id = [&]() __attribute__((always_inline)) -> unsigned long long {
-        if (chunk_i == draw_chunk) {
-            chunk_cur = uniform64(chunk_next);
-            if (lane == 0) chunk_next = atomicAdd(next_item, (unsigned long long)draw_chunk);
+    // items are drawn faster than that). The atomic of the next chunk is issued at the top of the iteration that hands out
+    // the current chunk's last position and consumed at the bottom of the SAME iteration: in between lies straight-line code,
+    // so the compiler can count what was issued after it and waits for the atomic alone — carried across the loop it would
+    // wait for everything outstanding, i.e. drain the prefetches.
+    unsigned long long chunk_cur = 0ull, chunk_pending = 0ull;
+    int chunk_i = 0;
+    bool chunk_wanted = false;
+    if (fresh_lane() == 0) chunk_pending = atomicAdd(next_item, (unsigned long long)draw_chunk);
+    chunk_cur = uniform64(chunk_pending);
+    auto next_item_id = [&]() __attribute__((always_inline)) -> unsigned long long {       // top of an iteration
+        const unsigned long long id = chunk_cur + (unsigned long long)chunk_i;
+        if (++chunk_i == draw_chunk) {
+            if (fresh_lane() == 0) chunk_pending = atomicAdd(next_item, (unsigned long long)draw_chunk);
+            chunk_wanted = true;
+        }
+        return id;
+    };
+    auto finish_draw = [&]() __attribute__((always_inline)) {                               // bottom of the same iteration
+        __builtin_amdgcn_sched_barrier(0);              // not to be hoisted in front of the iteration's loads (it would wait there)
+        if (chunk_wanted) {
+            chunk_cur = uniform64(chunk_pending);
             chunk_i = 0;
+            chunk_wanted = false;
         }
-        return chunk_cur + (unsigned long long)(chunk_i++);
     };
-    auto table_ptr = [&](const TabSlot& h) __attribute__((always_inline)) -> const unsigned long long* {
-        const bool act = h.item < total && h.local >= 0 && jl < h.nj;
-        return tables + table_word_index((unsigned long long)(act ? h.local : 0) * dof + (act ? h.j0 + jl : 0), 0);
-    };
-    auto request = [&](TabSlot& h, unsigned long long item) __attribute__((always_inline)) {   // issues every load of the item; nothing here waits
-        h.item = item; h.local = -1; h.j0 = 0; h.nj = 0; h.len = 0; h.off = 0ull;
+    // item -> (plan inside [first, first + count) or -1, first joint, joints). 64-bit divisions are ~10^2 instructions each on
+    // this machine and the loader pays them per item: one joint group (dof <= 7) and a power-of-two interleave (the default,
+    // 64) need none, anything else that fits 32 bits uses 32-bit division.
+    const int spread_log2 = (spread & (spread - 1)) == 0 ? 31 - __builtin_clz((unsigned)spread) : -1;
+    auto decode = [&](unsigned long long item, long long& local, int& j0, int& nj) __attribute__((always_inline)) {
+        local = -1; j0 = 0; nj = 0;
         if (item >= total) return;
-        const int group = (int)(item % ngroups);
-        const long long slot = (long long)(item / ngroups);
-        const long long local = (slot % spread) * per + slot / spread;
-        h.j0 = group * kTabJointGroup;
-        h.nj = (dof - h.j0) < kTabJointGroup ? (dof - h.j0) : kTabJointGroup;
-        if (local >= count) return;
-        h.local = local;
-        h.len = rec.traj_len[first + local];
-        h.off = offsets[first + local];
-        const unsigned long long* tp = table_ptr(h);
-#pragma unroll
-        for (int r = 0; r < kTabBatch; ++r) h.v[r] = tp[(unsigned)(ws + 8 * r) * 64u];
+        unsigned long long slot = item;
+        int group = 0;
+        if (ngroups > 1) {
+            if (total <= 0xffffffffull) { group = (int)((unsigned)item % (unsigned)ngroups); slot = (unsigned)item / (unsigned)ngroups; }
+            else { group = (int)(item % (unsigned long long)ngroups); slot = item / (unsigned long long)ngroups; }
+        }
+        long long l;
+        if (spread_log2 >= 0) l = (long long)(slot & (unsigned long long)(spread - 1)) * per + (long long)(slot >> spread_log2);
+        else if (total <= 0xffffffffull) l = (long long)((unsigned)slot % (unsigned)spread) * per + (long long)((unsigned)slot / (unsigned)spread);
+        else l = (long long)(slot % (unsigned long long)spread) * per + (long long)(slot / (unsigned long long)spread);
+        j0 = group * kTabJointGroup;
+        nj = (dof - j0) < kTabJointGroup ? (dof - j0) : kTabJointGroup;
+        if (l < count) local = l;
     };
-    auto install = [&](TabBuffer& B, TabSlot& h) __attribute__((always_inline)) {
-        if (h.item >= total) {
-            if (lane == 0) B.hdr.done = 1;
-            return;
+    // issues the kPerItem loads of an item into buffer B (nothing here waits)
+    auto request = [&](TabBuffer& B, unsigned long long item) __attribute__((always_inline)) {
+        long long local; int j0, nj;
+        decode(item, local, j0, nj);
+        const bool real = local >= 0;
+        const long long pl = real ? first + local : first;                       // holes re-read plan `first`: harmless
+        const int lane = fresh_lane();
+        // header: traj_len (one dword, lane 0) and offsets[p], offsets[p + 1] (16 bytes, lane 0)
+        const __amdgpu_buffer_rsrc_t r_len = __builtin_amdgcn_make_buffer_rsrc(rec.traj_len + pl, 0, 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t r_off = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned long long*>(offsets) + pl, 0, 16, 0x00020000);
+        if (lane == 0) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(r_len, (lds_ptr)&B.raw_len[0], 4, 0, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(r_off, (lds_ptr)&B.raw_off[0], 16, 0, 0, 0, 0);
         }
-        int slen = 0;
-        unsigned long long rel = 0ull;
-        if (h.local >= 0) {
-            const int len = __builtin_amdgcn_readfirstlane(h.len);
-            slen = stored_len(len, rows);
-            rel = uniform64(h.off) - off0;
-            const unsigned long long stride = ((unsigned long long)slen + (kRowAlign - 1)) / kRowAlign * kRowAlign;
-            if (slen > 0 && rel + 4ull * dof * stride > capacity) {
-                if (lane == 0 && h.j0 == 0) atomicOr(&rec.status[first + h.local], kStatusOverflow);
-                slen = 0;
-            }
-        }
-        if (lane == 0) { B.hdr.rel = rel; B.hdr.slen = slen; B.hdr.j0 = h.j0; B.hdr.nj = h.nj; B.hdr.done = 0; B.hdr.item = h.item; }
-        if (stamps && lane == 0) stamps[8 * h.item + 0] = wall_clock64();
-        if (slen <= 0) return;
-        // word 0 of joint slot x (its run count) sits in lane x (ws == 0, r == 0)
-        const bool act = jl < h.nj;
-        const int nseg_lane = (int)(unsigned)h.v[0];
-        int nseg_max = 0;
+        // tables: per joint slot one (capped rows) or two loads of 64 word pairs; a descriptor over the two tiles the item's
+        // joints can lie in, one 32-bit offset per lane
+        const unsigned long long l0 = (unsigned long long)(real ? local : 0) * dof + (real ? j0 : 0);       // wave-uniform
+        const __amdgpu_buffer_rsrc_t r_tab = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<unsigned long long*>(tables) + (l0 >> 6) * (unsigned long long)(kTableWords * 64), 0, (int)(2u * kTileBytes), 0x00020000);
 #pragma unroll
         for (int x = 0; x < kTabJointGroup; ++x) {
-            const int nx = x < h.nj ? __builtin_amdgcn_readlane(nseg_lane, x) : 0;
-            nseg_max = nx > nseg_max ? nx : nseg_max;
-        }
-        const int nwords_max = 1 + (kMaxSegments + 2) / 2 + nseg_max * kRunCoefs;
-        unsigned long long* dst = reinterpret_cast<unsigned long long*>(&B.jt[act ? jl : 0]);
-        // the LDS copy is written for every word of the batch: entries past a joint's run count are never read
-#pragma unroll
-        for (int r = 0; r < kTabBatch; ++r)
-            if (act) dst[ws + 8 * r] = h.v[r];
-        for (int base = 8 * kTabBatch; base < nwords_max; base += 8 * kTabBatch) {   // longer tables: the rest, now
-            const unsigned long long* tp = table_ptr(h);
-#pragma unroll
-            for (int r = 0; r < kTabBatch; ++r) {
-                const int w = base + ws + 8 * r;
-                h.v[r] = tp[(unsigned)(w < kTableWords ? w : 0) * 64u];
-            }
-#pragma unroll
-            for (int r = 0; r < kTabBatch; ++r) {
-                const int w = base + ws + 8 * r;
-                if (act && w < kTableWords) dst[w] = h.v[r];
+            const unsigned long long li = l0 + (unsigned)((real && x < nj) ? x : 0);
+            const unsigned base = (unsigned)((li >> 6) - (l0 >> 6)) * kTileBytes + (unsigned)(li & 63ull) * 16u;
+            if (lane < (whole_tables ? 64 : 40))
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(r_tab, (lds_ptr)&B.jt[x], 16, base + (unsigned)lane * 1024u, 0, 0, 0);
+            if (whole_tables) {
+                if (lane < kTableWords / 2 - 64)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(r_tab, (lds_ptr)(reinterpret_cast<char*>(&B.jt[x]) + 1024), 16,
+                                                             base + (unsigned)(64 + lane) * 1024u, 0, 0, 0);
             }
         }
-        if (stamps && lane == 0) { stamps[8 * h.item + 1] = wall_clock64(); stamps[8 * h.item + 2] = stamps[8 * h.item + 1]; }
     };
-    // one loader iteration: install the item of slot h into B, then reuse the slot for the item two places further on
-    auto iterate = [&](TabBuffer& B, TabSlot& h) __attribute__((always_inline)) -> bool {
-        install(B, h);
-        const unsigned long long installed = h.item;
-        __builtin_amdgcn_sched_barrier(0);
-        request(h, next_item_id());
-        if (stamps && lane == 0 && installed < total) stamps[8 * installed + 3] = wall_clock64();
-        __syncthreads();
-        if (stamps && lane == 0 && installed < total) stamps[8 * installed + 7] = wall_clock64();
-        return installed >= total;                     // the buffer just published says done: everyone leaves after using it
+    // header of an item whose loads are in: what the streaming waves read
+    auto publish_header = [&](TabBuffer& B, unsigned long long item) __attribute__((always_inline)) {
+        const int lane = fresh_lane();
+        if (item >= total) {
+            if (lane == 0) lds_poke32(lds_offset(&B.hdr.done), 1);
+            return;
+        }
+        long long local; int j0, nj;
+        decode(item, local, j0, nj);
+        int slen = 0;
+        unsigned long long rel = 0ull;
+        if (local >= 0) {
+            const int len = __builtin_amdgcn_readfirstlane(lds_peek32(lds_offset(&B.raw_len[0])));
+            slen = stored_len(len, rows);
+            rel = uniform64(lds_peek64(lds_offset(&B.raw_off[0]))) - off0;
+            const unsigned long long stride = ((unsigned long long)slen + (kRowAlign - 1)) / kRowAlign * kRowAlign;
+            if (slen > 0 && rel + 4ull * dof * stride > capacity) {
+                if (lane == 0 && j0 == 0) atomicOr(&rec.status[first + local], kStatusOverflow);
+                slen = 0;
+            }
+            if (slen > 0 && !whole_tables) {
+                // a capped row whose joint has more than 6 runs inside the cap (short trajectories): fetch the rest now
+                int nseg_max = 0;
+#pragma unroll
+                for (int x = 0; x < kTabJointGroup; ++x) {
+                    const int nx = x < nj ? __builtin_amdgcn_readfirstlane(lds_peek32(lds_offset(&B.jt[x].nseg))) : 0;
+                    nseg_max = nx > nseg_max ? nx : nseg_max;
+                }
+                if (1 + (kMaxSegments + 2) / 2 + nseg_max * kRunCoefs > 80) {
+                    const unsigned long long l0 = (unsigned long long)local * dof + j0;
+                    const __amdgpu_buffer_rsrc_t r_tab = __builtin_amdgcn_make_buffer_rsrc(
+                        const_cast<unsigned long long*>(tables) + (l0 >> 6) * (unsigned long long)(kTableWords * 64), 0, (int)(2u * kTileBytes), 0x00020000);
+#pragma unroll
+                    for (int x = 0; x < kTabJointGroup; ++x) {
+                        const unsigned long long li = l0 + (unsigned)(x < nj ? x : 0);
+                        const unsigned base = (unsigned)((li >> 6) - (l0 >> 6)) * kTileBytes + (unsigned)(li & 63ull) * 16u;
+                        if (lane < 24) __builtin_amdgcn_raw_ptr_buffer_load_lds(r_tab, (lds_ptr)(reinterpret_cast<char*>(&B.jt[x]) + 640), 16,
+                                                                                base + (unsigned)(40 + lane) * 1024u, 0, 0, 0);
+                        if (lane < kTableWords / 2 - 64)
+                            __builtin_amdgcn_raw_ptr_buffer_load_lds(r_tab, (lds_ptr)(reinterpret_cast<char*>(&B.jt[x]) + 1024), 16,
+                                                                     base + (unsigned)(64 + lane) * 1024u, 0, 0, 0);
+                    }
+                    LTP_WAIT_VMCNT(0);                          // rare: drain everything (later waits only get easier)
+                }
+            }
+        }
+        if (lane == 0) {
+            lds_poke64(lds_offset(&B.hdr.rel), rel);
+            lds_poke32(lds_offset(&B.hdr.slen), slen);
+            lds_poke32(lds_offset(&B.hdr.j0), j0);
+            lds_poke32(lds_offset(&B.hdr.nj), nj);
+            lds_poke32(lds_offset(&B.hdr.done), 0);
+            lds_poke64(lds_offset(&B.hdr.item), item);
+        }
+    };
+    // waits until every streaming wave is past the item that last used buffer seq % kTabBuffers (lane w < 7 watches wave w)
+    auto wait_buffer_free = [&](int seq) __attribute__((always_inline)) {
+        if (seq < kTabBuffers) return;
+        const int need = seq - kTabBuffers + 1;
+        const int lane = fresh_lane();
+        const unsigned watch = lds_offset(&s_consumed[lane < kTabStreamWaves ? lane : 0]);
+        for (;;) {
+            const int c = lds_peek32(watch);
+            if (!__builtin_amdgcn_ballot_w64(c < need)) break;
+            __builtin_amdgcn_s_sleep(1);
+        }
     };
 
-    TabSlot A, Bs;
-    request(A, next_item_id());                        // item 0
-    request(Bs, next_item_id());                       // item 1
-    // item 0 -> buf[0]; its barrier releases the streaming waves' first iteration
-    bool done = iterate(buf[0], A);
-    while (!done) {
-        // streaming waves are on buf[0]: fill buf[1]; then the other way round
-        done = iterate(buf[1], Bs);
-        if (done) break;
-        done = iterate(buf[0], A);
+    // items in flight: seq (to be published next) .. seq + kTabAhead - 1; their queue positions
+    unsigned long long ids[kTabAhead + 1];
+#pragma unroll
+    for (int d = 0; d < kTabAhead; ++d) {
+        ids[d] = next_item_id();
+        request(buf[d], ids[d]);
+        finish_draw();
     }
+    for (int seq = 0;; ++seq) {
+        // request item seq + kTabAhead into its buffer, as soon as the streaming waves have left it (the spin loop comes
+        // before the queue draw: between the draw's atomic and its use there must be no loop, see next_item_id)
+        wait_buffer_free(seq + kTabAhead);
+        ids[kTabAhead] = next_item_id();
+        request(buf[(seq + kTabAhead) % kTabBuffers], ids[kTabAhead]);
+        // item seq is in when at most the loads of the kTabAhead younger items are outstanding
+        if (whole_tables) LTP_WAIT_VMCNT(kTabAhead * (2 + 2 * kTabJointGroup));
+        else LTP_WAIT_VMCNT(kTabAhead * (2 + kTabJointGroup));
+        TabBuffer& B = buf[seq % kTabBuffers];
+        const unsigned long long item = ids[0];
+        if (stamps && fresh_lane() == 0 && item < total) stamps[8 * item + 1] = wall_clock64();
+        publish_header(B, item);
+        // Publishing is a plain LDS write: the table data is in LDS (the wait above), the header was written by this same
+        // lane and LDS serves a wave's requests in order.
+        if (fresh_lane() == 0) lds_poke32(lds_offset(&s_ready[seq % kTabBuffers]), seq + 1);
+        if (stamps && fresh_lane() == 0 && item < total) stamps[8 * item + 3] = wall_clock64();
+        finish_draw();
+        if (item >= total) break;                       // the item just published says done: everyone leaves on reading it
+#pragma unroll
+        for (int d = 0; d < kTabAhead; ++d) ids[d] = ids[d + 1];
+    }
+    LTP_WAIT_VMCNT(0);                                  // nothing may still be landing in LDS when the wave ends
 }
 
 // The register budget decides how many streaming waves a CU holds, and attributes cannot depend on template parameters:
@@ -1359,26 +1478,27 @@ k_build_tables(long long first, long long count, int dof, double t_sample, Limit
     const long long local = idx / dof;
     const int j = (int)(idx - local * dof);
     const long long p = first + local;
-    unsigned long long* const T = tables + table_word_index((unsigned long long)idx, 0);
+    const unsigned long long lane_id = (unsigned long long)idx;
+    auto word = [&](int w) -> unsigned long long* { return tables + table_word_index(lane_id, w); };
     const int len = rec.traj_len[p];
-    if (len <= 0) { T[0] = 0ull; return; }                     // nseg 0: the sampler skips such plans anyway
+    if (len <= 0) { *word(0) = 0ull; return; }                 // nseg 0: the sampler skips such plans anyway
     const long long ix = p * in.sq + (long long)j * in.sj;
     double q = in.q_0[ix], v = in.v_0[ix], a = in.a_0[ix];
     int run = 0;
     int last_b = len;
     for_each_run(lim, rec, p * dof + j, j, len, t_sample, q, v, a, [&](int b, int, const RunCoef& rc) {
         if (b < needed_end) {
-            reinterpret_cast<int*>(T + (1 + (run >> 1)) * 64)[run & 1] = b;
+            reinterpret_cast<int*>(word(1 + (run >> 1)))[run & 1] = b;
 #pragma unroll
-            for (int x = 0; x < kRunCoefs; ++x) T[(1 + (kMaxSegments + 2) / 2 + run * kRunCoefs + x) * 64] = __builtin_bit_cast(unsigned long long, rc.c[x]);
+            for (int x = 0; x < kRunCoefs; ++x) *word(1 + (kMaxSegments + 2) / 2 + run * kRunCoefs + x) = __builtin_bit_cast(unsigned long long, rc.c[x]);
             ++run;
         } else if (last_b == len) {
             last_b = b;                                        // first run that is not stored: it ends the last stored one
         }
         return false;                                          // the walk still goes to the last sample: end-limit check
     });
-    reinterpret_cast<int*>(T + (1 + (run >> 1)) * 64)[run & 1] = last_b;
-    T[0] = (unsigned long long)(unsigned)run;
+    reinterpret_cast<int*>(word(1 + (run >> 1)))[run & 1] = last_b;
+    *word(0) = (unsigned long long)(unsigned)run;
     if (q < lim.q_min[j] || q > lim.q_max[j]) atomicOr(&rec.status[p], kStatusEndLimit);   // cc:59-61: q is sample len-1
 }
 
@@ -1685,7 +1805,8 @@ void launch_sample_tab(hipStream_t s, long long first, long long count, long lon
     long long blocks = resident_blocks > 0 ? resident_blocks : 768;
     if (blocks > count * ngroups) blocks = count * ngroups;
     const dim3 grid((unsigned)blocks), block(kTabThreads);
-    const int draw_chunk = queue_draw_chunk(rows, f32, dof < kTabJointGroup ? dof : kTabJointGroup);
+    // (the loader pays one exposed atomic round trip per draw: larger chunks than k_sample's)
+    const int draw_chunk = 2 * queue_draw_chunk(rows, f32, dof < kTabJointGroup ? dof : kTabJointGroup);
 #define LTP_TAB_CASE(K, TY) hipLaunchKernelGGL(K, grid, block, 0, s, first, count, base_first, dof, rec, offsets, (TY*)out, capacity, spread, rows, next_item, tables, draw_chunk, stamps)
     switch ((flags & 1) | (f32 ? 2 : 0)) {
     case 0: LTP_TAB_CASE(k_sample_tab_f64, double); break;
