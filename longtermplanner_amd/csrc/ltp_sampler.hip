@@ -1000,7 +1000,8 @@ LTP_DEV void sample_tab_body(long long first, long long count, long long base_fi
     const unsigned long long total = (unsigned long long)per * spread * ngroups;
     const unsigned long long off0 = offsets[base_first];
     constexpr unsigned kTileBytes = (unsigned)kTableWords * 64u * 8u;
-    // capped rows only touch the first runs: 40 word pairs (80 words, 6 runs) per joint; whole tables are 106 pairs
+    // capped rows mostly touch the first runs only (a switch of the jerk profile cuts up to three runs: 8 runs is what
+    // 256 samples of a 7-DoF plan typically need): 64 word pairs (128 words, 11 runs) per joint; whole tables are 106 pairs
     const bool whole_tables = rows.max_samples <= 0;
     typedef __attribute__((address_space(3))) void* lds_ptr;
     auto uniform64 = [](unsigned long long x) -> unsigned long long {
@@ -1077,8 +1078,7 @@ LTP_DEV void sample_tab_body(long long first, long long count, long long base_fi
         for (int x = 0; x < kTabJointGroup; ++x) {
             const unsigned long long li = l0 + (unsigned)((real && x < nj) ? x : 0);
             const unsigned base = (unsigned)((li >> 6) - (l0 >> 6)) * kTileBytes + (unsigned)(li & 63ull) * 16u;
-            if (lane < (whole_tables ? 64 : 40))
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(r_tab, (lds_ptr)&B.jt[x], 16, base + (unsigned)lane * 1024u, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(r_tab, (lds_ptr)&B.jt[x], 16, base + (unsigned)lane * 1024u, 0, 0, 0);
             if (whole_tables) {
                 if (lane < kTableWords / 2 - 64)
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(r_tab, (lds_ptr)(reinterpret_cast<char*>(&B.jt[x]) + 1024), 16,
@@ -1098,23 +1098,26 @@ LTP_DEV void sample_tab_body(long long first, long long count, long long base_fi
         int slen = 0;
         unsigned long long rel = 0ull;
         if (local >= 0) {
-            const int len = __builtin_amdgcn_readfirstlane(lds_peek32(lds_offset(&B.raw_len[0])));
+            // everything the header needs from what the loads brought, in one LDS round trip: lanes 0..6 read the joints' run
+            // counts, lane 7 the trajectory length, lanes 8 and 9 the halves of the plan's offset
+            const unsigned peek_at = lane < kTabJointGroup ? lds_offset(&B.jt[lane].nseg)
+                                     : (lane == kTabJointGroup ? lds_offset(&B.raw_len[0])
+                                                               : lds_offset(reinterpret_cast<const int*>(&B.raw_off[0]) + (lane == kTabJointGroup + 2 ? 1 : 0)));
+            const int peeked = lds_peek32(peek_at);
+            const int len = __builtin_amdgcn_readlane(peeked, kTabJointGroup);
             slen = stored_len(len, rows);
-            rel = uniform64(lds_peek64(lds_offset(&B.raw_off[0]))) - off0;
+            rel = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(peeked, kTabJointGroup + 2) << 32 |
+                   (unsigned long long)(unsigned)__builtin_amdgcn_readlane(peeked, kTabJointGroup + 1)) - off0;
             const unsigned long long stride = ((unsigned long long)slen + (kRowAlign - 1)) / kRowAlign * kRowAlign;
             if (slen > 0 && rel + 4ull * dof * stride > capacity) {
                 if (lane == 0 && j0 == 0) atomicOr(&rec.status[first + local], kStatusOverflow);
                 slen = 0;
             }
             if (slen > 0 && !whole_tables) {
-                // a capped row whose joint has more than 6 runs inside the cap (short trajectories): fetch the rest now
-                int nseg_max = 0;
-#pragma unroll
-                for (int x = 0; x < kTabJointGroup; ++x) {
-                    const int nx = x < nj ? __builtin_amdgcn_readfirstlane(lds_peek32(lds_offset(&B.jt[x].nseg))) : 0;
-                    nseg_max = nx > nseg_max ? nx : nseg_max;
-                }
-                if (1 + (kMaxSegments + 2) / 2 + nseg_max * kRunCoefs > 80) {
+                // a capped row whose joint has more than 11 runs inside the cap (short trajectories): fetch the rest now
+                const bool long_table = __builtin_amdgcn_ballot_w64(lane < nj && 1 + (kMaxSegments + 2) / 2 + peeked * kRunCoefs > 128) != 0ull;
+                if (stamps && lane == 0) stamps[8 * item + 2] = (unsigned long long)long_table;
+                if (long_table) {
                     const unsigned long long l0 = (unsigned long long)local * dof + j0;
                     const __amdgpu_buffer_rsrc_t r_tab = __builtin_amdgcn_make_buffer_rsrc(
                         const_cast<unsigned long long*>(tables) + (l0 >> 6) * (unsigned long long)(kTableWords * 64), 0, (int)(2u * kTileBytes), 0x00020000);
@@ -1122,8 +1125,6 @@ LTP_DEV void sample_tab_body(long long first, long long count, long long base_fi
                     for (int x = 0; x < kTabJointGroup; ++x) {
                         const unsigned long long li = l0 + (unsigned)(x < nj ? x : 0);
                         const unsigned base = (unsigned)((li >> 6) - (l0 >> 6)) * kTileBytes + (unsigned)(li & 63ull) * 16u;
-                        if (lane < 24) __builtin_amdgcn_raw_ptr_buffer_load_lds(r_tab, (lds_ptr)(reinterpret_cast<char*>(&B.jt[x]) + 640), 16,
-                                                                                base + (unsigned)(40 + lane) * 1024u, 0, 0, 0);
                         if (lane < kTableWords / 2 - 64)
                             __builtin_amdgcn_raw_ptr_buffer_load_lds(r_tab, (lds_ptr)(reinterpret_cast<char*>(&B.jt[x]) + 1024), 16,
                                                                      base + (unsigned)(64 + lane) * 1024u, 0, 0, 0);
@@ -1162,12 +1163,15 @@ LTP_DEV void sample_tab_body(long long first, long long count, long long base_fi
         request(buf[d], ids[d]);
         finish_draw();
     }
+    unsigned long long t_prev_pub = 0ull;
     for (int seq = 0;; ++seq) {
         // request item seq + kTabAhead into its buffer, as soon as the streaming waves have left it (the spin loop comes
         // before the queue draw: between the draw's atomic and its use there must be no loop, see next_item_id)
         wait_buffer_free(seq + kTabAhead);
+        const unsigned long long t_top = stamps ? wall_clock64() : 0ull;
         ids[kTabAhead] = next_item_id();
         request(buf[(seq + kTabAhead) % kTabBuffers], ids[kTabAhead]);
+        const unsigned long long t_req = stamps ? wall_clock64() : 0ull;
         // item seq is in when at most the loads of the kTabAhead younger items are outstanding
         if (whole_tables) LTP_WAIT_VMCNT(kTabAhead * (2 + 2 * kTabJointGroup));
         else LTP_WAIT_VMCNT(kTabAhead * (2 + kTabJointGroup));
@@ -1178,7 +1182,8 @@ LTP_DEV void sample_tab_body(long long first, long long count, long long base_fi
         // Publishing is a plain LDS write: the table data is in LDS (the wait above), the header was written by this same
         // lane and LDS serves a wave's requests in order.
         if (fresh_lane() == 0) lds_poke32(lds_offset(&s_ready[seq % kTabBuffers]), seq + 1);
-        if (stamps && fresh_lane() == 0 && item < total) stamps[8 * item + 3] = wall_clock64();
+        if (stamps && fresh_lane() == 0 && item < total) { stamps[8 * item + 3] = wall_clock64(); stamps[8 * item + 0] = t_top; stamps[8 * item + 6] = t_req; stamps[8 * item + 7] = t_prev_pub; }
+        if (stamps) t_prev_pub = wall_clock64();
         finish_draw();
         if (item >= total) break;                       // the item just published says done: everyone leaves on reading it
 #pragma unroll
