@@ -136,7 +136,7 @@ def parse_args(argv=None):
                          "--max-samples samples, restart every query from stored sample K (ltp_replan_states_batch); value counts every replan")
     ap.add_argument("--table-pass", default="auto", choices=["auto", "on", "off"],
                     help="where the sampler's run tables are built: by the table pass (a kernel of its own) or inside the sampler kernel (ltp_set_table_pass)")
-    ap.add_argument("--table-gib", type=float, default=0.0, help="upper bound of the table-pass workspace (default: library default, 4 GiB)")
+    ap.add_argument("--table-gib", type=float, default=0.0, help="upper bound of the table-pass workspace (default: library default, 1/16 of device memory)")
     ap.add_argument("--sample-blocks", type=int, default=0, help="TUNING: size of the sampler's persistent grid (0 = library default)")
     ap.add_argument("--gather", action="store_true", help="also all_gather t_required over RCCL each step (optional path)")
     ap.add_argument("--checksum", action="store_true",

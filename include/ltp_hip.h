@@ -127,7 +127,8 @@ int ltp_get_goal_check(const ltp_planner* p);
  * 1024 for float32 rows), 1 = always, -1 = never. ltp_sample_batch's flags bits 2 / 3 force the pass / the fused build per call. */
 int ltp_set_table_pass(ltp_planner* p, int mode);
 int ltp_get_table_pass(const ltp_planner* p);
-/* Upper bound (bytes, default 4 GiB) of the table workspace; ranges whose tables do not fit are processed in pieces. */
+/* Upper bound (bytes) of the table workspace; default: the larger of 4 GiB and 1/16 of the device's memory (18 GiB on MI355X).
+ * Ranges whose tables do not fit are processed in pieces; if the device cannot spare that much, the workspace is smaller. */
 int ltp_set_table_workspace(ltp_planner* p, unsigned long long bytes);
 
 /* ---- batched hot path (device pointers, asynchronous on `stream`) -------------------------- */

@@ -36,7 +36,8 @@ struct ltp_planner {
     int table_pass = 0;                    // 0 = automatic, 1 = always, -1 = never (ltp_set_table_pass)
     unsigned long long* d_tables = nullptr;   // run tables of the table pass (k_build_tables); part of the workspace
     unsigned long long tables_bytes = 0;      // allocated
-    unsigned long long tables_cap = 4ull << 30;   // upper bound for d_tables; longer ranges are processed in pieces
+    unsigned long long tables_cap = 4ull << 30;   // upper bound for d_tables (ltp_create: 1/16 of the device's memory if that
+                                                  // is more — 18 GiB of 288); longer ranges are processed in pieces
     double* d_small = nullptr;             // 16 doubles for the one-lane entry points
     unsigned long long* dbg_stamps = nullptr; // diagnostic: per-block start/end stamps of k_sample (caller-owned)
     // persistent buffers of the small synchronous host-pointer calls (no hipMalloc per call)
@@ -248,7 +249,15 @@ int ensure_tables(ltp_planner* p, long long count, long long* plans_per_piece)
         if (p->d_tables) LTP_HIP_TRY(p, hipFree(p->d_tables));
         p->d_tables = nullptr;
         p->tables_bytes = 0;
-        LTP_HIP_TRY(p, hipMalloc((void**)&p->d_tables, (size_t)want));
+        // the workspace is a convenience: when the device cannot spare `want` bytes, take what it can (more pieces)
+        for (;;) {
+            const hipError_t e = hipMalloc((void**)&p->d_tables, (size_t)want);
+            if (e == hipSuccess) break;
+            p->d_tables = nullptr;
+            (void)hipGetLastError();
+            if (e != hipErrorOutOfMemory || want / 2 < per_tile * (unsigned long long)dof) LTP_HIP_TRY(p, e);
+            want = want / 2 / per_tile * per_tile;
+        }
         p->tables_bytes = want;
     }
     long long plans = (long long)(p->tables_bytes / per_tile) * 64 / dof;
@@ -308,6 +317,9 @@ int ltp_create(int dof, double t_sample, const double* q_min, const double* q_ma
     int rc = upload_limits(p);
     if (rc == LTP_OK) rc = reserve(p, 1);
     if (rc != LTP_OK) { ltp_destroy(p); return rc; }
+    size_t mem_free = 0, mem_total = 0;
+    if (hipMemGetInfo(&mem_free, &mem_total) == hipSuccess && (unsigned long long)mem_total / 16 > p->tables_cap)
+        p->tables_cap = (unsigned long long)mem_total / 16;
     *out = p;
     return LTP_OK;
 }

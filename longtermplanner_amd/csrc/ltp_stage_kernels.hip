@@ -150,12 +150,19 @@ __global__ void __launch_bounds__(kQueriesPerBlock* kMaxJointSlots)
 k_reduce_scale(long long n, int dof, double t_sample, Limits lim, Queries in, Records out,
                const signed char* __restrict__ lane_flags, Queue queue)
 {
-    __shared__ unsigned long long s_cnt[kMaxJointSlots + 1];
     __shared__ double s_t[kMaxJointSlots][kQueriesPerBlock];
     __shared__ int s_j[kMaxJointSlots][kQueriesPerBlock];
     __shared__ int s_f[kMaxJointSlots][kQueriesPerBlock];
+    __shared__ double s_treq[kQueriesPerBlock];
+    __shared__ int s_len[kQueriesPerBlock], s_bad[kQueriesPerBlock];
+    // lanes whose first candidate was rejected (local lane ids); (query, joint) records for queue B
+    __shared__ unsigned short s_second[kMaxJointSlots * kQueriesPerBlock];
+    __shared__ unsigned long long s_slow[kMaxJointSlots * kQueriesPerBlock];
+    __shared__ int s_nsecond, s_nslow;
+    __shared__ unsigned long long s_base;
 
     const int x = threadIdx.x, y = threadIdx.y, JB = blockDim.y;
+    const int tid = y * kQueriesPerBlock + x;
     const long long q = (long long)blockIdx.x * kQueriesPerBlock + x;
     const bool live = q < n;
 
@@ -173,6 +180,7 @@ k_reduce_scale(long long n, int dof, double t_sample, Limits lim, Queries in, Re
     s_t[y][x] = best_t;
     s_j[y][x] = best_j;
     s_f[y][x] = flags;
+    if (tid == 0) { s_nsecond = 0; s_nslow = 0; }
     __syncthreads();
     double t_required = -1.0;
     int slowest = -1;
@@ -185,25 +193,55 @@ k_reduce_scale(long long n, int dof, double t_sample, Limits lim, Queries in, Re
     }
     if (slowest < 0) flags |= kStatusNoSlowest;
     if (flags & kLaneGoalOutside) flags = (flags & ~kLaneGoalOutside) | kStatusGoalOutside;
-    if (live && y == 0) {
-        out.t_required[q] = t_required;
-        out.slowest[q] = slowest;
-        out.status[q] = flags;
+    if (y == 0) {
+        s_treq[x] = t_required;
+        s_len[x] = 0;
+        s_bad[x] = 0;
+        if (live) {
+            out.t_required[q] = t_required;
+            out.slowest[q] = slowest;
+            out.status[q] = flags;
+        }
     }
+    __syncthreads();
 
-    // cc:43-55 with the closed-form candidates c1, c2 (cc:378-446)
-    int my_len = 0, nonfinite = 0;
-    for (int jb = 0; jb < dof; jb += JB) {   // same number of rounds in every wave: block_push() contains barriers
+    // cc:43-55 with the closed-form candidates c1, c2 (cc:378-446). A finished (query, joint) lane stores its record and
+    // folds its length into s_len / s_bad (traj_len, cc:716-719; queue-B lanes add theirs with atomicMax later).
+    auto finish = [&](long long rj, int col, bool valid, double (&ts)[7], double vd, int mod) {
+        if (valid) {
+            // cc:50-55: no scaled solution (or the slowest joint) -> optimal times
+            double mx = ts[0];
+#pragma unroll
+            for (int k = 1; k < 7; ++k) if (mx < ts[k]) mx = ts[k];
+            if (mx <= 0.0) {
+#pragma unroll
+                for (int k = 0; k < 7; ++k) ts[k] = out.t_opt[rj * 7 + k];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 7; ++k) out.t_scaled[rj * 7 + k] = ts[k];
+        out.v_drive[rj] = vd;
+        out.mod[rj] = (signed char)mod;
+        if (valid) {
+            const int l = joint_len(ts, t_sample);
+            if (l < 0) atomicOr(&s_bad[col], 1);
+            else atomicMax(&s_len[col], l);
+        }
+    };
+    for (int jb = 0; jb < dof; jb += JB) {   // same number of rounds in every wave: the loop contains barriers
+        // (1) the first candidate, lane = (query, joint), limits wave-uniform. 85 % of the scaled joints end here; a lane
+        //     whose c1 is rejected only leaves its id, so that the second candidate — twenty divisions and another
+        //     optSwitchTimes, which every wave would otherwise execute for the sake of a few of its lanes — is evaluated
+        //     by full waves in (2).
         const int j = jb + y;
         const bool active = live && j < dof;
         const JointLimits L = load_limits(lim, j < dof ? j : dof - 1);
-        bool need_slow = false;
-        int lane_len = 0;
         const long long rj = q * dof + j;
         if (active) {
             double ts[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
             double vd = L.v_max;
             int mod = 0;   // failed query: zero record, never sampled
+            int acc = kOptTrue;
             if (flags == 0) {
                 mod = out.mod[rj];
                 if (j != slowest) {
@@ -213,49 +251,50 @@ k_reduce_scale(long long n, int dof, double t_sample, Limits lim, Queries in, Re
                     const double dir = out.dir[rj];
                     if (dir < 0.0) { v0 = -v0; a0 = -a0; }
                     vd = v_drive_candidate<1>(L.a_max, L.j_max, qg, q0, v0, a0, dir, t_required);
-                    int acc = try_v_drive<false>(L.a_max, L.j_max, t_sample, qg, q0, v0, a0, dir, t_required, vd, ts, mod);
-                    if (acc == kOptFalse) {
-                        vd = v_drive_candidate<2>(L.a_max, L.j_max, qg, q0, v0, a0, dir, t_required);
-                        acc = try_v_drive<false>(L.a_max, L.j_max, t_sample, qg, q0, v0, a0, dir, t_required, vd, ts, mod);
-                    }
-                    need_slow = (acc != kOptTrue);
-                }
-                if (!need_slow) {
-                    // cc:50-55: no scaled solution (or the slowest joint) -> optimal times
-                    double mx = ts[0];
-#pragma unroll
-                    for (int k = 1; k < 7; ++k) if (mx < ts[k]) mx = ts[k];
-                    if (mx <= 0.0) {
-#pragma unroll
-                        for (int k = 0; k < 7; ++k) ts[k] = out.t_opt[rj * 7 + k];
-                    }
+                    acc = try_v_drive<false>(L.a_max, L.j_max, t_sample, qg, q0, v0, a0, dir, t_required, vd, ts, mod);
                 }
             }
-            if (!need_slow) {
-#pragma unroll
-                for (int k = 0; k < 7; ++k) out.t_scaled[rj * 7 + k] = ts[k];
-                out.v_drive[rj] = vd;
-                out.mod[rj] = (signed char)mod;
-                if (flags == 0) lane_len = joint_len(ts, t_sample);
-            }
+            if (acc == kOptTrue) finish(rj, x, flags == 0, ts, vd, mod);
+            else if (acc == kOptFalse) s_second[atomicAdd(&s_nsecond, 1)] = (unsigned short)tid;
+            else s_slow[atomicAdd(&s_nslow, 1)] = (unsigned long long)rj;      // c1 reached a quartic site: all of it in queue B
         }
-        block_push(need_slow, (unsigned long long)rj, queue, s_cnt);
-        if (lane_len < 0) nonfinite = 1;
-        else my_len = lane_len > my_len ? lane_len : my_len;
+        __syncthreads();
+        // (2) the second candidate for the lanes that need it, densely: thread e takes the e-th such lane (limits per lane)
+        const int nsecond = s_nsecond;
+        if (tid < nsecond) {
+            const int who = s_second[tid];
+            const int x2 = who & (kQueriesPerBlock - 1), j2 = jb + who / kQueriesPerBlock;
+            const long long q2 = (long long)blockIdx.x * kQueriesPerBlock + x2;
+            const long long rj2 = q2 * dof + j2;
+            const JointLimits L2 = load_limits(lim, j2);
+            const long long ix = q2 * in.sq + (long long)j2 * in.sj;
+            const double qg = in.q_goal[ix], q0 = in.q_0[ix];
+            double v0 = in.v_0[ix], a0 = in.a_0[ix];
+            const double dir = out.dir[rj2], tr = s_treq[x2];
+            if (dir < 0.0) { v0 = -v0; a0 = -a0; }
+            double ts[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+            int mod = 0;
+            const double vd = v_drive_candidate<2>(L2.a_max, L2.j_max, qg, q0, v0, a0, dir, tr);
+            const int acc = try_v_drive<false>(L2.a_max, L2.j_max, t_sample, qg, q0, v0, a0, dir, tr, vd, ts, mod);
+            if (acc == kOptTrue) finish(rj2, x2, true, ts, vd, mod);
+            else s_slow[atomicAdd(&s_nslow, 1)] = (unsigned long long)rj2;
+        }
+        __syncthreads();
+        // (3) what neither closed form settled goes to queue B: one reservation per block and round
+        const int nslow = s_nslow;
+        if (nslow > 0) {
+            const int shard = blockIdx.x & (kQueueShards - 1);
+            if (tid == 0) s_base = atomicAdd(&queue.counts[shard], (unsigned long long)nslow);
+            __syncthreads();
+            if (tid < nslow) queue.items[(unsigned long long)shard * queue.segment + s_base + tid] = s_slow[tid];
+        }
+        __syncthreads();
+        if (tid == 0) { s_nsecond = 0; s_nslow = 0; }
+        __syncthreads();
     }
-    // traj_len (cc:716-719) over the joints finished here; queue-B lanes add theirs with atomicMax later
-    __syncthreads();
-    s_j[y][x] = my_len;
-    s_f[y][x] = nonfinite;
-    __syncthreads();
     if (live && y == 0) {
-        int len = 0, bad = 0;
-        for (int yy = 0; yy < JB; ++yy) {
-            len = s_j[yy][x] > len ? s_j[yy][x] : len;
-            bad |= s_f[yy][x];
-        }
-        out.traj_len[q] = flags == 0 ? len : 0;
-        if (bad) out.status[q] = flags | kStatusNonFinite;
+        out.traj_len[q] = flags == 0 ? s_len[x] : 0;
+        if (s_bad[x]) out.status[q] = flags | kStatusNonFinite;
     }
 }
 

@@ -42,6 +42,8 @@
 #include <stdint.h>
 
 /* ---------- root finder, instantiated for double and float ---------- */
+static int ltpo_schur_iterations = 0;
+int ltpo_last_schur_iterations(void) { return ltpo_schur_iterations; }
 #define REAL double
 #define REAL_MIN DBL_MIN
 #define REAL_EPS DBL_EPSILON
