@@ -1494,8 +1494,16 @@ k_build_tables(long long first, long long count, int dof, double t_sample, Limit
     for_each_run(lim, rec, p * dof + j, j, len, t_sample, q, v, a, [&](int b, int, const RunCoef& rc) {
         if (b < needed_end) {
             reinterpret_cast<int*>(word(1 + (run >> 1)))[run & 1] = b;
+            // coefficients as whole word pairs: 16 bytes per lane, a full 1 KiB line per wave instruction
+            static_assert((1 + (kMaxSegments + 2) / 2) % 2 == 0 && kRunCoefs % 2 == 0, "a run's coefficients start on a word pair");
+            typedef double pair_t __attribute__((ext_vector_type(2)));
 #pragma unroll
-            for (int x = 0; x < kRunCoefs; ++x) *word(1 + (kMaxSegments + 2) / 2 + run * kRunCoefs + x) = __builtin_bit_cast(unsigned long long, rc.c[x]);
+            for (int x = 0; x < kRunCoefs; x += 2) {
+                pair_t v2;
+                v2[0] = rc.c[x];
+                v2[1] = rc.c[x + 1];
+                *reinterpret_cast<pair_t*>(word(1 + (kMaxSegments + 2) / 2 + run * kRunCoefs + x)) = v2;
+            }
             ++run;
         } else if (last_b == len) {
             last_b = b;                                        // first run that is not stored: it ends the last stored one
