@@ -1502,7 +1502,7 @@ k_build_tables(long long first, long long count, int dof, double t_sample, Limit
                 pair_t v2;
                 v2[0] = rc.c[x];
                 v2[1] = rc.c[x + 1];
-                *reinterpret_cast<pair_t*>(word(1 + (kMaxSegments + 2) / 2 + run * kRunCoefs + x)) = v2;
+                __builtin_nontemporal_store(v2, reinterpret_cast<pair_t*>(word(1 + (kMaxSegments + 2) / 2 + run * kRunCoefs + x)));
             }
             ++run;
         } else if (last_b == len) {
