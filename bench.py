@@ -136,6 +136,8 @@ def parse_args(argv=None):
                          "--max-samples samples, restart every query from stored sample K (ltp_replan_states_batch); value counts every replan")
     ap.add_argument("--table-pass", default="auto", choices=["auto", "on", "off"],
                     help="where the sampler's run tables are built: by the table pass (a kernel of its own) or inside the sampler kernel (ltp_set_table_pass)")
+    ap.add_argument("--in-flight", type=int, default=1, help="switching times only: steps alternate between this many planner handles, each on its own stream "
+                    "(two batches in flight: the latency-bound queue-B kernel of one step runs under the next step's stages); 1 = one batch at a time")
     ap.add_argument("--table-gib", type=float, default=0.0, help="upper bound of the table-pass workspace (default: library default, 1/16 of device memory)")
     ap.add_argument("--sample-blocks", type=int, default=0, help="TUNING: size of the sampler's persistent grid (0 = library default)")
     ap.add_argument("--gather", action="store_true", help="also all_gather t_required over RCCL each step (optional path)")
@@ -191,6 +193,7 @@ class Workload:
         self.sample_blocks, self.gather, self.checksum, self.seed = args.sample_blocks, args.gather, args.checksum, args.seed
         self.table_pass, self.table_gib = args.table_pass, args.table_gib
         self.end_limit = args.end_limit
+        self.in_flight = args.in_flight
         self.name = "primary"
         for k, v in over.items():
             setattr(self, k, v)
@@ -233,12 +236,32 @@ def run_workload(wl, ctx):
         tile = tile_bytes.view(torch.float32 if wl.f32 else torch.float64)
     offsets_pinned = torch.empty(n + 1, dtype=torch.int64, pin_memory=True)
     batch = None
+    # --in-flight K (switching times only): K handles (each owns its device workspace), K streams, K record sets
+    lanes = None
+    if wl.in_flight > 1:
+        if not wl.switch_only or wl.receding:
+            raise SystemExit("bench.py: --in-flight applies to --switch-only")
+        # the streams are made once per process and shared by the workloads: HIP deals streams to a few hardware queues, and
+        # two streams that land on the same queue do not overlap (seen: the second in-flight workload of a run gained nothing)
+        pool = ctx.setdefault("streams", [])
+        while len(pool) < wl.in_flight:
+            pool.append(torch.cuda.Stream())
+        lanes = [{"ltp": ltp if i == 0 else LongTermPlanner(dof, wl.t_sample, device=local_rank, **lim), "stream": pool[i], "batch": None}
+                 for i in range(wl.in_flight)]
+    step_no = 0
     gather_buf = [torch.empty(n, dtype=torch.float64, device=cdev) for _ in range(world)] if (wl.gather and world > 1 and not wl.global_batch) else None
     ev_pairs = []
     n_chunks = 0
 
     def step(timed):
-        nonlocal batch, n_chunks
+        nonlocal batch, n_chunks, step_no
+        if lanes:
+            lane = lanes[step_no % len(lanes)]
+            step_no += 1
+            with torch.cuda.stream(lane["stream"]):
+                lane["batch"] = lane["ltp"].planSwitchTimesBatch(qg, q0, v0, a0, layout=wl.layout, batch=lane["batch"], end_limit=wl.end_limit)
+            batch = lane["batch"]
+            return
         if rec_spec:
             # every round: stages 1-3 (+ end-limit verdict), first-N rows of all plans into the tile (they fit: N is small), new start states
             s0, s1, s2 = q0, v0, a0
@@ -380,14 +403,15 @@ def run_workload(wl, ctx):
             "workload": ((f"{wl.global_batch} x {dof}-DoF queries per step sharded over {world} GPU(s) ({n} on rank 0)" if wl.global_batch else
                           f"{n} x {dof}-DoF queries per GPU per step") + f", limits '{wl.limits}', Tsample {wl.t_sample} s, "
                          + (f"{rec_spec[0]} receding-horizon cycles per step on the device (plan, " + ("state at sample" if rec_direct else f"first {wl.max_samples} samples, replan from stored sample") + f" {rec_spec[1]}); value counts replans; " if rec_spec else "")
-                         + (("switching times only (stages 1-3" + (" + end-limit check" if wl.end_limit else "; status = pre-sampling verdict") + ", no rows)") if wl.switch_only else
+                         + (("switching times only (stages 1-3" + (" + end-limit check" if wl.end_limit else "; status = pre-sampling verdict") + ", no rows)"
+                             + (f"; {wl.in_flight} batches in flight (steps alternate between {wl.in_flight} handles and streams)" if wl.in_flight > 1 else "")) if wl.switch_only else
                             "no rows stored (ltp_state_at_batch)" if rec_direct else
                             f"on-device envelope consumer: [min q, max q] over {env_spec[1]} windows of {env_spec[0]} samples per joint, no dense rows" if env_spec else
                             ("full q/v/a/j sampling" if not (wl.max_samples or wl.sample_stride > 1) else
                              f"q/v/a/j rows: every {wl.sample_stride}-th sample" + (f", first {wl.max_samples} stored" if wl.max_samples else ""))
                             + f" into a reused {tile_gib} GiB tile ({n_chunks} chunks per step)")),
             "batch_per_gpu": n if not wl.global_batch else None, "global_batch": total_queries, "dof": dof, "t_sample": wl.t_sample,
-            "limits": wl.limits, "input_layout": wl.layout, "table_pass": wl.table_pass,
+            "limits": wl.limits, "input_layout": wl.layout, "table_pass": wl.table_pass, "batches_in_flight": wl.in_flight,
             "sharding": "contiguous query ranges per rank, no data-path collective" + (", RCCL all_gather of t_required" if gather_buf else ""),
             "plans_ok_frac": round(ok_total / total_queries, 5),
             "plans_ok_is": ("planTrajectory's bool" if (wl.end_limit or not (wl.switch_only or rec_direct)) else
@@ -464,7 +488,7 @@ def main():
     out = run_workload(primary, ctx)
 
     variant = (args.switch_only or args.end_limit or args.f32 or args.max_samples or args.sample_stride > 1 or args.envelope or args.receding or args.dry_sampler
-               or args.table_pass != "auto" or args.limits != "panda" or args.batch != 1_000_000 or args.global_batch or args.window_gib or args.layout != "query_major")
+               or args.in_flight > 1 or args.table_pass != "auto" or args.limits != "panda" or args.batch != 1_000_000 or args.global_batch or args.window_gib or args.layout != "query_major")
     secondary = []
     if not args.no_secondary and not variant:
         few = max(1, min(args.steps, 2))
@@ -476,10 +500,14 @@ def main():
                  dict(batch=100_000, switch_only=True, steps=max(args.steps, 20), warmup=2)),
                 ("configs[1] + planTrajectory's end-limit verdict without sampling (ltp_end_limit_batch)",
                  dict(batch=100_000, switch_only=True, end_limit=True, steps=max(args.steps, 20), warmup=2)),
+                ("configs[1] as throughput: two batches in flight (two handles, two streams; a step is still one whole batch)",
+                 dict(batch=100_000, switch_only=True, in_flight=2, steps=max(args.steps, 40), warmup=4)),
                 ("configs[1] with the reference's limits",
                  dict(limits="ref", batch=100_000, switch_only=True, steps=max(args.steps, 20), warmup=2)),
                 ("switching times only, 1 M x 7-DoF",
                  dict(switch_only=True, steps=max(args.steps, 10), warmup=2)),
+                ("switching times only, 1 M x 7-DoF, two batches in flight",
+                 dict(switch_only=True, in_flight=2, steps=max(args.steps, 20), warmup=4)),
                 ("configs[4]: 1 M x 30-DoF (S-ref30), full sampling through the reused tile",
                  dict(limits="ref30", steps=few, warmup=1)),
             ]

@@ -69,6 +69,21 @@ def test_bench_spawns_its_ranks_and_shards_one_global_batch():
     assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["config"]["global_batch"] == 40000
 
 
+def test_two_batches_in_flight_give_the_same_records():
+    """`bench.py --switch-only --in-flight 2` alternates its steps between two handles on two streams (the queue-B kernel of
+    one step runs under the next step's stages): the records are those of one batch at a time."""
+    sums = {}
+    for k in (1, 2, 3):
+        p = _bench("--switch-only", "--batch", "30001", "--limits", "ref", "--checksum", "--in-flight", str(k), "--steps", "5", "--end-limit")
+        assert p.returncode == 0, p.stderr[-2000:]
+        line = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][0])
+        assert line["config"]["batches_in_flight"] == k and line["steps"] == 5
+        sums[k] = (line["config"]["records_checksum"], line["config"]["plans_ok_frac"], line["config"]["mean_traj_len"])
+    assert sums[2] == sums[1] and sums[3] == sums[1]
+    p = _bench("--in-flight", "2")                        # only the switching-times workload can be interleaved like this
+    assert p.returncode != 0
+
+
 def test_bench_never_reports_fewer_gpus_than_requested():
     # a launcher that started a different number of ranks: refuse (exit code, no JSON line)
     env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
