@@ -793,13 +793,14 @@ k_sample(long long first, long long count, int dof, double t_sample, Limits lim,
 // is most of the item (measured: 3.6-3.8 TB/s for 256-sample rows, the same with and without the table build).
 // Here the roles are split between the waves of a block:
 //   * the run tables come from the table pass (k_build_tables), compact: only the runs the stored samples touch;
-//   * the last wave, the loader, draws the coming items and copies the next item's tables into the OTHER of two LDS
-//     buffers; it issues loads but never row stores;
-//   * the other waves, the streaming waves, each own one joint of the current item: boundary slots (pass B), then the
-//     joint's rows (pass A) from the current buffer; they issue stores but never loads, so nothing they execute ever waits
-//     for a store to complete;
-//   * one block barrier per item hands the buffers over (s_barrier does not wait for outstanding stores).
-// Rows are bit-identical to k_sample's: same tables (for_each_run == the cooperative build), same boundary_slot / pass A.
+//   * the last wave, the loader, draws the coming items and brings their tables into one of kTabBuffers LDS buffers with
+//     LDS-direct loads, two items ahead; it issues loads but never row stores;
+//   * the other waves, the streaming waves, each own one joint of the current item and write its rows from the item's
+//     buffer, slots with a run boundary evaluated in place; they issue stores but never loads, so nothing they execute ever
+//     waits for a store to complete;
+//   * buffers change hands through LDS flags (s_ready / s_consumed in sample_tab_body), not block barriers: a fast wave
+//     runs up to kTabBuffers - 1 items ahead of a slow one.
+// Rows are bit-identical to k_sample's: same tables (for_each_run == the cooperative build), same per-sample arithmetic.
 // ---------------------------------------------------------------------------------------
 constexpr int kTabStreamWaves = 7;                              // streaming waves per block; wave kTabStreamWaves is the loader
 constexpr int kTabThreads = (kTabStreamWaves + 1) * 64;          // 8 waves: two per SIMD
@@ -952,6 +953,9 @@ LTP_DEV void sample_tab_body(long long first, long long count, long long base_fi
                              RowSpec rows, unsigned long long* __restrict__ next_item, const unsigned long long* __restrict__ tables,
                              int draw_chunk, unsigned long long* __restrict__ stamps /* diagnostic: 8 per item, nullptr in product calls */)
 {
+    // stamps[8 * item + k] (wall clock, tools/tab_probe.py): loader — 0 its iteration starts (a buffer is free), 6 the next
+    // item's loads are issued, 1 this item's loads are in, 3 it is published, 7 the previous publication, 2 = 1 if the tables
+    // needed the second fetch; streaming wave 0 — 4 it starts the item, 5 its rows are issued.
     // Hand-over of the table buffers without block barriers: buffer s % kTabBuffers holds the block's s-th item once the
     // loader has set s_ready[s % kTabBuffers] = s + 1; streaming wave w has finished s_consumed[w] items. The loader reuses
     // a buffer when every wave is past the item that was in it; a fast wave may thus run kTabBuffers - 1 items ahead of a
