@@ -998,6 +998,7 @@ LTP_DEV void sample_tab_body(long long first, long long count, long long base_fi
     // ALU busy: it runs at raised issue priority. ----
     __builtin_amdgcn_s_setprio(3);
     constexpr int kTabAhead = 2;
+    constexpr int kCappedPairs = 46;           // 12 header words + 8 runs x 10 coefficients
     static_assert(kTabAhead + 2 <= kTabBuffers, "buffers: one being streamed, one being published, kTabAhead in flight");
     const int ngroups = (dof + kTabJointGroup - 1) / kTabJointGroup;
     const long long per = (count + spread - 1) / spread;
@@ -1005,7 +1006,8 @@ LTP_DEV void sample_tab_body(long long first, long long count, long long base_fi
     const unsigned long long off0 = offsets[base_first];
     constexpr unsigned kTileBytes = (unsigned)kTableWords * 64u * 8u;
     // capped rows mostly touch the first runs only (a switch of the jerk profile cuts up to three runs: 8 runs is what
-    // 256 samples of a 7-DoF plan typically need): 64 word pairs (128 words, 11 runs) per joint; whole tables are 106 pairs
+    // 256 samples of a 7-DoF plan need in 99.95 % of the items): kCappedPairs word pairs (92 words, 8 runs) per joint — an
+    // item's joints are neighbours in the table tile, so its seven loads fetch 46 lines of 128 bytes; whole tables are 106 pairs
     const bool whole_tables = rows.max_samples <= 0;
     typedef __attribute__((address_space(3))) void* lds_ptr;
     auto uniform64 = [](unsigned long long x) -> unsigned long long {
@@ -1082,7 +1084,8 @@ LTP_DEV void sample_tab_body(long long first, long long count, long long base_fi
         for (int x = 0; x < kTabJointGroup; ++x) {
             const unsigned long long li = l0 + (unsigned)((real && x < nj) ? x : 0);
             const unsigned base = (unsigned)((li >> 6) - (l0 >> 6)) * kTileBytes + (unsigned)(li & 63ull) * 16u;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(r_tab, (lds_ptr)&B.jt[x], 16, base + (unsigned)lane * 1024u, 0, 0, 0);
+            if (whole_tables || lane < kCappedPairs)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(r_tab, (lds_ptr)&B.jt[x], 16, base + (unsigned)lane * 1024u, 0, 0, 0);
             if (whole_tables) {
                 if (lane < kTableWords / 2 - 64)
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(r_tab, (lds_ptr)(reinterpret_cast<char*>(&B.jt[x]) + 1024), 16,
@@ -1118,8 +1121,8 @@ LTP_DEV void sample_tab_body(long long first, long long count, long long base_fi
                 slen = 0;
             }
             if (slen > 0 && !whole_tables) {
-                // a capped row whose joint has more than 11 runs inside the cap (short trajectories): fetch the rest now
-                const bool long_table = __builtin_amdgcn_ballot_w64(lane < nj && 1 + (kMaxSegments + 2) / 2 + peeked * kRunCoefs > 128) != 0ull;
+                // a capped row whose joint has more than 8 runs inside the cap (short trajectories): fetch the rest now
+                const bool long_table = __builtin_amdgcn_ballot_w64(lane < nj && 1 + (kMaxSegments + 2) / 2 + peeked * kRunCoefs > 2 * kCappedPairs) != 0ull;
                 if (stamps && lane == 0) stamps[8 * item + 2] = (unsigned long long)long_table;
                 if (long_table) {
                     const unsigned long long l0 = (unsigned long long)local * dof + j0;
@@ -1129,6 +1132,8 @@ LTP_DEV void sample_tab_body(long long first, long long count, long long base_fi
                     for (int x = 0; x < kTabJointGroup; ++x) {
                         const unsigned long long li = l0 + (unsigned)(x < nj ? x : 0);
                         const unsigned base = (unsigned)((li >> 6) - (l0 >> 6)) * kTileBytes + (unsigned)(li & 63ull) * 16u;
+                        if (lane >= kCappedPairs)
+                            __builtin_amdgcn_raw_ptr_buffer_load_lds(r_tab, (lds_ptr)&B.jt[x], 16, base + (unsigned)lane * 1024u, 0, 0, 0);
                         if (lane < kTableWords / 2 - 64)
                             __builtin_amdgcn_raw_ptr_buffer_load_lds(r_tab, (lds_ptr)(reinterpret_cast<char*>(&B.jt[x]) + 1024), 16,
                                                                      base + (unsigned)(64 + lane) * 1024u, 0, 0, 0);

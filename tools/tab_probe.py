@@ -37,7 +37,7 @@ for rep in range(2):
     okl = s[:, 7] > 0
     print(f"   loader iteration: wait for a free buffer {np.mean((s[:,0]-s[:,7])[okl]):.2f}, draw + request {np.mean((s[:,6]-s[:,0])[okl]):.2f}, "
           f"wait for the loads {np.mean((s[:,1]-s[:,6])[okl]):.2f}, publish {np.mean((s[:,3]-s[:,1])[okl]):.2f}")
-    print(f"   items whose tables needed the second fetch (more than 11 runs of a joint inside the cap): {int((s[:, 2] > 0).sum())}")
+    print(f"   items whose tables needed the second fetch (more than 8 runs of a joint inside the cap): {int((s[:, 2] > 0).sum())}")
     t = np.sort(s[:, 3])
     print(f"   span {(s[:,5].max()-s[:,1].min())/1e3:.2f} ms; items published per us over the middle half: {len(t)/2/(t[3*len(t)//4]-t[len(t)//4]):.1f}")
 ltp._lib.ltp_debug_set_sample_stamps(ltp._h, None)
