@@ -517,7 +517,7 @@ static int sample_batch_any(ltp_planner* p, long long first, long long count, co
             const long long c = first + count - f < piece ? first + count - f : piece;
             unsigned long long* head = p->d_sample_next + (p->sample_next_slot++ & 63u);
             LTP_HIP_TRY(p, hipMemsetAsync(head, 0, sizeof(unsigned long long), s));
-            ltp::launch_build_tables(s, f, c, p->dof, p->t_sample, dev_limits(p), to_dev(in), to_dev(rec), rows, false, p->d_tables);
+            ltp::launch_build_tables(s, f, c, p->dof, p->t_sample, dev_limits(p), to_dev(in), to_dev(rec), rows, false, offsets, first, p->d_tables);
             ltp::launch_sample_tab(s, f, c, first, p->dof, to_dev(rec), offsets, out, f32, capacity, flags, rows, head,
                                    p->sample_blocks_override > 0 ? p->sample_blocks_override : p->sample_blocks[f32 ? 4 : 3], p->d_tables, p->dbg_stamps);
         }
@@ -568,7 +568,7 @@ int ltp_envelope_batch(ltp_planner* p, long long first, long long count, const l
             const long long c = first + count - f < piece ? first + count - f : piece;
             unsigned long long* head = p->d_sample_next + (p->sample_next_slot++ & 63u);
             LTP_HIP_TRY(p, hipMemsetAsync(head, 0, sizeof(unsigned long long), s));
-            ltp::launch_build_tables(s, f, c, p->dof, p->t_sample, dev_limits(p), to_dev(in), to_dev(rec), ltp::RowSpec{0, 1}, true, p->d_tables);
+            ltp::launch_build_tables(s, f, c, p->dof, p->t_sample, dev_limits(p), to_dev(in), to_dev(rec), ltp::RowSpec{0, 1}, true, nullptr, f, p->d_tables);
             ltp::launch_envelope(s, f, c, first, p->dof, p->t_sample, dev_limits(p), to_dev(in), to_dev(rec), window, n_windows, env, head,
                                  blocks, nullptr, p->d_tables);
         }

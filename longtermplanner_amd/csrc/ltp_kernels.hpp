@@ -86,7 +86,9 @@ void launch_offsets(hipStream_t s, long long n, int dof, double t_sample, Record
 // range is processed in pieces that share one table buffer).
 unsigned long long table_bytes(long long lanes /* plans * dof */);
 void launch_build_tables(hipStream_t s, long long first, long long count, int dof, double t_sample, Limits lim, Queries in, Records rec,
-                         RowSpec rows, bool whole_trajectory /* false: only the runs capped rows touch */, unsigned long long* tables);
+                         RowSpec rows, bool whole_trajectory /* false: only the runs capped rows touch */,
+                         const unsigned long long* offsets /* or nullptr */, long long base_first /* row offsets relative to this plan */,
+                         unsigned long long* tables);
 void launch_sample(hipStream_t s, long long first, long long count, int dof, double t_sample, Limits lim, Queries in,
                    Records rec, const unsigned long long* offsets, void* out, bool f32, unsigned long long capacity,
                    int flags, RowSpec rows, unsigned long long* next_item /* zeroed on the same stream */,

@@ -52,8 +52,10 @@ struct SegScratch {              // scratch of the cooperative table build, dead
 // pass (k_build_tables) writes to global memory for the sampler variants that do not build tables themselves.
 struct JointTable {
     int nseg;                               // word 0 (low half)
-    int reserved;
-    int start[kMaxSegments + 2];            // words 1..11: first sample of run k; start[nseg] = traj_len
+    int len;                                // table pass only: traj_len of the plan (the fused build leaves it unset)
+    int start[kMaxSegments + 2];            // words 1..11: first sample of run k; start[nseg] = traj_len (or the first run
+                                            // that is not stored); table pass only: start[kMaxSegments + 1] = the plan's row
+                                            // offset inside the sampled range, in units of kRowAlign elements
     double c[kMaxSegments][kRunCoefs];      // words 12..211
 };
 constexpr int kTableWords = 1 + (kMaxSegments + 2) / 2 + kMaxSegments * kRunCoefs;
@@ -815,8 +817,6 @@ struct TabItem {
 };
 struct alignas(16) TabBuffer {
     JointTable jt[kTabJointGroup];        // filled by LDS-direct loads (16 bytes per lane) from the table pass's output
-    unsigned long long raw_off[2];        // offsets[plan], offsets[plan + 1]: landing zone of an LDS-direct load
-    int raw_len[4];                       // traj_len[plan] (one dword lands here)
     TabItem hdr;                          // what the streaming waves read, written by the loader when the loads are in
 };
 static_assert(sizeof(JointTable) % 16 == 0, "LDS-direct loads land 16 bytes per lane");
@@ -1003,7 +1003,6 @@ LTP_DEV void sample_tab_body(long long first, long long count, long long base_fi
     const int ngroups = (dof + kTabJointGroup - 1) / kTabJointGroup;
     const long long per = (count + spread - 1) / spread;
     const unsigned long long total = (unsigned long long)per * spread * ngroups;
-    const unsigned long long off0 = offsets[base_first];
     constexpr unsigned kTileBytes = (unsigned)kTableWords * 64u * 8u;
     // capped rows mostly touch the first runs only (a switch of the jerk profile cuts up to three runs: 8 runs is what
     // 256 samples of a 7-DoF plan need in 99.95 % of the items): kCappedPairs word pairs (92 words, 8 runs) per joint — an
@@ -1066,15 +1065,8 @@ LTP_DEV void sample_tab_body(long long first, long long count, long long base_fi
         long long local; int j0, nj;
         decode(item, local, j0, nj);
         const bool real = local >= 0;
-        const long long pl = real ? first + local : first;                       // holes re-read plan `first`: harmless
         const int lane = fresh_lane();
-        // header: traj_len (one dword, lane 0) and offsets[p], offsets[p + 1] (16 bytes, lane 0)
-        const __amdgpu_buffer_rsrc_t r_len = __builtin_amdgcn_make_buffer_rsrc(rec.traj_len + pl, 0, 4, 0x00020000);
-        const __amdgpu_buffer_rsrc_t r_off = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned long long*>(offsets) + pl, 0, 16, 0x00020000);
-        if (lane == 0) {
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(r_len, (lds_ptr)&B.raw_len[0], 4, 0, 0, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(r_off, (lds_ptr)&B.raw_off[0], 16, 0, 0, 0, 0);
-        }
+        // (the plan's length and row offset come with its tables: JointTable::len, start[kMaxSegments + 1]; holes re-read plan `first`)
         // tables: per joint slot one (capped rows) or two loads of 64 word pairs; a descriptor over the two tiles the item's
         // joints can lie in, one 32-bit offset per lane
         const unsigned long long l0 = (unsigned long long)(real ? local : 0) * dof + (real ? j0 : 0);       // wave-uniform
@@ -1106,15 +1098,13 @@ LTP_DEV void sample_tab_body(long long first, long long count, long long base_fi
         unsigned long long rel = 0ull;
         if (local >= 0) {
             // everything the header needs from what the loads brought, in one LDS round trip: lanes 0..6 read the joints' run
-            // counts, lane 7 the trajectory length, lanes 8 and 9 the halves of the plan's offset
+            // counts, lane 7 the trajectory length, lane 8 the plan's row offset (both written by the table pass)
             const unsigned peek_at = lane < kTabJointGroup ? lds_offset(&B.jt[lane].nseg)
-                                     : (lane == kTabJointGroup ? lds_offset(&B.raw_len[0])
-                                                               : lds_offset(reinterpret_cast<const int*>(&B.raw_off[0]) + (lane == kTabJointGroup + 2 ? 1 : 0)));
+                                     : (lane == kTabJointGroup ? lds_offset(&B.jt[0].len) : lds_offset(&B.jt[0].start[kMaxSegments + 1]));
             const int peeked = lds_peek32(peek_at);
             const int len = __builtin_amdgcn_readlane(peeked, kTabJointGroup);
             slen = stored_len(len, rows);
-            rel = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(peeked, kTabJointGroup + 2) << 32 |
-                   (unsigned long long)(unsigned)__builtin_amdgcn_readlane(peeked, kTabJointGroup + 1)) - off0;
+            rel = (unsigned long long)(unsigned)__builtin_amdgcn_readlane(peeked, kTabJointGroup + 1) * (unsigned long long)kRowAlign;
             const unsigned long long stride = ((unsigned long long)slen + (kRowAlign - 1)) / kRowAlign * kRowAlign;
             if (slen > 0 && rel + 4ull * dof * stride > capacity) {
                 if (lane == 0 && j0 == 0) atomicOr(&rec.status[first + local], kStatusOverflow);
@@ -1182,8 +1172,8 @@ LTP_DEV void sample_tab_body(long long first, long long count, long long base_fi
         request(buf[(seq + kTabAhead) % kTabBuffers], ids[kTabAhead]);
         const unsigned long long t_req = stamps ? wall_clock64() : 0ull;
         // item seq is in when at most the loads of the kTabAhead younger items are outstanding
-        if (whole_tables) LTP_WAIT_VMCNT(kTabAhead * (2 + 2 * kTabJointGroup));
-        else LTP_WAIT_VMCNT(kTabAhead * (2 + kTabJointGroup));
+        if (whole_tables) LTP_WAIT_VMCNT(kTabAhead * 2 * kTabJointGroup);
+        else LTP_WAIT_VMCNT(kTabAhead * kTabJointGroup);
         TabBuffer& B = buf[seq % kTabBuffers];
         const unsigned long long item = ids[0];
         if (stamps && fresh_lane() == 0 && item < total) stamps[8 * item + 1] = wall_clock64();
@@ -1485,6 +1475,7 @@ k_end_limit(long long first, long long count, int dof, double t_sample, Limits l
 __global__ void __launch_bounds__(256)
 k_build_tables(long long first, long long count, int dof, double t_sample, Limits lim, Queries in, Records rec,
                int needed_end /* runs that start at or after this sample are not stored (capped rows) */,
+               const unsigned long long* __restrict__ offsets /* nullptr: no row offsets wanted */, long long base_first,
                unsigned long long* __restrict__ tables)
 {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1520,7 +1511,10 @@ k_build_tables(long long first, long long count, int dof, double t_sample, Limit
         return false;                                          // the walk still goes to the last sample: end-limit check
     });
     reinterpret_cast<int*>(word(1 + (run >> 1)))[run & 1] = last_b;
-    *word(0) = (unsigned long long)(unsigned)run;
+    *word(0) = (unsigned long long)(unsigned)run | ((unsigned long long)(unsigned)len << 32);
+    // where the plan's rows start inside the range the sampler is called for: what k_sample_tab's loader would otherwise
+    // have to load per item (plan sizes are multiples of kRowAlign elements)
+    if (offsets) reinterpret_cast<unsigned*>(word(1 + (kMaxSegments + 1) / 2))[(kMaxSegments + 1) & 1] = (unsigned)((offsets[p] - offsets[base_first]) / kRowAlign);
     if (q < lim.q_min[j] || q > lim.q_max[j]) atomicOr(&rec.status[p], kStatusEndLimit);   // cc:59-61: q is sample len-1
 }
 
@@ -1793,7 +1787,7 @@ unsigned long long table_bytes(long long lanes)
 }
 
 void launch_build_tables(hipStream_t s, long long first, long long count, int dof, double t_sample, Limits lim, Queries in, Records rec,
-                         RowSpec rows, bool whole_trajectory, unsigned long long* tables)
+                         RowSpec rows, bool whole_trajectory, const unsigned long long* offsets, long long base_first, unsigned long long* tables)
 {
     if (count <= 0 || dof <= 0) return;
     const long long total = count * dof;
@@ -1802,7 +1796,7 @@ void launch_build_tables(hipStream_t s, long long first, long long count, int do
     if (!whole_trajectory && rows.max_samples > 0) needed = (long long)rows.max_samples * (rows.stride > 1 ? rows.stride : 1);
     if (needed > 0x7fffffffll) needed = 0x7fffffffll;
     hipLaunchKernelGGL(k_build_tables, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, first, count, dof, t_sample, lim, in, rec,
-                       (int)needed, tables);
+                       (int)needed, offsets, base_first, tables);
 }
 
 int sample_tab_resident_blocks(int device, bool f32)
