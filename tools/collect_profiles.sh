@@ -1,0 +1,29 @@
+#!/bin/bash
+# After `gpurun -- bash tools/refresh_profiles.sh TAG` has merged its output into gpurun_out/: condense it into profiles/.
+TAG=${1:-r02}
+cd "$(dirname "$0")/.."
+python profiles/summarize.py $TAG gpurun_out/prof_stats gpurun_out/prof_write gpurun_out/prof_fetch || exit 1
+cp gpurun_out/bench_default.json profiles/${TAG}_bench.json
+cp gpurun_out/bench_variants.jsonl profiles/${TAG}_bench_variants.jsonl
+cp gpurun_out/bench_dry.jsonl profiles/${TAG}_dry_sampler_ceilings.jsonl
+cp gpurun_out/bench_2ranks_gloo.json profiles/${TAG}_bench_2ranks_one_gpu_gloo.json
+cp gpurun_out/bench_4ranks_gloo_global.json profiles/${TAG}_bench_4ranks_one_gpu_gloo_global_batch.json
+cp "$(find gpurun_out/prof_tab_stats -name '*_kernel_stats.csv' | xargs ls -t | head -1)" profiles/${TAG}_table_pass_first256_kernel_stats.csv
+python - <<PY
+import json, csv
+b = json.loads(open("profiles/${TAG}_bench.json").read())
+print("headline", b["value"], b["ms_per_step"], b["roofline"]["achieved"], b["roofline"]["frac"], b["roofline"]["avg_launch_ms"])
+for s in b.get("secondary", []):
+    print("  ", s["name"][:72], s.get("value"), s.get("ms_per_step"), (s.get("roofline") or {}).get("achieved"), s.get("error"))
+for f in ["profiles/${TAG}_bench_variants.jsonl", "profiles/${TAG}_dry_sampler_ceilings.jsonl", "profiles/${TAG}_bench_2ranks_one_gpu_gloo.json",
+          "profiles/${TAG}_bench_4ranks_one_gpu_gloo_global_batch.json"]:
+    print(f)
+    for ln in open(f):
+        ln = ln.strip()
+        if not ln.startswith("{"):
+            continue
+        d = json.loads(ln); r = d.get("roofline") or {}; c = d["config"]
+        print("  %-80s | %9.3f M | %8.3f ms | %s | tp=%s" % (c["workload"][48:128], d["value"] / 1e6, d["ms_per_step"], r.get("achieved"), c.get("table_pass")))
+for r in list(csv.DictReader(open("profiles/${TAG}_table_pass_first256_kernel_stats.csv")))[:3]:
+    print("  ", r["Name"][:30], r["Calls"], round(float(r["AverageNs"]) / 1e3, 1))
+PY
