@@ -1514,7 +1514,11 @@ k_build_tables(long long first, long long count, int dof, double t_sample, Limit
     *word(0) = (unsigned long long)(unsigned)run | ((unsigned long long)(unsigned)len << 32);
     // where the plan's rows start inside the range the sampler is called for: what k_sample_tab's loader would otherwise
     // have to load per item (plan sizes are multiples of kRowAlign elements)
-    if (offsets) reinterpret_cast<unsigned*>(word(1 + (kMaxSegments + 1) / 2))[(kMaxSegments + 1) & 1] = (unsigned)((offsets[p] - offsets[base_first]) / kRowAlign);
+    // (saturated: an offset that does not fit 32 bits is beyond any tile, and the sampler then flags the plan as not fitting)
+    if (offsets) {
+        const unsigned long long rel = (offsets[p] - offsets[base_first]) / kRowAlign;
+        reinterpret_cast<unsigned*>(word(1 + (kMaxSegments + 1) / 2))[(kMaxSegments + 1) & 1] = rel > 0xffffffffull ? 0xffffffffu : (unsigned)rel;
+    }
     if (q < lim.q_min[j] || q > lim.q_max[j]) atomicOr(&rec.status[p], kStatusEndLimit);   // cc:59-61: q is sample len-1
 }
 
