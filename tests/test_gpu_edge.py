@@ -695,7 +695,8 @@ def test_table_pass_gives_the_bits_of_the_fused_build(amd, limits, n):
     ltp = amd.LongTermPlanner(D, 0.001, device=0, **lim)
     qm = ltp.generateQueries(n, seed=77)
     qm[1][11, 0] = 99.0                                         # a rejected plan in the middle
-    for cap, stride in ((0, 1), (200, 1), (0, 3), (64, 2)):
+    # (1200, 1): most plans have all their runs inside the cap, i.e. more than the 8 runs the capped loader fetches up front
+    for cap, stride in ((0, 1), (200, 1), (0, 3), (64, 2), (1200, 1)):
         ltp.setMaxSamples(cap); ltp.setSampleStride(stride)
         res = {}
         for mode in ("fused", "tables", "tables_small_workspace"):
