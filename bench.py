@@ -432,6 +432,9 @@ def main():
     if args.gpus < 1:
         print("bench.py: --gpus must be >= 1", file=sys.stderr)
         return 2
+    if args.in_flight < 1 or (args.in_flight > 1 and (not args.switch_only or args.receding)):
+        print("bench.py: --in-flight K (K >= 1) interleaves whole switching-times batches: it needs --switch-only", file=sys.stderr)
+        return 2
     env_world = os.environ.get("WORLD_SIZE")
     if env_world is None and args.gpus > 1:
         return spawn_ranks(args)            # no torch, no GPU in this process

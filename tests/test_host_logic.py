@@ -109,3 +109,11 @@ def test_bench_spawns_ranks_itself_and_propagates_their_failure():
     # nccl with every rank pinned to one device is refused up front
     p = _run_bench(["--gpus", "2", "--device", "0", "--steps", "1"])
     assert p.returncode != 0 and "gloo" in p.stderr
+
+
+def test_bench_in_flight_needs_the_switching_times_workload():
+    # batches in flight interleave whole switching-times calls on several handles; with rows the tile has one user
+    p = _run_bench(["--in-flight", "2", "--steps", "1"])
+    assert p.returncode != 0 and "{" not in p.stdout and "--switch-only" in p.stderr
+    p = _run_bench(["--in-flight", "0", "--switch-only"])
+    assert p.returncode != 0 and "{" not in p.stdout
