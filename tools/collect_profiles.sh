@@ -9,6 +9,29 @@ cp gpurun_out/bench_dry.jsonl profiles/${TAG}_dry_sampler_ceilings.jsonl
 cp gpurun_out/bench_2ranks_gloo.json profiles/${TAG}_bench_2ranks_one_gpu_gloo.json
 cp gpurun_out/bench_4ranks_gloo_global.json profiles/${TAG}_bench_4ranks_one_gpu_gloo_global_batch.json
 cp "$(find gpurun_out/prof_tab_stats -name '*_kernel_stats.csv' | xargs ls -t | head -1)" profiles/${TAG}_table_pass_first256_kernel_stats.csv
+cp "$(find gpurun_out/prof_switch_100000 -name '*_kernel_stats.csv' | xargs ls -t | head -1)" profiles/${TAG}_switch_only_100k_kernel_stats.csv
+cp "$(find gpurun_out/prof_switch_1000000 -name '*_kernel_stats.csv' | xargs ls -t | head -1)" profiles/${TAG}_switch_only_1M_kernel_stats.csv
+python - <<PY
+import csv, glob, collections, json
+out = {"command": "rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary <workload>",
+       "note": "per-launch means over all launches of the run (warm-up included); SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles (MI355X_MICROARCH.md)", "workloads": {}}
+for d, name in (("prof_sq_first256", "--max-samples 256 (1 M plans, first 256 samples, table pass)"), ("prof_sq_switch100k", "--switch-only --batch 100000 (config 2)")):
+    f = max(glob.glob(f"gpurun_out/{d}/**/*_counter_collection.csv", recursive=True), key=lambda x: __import__("os").path.getmtime(x))
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(f)):
+        agg[r["Kernel_Name"].split("(")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    w = {}
+    for k, c in agg.items():
+        if "ltp::" not in k:
+            continue
+        e = {n: round(sum(v) / len(v), 1) for n, v in c.items()}
+        e["launches"] = len(next(iter(c.values())))
+        if e.get("SQ_WAVE_CYCLES"):
+            e["wait_any_frac"] = round(e.get("SQ_WAIT_ANY", 0) / e["SQ_WAVE_CYCLES"], 3)
+        w[k] = e
+    out["workloads"][name] = w
+json.dump(out, open("profiles/${TAG}_sq_counters.json", "w"), indent=1)
+PY
 python - <<PY
 import json, csv
 b = json.loads(open("profiles/${TAG}_bench.json").read())

@@ -5,13 +5,14 @@ set -o pipefail
 TAG=${1:-r02}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$R/gpurun_out
-mkdir -p $O && rm -rf $O/prof_stats $O/prof_write $O/prof_fetch $O/prof_tab_stats
+mkdir -p $O && rm -rf $O/prof_stats $O/prof_write $O/prof_fetch $O/prof_tab_stats $O/prof_switch_100000 $O/prof_switch_1000000 $O/prof_sq_first256 $O/prof_sq_switch100k
 cd $R
 timeout -k 10 400 python bench.py > $O/bench_default.json 2> $O/bench_default.err || exit 1
 echo "default done"; cut -c1-300 $O/bench_default.json
 : > $O/bench_variants.jsonl
 for a in "--limits ref" "--limits ref30 --batch 200000" "--switch-only --batch 100000" "--switch-only --batch 100000 --end-limit" "--switch-only" \
          "--switch-only --end-limit" "--switch-only --limits ref" \
+         "--switch-only --batch 100000 --in-flight 2 --steps 40 --warmup 4" "--switch-only --in-flight 2 --steps 20 --warmup 4" \
          "--max-samples 256" "--max-samples 256 --table-pass off" "--max-samples 64" "--sample-stride 4" "--f32" "--f32 --limits ref" \
          "--f32 --max-samples 256" "--f32 --max-samples 256 --table-pass off" "--f32 --max-samples 1024" "--envelope 64:32" \
          "--envelope 64:32 --table-pass off" "--envelope 64:32 --limits ref" "--receding 10:100" "--receding 10:100 --end-limit" \
@@ -38,5 +39,13 @@ timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv 
 echo "FETCH_SIZE pass done"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_tab_stats -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary --max-samples 256 > $O/prof_tab_stats.log 2>&1 || exit 1
 echo "table-pass stats pass done"
+for b in 100000 1000000; do
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_switch_$b -- python3 $R/bench.py --steps 10 --warmup 1 --no-cpu-baseline --no-secondary --switch-only --batch $b > $O/prof_switch_$b.log 2>&1 || exit 1
+done
+echo "switching-times stats passes done"
+SQ="SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU"
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d $O/prof_sq_first256 -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary --max-samples 256 > $O/prof_sq_first256.log 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d $O/prof_sq_switch100k -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary --switch-only --batch 100000 > $O/prof_sq_switch100k.log 2>&1 || exit 1
+echo "SQ counter passes done"
 # keep only the small CSVs
-find $O/prof_stats $O/prof_write $O/prof_fetch $O/prof_tab_stats -type f ! -name "*_kernel_stats.csv" ! -name "*_counter_collection.csv" -delete
+find $O/prof_stats $O/prof_write $O/prof_fetch $O/prof_tab_stats $O/prof_switch_100000 $O/prof_switch_1000000 $O/prof_sq_first256 $O/prof_sq_switch100k -type f ! -name "*_kernel_stats.csv" ! -name "*_counter_collection.csv" -delete
