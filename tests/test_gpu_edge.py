@@ -710,7 +710,13 @@ def test_table_pass_gives_the_bits_of_the_fused_build(amd, limits, n):
             # a sub-range into its own tile: offsets are relative to the first plan of the call
             sub = torch.full((int((b.offsets[n - 3] - b.offsets[40]).item()) + 8,), 3.0, dtype=torch.float64, device="cuda")
             ltp.sampleBatch(b, 40, n - 43, sub, tables=(mode != "fused"))
+            # block interleave factors that are not a power of two / larger than the range / 1: other item -> plan maps
+            t48 = torch.full((total,), 3.0, dtype=torch.float64, device="cuda")
+            ltp.sampleBatch(b, 0, n, t48, tables=(mode != "fused"), spread=48)
+            t1 = torch.full((total,), 3.0, dtype=torch.float64, device="cuda")
+            ltp.sampleBatch(b, 0, n, t1, tables=(mode != "fused"), spread=1 if mode == "tables" else 5000)
             torch.cuda.synchronize()
+            assert torch.equal(t48, t64) and torch.equal(t1, t64), (cap, stride, mode, "spread")
             res[mode] = (t64, t32, sub, b.status.clone(), b.traj_len.clone())
         for mode in ("tables", "tables_small_workspace"):
             for got, want in zip(res[mode], res["fused"]):
