@@ -775,3 +775,34 @@ def test_fused_small_batch_path_has_the_bits_of_the_batched_path(amd, limits, ts
         a = slow.planBatchHost(qg[:1], q0[:1], v0[:1], a0[:1], sample=True)
         b = slow.planBatchHost(qg[:40], q0[:40], v0[:40], a0[:40], sample=True)
         assert a["packed"].size * 8 > (8 << 20) and a["packed"].tobytes() == b["packed"][: int(b["offsets"][1])].tobytes()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("limits,n,cap", [("panda", 70001, 64), ("ref30", 66000, 16)])
+def test_table_pass_matches_the_fused_sampler_on_a_large_range(amd, limits, n, cap):
+    """The short-row sampler on a range of tens of thousands of plans (every resident block draws many items, the table
+    workspace is reused by calls right behind each other and from a second stream of the same handle): rows and statuses must
+    equal the fused sampler's."""
+    import torch
+    D, lim = amd.limit_set(limits)
+    ltp = amd.LongTermPlanner(D, 0.001, device=0, **lim)
+    qm = ltp.generateQueries(n, seed=5)
+    qm[1][4242, 0] = 99.0                                        # a rejected plan
+    ltp.setMaxSamples(cap)
+    res = {}
+    for mode in ("fused", "tables"):
+        b = ltp.planSwitchTimesBatch(*qm)
+        total = int(b.offsets[-1].item())
+        t64 = torch.full((total,), 3.0, dtype=torch.float64, device="cuda")
+        t32 = torch.full((total,), 3.0, dtype=torch.float32, device="cuda")
+        ltp.sampleBatch(b, 0, n, t64, tables=(mode != "fused"))
+        ltp.sampleBatch(b, 0, n, t32, tables=(mode != "fused"))          # right behind: the table workspace is reused
+        s2 = torch.cuda.Stream()
+        sub = torch.full((int((b.offsets[n - 5] - b.offsets[100]).item()),), 3.0, dtype=torch.float64, device="cuda")
+        with torch.cuda.stream(s2):                                       # another stream of the same handle: serialised by the library
+            s2.wait_stream(torch.cuda.current_stream())
+            ltp.sampleBatch(b, 100, n - 105, sub, tables=(mode != "fused"))
+        torch.cuda.synchronize()
+        res[mode] = (t64, t32, sub, b.status.clone())
+    for got, want in zip(res["tables"], res["fused"]):
+        assert torch.equal(got, want)
