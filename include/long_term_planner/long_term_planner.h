@@ -13,8 +13,8 @@
 //   * the reference's std::cerr diagnostic at cc:343 is not printed;
 //   * corners the reference leaves undefined (out-of-range writes of the sampler,
 //     non-finite switching times) are defined: dropped writes / `false`;
-//   * NEW: planTrajectoryBatch(), the batched overload this library exists for, and planTrajectoryBatchSharded(),
-//     the same over several devices from one process (contiguous query ranges, no collective).
+//   * NEW: planTrajectoryBatch(), the batched overload this library exists for; planTrajectoryBatchSharded() and
+//     planEnvelopeBatchSharded(), the same over several devices from one process (contiguous query ranges, no collective).
 // Threading: as with the reference, concurrent planTrajectory / planTrajectoryBatch calls on one object are allowed as
 // long as no setter runs at the same time (the lazily created device handle is guarded by a mutex).
 #ifndef long_term_planner_H
@@ -287,6 +287,37 @@ class LongTermPlanner {
                     b.length.data(), b.status.data()};
     const int rc = ltp_plan_envelope_host(h, n, q_goal, q_0, v_0, a_0, window, n_windows, &rec, env.empty() ? &dummy_d : env.data());
     if (rc != LTP_OK) raise(h, rc, "ltp_plan_envelope_host");
+    long long ok = 0;
+    for (long long p = 0; p < n; ++p) ok += b.status[p] == 0;
+    return ok;
+  }
+
+  /**
+   * @brief NEW: planEnvelopeBatch over several devices from ONE process — shard g, the contiguous query
+   * range ltp_shard_range(n, g, devices.size()), is planned and reduced on HIP device devices[g] by its own handle and host
+   * thread (ltp_plan_envelope_multi_host); `env` and `out` are bit-identical to planEnvelopeBatch over all n queries. This
+   * is the sharded call that makes sense at scale: envelopes are 16 bytes per window, the dense rows never leave a device.
+   * @return number of queries for which planTrajectory would have returned true.
+   */
+  long long planEnvelopeBatchSharded(long long n, const double* q_goal, const double* q_0, const double* v_0, const double* a_0,
+                                     int window, int n_windows, std::vector<double>& env, const std::vector<int>& devices,
+                                     BatchTrajectory* out = nullptr) {
+    if (devices.empty()) throw std::runtime_error("long_term_planner (MI355X): planEnvelopeBatchSharded needs at least one device");
+    std::vector<ltp_planner*> hs(devices.size());
+    {
+      std::lock_guard<std::mutex> g(mu_);
+      if (shards_.size() < devices.size()) shards_.resize(devices.size());
+      for (std::size_t i = 0; i < devices.size(); ++i) hs[i] = ready(shards_[i], devices[i]);
+    }
+    BatchTrajectory local;
+    BatchTrajectory& b = out ? *out : local;
+    double dummy_d = 0; signed char dummy_c = 0;
+    const ltp_records rec = prepare(n, b, dummy_d, dummy_c);
+    const std::size_t nd = static_cast<std::size_t>(n) * dof_;
+    env.assign(nd * static_cast<std::size_t>(n_windows > 0 ? n_windows : 0) * 2, 0.0);
+    const int rc = ltp_plan_envelope_multi_host(hs.data(), static_cast<int>(hs.size()), n, q_goal, q_0, v_0, a_0, window, n_windows, &rec,
+                                                env.empty() ? &dummy_d : env.data());
+    if (rc != LTP_OK) raise(hs[0], rc, "ltp_plan_envelope_multi_host");
     long long ok = 0;
     for (long long p = 0; p < n; ++p) ok += b.status[p] == 0;
     return ok;

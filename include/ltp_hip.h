@@ -98,6 +98,9 @@ int ltp_set_dof(ltp_planner* p, int dof);
 int ltp_get_dof(const ltp_planner* p);
 double ltp_get_sample_time(const ltp_planner* p);
 const char* ltp_last_error(const ltp_planner* p);
+/* name of the kernel that wrote the rows / envelopes of the latest ltp_sample_batch* / ltp_envelope_batch call of this
+ * handle ("k_sample", "k_sample_tab_f64_nt", ...: the fused sampler or the table-pass sampler, see ltp_set_table_pass) */
+const char* ltp_last_sampler_kernel(const ltp_planner* p);
 /* rows of the packed trajectory layout are padded to this many elements (a multiple of 32) */
 int ltp_row_stride(int stored_samples);
 /* SURVEY.md §8(f).2 "first N samples only": store min(traj_len, max_samples) samples per row (0 = all of them, which
@@ -135,9 +138,17 @@ int ltp_set_table_workspace(ltp_planner* p, unsigned long long bytes);
 
 /* Allocates the handle's device workspace for batches of up to n queries now. The batched calls below grow it on
  * demand (hipMalloc / hipFree), which is not allowed while `stream` is being captured into a hipGraph: call this once
- * before hipStreamBeginCapture, then ltp_plan_switch_times_batch / ltp_sample_batch / ltp_envelope_batch /
- * ltp_replan_states_batch only enqueue memset and kernel nodes and the graph can be replayed on new inputs in place. */
+ * before hipStreamBeginCapture — and ltp_reserve_tables if the captured calls take the table pass — then
+ * ltp_plan_switch_times_batch / ltp_sample_batch / ltp_envelope_batch / ltp_replan_states_batch only enqueue memset and
+ * kernel nodes and the graph can be replayed on new inputs in place. Growing a workspace later (a larger n, a larger
+ * ltp_reserve_tables) frees the old buffers: graphs instantiated before that must not be replayed any more. */
 int ltp_reserve_batch(ltp_planner* p, long long n);
+/* Allocates the table-pass workspace for ranges of up to n plans (at most ltp_set_table_workspace bytes; longer ranges
+ * are processed in pieces). Needed before capturing a call that takes the table pass — ltp_envelope_batch by default,
+ * ltp_sample_batch* when max_samples is at most 256 (float64) / 1024 (float32) or flag bit 2 is set: while a stream is
+ * being captured the library neither allocates nor frees; it cuts the range into pieces that fit the workspace it has
+ * and returns LTP_ERR_INVALID_ARGUMENT if it has none. */
+int ltp_reserve_tables(ltp_planner* p, long long n);
 
 /* planTrajectory stages 1-3 for n queries (cc:14-55): checkInputs, optSwitchTimes per joint,
  * slowest-joint reduction, timeScaling per other joint, fallback copy; then traj_len (cc:716-719).
@@ -234,6 +245,34 @@ void ltp_shard_range(long long n, int rank, int world, long long* first, long lo
 int ltp_plan_batch_multi(ltp_planner* const* planners, int k, long long n, const double* q_goal, const double* q_0,
                          const double* v_0, const double* a_0, const ltp_records* host_records, unsigned long long* offsets,
                          double** packed);
+
+/* The same sharding with DEVICE-RESIDENT shards: nothing passes through the host. Shard g = queries ltp_shard_range(n, g, k)
+ * of one batch of n; its queries, records and offsets live on planners[g]'s device as SHARD-LOCAL arrays (element 0 is the
+ * shard's first query). One host thread per shard enqueues the work on shards[g].stream; the calls return when everything
+ * is enqueued (asynchronous like the _batch calls; ltp_synchronize_multi waits for all shards). Results are bit-identical
+ * to the single-handle calls over the whole batch, shard by shard. Planners as for ltp_plan_batch_multi (distinct
+ * handles, identically configured, devices may repeat). */
+typedef struct {
+    ltp_queries in;                /* device pointers, shard-local */
+    ltp_records out;               /* device pointers, shard-local, all non-NULL */
+    unsigned long long* offsets;   /* device [count + 1] or NULL */
+    void* stream;                  /* hipStream_t on planners[g]'s device, NULL = its default stream */
+} ltp_shard;
+/* ltp_plan_switch_times_batch per shard; end_limit != 0 adds ltp_end_limit_batch (status == 0 is then planTrajectory's bool) */
+int ltp_plan_switch_times_multi(ltp_planner* const* planners, int k, long long n, const ltp_shard* shards, int end_limit);
+/* ltp_envelope_batch per shard of a batch planned by ltp_plan_switch_times_multi; env[g]: device, count_g*dof*n_windows*2 doubles */
+int ltp_envelope_multi(ltp_planner* const* planners, int k, long long n, const ltp_shard* shards, int window, int n_windows,
+                       double* const* env);
+/* ltp_state_at_batch per shard (receding horizon without rows). sample_index: NULL or per-shard device int arrays (entries may
+ * be NULL); q_0[g], v_0[g], a_0[g]: device arrays laid out like the shard's queries (same strides) */
+int ltp_state_at_multi(ltp_planner* const* planners, int k, long long n, const ltp_shard* shards, const int* const* sample_index,
+                       int uniform_index, double* const* q_0, double* const* v_0, double* const* a_0);
+int ltp_synchronize_multi(ltp_planner* const* planners, int k, const ltp_shard* shards);
+/* ltp_plan_envelope_host over k planners: host arrays in, host envelopes and records out at their global query index
+ * (what LongTermPlanner::planEnvelopeBatchSharded calls) */
+int ltp_plan_envelope_multi_host(ltp_planner* const* planners, int k, long long n, const double* q_goal, const double* q_0,
+                                 const double* v_0, const double* a_0, int window, int n_windows, const ltp_records* host_records,
+                                 double* env);
 
 /* planTrajectory stages 1-3 + the on-device envelope consumer (ltp_envelope_batch) for host arrays: a host caller
  * cannot take in the dense trajectories of a large batch (32*dof*traj_len bytes per plan over PCIe), but it can take

@@ -46,6 +46,11 @@ class Records(C.Structure):
                 ("status", C.c_void_p)]
 
 
+class Shard(C.Structure):
+    """ltp_shard: one device-resident shard of a *_multi call (include/ltp_hip.h)."""
+    _fields_ = [("in_", Queries), ("out", Records), ("offsets", C.c_void_p), ("stream", C.c_void_p)]
+
+
 def build(force=False):
     """Compile libltp_hip.so for gfx950 (hipcc cross-compiles without a GPU)."""
     srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".hpp", "Makefile"))]
@@ -76,6 +81,15 @@ _SIGNATURES = {
     "ltp_debug_set_sample_blocks": (C.c_int, [C.c_void_p, C.c_int]),
     "ltp_debug_get_sample_blocks": (C.c_int, [C.c_void_p, C.c_int]),
     "ltp_reserve_batch": (C.c_int, [C.c_void_p, C.c_longlong]),
+    "ltp_reserve_tables": (C.c_int, [C.c_void_p, C.c_longlong]),
+    "ltp_last_sampler_kernel": (C.c_char_p, [C.c_void_p]),
+    "ltp_plan_switch_times_multi": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_longlong, C.POINTER(Shard), C.c_int]),
+    "ltp_envelope_multi": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_longlong, C.POINTER(Shard), C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "ltp_state_at_multi": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_longlong, C.POINTER(Shard), C.POINTER(C.c_void_p), C.c_int,
+                                     C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
+    "ltp_synchronize_multi": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.POINTER(Shard)]),
+    "ltp_plan_envelope_multi_host": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_longlong, _dp, _dp, _dp, _dp, C.c_int, C.c_int,
+                                               C.POINTER(Records), _dp]),
     "ltp_plan_envelope_host": (C.c_int, [C.c_void_p, C.c_longlong, _dp, _dp, _dp, _dp, C.c_int, C.c_int, C.POINTER(Records), _dp]),
     "ltp_state_at_batch": (C.c_int, [C.c_void_p, C.c_longlong, C.c_longlong, C.POINTER(Queries), C.POINTER(Records), C.c_void_p, C.c_int,
                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_longlong, C.c_void_p]),

@@ -4,6 +4,7 @@
 #include "../../include/ltp_hip.h"
 #include "ltp_kernels.hpp"
 
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -39,6 +40,9 @@ struct ltp_planner {
     unsigned long long tables_cap = 4ull << 30;   // upper bound for d_tables (ltp_create: 1/16 of the device's memory if that
                                                   // is more — 18 GiB of 288); longer ranges are processed in pieces
     double* d_small = nullptr;             // 16 doubles for the one-lane entry points
+    bool small_dirty = false;              // a fused small-batch call failed: k_plan_small's arrival word may be non-zero
+    const char* last_kernel = "";          // row / envelope kernel of the latest ltp_sample_batch* / ltp_envelope_batch
+    int semantics = 0;                     // LTP_SEMANTICS_CPP (the reference's C++, default) or LTP_SEMANTICS_MATLAB
     unsigned long long* dbg_stamps = nullptr; // diagnostic: per-block start/end stamps of k_sample (caller-owned)
     // persistent buffers of the small synchronous host-pointer calls (no hipMalloc per call)
     std::mutex host_mu;
@@ -237,14 +241,24 @@ bool want_table_pass(const ltp_planner* p, unsigned long long row_bytes, bool f3
     return row_bytes > 0 && row_bytes <= (f32 ? 16384ull : 8192ull);
 }
 
-// plans per piece so that the tables of a piece fit the workspace; grows the workspace (up to tables_cap) if needed
-int ensure_tables(ltp_planner* p, long long count, long long* plans_per_piece)
+// plans per piece so that the tables of a piece fit the workspace; grows the workspace (up to tables_cap) if needed.
+// While a stream is being captured into a hipGraph nothing may be allocated or freed (and a graph that was already
+// instantiated keeps the old pointer): then the range is cut into pieces that fit the workspace as it is
+// (ltp_reserve_tables sizes it ahead of time), and a handle without any table workspace is an error.
+int ensure_tables(ltp_planner* p, long long count, bool capturing, long long* plans_per_piece)
 {
     const long long dof = p->dof;
     const unsigned long long per_tile = ltp::table_bytes(64);
     unsigned long long want = ltp::table_bytes(count * dof);
     const unsigned long long cap = p->tables_cap < per_tile * (unsigned long long)dof ? per_tile * (unsigned long long)dof : p->tables_cap;
     if (want > cap) want = cap / per_tile * per_tile;
+    if (want > p->tables_bytes && capturing) {
+        if (p->tables_bytes < per_tile * (unsigned long long)dof)
+            return fail(p, LTP_ERR_INVALID_ARGUMENT,
+                        "the table pass needs its workspace, which cannot be allocated while the stream is being captured: "
+                        "call ltp_reserve_tables before hipStreamBeginCapture");
+        want = p->tables_bytes;   // more pieces, same buffer
+    }
     if (want > p->tables_bytes) {
         if (p->d_tables) LTP_HIP_TRY(p, hipFree(p->d_tables));
         p->d_tables = nullptr;
@@ -422,6 +436,7 @@ int ltp_stored_samples(const ltp_planner* p, int traj_len)
 int ltp_get_dof(const ltp_planner* p) { return p ? p->dof : -1; }
 double ltp_get_sample_time(const ltp_planner* p) { return p ? p->t_sample : 0.0; }
 const char* ltp_last_error(const ltp_planner* p) { return p ? p->err.c_str() : "null planner"; }
+const char* ltp_last_sampler_kernel(const ltp_planner* p) { return p ? p->last_kernel : ""; }
 int ltp_row_stride(int traj_len)
 {
     if (traj_len <= 0) return 0;
@@ -435,6 +450,18 @@ int ltp_reserve_batch(ltp_planner* p, long long n)
     int rc = check_config(p);
     if (rc != LTP_OK) return rc;
     return reserve(p, n);
+}
+
+int ltp_reserve_tables(ltp_planner* p, long long n)
+{
+    if (!p || n < 0) return fail(p, LTP_ERR_INVALID_ARGUMENT, "n < 0");
+    std::lock_guard<std::mutex> g(p->mu);
+    int rc = check_config(p);
+    if (rc != LTP_OK) return rc;
+    if (n == 0 || p->dof == 0) return LTP_OK;
+    LTP_HIP_TRY(p, hipSetDevice(p->device));
+    long long piece = 0;
+    return ensure_tables(p, n, false, &piece);
 }
 
 int ltp_plan_switch_times_batch(ltp_planner* p, long long n, const ltp_queries* in, const ltp_records* out,
@@ -512,7 +539,7 @@ static int sample_batch_any(ltp_planner* p, long long first, long long count, co
         bool capturing = false;
         if ((rc = workspace_acquire(p, s, capturing)) != LTP_OK) return rc;
         long long piece = 0;
-        if ((rc = ensure_tables(p, count, &piece)) != LTP_OK) return rc;
+        if ((rc = ensure_tables(p, count, capturing, &piece)) != LTP_OK) return rc;
         for (long long f = first; f < first + count; f += piece) {
             const long long c = first + count - f < piece ? first + count - f : piece;
             unsigned long long* head = p->d_sample_next + (p->sample_next_slot++ & 63u);
@@ -522,11 +549,13 @@ static int sample_batch_any(ltp_planner* p, long long first, long long count, co
                                    p->sample_blocks_override > 0 ? p->sample_blocks_override : p->sample_blocks[f32 ? 4 : 3], p->d_tables, p->dbg_stamps);
         }
         LTP_HIP_TRY(p, hipGetLastError());
+        p->last_kernel = f32 ? ((flags & 1) ? "k_sample_tab_f32_nt" : "k_sample_tab_f32") : ((flags & 1) ? "k_sample_tab_f64_nt" : "k_sample_tab_f64");
         return workspace_release(p, s, capturing);
     }
     // each launch gets its own work-queue head from a ring of 64, zeroed in stream order just before the kernel
     unsigned long long* head = p->d_sample_next + (p->sample_next_slot++ & 63u);
     LTP_HIP_TRY(p, hipMemsetAsync(head, 0, sizeof(unsigned long long), s));
+    p->last_kernel = "k_sample";
     ltp::launch_sample(s, first, count, p->dof, p->t_sample, dev_limits(p), to_dev(in), to_dev(rec), offsets,
                        out, f32, capacity, flags, rows, head, blocks, p->dbg_stamps);
     LTP_HIP_TRY(p, hipGetLastError());
@@ -563,7 +592,7 @@ int ltp_envelope_batch(ltp_planner* p, long long first, long long count, const l
         bool capturing = false;
         if ((rc = workspace_acquire(p, s, capturing)) != LTP_OK) return rc;
         long long piece = 0;
-        if ((rc = ensure_tables(p, count, &piece)) != LTP_OK) return rc;
+        if ((rc = ensure_tables(p, count, capturing, &piece)) != LTP_OK) return rc;
         for (long long f = first; f < first + count; f += piece) {
             const long long c = first + count - f < piece ? first + count - f : piece;
             unsigned long long* head = p->d_sample_next + (p->sample_next_slot++ & 63u);
@@ -573,10 +602,12 @@ int ltp_envelope_batch(ltp_planner* p, long long first, long long count, const l
                                  blocks, nullptr, p->d_tables);
         }
         LTP_HIP_TRY(p, hipGetLastError());
+        p->last_kernel = "k_envelope (run tables from k_build_tables)";
         return workspace_release(p, s, capturing);
     }
     unsigned long long* head = p->d_sample_next + (p->sample_next_slot++ & 63u);
     LTP_HIP_TRY(p, hipMemsetAsync(head, 0, sizeof(unsigned long long), s));
+    p->last_kernel = "k_envelope";
     ltp::launch_envelope(s, first, count, first, p->dof, p->t_sample, dev_limits(p), to_dev(in), to_dev(rec), window,
                          n_windows, env, head, blocks, p->dbg_stamps);
     LTP_HIP_TRY(p, hipGetLastError());
@@ -717,7 +748,10 @@ struct PinnedPool {
         for (auto& b : bufs)
             if (!b.used && b.bytes >= bytes) { b.used = true; return b.ptr; }
         void* ptr = nullptr;
-        if (hipHostMalloc(&ptr, bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        // the pool is process-wide and its buffers are handed to kernels on any device (ltp_plan_batch_multi): portable, and
+        // explicitly coherent — Portable alone makes the memory non-coherent, and the completion word the host spins on
+        // (wait_done) as well as the rows themselves rely on coherence
+        if (hipHostMalloc(&ptr, bytes, hipHostMallocPortable | hipHostMallocCoherent) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
         bufs.push_back(Buf{ptr, bytes, true});
         return ptr;
     }
@@ -752,6 +786,7 @@ int wait_done(ltp_planner* p, volatile int* done)
         __builtin_ia32_pause();
 #endif
     }
+    std::atomic_thread_fence(std::memory_order_acquire);   // the result buffers are read after the flag
     return LTP_OK;
 }
 
@@ -878,6 +913,13 @@ int plan_batch_host_fused(ltp_planner* p, long long n, const double* const (&h_i
         rows = (double*)g_pinned.acquire(kFusedRowsBytes);
         if (!rows) return LTP_OK;                                // no pinned memory to be had: staged path
     }
+    if (p->small_dirty) {
+        // an earlier fused call failed or was abandoned: whatever it left running must be over and k_plan_small's arrival
+        // word zero again before the next launch counts on it
+        LTP_HIP_TRY(p, hipStreamSynchronize(nullptr));
+        LTP_HIP_TRY(p, hipMemset(p->d_small, 0, sizeof(unsigned int)));
+        p->small_dirty = false;
+    }
     volatile int* done = (volatile int*)(p->h_arena + flag_at);
     *done = 0;
     const double* in[4] = {(const double*)(p->h_arena + L.in[0]), (const double*)(p->h_arena + L.in[1]),
@@ -889,10 +931,17 @@ int plan_batch_host_fused(ltp_planner* p, long long n, const double* const (&h_i
                                to_dev(&hr), (unsigned long long*)(p->h_arena + L.offsets), rows, kFusedRowsBytes / sizeof(double),
                                (int*)(p->h_arena + ends_at), (unsigned int*)p->d_small, done, given != nullptr);
         hipError_t e = hipGetLastError();
-        if (e != hipSuccess) { if (rows) g_pinned.release(rows); return hip_fail(p, e, "k_plan_small"); }
+        if (e != hipSuccess) { if (rows) g_pinned.release(rows); return hip_fail(p, e, "k_plan_small"); }   // nothing was launched
     }
     rc = wait_done(p, done);
-    if (rc != LTP_OK) { if (rows) g_pinned.release(rows); return rc; }
+    if (rc != LTP_OK) {
+        // the kernel may still be running (or have died half way): its arrival word is suspect, and `rows` goes back to the
+        // pool only once the stream is known to be idle — otherwise it stays allocated (leaked) rather than be written behind a later owner's back
+        p->small_dirty = true;
+        if (rows && hipStreamSynchronize(nullptr) == hipSuccess) g_pinned.release(rows);
+        (void)hipGetLastError();
+        return rc;
+    }
     if (*done == 2) {                                            // rows larger than the pinned buffer
         g_pinned.release(rows);
         return LTP_OK;
@@ -1039,18 +1088,16 @@ void ltp_shard_range(long long n, int rank, int world, long long* first, long lo
     if (count) *count = c;
 }
 
-int ltp_plan_batch_multi(ltp_planner* const* planners, int k, long long n, const double* q_goal, const double* q_0,
-                         const double* v_0, const double* a_0, const ltp_records* host_records, unsigned long long* offsets,
-                         double** packed)
+namespace {
+
+// all planners of a *_multi call must be distinct handles configured like planners[0]; the error text lands in planners[0]
+int check_shard_planners(ltp_planner* const* planners, int k)
 {
-    if (!planners || k < 1 || !planners[0]) return LTP_ERR_INVALID_ARGUMENT;
     ltp_planner* p0 = planners[0];
-    if (n < 0 || (packed && !offsets)) return fail(p0, LTP_ERR_INVALID_ARGUMENT, "null argument");
-    if (packed) *packed = nullptr;
     for (int g = 1; g < k; ++g) {
         const ltp_planner* pg = planners[g];
         bool same = pg && pg->dof == p0->dof && pg->t_sample == p0->t_sample && pg->max_samples == p0->max_samples &&
-                    pg->sample_stride == p0->sample_stride && pg->goal_check == p0->goal_check;
+                    pg->sample_stride == p0->sample_stride && pg->goal_check == p0->goal_check && pg->semantics == p0->semantics;
         for (int l = 0; same && l < 5; ++l) {
             same = (int)pg->h_lim[l].size() >= p0->dof && (int)p0->h_lim[l].size() >= p0->dof;
             for (int j = 0; same && j < p0->dof; ++j) same = pg->h_lim[l][j] == p0->h_lim[l][j];
@@ -1059,13 +1106,55 @@ int ltp_plan_batch_multi(ltp_planner* const* planners, int k, long long n, const
         for (int h = 0; h < g; ++h)
             if (planners[h] == pg) return fail(p0, LTP_ERR_INVALID_ARGUMENT, "the same planner handle is listed twice");
     }
+    return LTP_OK;
+}
+
+// run(g) for every shard, one host thread per shard (each binds its own device); a thread that cannot be created
+// (std::system_error must not cross the C boundary) runs its shard inline instead. Returns the first failing shard's code.
+extern "C++" {
+template <class Run>
+int run_shards(ltp_planner* const* planners, int k, Run run)
+{
+    std::vector<int> rcs((size_t)k, LTP_OK);
+    {
+        std::vector<std::thread> th;
+        th.reserve((size_t)k);
+        for (int g = 1; g < k; ++g) {
+            try {
+                th.emplace_back([&rcs, &run, g] { rcs[(size_t)g] = run(g); });
+            } catch (const std::system_error&) {
+                rcs[(size_t)g] = run(g);
+            }
+        }
+        rcs[0] = run(0);
+        for (auto& t : th) t.join();
+    }
+    for (int g = 0; g < k; ++g)
+        if (rcs[(size_t)g] != LTP_OK)
+            return fail(planners[0], rcs[(size_t)g],
+                        "shard " + std::to_string(g) + " (device " + std::to_string(planners[g]->device) + "): " + (g ? planners[g]->err : std::string(planners[0]->err)));
+    return LTP_OK;
+}
+}  // extern "C++"
+
+}  // namespace
+
+int ltp_plan_batch_multi(ltp_planner* const* planners, int k, long long n, const double* q_goal, const double* q_0,
+                         const double* v_0, const double* a_0, const ltp_records* host_records, unsigned long long* offsets,
+                         double** packed)
+{
+    if (!planners || k < 1 || !planners[0]) return LTP_ERR_INVALID_ARGUMENT;
+    ltp_planner* p0 = planners[0];
+    if (n < 0 || (packed && !offsets)) return fail(p0, LTP_ERR_INVALID_ARGUMENT, "null argument");
+    if (packed) *packed = nullptr;
+    int rc = check_shard_planners(planners, k);
+    if (rc != LTP_OK) return rc;
     const int dof = p0->dof;
     std::vector<long long> first((size_t)k), count((size_t)k);
     for (int g = 0; g < k; ++g) ltp_shard_range(n, g, k, &first[g], &count[g]);
-    std::vector<int> rcs((size_t)k, LTP_OK);
     std::vector<double*> parts((size_t)k, nullptr);
     std::vector<std::vector<unsigned long long>> offs((size_t)k);
-    auto run = [&](int g) {
+    auto run = [&](int g) -> int {
         const long long f = first[g], c = count[g];
         const size_t fd = (size_t)f * dof;
         ltp_records r{};
@@ -1082,21 +1171,11 @@ int ltp_plan_batch_multi(ltp_planner* const* planners, int k, long long n, const
             if (r.status) r.status += f;
         }
         offs[g].assign((size_t)c + 1, 0ull);
-        rcs[g] = ltp_plan_batch_host(planners[g], c, q_goal ? q_goal + fd : nullptr, q_0 ? q_0 + fd : nullptr, v_0 ? v_0 + fd : nullptr,
-                                     a_0 ? a_0 + fd : nullptr, host_records ? &r : nullptr, offsets ? offs[g].data() : nullptr,
-                                     packed ? &parts[g] : nullptr);
+        return ltp_plan_batch_host(planners[g], c, q_goal ? q_goal + fd : nullptr, q_0 ? q_0 + fd : nullptr, v_0 ? v_0 + fd : nullptr,
+                                   a_0 ? a_0 + fd : nullptr, host_records ? &r : nullptr, offsets ? offs[g].data() : nullptr,
+                                   packed ? &parts[g] : nullptr);
     };
-    {
-        // one host thread per shard: the _host calls are synchronous, and each thread binds its own device
-        std::vector<std::thread> th;
-        for (int g = 1; g < k; ++g) th.emplace_back(run, g);
-        run(0);
-        for (auto& t : th) t.join();
-    }
-    int rc = LTP_OK;
-    for (int g = 0; g < k && rc == LTP_OK; ++g)
-        if (rcs[g] != LTP_OK)
-            rc = fail(p0, rcs[g], "shard " + std::to_string(g) + " (device " + std::to_string(planners[g]->device) + "): " + planners[g]->err);
+    rc = run_shards(planners, k, run);
     if (rc == LTP_OK && offsets) {
         unsigned long long base = 0ull;
         for (int g = 0; g < k; ++g) {
@@ -1120,6 +1199,110 @@ int ltp_plan_batch_multi(ltp_planner* const* planners, int k, long long n, const
     }
     for (int g = 0; g < k; ++g) ltp_free_host(parts[g]);   // small shards come from the pinned result pool
     return rc;
+}
+
+// ---- device-resident shards: per-shard device pointers, nothing passes through the host ----
+namespace {
+int check_shards(ltp_planner* const* planners, int k, long long n, const ltp_shard* shards)
+{
+    if (!planners || k < 1 || !planners[0]) return LTP_ERR_INVALID_ARGUMENT;
+    if (n < 0 || !shards) return fail(planners[0], LTP_ERR_INVALID_ARGUMENT, "null argument");
+    return check_shard_planners(planners, k);
+}
+}  // namespace
+
+int ltp_plan_switch_times_multi(ltp_planner* const* planners, int k, long long n, const ltp_shard* shards, int end_limit)
+{
+    int rc = check_shards(planners, k, n, shards);
+    if (rc != LTP_OK) return rc;
+    return run_shards(planners, k, [&](int g) -> int {
+        long long f = 0, c = 0;
+        ltp_shard_range(n, g, k, &f, &c);
+        if (c == 0) return LTP_OK;
+        int r = ltp_plan_switch_times_batch(planners[g], c, &shards[g].in, &shards[g].out, shards[g].offsets, shards[g].stream);
+        if (r == LTP_OK && end_limit) r = ltp_end_limit_batch(planners[g], 0, c, &shards[g].in, &shards[g].out, shards[g].stream);
+        return r;
+    });
+}
+
+int ltp_envelope_multi(ltp_planner* const* planners, int k, long long n, const ltp_shard* shards, int window, int n_windows,
+                       double* const* env)
+{
+    int rc = check_shards(planners, k, n, shards);
+    if (rc != LTP_OK) return rc;
+    if (!env) return fail(planners[0], LTP_ERR_INVALID_ARGUMENT, "null argument");
+    return run_shards(planners, k, [&](int g) -> int {
+        long long f = 0, c = 0;
+        ltp_shard_range(n, g, k, &f, &c);
+        if (c == 0) return LTP_OK;
+        return ltp_envelope_batch(planners[g], 0, c, &shards[g].in, &shards[g].out, window, n_windows, env[g], shards[g].stream);
+    });
+}
+
+int ltp_state_at_multi(ltp_planner* const* planners, int k, long long n, const ltp_shard* shards, const int* const* sample_index,
+                       int uniform_index, double* const* q_0, double* const* v_0, double* const* a_0)
+{
+    int rc = check_shards(planners, k, n, shards);
+    if (rc != LTP_OK) return rc;
+    if (!q_0 || !v_0 || !a_0) return fail(planners[0], LTP_ERR_INVALID_ARGUMENT, "null argument");
+    return run_shards(planners, k, [&](int g) -> int {
+        long long f = 0, c = 0;
+        ltp_shard_range(n, g, k, &f, &c);
+        if (c == 0) return LTP_OK;
+        // the states are laid out like the shard's queries: they are the next batch's q_0, v_0, a_0
+        return ltp_state_at_batch(planners[g], 0, c, &shards[g].in, &shards[g].out, sample_index ? sample_index[g] : nullptr,
+                                  uniform_index, q_0[g], v_0[g], a_0[g], shards[g].in.query_stride, shards[g].in.joint_stride, shards[g].stream);
+    });
+}
+
+int ltp_synchronize_multi(ltp_planner* const* planners, int k, const ltp_shard* shards)
+{
+    if (!planners || k < 1 || !planners[0]) return LTP_ERR_INVALID_ARGUMENT;
+    if (!shards) return fail(planners[0], LTP_ERR_INVALID_ARGUMENT, "null argument");
+    for (int g = 0; g < k; ++g) {
+        ltp_planner* p = planners[g];
+        if (!p) return fail(planners[0], LTP_ERR_INVALID_ARGUMENT, "null planner");
+        hipError_t e = hipSetDevice(p->device);
+        if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)shards[g].stream);
+        if (e != hipSuccess) {
+            const int code = hip_fail(p, e, "hipStreamSynchronize");
+            return g ? fail(planners[0], code, "shard " + std::to_string(g) + ": " + p->err) : code;
+        }
+    }
+    return LTP_OK;
+}
+
+int ltp_plan_envelope_multi_host(ltp_planner* const* planners, int k, long long n, const double* q_goal, const double* q_0,
+                                 const double* v_0, const double* a_0, int window, int n_windows, const ltp_records* host_records,
+                                 double* env)
+{
+    if (!planners || k < 1 || !planners[0]) return LTP_ERR_INVALID_ARGUMENT;
+    ltp_planner* p0 = planners[0];
+    if (n < 0 || !env) return fail(p0, LTP_ERR_INVALID_ARGUMENT, "null argument");
+    int rc = check_shard_planners(planners, k);
+    if (rc != LTP_OK) return rc;
+    const int dof = p0->dof;
+    return run_shards(planners, k, [&](int g) -> int {
+        long long f = 0, c = 0;
+        ltp_shard_range(n, g, k, &f, &c);
+        const size_t fd = (size_t)f * dof;
+        ltp_records r{};
+        if (host_records) {
+            r = *host_records;
+            if (r.t_opt) r.t_opt += fd * 7;
+            if (r.t_scaled) r.t_scaled += fd * 7;
+            if (r.dir) r.dir += fd;
+            if (r.v_drive) r.v_drive += fd;
+            if (r.mod) r.mod += fd;
+            if (r.t_required) r.t_required += f;
+            if (r.slowest) r.slowest += f;
+            if (r.traj_len) r.traj_len += f;
+            if (r.status) r.status += f;
+        }
+        return ltp_plan_envelope_host(planners[g], c, q_goal ? q_goal + fd : nullptr, q_0 ? q_0 + fd : nullptr, v_0 ? v_0 + fd : nullptr,
+                                      a_0 ? a_0 + fd : nullptr, window, n_windows, host_records ? &r : nullptr,
+                                      env + fd * (size_t)n_windows * 2);
+    });
 }
 
 int ltp_plan_envelope_host(ltp_planner* p, long long n, const double* q_goal, const double* q_0, const double* v_0,
@@ -1332,8 +1515,24 @@ int ltp_time_scaling_host(ltp_planner* p, int joint, double q_goal, double q_0, 
 static int roots_host_any(ltp_planner* p, long long n, int degree, bool f32, const void* coef, void* re, void* im)
 {
     if (!p || n < 0 || degree < 1 || degree > 8 || !coef || !re || !im) return fail(p, LTP_ERR_INVALID_ARGUMENT, "bad argument (degree 1..8)");
+    // long_term_planner/roots.h routes every roots() call of a process through one handle: serialise them, and stage through
+    // the handle's pinned arena (host memory the kernel reads and writes directly) instead of three allocations and copies per call
+    std::lock_guard<std::mutex> hg(p->host_mu);
     LTP_HIP_TRY(p, hipSetDevice(p->device));
+    if (n == 0) return LTP_OK;
     const size_t es = f32 ? sizeof(float) : sizeof(double);
+    const size_t cb = ((size_t)n * (degree + 1) * es + 15) & ~(size_t)15, rb = ((size_t)n * degree * es + 15) & ~(size_t)15;
+    if (cb + 2 * rb <= kSmallHostBytes) {
+        int rc = ensure_arena(p, cb + 2 * rb);
+        if (rc != LTP_OK) return rc;
+        memcpy(p->h_arena, coef, (size_t)n * (degree + 1) * es);
+        ltp::launch_roots_all(nullptr, n, degree, f32, p->h_arena, p->h_arena + cb, p->h_arena + cb + rb);
+        LTP_HIP_TRY(p, hipGetLastError());
+        LTP_HIP_TRY(p, hipStreamSynchronize(nullptr));
+        memcpy(re, p->h_arena + cb, (size_t)n * degree * es);
+        memcpy(im, p->h_arena + cb + rb, (size_t)n * degree * es);
+        return LTP_OK;
+    }
     void *dc = nullptr, *dr = nullptr, *di = nullptr;
     DevRecords holder;
     LTP_HIP_TRY(p, holder.alloc((char**)&dc, (size_t)n * (degree + 1) * es));

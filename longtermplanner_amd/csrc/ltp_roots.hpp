@@ -129,6 +129,15 @@ __device__ bool real_schur_companion(const R (&p)[N + 1], R (&T)[N][N], R& scale
     for (int i = 0; i < N; ++i)
 #pragma unroll
         for (int j = 0; j < N; ++j) scale = rmax(scale, rabs(T[i][j]));
+    if constexpr (N == 1) {
+        // Eigen: a matrix with max|a_ij| < the smallest normal number is "considered zero" — T = 0, Success. Only degree 1
+        // can get here (a x + 0): from degree 2 on the sub-diagonal ones make scale >= 1.
+        if (scale < RealTraits<R>::min()) {
+            T[0][0] = R(0);
+            scale_out = R(1);
+            return true;
+        }
+    }
 #pragma unroll
     for (int i = 0; i < N; ++i)
 #pragma unroll

@@ -77,8 +77,9 @@ __device__ const signed char kCutBase[kCutSlots] = {0, 0, 0, 0, 1, 1, 2, 2, 2, 3
 __device__ const signed char kCutDelta[kCutSlots] = {0, 0, 1, 2, 0, 1, 0, 1, 2, -1, 0, 1, 0, 1, 2, 0, 1, 0, 1, 2};
 
 // value of the reference's j_traj[joint][i] after the seven range fills (cc:759-766, last writer wins) and the up
-// to eight "+=" fractional corrections (cc:768-807), applied in the reference's order. s = sampled switch indices,
-// Jp = jerk of the seven phases, corr = the nine possible correction terms, all in LDS.
+// to eight "+=" fractional corrections (cc:768-807), applied in the reference's order and association (cc:781 and
+// cc:798 add two / three terms to the element one after the other). s = sampled switch indices,
+// Jp = jerk of the seven phases, corr = the correction terms, all in LDS.
 LTP_DEV double jerk_at(const int* s, const double* Jp, const double* corr, int i)
 {
     const int s0 = s[0], s1 = s[1], s2 = s[2], s3 = s[3], s4 = s[4], s5 = s[5], s6 = s[6];
@@ -95,13 +96,13 @@ LTP_DEV double jerk_at(const int* s, const double* Jp, const double* corr, int i
         if (s1 > 0 && i == s1) val = val + corr[1];
         if (i == s2 + 1) val = val + corr[2];
     } else {
-        if (s1 > 0 && i == s1) val = val + corr[3];
+        if (s1 > 0 && i == s1) val = (val + corr[0]) + corr[3];             // cc:781: j + A + B, left to right
     }
     if (s3 > 0 && i == s3) val = val + corr[4];
     if (s2 - s0 > 0) {
         if (i == s4 + 1) val = val + corr[5];
     } else {
-        if (s4 > 0 && i == s4) val = val + corr[6];
+        if (s4 > 0 && i == s4) val = ((val + corr[5]) + corr[0]) + corr[3]; // cc:798: j + A + B + C, left to right
     }
     if (s5 > 0 && i == s5) val = val + corr[7];
     if (i == s6 + 1) val = val + corr[8];
@@ -267,10 +268,10 @@ LTP_DEV void build_run_tables(SegTable& tab, long long p, int j0, int nj, int le
         tab.w.corr[jl][0] = ft[0] * J0;                                   // j[s0+1]   cc:771
         tab.w.corr[jl][1] = (1 - ft[1]) * J2;                             // j[s1]     cc:773
         tab.w.corr[jl][2] = ft[2] * J2;                                   // j[s2+1]   cc:776
-        tab.w.corr[jl][3] = ft[0] * J0 + d20 * J2;                        // j[s1]     cc:781 (phase 2 absent)
+        tab.w.corr[jl][3] = d20 * J2;                                     // j[s1]     cc:781 (phase 2 absent): [0] then [3]
         tab.w.corr[jl][4] = (1 - ft[3]) * J4;                             // j[s3]     cc:787
         tab.w.corr[jl][5] = ft[4] * J4;                                   // j[s4+1]   cc:793
-        tab.w.corr[jl][6] = ft[4] * J4 + ft[0] * J0 + d20 * J2;           // j[s4]     cc:798 (phases 2, 3 absent)
+        tab.w.corr[jl][6] = 0.0;                                          // (cc:798, phases 2, 3 absent: [5], [0], [3] one by one)
         tab.w.corr[jl][7] = (1 - ft[5]) * J6;                             // j[s5]     cc:804
         tab.w.corr[jl][8] = ft[6] * J6;                                   // j[s6+1]   cc:807
     }
@@ -391,156 +392,11 @@ LTP_DEV void install_run_tables(SegTable& tab, int nj, const unsigned long long 
     }
 }
 
-// Pass B of an item, one (joint, boundary) task: the 16-byte slot that contains run boundary k (k >= 1) — or, for
-// k == 0, the last slot of the row if the row ends inside it — evaluated sample by sample and parked in bnd[k][0..3]
-// ([q, v, a, j]), if that slot really straddles the boundary and boundary k-1 has not claimed the same slot.
-// There are at most 19 such slots per row, but in the row-by-row loop of pass A most 64-slot wave steps contain one, and a
-// wave that has one would execute the per-sample path for all its lanes; with the finished values waiting in LDS pass A
-// still writes every row as full contiguous wave stores (leaving holes for scattered 16-byte stores costs 13 % of the
-// float64 bandwidth).
-template <typename T>
-LTP_DEV void boundary_slot(const JointTable& jt, double2_t (*bnd)[4], int k, int slen, int sstride)
-{
-    typedef typename OutVec<T>::type V;
-    constexpr int N = OutVec<T>::N;
-    const int nslots = (slen + N - 1) / N;
-    const int nruns = jt.nseg;
-    if (k >= nruns) return;
-    const int* st = jt.start;
-    // k >= 1: the slot of boundary k; k == 0: the last slot of the row if the row ends inside it (its tail is padding), so
-    // that pass A never has to mask anything
-    const int u = k >= 1 ? (st[k] + sstride - 1) / sstride      // first stored sample at or after boundary k
-                         : slen;
-    bool mine = (u % N) != 0 && u < N * nslots;
-    if (mine && k > 1) {
-        const int up = (st[k - 1] + sstride - 1) / sstride;
-        if ((up % N) != 0 && up / N == u / N) mine = false;     // boundary k-1 owns this slot
-    }
-    if (!mine) return;
-    const int i0 = u / N * N, t0 = i0 * sstride;
-    int kh = k >= 1 ? k - 1 : nruns - 1;
-    while (st[kh] > t0) --kh;                                   // run of the slot's first sample (st[0] = 0)
-    int ch = st[kh], nh = kh + 1 < nruns ? st[kh + 1] : 0x7fffffff;
-    V o[4];
-#pragma unroll
-    for (int h = 0; h < N; ++h) {
-        const int i = t0 + h * sstride;
-        while (nh <= i) {
-            ++kh;
-            ch = nh;
-            nh = kh + 1 < nruns ? st[kh + 1] : 0x7fffffff;
-        }
-        const bool pad = i0 + h >= slen;                        // the tail of the last slot is row padding
-        double x4[4];
-        run_eval(jt.c[kh], i - ch + 1, x4[0], x4[1], x4[2], x4[3]);
-#pragma unroll
-        for (int x = 0; x < 4; ++x) o[x][h] = pad ? (T)0 : (T)x4[x];
-    }
-#pragma unroll
-    for (int x = 0; x < 4; ++x) *reinterpret_cast<V*>(&bnd[k][x]) = o[x];
-}
-
-// Pass A of an item: row by row; the N samples of every slot that pass B did not take lie in one run, whose coefficients
-// are read once. Called by the four streaming waves of a block (wave = 0..3).
-template <bool STREAMING, bool DRY, typename T>
-LTP_DEV void stream_pass_a(const JointTable* jt, double2_t (*bnd)[kMaxSegments][4], int j0, int nj, int dof, int slen,
-                           unsigned long long stride, T* __restrict__ plan_base, int sstride, int wave, int lane)
-{
-    // Per joint, every lane produces q, v, a and j of N consecutive samples (a "slot": N = 2 doubles or 4 floats)
-    // and issues four 16-B stores, i.e. four 1 KiB wave stores into the four rows of that joint. (Measured on
-    // MI355X: for float64 rows this runs at the same rate as the identical store pattern without any arithmetic;
-    // deeper unrolling, writing the rows one after the other, and walking the (joint, slot) space as one flat sequence
-    // so that no step has idle lanes are all slower, the last one by 15 %.) float rows hold the binary64 results
-    // rounded once.
-    typedef typename OutVec<T>::type V;
-    constexpr int N = OutVec<T>::N;
-    const unsigned long long arr_stride = (unsigned long long)dof * stride;   // distance between q, v, a, j blocks
-    const int nslots = (slen + N - 1) / N;
-    // Rows shorter than the block (first-N-samples rows) are shared out so that no wave idles: wpr waves per row,
-    // 4 / wpr rows at a time. Long rows: wpr = 4, i.e. all 256 lanes on one row after the other.
-    const int lw = nslots <= 64 ? 0 : (nslots <= 128 ? 1 : 2);                      // wpr = 1 << lw
-    // Streaming float64 rows: buffer stores through descriptors of the four rows being written (base and size in SGPRs,
-    // one 32-bit lane offset for all four stores, anything beyond the row dropped by the hardware's range check),
-    // non-temporal at agent scope ("sc1 nt"; only the buffer builtins take the cache-policy bits). Measured on MI355X
-    // against the compiler's non-temporal global store, same box: +0.5-0.9 % for float64 rows (7.06 -> 7.09, 6.97 -> 7.02
-    // TB/s), but -3 % for float32 rows, which therefore keep the global store. A descriptor spans at most 1 GiB, so a
-    // longer row — 64 M float64 samples — is written window by window; any realistic row is one window.
-    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-    constexpr int kWindowSlots = 1 << 26;
-    constexpr bool kBufferStores = STREAMING && sizeof(T) == 8;
-    for (int jl2 = wave >> lw; jl2 < nj; jl2 += 4 >> lw) {
-        T* const row = plan_base + (unsigned long long)(j0 + jl2) * stride;
-        const int* st = jt[jl2].start;
-        const int nruns = jt[jl2].nseg;
-        // run cursor of this lane: samples [cur, nxt) belong to run kr (nxt = INT_MAX for the last run)
-        int kr = 0, cur = 0, nxt = nruns > 1 ? st[1] : 0x7fffffff;
-        for (int wbase = 0; wbase < nslots; wbase += kWindowSlots) {
-            const int wend = nslots - wbase < kWindowSlots ? nslots : wbase + kWindowSlots;
-            __amdgpu_buffer_rsrc_t rsrc[4];
-            if constexpr (kBufferStores) {
-#pragma unroll
-                for (int x = 0; x < 4; ++x) {
-                    // (plan_base and everything else in this address is wave-uniform: scalar arithmetic)
-                    rsrc[x] = __builtin_amdgcn_make_buffer_rsrc(row + x * arr_stride + (unsigned long long)wbase * N, 0,
-                                                                (wend - wbase) * (int)sizeof(V), 0x00020000);
-                }
-            }
-            for (int slot = wbase + ((wave & ((1 << lw) - 1)) << 6) + lane; slot < wend; slot += 64 << lw) {
-                const int i0 = N * slot;              // first stored sample of this slot; it is sample i0*sstride of the trajectory
-                V o[4];
-                if constexpr (DRY) {
-#pragma unroll
-                    for (int x = 0; x < 4; ++x)
-#pragma unroll
-                        for (int h = 0; h < N; ++h) o[x][h] = (T)(i0 + h);
-                } else {
-                    const int t0 = i0 * sstride;
-                    while (nxt <= t0) {
-                        ++kr;
-                        cur = nxt;
-                        nxt = kr + 1 < nruns ? st[kr + 1] : 0x7fffffff;
-                    }
-                    const bool straddles = t0 + (N - 1) * sstride >= nxt;
-                    if (straddles || i0 + N > slen) {
-                        // run boundary kr+1 lies inside the slot, or the row ends inside it: pass B has left the
-                        // finished values in LDS (entry 0 is the row's last slot)
-                        const int e = straddles ? kr + 1 : 0;
-#pragma unroll
-                        for (int x = 0; x < 4; ++x) o[x] = *reinterpret_cast<const V*>(&bnd[jl2][e][x]);
-                    } else {
-                        double c[kRunCoefs];
-#pragma unroll
-                        for (int x = 0; x < kRunCoefs; ++x) c[x] = jt[jl2].c[kr][x];
-#pragma unroll
-                        for (int h = 0; h < N; ++h) {
-                            double x4[4];
-                            run_eval(c, t0 + h * sstride - cur + 1, x4[0], x4[1], x4[2], x4[3]);
-#pragma unroll
-                            for (int x = 0; x < 4; ++x) o[x][h] = (T)x4[x];
-                        }
-                    }
-                }
-                if constexpr (kBufferStores) {
-                    const unsigned voff = (unsigned)(slot - wbase) * (unsigned)sizeof(V);
-#pragma unroll
-                    for (int x = 0; x < 4; ++x)
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o[x]), rsrc[x], voff, 0, /*nt | sc1*/ 2 | 16);
-                } else if constexpr (STREAMING) {
-#pragma unroll
-                    for (int x = 0; x < 4; ++x) __builtin_nontemporal_store(o[x], reinterpret_cast<V*>(row + x * arr_stride + i0));
-                } else {
-#pragma unroll
-                    for (int x = 0; x < 4; ++x) *reinterpret_cast<V*>(row + x * arr_stride + i0) = o[x];
-                }
-            }
-        }
-    }
-}
-
 // Streams the rows of one item (plan x joint group) from the run tables in LDS. Every thread of the block calls this.
-// (Pass B and pass A are boundary_slot() and stream_pass_a() above, written out in place: composed from those two
-// functions k_sample needs 96 instead of 89 VGPRs — one more than its budget of 5 blocks per CU allows — and the spill
-// reload sits behind the look-ahead loads. Keep the three in step; tests/test_gpu_edge.py compares their rows bit for bit.)
+// (Pass B and pass A are written out in place: composed from two helper functions k_sample needed 96 instead of 89 VGPRs —
+// one more than its budget of 5 blocks per CU allows — and the spill reload sat behind the look-ahead loads. tab_stream()
+// below carries the same slot arithmetic for the table-pass sampler; tests/test_gpu_edge.py compares the rows of the two bit
+// for bit.)
 template <bool STREAMING, bool DRY, typename T>
 LTP_DEV void stream_rows(SegTable& tab, int j0, int nj, int dof, int slen, unsigned long long stride, T* __restrict__ plan_base,
                          RowSpec rows)
@@ -822,9 +678,9 @@ struct alignas(16) TabBuffer {
 static_assert(sizeof(JointTable) % 16 == 0, "LDS-direct loads land 16 bytes per lane");
 
 // What a streaming wave does with an item: wave w owns joint w (nj <= 3: several waves share a joint) and writes the
-// joint's four rows, 64 slots = 1 KiB per row and step. Same slot arithmetic as stream_pass_a, except that a slot which
-// contains a run boundary (or the end of the row) is evaluated sample by sample in place, by exactly boundary_slot()'s
-// steps, instead of being picked up from a pass B: rows this kernel is meant for are one or two wave steps long, and a
+// joint's four rows, 64 slots = 1 KiB per row and step. Same slot arithmetic as stream_rows' pass A, except that a slot which
+// contains a run boundary (or the end of the row) is evaluated sample by sample in place, by exactly the steps of
+// stream_rows' pass B, instead of being picked up from LDS: rows this kernel is meant for are one or two wave steps long, and a
 // pass B costs the wave ~2 us per item in which it issues no store.
 template <bool STREAMING, typename T>
 LTP_DEV void tab_stream(const TabBuffer& B, int dof, T* __restrict__ out, int sstride, int wave)
@@ -1390,8 +1246,8 @@ LTP_DEV void for_each_run(const Limits& lim, const Records& rec, long long rj, i
     const double J0 = dj * (modp ? -1.0 : 1.0), J2 = dj * (modp ? 1.0 : -1.0), J4 = dj * -1.0, J6 = dj * 1.0;
     const double Jp[7] = {J0, dj * 0.0, J2, dj * 0.0, J4, dj * 0.0, J6};
     const double d20 = (fr[2] - fr[0]) / Ts;
-    const double corr[9] = {frts[0] * J0, (1 - frts[1]) * J2, frts[2] * J2, frts[0] * J0 + d20 * J2, (1 - frts[3]) * J4,
-                            frts[4] * J4, frts[4] * J4 + frts[0] * J0 + d20 * J2, (1 - frts[5]) * J6, frts[6] * J6};
+    const double corr[9] = {frts[0] * J0, (1 - frts[1]) * J2, frts[2] * J2, d20 * J2, (1 - frts[3]) * J4,
+                            frts[4] * J4, 0.0, (1 - frts[5]) * J6, frts[6] * J6};
     // candidate cut points (slot 0 = index 0 starts the first run and is not needed here)
     constexpr int cut_base[kCutSlots] = {0, 0, 0, 0, 1, 1, 2, 2, 2, 3, 3, 3, 4, 4, 4, 5, 5, 6, 6, 6};
     constexpr int cut_delta[kCutSlots] = {0, 0, 1, 2, 0, 1, 0, 1, 2, -1, 0, 1, 0, 1, 2, 0, 1, 0, 1, 2};

@@ -261,6 +261,92 @@ class LongTermPlanner:
             lib.ltp_free_host(packed)
         return r
 
+    # ---- device-resident shards, one process: k planners, per-shard torch tensors, no host copies ----
+    @staticmethod
+    def _shard_args(planners, batches, streams=None):
+        handles = (C.c_void_p * len(planners))(*[pl._h for pl in planners])
+        shards = (_abi.Shard * len(planners))()
+        for g, (pl, b) in enumerate(zip(planners, batches)):
+            shards[g].in_ = b.queries
+            shards[g].out = b.c_records()
+            shards[g].offsets = b.offsets.data_ptr()
+            shards[g].stream = streams[g].cuda_stream if streams is not None else pl._stream().value
+        return handles, shards
+
+    @staticmethod
+    def planSwitchTimesSharded(planners, shard_inputs, n, layout="query_major", batches=None, end_limit=False, streams=None):
+        """NEW: ltp_plan_switch_times_multi. shard_inputs[g] = (q_goal, q_0, v_0, a_0) CUDA tensors of shard g — the queries
+        shard_range(n, g, k) of one batch of n — on planners[g]'s device. Returns the per-shard DeviceBatch list; the work
+        is enqueued on streams[g] (default: each device's current stream), not waited for."""
+        k = len(planners)
+        if batches is None:
+            batches = [None] * k
+        out = []
+        for g, (pl, ins) in enumerate(zip(planners, shard_inputs)):
+            cnt, q = LongTermPlanner._queries(*ins, layout)
+            b = batches[g]
+            if b is None or b.n != cnt or b.dof != pl.dof:
+                b = DeviceBatch(cnt, pl.dof, ins[1].device)
+            b.queries, b.inputs = q, ins
+            out.append(b)
+        handles, shards = LongTermPlanner._shard_args(planners, out, streams)
+        planners[0]._check(planners[0]._lib.ltp_plan_switch_times_multi(handles, k, int(n), shards, 1 if end_limit else 0))
+        return out
+
+    @staticmethod
+    def envelopeSharded(planners, batches, n, window, n_windows, outs=None, streams=None):
+        """NEW: ltp_envelope_multi over the shards planned by planSwitchTimesSharded; returns per-shard [count, dof, n_windows, 2]."""
+        import torch
+        k = len(planners)
+        if outs is None:
+            outs = [torch.empty((b.n, pl.dof, n_windows, 2), dtype=torch.float64, device=b.offsets.device) for pl, b in zip(planners, batches)]
+        handles, shards = LongTermPlanner._shard_args(planners, batches, streams)
+        envs = (C.c_void_p * k)(*[o.data_ptr() for o in outs])
+        planners[0]._check(planners[0]._lib.ltp_envelope_multi(handles, k, int(n), shards, int(window), int(n_windows), envs))
+        return outs
+
+    @staticmethod
+    def stateAtSharded(planners, batches, n, sample_index, streams=None):
+        """NEW: ltp_state_at_multi; sample_index: int, or a list of per-shard int32 CUDA tensors. Returns per shard (q, v, a)
+        laid out like the shard's queries."""
+        import torch
+        k = len(planners)
+        outs = [[torch.empty_like(b.inputs[1]) for _ in range(3)] for b in batches]
+        handles, shards = LongTermPlanner._shard_args(planners, batches, streams)
+        per = None if isinstance(sample_index, int) else (C.c_void_p * k)(*[x.data_ptr() for x in sample_index])
+        ptrs = [(C.c_void_p * k)(*[o[i].data_ptr() for o in outs]) for i in range(3)]
+        planners[0]._check(planners[0]._lib.ltp_state_at_multi(handles, k, int(n), shards, per, sample_index if per is None else 0, *ptrs))
+        return outs
+
+    @staticmethod
+    def synchronizeSharded(planners, batches, streams=None):
+        handles, shards = LongTermPlanner._shard_args(planners, batches, streams)
+        planners[0]._check(planners[0]._lib.ltp_synchronize_multi(handles, len(planners), shards))
+
+    @staticmethod
+    def planEnvelopeSharded(planners, q_goal, q_0, v_0, a_0, window, n_windows):
+        """NEW: planEnvelopeHost over several planners / devices from one process (ltp_plan_envelope_multi_host)."""
+        lib = planners[0]._lib
+        D = planners[0].dof
+        ins = [np.ascontiguousarray(np.asarray(x, dtype=np.float64).reshape(-1, D)) for x in (q_goal, q_0, v_0, a_0)]
+        n = ins[0].shape[0]
+        r = dict(t_opt=np.zeros((n, D, 7)), t_scaled=np.zeros((n, D, 7)), dir=np.zeros((n, D)), v_drive=np.zeros((n, D)),
+                 mod=np.zeros((n, D), dtype=np.int8), t_required=np.zeros(n), slowest=np.zeros(n, dtype=np.int32),
+                 traj_len=np.zeros(n, dtype=np.int32), status=np.zeros(n, dtype=np.int32))
+        rec = _abi.Records(*[r[k].ctypes.data for k in ("t_opt", "t_scaled", "dir", "v_drive", "mod", "t_required", "slowest", "traj_len", "status")])
+        env = np.zeros((n, D, int(n_windows), 2))
+        handles = (C.c_void_p * len(planners))(*[pl._h for pl in planners])
+        planners[0]._check(lib.ltp_plan_envelope_multi_host(handles, len(planners), n, *[_ptr(x) for x in ins], int(window), int(n_windows),
+                                                           C.byref(rec), _ptr(env)))
+        return r, env
+
+    def lastSamplerKernel(self):
+        """Name of the kernel that wrote the rows / envelopes of this handle's latest sampleBatch / envelopeBatch call."""
+        return (self._lib.ltp_last_sampler_kernel(self._h) or b"").decode()
+
+    def reserveTables(self, n):
+        self._check(self._lib.ltp_reserve_tables(self._h, int(n)))
+
     # ---- batched device calls (torch CUDA tensors, asynchronous on torch's current stream) ----
     def _stream(self):
         import torch

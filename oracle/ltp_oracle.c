@@ -632,13 +632,15 @@ void ltpo_get_trajectory(const ltpo_planner *P, const double *t /* [dof][7] */, 
             if (s[1] > 0) JADD(s[1], (1 - fr[1] / Ts) * jp[2]);
             JADD(s[2] + 1, fr[2] / Ts * jp[2]);
         } else {
-            if (s[1] > 0) JADD(s[1], fr[0] / Ts * jp[0] + (fr[2] - fr[0]) / Ts * jp[2]);
+            /* cc:781: j = j + A + B, i.e. (j + A) + B: the terms are added one by one, left to right */
+            if (s[1] > 0) { JADD(s[1], fr[0] / Ts * jp[0]); JADD(s[1], (fr[2] - fr[0]) / Ts * jp[2]); }
         }
         if (s[3] > 0) JADD(s[3], (1 - fr[3] / Ts) * jp[4]);
         if (s[2] - s[0] > 0) {
             JADD(s[4] + 1, fr[4] / Ts * jp[4]);
         } else {
-            if (s[4] > 0) JADD(s[4], fr[4] / Ts * jp[4] + fr[0] / Ts * jp[0] + (fr[2] - fr[0]) / Ts * jp[2]);
+            /* cc:798: ((j + A) + B) + C */
+            if (s[4] > 0) { JADD(s[4], fr[4] / Ts * jp[4]); JADD(s[4], fr[0] / Ts * jp[0]); JADD(s[4], (fr[2] - fr[0]) / Ts * jp[2]); }
         }
         if (s[5] > 0) JADD(s[5], (1 - fr[5] / Ts) * jp[6]);
         JADD(s[6] + 1, fr[6] / Ts * jp[6]);

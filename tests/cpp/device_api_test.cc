@@ -4,7 +4,9 @@
 //   2. the host-pointer convenience path (ltp_plan_batch_host) must return the same bits for the same queries;
 //   3. the plan + sample sequence is captured into a hipGraph after ltp_reserve_batch and replayed on new inputs in
 //      place; the replay must equal the eager calls bit for bit;
-//   4. the envelope consumer equals min / max over windows of the sampled rows.
+//   4. the envelope consumer equals min / max over windows of the sampled rows;
+//   6. the table-pass calls (envelopes, capped rows) inside a capture: refused on a handle without a table workspace (nothing
+//      may be allocated while capturing), captured and replayed in pieces after ltp_reserve_tables.
 // Built with g++ against the HIP runtime API only; prints "0 failures" on success.
 #include <hip/hip_runtime_api.h>
 
@@ -207,6 +209,73 @@ int main()
         std::printf("hipGraph replay of plan + sample, %lld plans: %.3f ms per replay\n", n, ms / 20);
         HIP(hipGraphExecDestroy(exec));
         HIP(hipGraphDestroy(graph));
+    }
+
+    // ---- 6. table-pass calls under capture (envelopes take the table pass by default, rows capped at <= 256 samples too) ----
+    {
+        ltp_planner* h1 = h;
+        ltp_planner* h = nullptr;                         // the LTP macro reports this handle's error text
+        if (ltp_create(dof, 0.001, q_min, q_max, v_max, a_max, j_max, 0, &h) != LTP_OK) { std::printf("second ltp_create failed\n"); return 2; }
+        const int cap_samples = 128;
+        LTP(ltp_set_max_samples(h, cap_samples));
+        LTP(ltp_reserve_batch(h, n));
+        unsigned long long* offsets2;
+        double *tile3, *tile4, *env2, *env3;
+        const unsigned long long cap3 = (unsigned long long)n * 4 * dof * (unsigned long long)ltp_row_stride(cap_samples);
+        HIP(hipMalloc((void**)&offsets2, (n + 1) * sizeof(unsigned long long)));
+        HIP(hipMalloc((void**)&tile3, cap3 * sizeof(double)));
+        HIP(hipMalloc((void**)&tile4, cap3 * sizeof(double)));
+        HIP(hipMalloc((void**)&env2, nd * K * 2 * sizeof(double)));
+        HIP(hipMalloc((void**)&env3, nd * K * 2 * sizeof(double)));
+        hipGraph_t graph;
+        // (a) cold handle: the table workspace does not exist yet and must not be allocated inside the capture
+        HIP(hipStreamBeginCapture(s, hipStreamCaptureModeGlobal));
+        const int ra = ltp_plan_switch_times_batch(h, n, &q, &rec, offsets2, s);
+        const int rb = ltp_envelope_batch(h, 0, n, &q, &rec, W, K, env2, s);
+        const int rc4 = ltp_sample_batch(h, 0, n, &q, &rec, offsets2, tile3, cap3, 1, s);
+        HIP(hipStreamEndCapture(s, &graph));
+        HIP(hipGraphDestroy(graph));
+        CHECK(ra == LTP_OK && rb == LTP_ERR_INVALID_ARGUMENT && rc4 == LTP_ERR_INVALID_ARGUMENT);
+        // (b) a workspace bounded to 16 MiB, about a third of the batch: the captured calls run in pieces, nothing is allocated
+        // or freed — neither inside the capture nor by the eager calls below (growing the workspace would free the buffer the
+        // instantiated graph points to)
+        LTP(ltp_set_table_workspace(h, 16ull << 20));
+        LTP(ltp_reserve_tables(h, n));
+        hipGraphExec_t exec;
+        HIP(hipStreamBeginCapture(s, hipStreamCaptureModeGlobal));
+        const int r1 = ltp_plan_switch_times_batch(h, n, &q, &rec, offsets2, s);
+        const int r2 = ltp_envelope_batch(h, 0, n, &q, &rec, W, K, env2, s);
+        const int r3 = ltp_sample_batch(h, 0, n, &q, &rec, offsets2, tile3, cap3, 1, s);
+        HIP(hipStreamEndCapture(s, &graph));
+        CHECK(r1 == LTP_OK && r2 == LTP_OK && r3 == LTP_OK);
+        CHECK(std::strncmp(ltp_last_sampler_kernel(h), "k_sample_tab_f64", 16) == 0);
+        HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+        for (unsigned long long seed = 7; seed <= 8; ++seed) {
+            LTP(ltp_generate_queries_batch(h, n, seed, 0, in[0], in[1], in[2], in[3], dof, 1, s));
+            HIP(hipMemsetAsync(tile3, 0, cap3 * sizeof(double), s));
+            HIP(hipMemsetAsync(tile4, 0, cap3 * sizeof(double), s));
+            HIP(hipGraphLaunch(exec, s));
+            HIP(hipStreamSynchronize(s));
+            const std::vector<unsigned long long> off_g = download(offsets2, (size_t)n + 1);
+            const std::vector<int> st_g = download(status, (size_t)n);
+            CHECK(off_g[n] <= cap3 && off_g[n] > 0);
+            const std::vector<double> rows_g = download(tile3, (size_t)off_g[n]), env_g = download(env2, nd * K * 2);
+            // the same eagerly, rows by the fused kernel for good measure
+            LTP(ltp_plan_switch_times_batch(h, n, &q, &rec, offsets2, s));
+            LTP(ltp_envelope_batch(h, 0, n, &q, &rec, W, K, env3, s));
+            LTP(ltp_sample_batch(h, 0, n, &q, &rec, offsets2, tile4, cap3, 1 | 8, s));
+            HIP(hipStreamSynchronize(s));
+            CHECK(std::strcmp(ltp_last_sampler_kernel(h), "k_sample") == 0);
+            CHECK(download(offsets2, (size_t)n + 1) == off_g);
+            CHECK(download(status, (size_t)n) == st_g);
+            const std::vector<double> rows_e = download(tile4, (size_t)off_g[n]), env_e = download(env3, nd * K * 2);
+            CHECK(std::memcmp(rows_e.data(), rows_g.data(), rows_e.size() * sizeof(double)) == 0);
+            CHECK(std::memcmp(env_e.data(), env_g.data(), env_e.size() * sizeof(double)) == 0);
+        }
+        HIP(hipGraphExecDestroy(exec));
+        HIP(hipGraphDestroy(graph));
+        ltp_destroy(h);
+        (void)h1;
     }
 
     // ---- 5. latency of one planTrajectory-sized call through the host-pointer path (config 1 of BASELINE.json) ----

@@ -302,6 +302,16 @@ static void testShardedBatch()
   ltp.planTrajectoryBatchSharded(2, qg.data(), q0.data(), v0.data(), a0.data(), tiny, {0, 0, 0, 0});
   ltp.planTrajectoryBatch(2, qg.data(), q0.data(), v0.data(), a0.data(), tiny1);
   EXPECT_TRUE(tiny.status == tiny1.status && same(tiny.packed, tiny1.packed) && tiny.offsets == tiny1.offsets);
+  // the envelope consumer over shards (ltp_plan_envelope_multi_host): envelopes and records of the unsharded call, bit for bit
+  std::vector<double> env1, env3, env9;
+  ltpn::BatchTrajectory r1, r3;
+  const long long e1 = ltp.planEnvelopeBatch(n, qg.data(), q0.data(), v0.data(), a0.data(), 25, 9, env1, &r1);
+  const long long e3 = ltp.planEnvelopeBatchSharded(n, qg.data(), q0.data(), v0.data(), a0.data(), 25, 9, env3, {0, 0, 0}, &r3);
+  EXPECT_TRUE(e1 == e3 && e1 == ok1 && env1.size() == (size_t)n * 6 * 9 * 2);
+  EXPECT_TRUE(env1.size() == env3.size() && std::memcmp(env1.data(), env3.data(), sizeof(double) * env1.size()) == 0);   // NaN rows of the failed plan included
+  EXPECT_TRUE(r1.status == r3.status && r1.length == r3.length && same(r1.t_scaled, r3.t_scaled) && r1.status == one.status);
+  ltp.planEnvelopeBatchSharded(3, qg.data(), q0.data(), v0.data(), a0.data(), 25, 9, env9, {0, 0, 0, 0, 0});   // empty tail shards
+  EXPECT_TRUE(env9.size() == 3u * 6 * 9 * 2 && std::memcmp(env9.data(), env1.data(), sizeof(double) * env9.size()) == 0);
 }
 
 int main()
