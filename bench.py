@@ -57,8 +57,10 @@ def cpu_baseline(dof, lim, t_sample, seed, sample_switch_only):
     from concurrent.futures import ThreadPoolExecutor
     import oracle
     from longtermplanner_amd import generate_queries
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    cores = max(1, min(cores, 16))   # a one-GPU box's CPU share
+    affinity = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    # threads actually used: the cores this process may run on, at most 16 (a one-GPU box's CPU share on the pool; the
+    # node's other cores belong to its other GPUs). Both counts are reported.
+    cores = max(1, min(affinity, 16))
     per_thread = 49152 if not sample_switch_only else 1000000
     n = per_thread * cores
     qg, q0, v0, a0 = generate_queries(n, lim, seed=seed)
@@ -90,7 +92,7 @@ def cpu_baseline(dof, lim, t_sample, seed, sample_switch_only):
         dtf1 = time.perf_counter() - t3
         flat = {"value": cores * (per_thread // 2) / dtf, "one_thread": n1 / dtf1, "unit": "plans/s",
                 "sample": f"{per_thread // 2} queries per thread on {cores} threads; {n1} on one thread"}
-    return {"value": n / dt, "unit": "plans/s", "cores": cores, "kind": "port",
+    return {"value": n / dt, "unit": "plans/s", "cores": cores, "host_cores_affinity": affinity, "host_cores_online": os.cpu_count(), "kind": "port",
             "one_thread": {"value": n1 / dt1, "unit": "plans/s", "sample": f"first {n1} queries, {dt1:.1f} s"},
             "flat_preallocated": flat,
             "sample": f"first {n} queries of the same synthetic batch, {per_thread} per thread, "
@@ -141,6 +143,10 @@ def parse_args(argv=None):
     ap.add_argument("--table-gib", type=float, default=0.0, help="upper bound of the table-pass workspace (default: library default, 1/16 of device memory)")
     ap.add_argument("--sample-blocks", type=int, default=0, help="TUNING: size of the sampler's persistent grid (0 = library default)")
     ap.add_argument("--gather", action="store_true", help="also all_gather t_required over RCCL each step (optional path)")
+    ap.add_argument("--one-process", action="store_true",
+                    help="--gpus N from ONE process: one planner handle, stream and host thread per device, device-resident shards "
+                         "(ltp_plan_switch_times_multi / ltp_envelope_multi / ltp_state_at_multi), no torch.distributed. Workloads without dense "
+                         "rows: --switch-only, --envelope, --receding R:K. With --device D all shards sit on device D (rehearsal)")
     ap.add_argument("--checksum", action="store_true",
                     help="add an order-independent checksum of all records of the batch (summed over ranks) to the line: equal for any sharding of one global batch")
     return ap.parse_args(argv)
@@ -364,7 +370,7 @@ def run_workload(wl, ctx):
         launches = len(ev_pairs)
         rounds = rec_spec[0] if rec_spec else 1    # receding variant: the lengths of the last round stand for all rounds
         achieved = alg_bytes_per_step * rounds * wl.steps / (kern_ms * 1e-3) / 1e9
-        roofline = {"kernel": "k_envelope" if env_spec else "k_sample", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        roofline = {"kernel": ltp.lastSamplerKernel(), "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4),
                     # HBM bytes per launch are a PMC measurement (rocprofv3 --pmc WRITE_SIZE, separate pass): not available inside
                     # this process. The committed measurement of the same workload, if any, is quoted with its provenance.
@@ -427,6 +433,104 @@ def run_workload(wl, ctx):
     return out
 
 
+def run_one_process(args):
+    """--one-process: N devices driven from this process through the *_multi entry points (one handle, one stream and one
+    host thread per device; shards are device-resident, nothing passes through the host). Returns the JSON object."""
+    import numpy as np
+    import torch
+    from longtermplanner_amd import LongTermPlanner, limit_set
+
+    k = args.gpus
+    if not (args.switch_only or args.envelope or (args.receding and not args.max_samples)):
+        raise SystemExit("bench.py: --one-process drives the calls that leave no dense rows behind: --switch-only, --envelope W:K or "
+                         "--receding R:K (rows stay a per-rank matter: use the default one-process-per-GPU mode for them)")
+    ndev = torch.cuda.device_count()
+    devices = [args.device] * k if args.device is not None else list(range(k))
+    if max(devices) >= ndev:
+        raise SystemExit(f"bench.py: --one-process --gpus {k} needs {k} visible devices (found {ndev}); --device D puts all shards on device D")
+    dof, lim = limit_set(args.limits)
+    total = args.global_batch if args.global_batch else args.batch * k
+    planners = [LongTermPlanner(dof, args.t_sample, device=d, **lim) for d in devices]
+    streams, inputs, counts = [], [], []
+    for g, d in enumerate(devices):
+        first, cnt = shard_range(total, g, k)
+        with torch.cuda.device(d):
+            streams.append(torch.cuda.Stream(device=d))
+            with torch.cuda.stream(streams[-1]):
+                inputs.append(planners[g].generateQueries(cnt, seed=args.seed, first_query=first, layout=args.layout))
+        counts.append(cnt)
+    env_spec = tuple(int(x) for x in args.envelope.split(":")) if args.envelope else None
+    rec_spec = tuple(int(x) for x in args.receding.split(":")) if args.receding else None
+    batches = None
+    envs = None
+    # restart states: two sets per shard, allocated once and used alternately (a round reads one set and writes the other)
+    state_sets = [[[torch.empty_like(inputs[g][1]) for _ in range(3)] for g in range(k)] for _ in range(2)] if rec_spec else None
+
+    def step():
+        nonlocal batches, envs
+        if rec_spec:
+            cur = inputs
+            for r in range(rec_spec[0]):
+                batches = LongTermPlanner.planSwitchTimesSharded(planners, cur, total, layout=args.layout, batches=batches,
+                                                                 end_limit=args.end_limit, streams=streams)
+                states = LongTermPlanner.stateAtSharded(planners, batches, total, rec_spec[1], streams=streams, outs=state_sets[r & 1])
+                cur = [(inputs[g][0], *states[g]) for g in range(k)]
+            return
+        batches = LongTermPlanner.planSwitchTimesSharded(planners, inputs, total, layout=args.layout, batches=batches,
+                                                         end_limit=args.switch_only and args.end_limit, streams=streams)
+        if env_spec:
+            envs = LongTermPlanner.envelopeSharded(planners, batches, total, env_spec[0], env_spec[1], outs=envs, streams=streams)
+
+    def sync_all():
+        for d in sorted(set(devices)):
+            torch.cuda.synchronize(d)
+
+    for _ in range(args.warmup):
+        step()
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    LongTermPlanner.synchronizeSharded(planners, batches, streams)
+    sync_all()
+    elapsed = time.perf_counter() - t0
+
+    ok = lens = 0
+    M, acc = 1 << 48, 0
+    for b in batches:
+        ok += int((b.status == 0).sum().item())
+        lens += int(b.traj_len.long().sum().item())
+        if args.checksum:
+            for x in (b.t_opt, b.t_scaled, b.dir, b.v_drive, b.t_required):
+                acc += int(x.contiguous().view(torch.int64).sum().item()) % M
+            for x in (b.mod, b.slowest, b.traj_len, b.status):
+                acc += int(x.to(torch.int64).sum().item()) % M
+    replans = rec_spec[0] if rec_spec else 1
+    what = (f"{rec_spec[0]} receding-horizon cycles per step on the device (plan, state at sample {rec_spec[1]}: ltp_state_at_multi); value counts replans"
+            if rec_spec else f"on-device envelope consumer: [min q, max q] over {env_spec[1]} windows of {env_spec[0]} samples per joint (ltp_envelope_multi)"
+            if env_spec else "switching times only (ltp_plan_switch_times_multi" + (" + end-limit check" if args.end_limit else "; status = pre-sampling verdict") + ")")
+    out = {
+        "metric": "7-DoF trajectory plans/sec (batch 1M)" if dof == 7 else f"{dof}-DoF trajectory plans/sec",
+        "value": round(total * args.steps * replans / elapsed, 1), "unit": "plans/s", "n_gpus": k, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
+        "scaling": "strong" if args.global_batch else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {
+            "workload": f"{total} x {dof}-DoF queries per step in {k} device-resident shard(s) ({counts[0]} in shard 0), limits '{args.limits}', "
+                        f"Tsample {args.t_sample} s, {what}, no rows",
+            "batch_per_gpu": None if args.global_batch else args.batch, "global_batch": total, "dof": dof, "t_sample": args.t_sample,
+            "limits": args.limits, "input_layout": args.layout, "devices": devices,
+            "sharding": "one process: one handle, stream and host thread per device, contiguous query ranges, device-resident shards, no collective",
+            "plans_ok_frac": round(ok / total, 5),
+            "plans_ok_is": "planTrajectory's bool" if (args.end_limit or env_spec) else "the pre-sampling verdict (cc:14-39); the end-limit check cc:59-61 was not run",
+            "mean_traj_len": round(lens / total, 1),
+            "bytes_per_plan": round(32.0 * dof * lens / total, 1),
+        },
+    }
+    if args.checksum:
+        out["config"]["records_checksum"] = acc % M
+    return out
+
+
 def main():
     args = parse_args()
     if args.gpus < 1:
@@ -435,6 +539,10 @@ def main():
     if args.in_flight < 1 or (args.in_flight > 1 and (not args.switch_only or args.receding)):
         print("bench.py: --in-flight K (K >= 1) interleaves whole switching-times batches: it needs --switch-only", file=sys.stderr)
         return 2
+    if args.one_process:
+        out = run_one_process(args)
+        print(json.dumps(out), flush=True)
+        return 0
     env_world = os.environ.get("WORLD_SIZE")
     if env_world is None and args.gpus > 1:
         return spawn_ranks(args)            # no torch, no GPU in this process

@@ -306,12 +306,14 @@ class LongTermPlanner:
         return outs
 
     @staticmethod
-    def stateAtSharded(planners, batches, n, sample_index, streams=None):
-        """NEW: ltp_state_at_multi; sample_index: int, or a list of per-shard int32 CUDA tensors. Returns per shard (q, v, a)
-        laid out like the shard's queries."""
+    def stateAtSharded(planners, batches, n, sample_index, streams=None, outs=None):
+        """NEW: ltp_state_at_multi; sample_index: int, or a list of per-shard int32 CUDA tensors. Returns per shard [q, v, a]
+        laid out like the shard's queries (outs: reuse these tensors — with side streams, buffers that are allocated once
+        are the safe choice: the caching allocator does not know about work pending on another stream)."""
         import torch
         k = len(planners)
-        outs = [[torch.empty_like(b.inputs[1]) for _ in range(3)] for b in batches]
+        if outs is None:
+            outs = [[torch.empty_like(b.inputs[1]) for _ in range(3)] for b in batches]
         handles, shards = LongTermPlanner._shard_args(planners, batches, streams)
         per = None if isinstance(sample_index, int) else (C.c_void_p * k)(*[x.data_ptr() for x in sample_index])
         ptrs = [(C.c_void_p * k)(*[o[i].data_ptr() for o in outs]) for i in range(3)]

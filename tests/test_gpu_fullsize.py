@@ -10,7 +10,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-CASES = [("panda", 1_000_000, 40, 24), ("ref30", 150_000, 120, 72)]   # (limit set, queries, tile GiB of pass 1 / pass 2)
+CASES = [("panda", 1_000_000, 40, 24), ("ref30", 1_000_000, 160, 96)]   # (limit set, queries, tile GiB of pass 1 / pass 2): BASELINE.json configs[2] and configs[4] at full size
 
 
 def _chunks(off, cap):

@@ -38,6 +38,144 @@ def test_virtual_shards_are_bit_identical_to_the_unsharded_batch(limits, n, k):
         amd.LongTermPlanner.planBatchSharded(shards, qg, q0, v0, a0)
 
 
+@pytest.mark.parametrize("limits,n,k,layout", [("panda", 20011, 3, "query_major"), ("ref", 5003, 8, "joint_major"), ("ref30", 1300, 4, "query_major"),
+                                               ("ref", 3, 5, "query_major")])
+def test_device_resident_shards_match_the_unsharded_calls(limits, n, k, layout):
+    """ltp_plan_switch_times_multi / ltp_envelope_multi / ltp_state_at_multi (k handles, one host thread and stream per shard,
+    shard-local device arrays, nothing through the host): every shard's records, envelopes and restart states must have the
+    bits of the corresponding rows of ONE unsharded call over the whole batch."""
+    import torch
+    import longtermplanner_amd as amd
+    from longtermplanner_amd.parallel import shard_range
+    D, lim = amd.limit_set(limits)
+    Ts = 0.002
+    one = amd.LongTermPlanner(D, Ts, device=0, **lim)
+    planners = [amd.LongTermPlanner(D, Ts, device=0, **lim) for _ in range(k)]
+    streams = [torch.cuda.Stream() for _ in range(k)]
+    whole = one.generateQueries(n, seed=77, layout="query_major")
+    if n > 100:
+        whole[1][n // 2, 0] = 99.0                                # a rejected query inside a shard
+    torch.cuda.synchronize()
+    shard_in = []
+    for g in range(k):
+        f, c = shard_range(n, g, k)
+        part = [x[f:f + c] for x in whole]
+        shard_in.append([p.t().contiguous() if layout == "joint_major" else p.contiguous() for p in part])
+    W, K = 40, 12
+    want = one.planSwitchTimesBatch(*whole)
+    want_env = one.envelopeBatch(want, 0, n, W, K)                # sets END_LIMIT bits like the sharded call below
+    idx = torch.arange(n, dtype=torch.int32, device="cuda") % 700
+    want_state = one.stateAt(want, 0, n, idx)
+    want_state_u = one.stateAt(want, 0, n, 150)
+    torch.cuda.synchronize()
+    got = amd.LongTermPlanner.planSwitchTimesSharded(planners, shard_in, n, layout=layout, streams=streams)
+    got_env = amd.LongTermPlanner.envelopeSharded(planners, got, n, W, K, streams=streams)
+    per_idx = [idx[shard_range(n, g, k)[0]:sum(shard_range(n, g, k))].contiguous() for g in range(k)]
+    got_state = amd.LongTermPlanner.stateAtSharded(planners, got, n, per_idx, streams=streams)
+    got_state_u = amd.LongTermPlanner.stateAtSharded(planners, got, n, 150, streams=streams)
+    amd.LongTermPlanner.synchronizeSharded(planners, got, streams)
+    for g in range(k):
+        f, c = shard_range(n, g, k)
+        assert got[g].n == c
+        for key in ("t_opt", "t_scaled", "dir", "v_drive", "mod", "t_required", "slowest", "traj_len", "status"):
+            a, b = getattr(got[g], key), getattr(want, key)[f:f + c]
+            assert torch.equal(a.view(torch.uint8), b.contiguous().view(torch.uint8)), (g, key)
+        lo = want.offsets[f:f + c + 1] - want.offsets[f]
+        assert torch.equal(got[g].offsets, lo), g
+        assert torch.equal(got_env[g].view(torch.int64), want_env[f:f + c].contiguous().view(torch.int64)), g      # NaN rows included
+        for x in range(3):
+            for gs, ws in ((got_state, want_state), (got_state_u, want_state_u)):
+                a = gs[g][x].t() if layout == "joint_major" else gs[g][x]
+                assert torch.equal(a.contiguous().view(torch.int64), ws[x][f:f + c].contiguous().view(torch.int64)), (g, x)
+    # the end-limit verdict without rows or envelopes: planTrajectory's bool per shard
+    got2 = amd.LongTermPlanner.planSwitchTimesSharded(planners, shard_in, n, layout=layout, end_limit=True, streams=streams)
+    amd.LongTermPlanner.synchronizeSharded(planners, got2, streams)
+    assert torch.equal(torch.cat([b.status for b in got2]), want.status)
+    # the host-pointer form of the envelope call (what the C++ planEnvelopeBatchSharded uses)
+    host = [x.cpu().numpy() for x in whole]
+    r1, e1 = one.planEnvelopeHost(*host, W, K)
+    rk, ek = amd.LongTermPlanner.planEnvelopeSharded(planners, *host, W, K)
+    assert e1.tobytes() == ek.tobytes() and e1.tobytes() == want_env.cpu().numpy().tobytes()
+    for key in r1:
+        assert r1[key].tobytes() == rk[key].tobytes(), key
+    # shards must be configured alike, and a handle may appear only once
+    planners[-1].setSampleTime(0.004)
+    with pytest.raises(amd.LtpError):
+        amd.LongTermPlanner.planSwitchTimesSharded(planners, shard_in, n, layout=layout, streams=streams)
+    planners[-1].setSampleTime(Ts)
+    if k > 1:
+        with pytest.raises(amd.LtpError):
+            amd.LongTermPlanner.planSwitchTimesSharded([planners[0]] * k, shard_in, n, layout=layout, streams=streams)
+
+
+def test_config4_ten_million_queries_in_eight_shards(oracle_mod):
+    """BASELINE.json configs[3] at its real size on the hardware at hand: 10 M x 7-DoF queries cut 8 ways. A GPU box allows six
+    processes on its card, so the 8-way cut runs as eight device-resident shards of ONE process (bench.py --one-process:
+    eight handles, streams and host threads on device 0) and the one-process-per-rank path as four gloo ranks sharing the
+    device, with full sampling (3.86 TB of rows). All of them must agree with the unsharded batch in an order-independent
+    checksum of every record, the ok-count and the bytes; the queries either side of every shard boundary are checked
+    against the oracle."""
+    import torch
+    import longtermplanner_amd as amd
+    from longtermplanner_amd.parallel import shard_range
+    G = 10_000_000
+    keys = ("records_checksum", "plans_ok_frac", "mean_traj_len", "bytes_per_plan")
+
+    def line(*args, tile="8"):
+        env = dict(os.environ)
+        for kk in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+            env.pop(kk, None)
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-secondary", "--steps", "1", "--warmup", "0",
+                            "--tile-gib", tile, "--global-batch", str(G), "--checksum", *args], capture_output=True, text=True, timeout=900, env=env)
+        assert p.returncode == 0, p.stderr[-2000:]
+        out = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+        assert len(out) == 1, p.stdout
+        return json.loads(out[0])
+
+    one = line("--gpus", "1", "--switch-only", "--end-limit")
+    eight = line("--gpus", "8", "--one-process", "--device", "0", "--switch-only", "--end-limit")
+    assert eight["n_gpus"] == 8 and eight["scaling"] == "strong" and eight["config"]["global_batch"] == G
+    assert one["n_gpus"] == 1 and one["config"]["global_batch"] == G
+    for key in keys:
+        assert eight["config"][key] == one["config"][key], key
+    # four ranks (processes) sharing the device, every trajectory sampled: the status words now come from the sampler's
+    # end-limit check and must still add up to the same checksum
+    four = line("--gpus", "4", "--backend", "gloo", "--device", "0", tile="96")
+    assert four["n_gpus"] == 4 and four["scaling"] == "strong"
+    assert four["roofline"]["kernel"] == "k_sample" and four["config"]["plans_ok_is"] == "planTrajectory's bool"
+    for key in keys:
+        assert four["config"][key] == one["config"][key], key
+    assert abs(four["config"]["bytes_per_plan"] - 385_800) < 2_000      # SURVEY §8(d): 384 938 B per panda plan
+    torch.cuda.empty_cache()
+
+    # shard boundaries against the oracle: eight device-resident shards, the three queries either side of every `first`
+    D, lim = amd.limit_set("panda")
+    planners = [amd.LongTermPlanner(D, 0.001, device=0, **lim) for _ in range(8)]
+    ins = []
+    for g in range(8):
+        f, c = shard_range(G, g, 8)
+        assert c == 1_250_000 and f == g * 1_250_000
+        ins.append(planners[g].generateQueries(c, seed=12345, first_query=f))
+    got = amd.LongTermPlanner.planSwitchTimesSharded(planners, ins, G, end_limit=True)
+    amd.LongTermPlanner.synchronizeSharded(planners, got)
+    orc = oracle_mod.Oracle(D, 0.001, **lim)
+    for g in range(8):
+        f, c = shard_range(G, g, 8)
+        for lo, cnt in ((0, 3), (c - 3, 3), (c // 2, 2)):
+            host = amd.generate_queries(cnt, lim, seed=12345, first_query=f + lo)
+            for x, y in zip(host, ins[g]):
+                assert np.array_equal(x, y[lo:lo + cnt].cpu().numpy()), "device generator == host generator at 10 M-scale indices"
+            o = orc.plan_batch(*host, sample=True)
+            sl = slice(lo, lo + cnt)
+            assert np.array_equal(got[g].traj_len[sl].cpu().numpy(), o["traj_len"])
+            assert np.array_equal(got[g].slowest[sl].cpu().numpy(), o["slowest"])
+            assert np.array_equal(got[g].mod[sl].cpu().numpy(), o["mod"])
+            assert np.array_equal(got[g].dir[sl].cpu().numpy(), o["dir"])
+            assert np.array_equal(got[g].status[sl].cpu().numpy() == 0, o["status"] == 1)      # planTrajectory's bool
+            for key in ("t_opt", "t_scaled", "v_drive", "t_required"):
+                assert np.max(np.abs(getattr(got[g], key)[sl].cpu().numpy() - o[key])) <= 1e-9, (g, key)
+
+
 def _bench(*args):
     env = dict(os.environ)
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
