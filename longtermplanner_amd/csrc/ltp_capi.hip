@@ -1218,7 +1218,14 @@ int ltp_plan_switch_times_multi(ltp_planner* const* planners, int k, long long n
     return run_shards(planners, k, [&](int g) -> int {
         long long f = 0, c = 0;
         ltp_shard_range(n, g, k, &f, &c);
-        if (c == 0) return LTP_OK;
+        if (c == 0) {
+            // an empty tail shard (more shards than queries): its offsets array is the single entry 0
+            if (shards[g].offsets) {
+                LTP_HIP_TRY(planners[g], hipSetDevice(planners[g]->device));
+                LTP_HIP_TRY(planners[g], hipMemsetAsync(shards[g].offsets, 0, sizeof(unsigned long long), (hipStream_t)shards[g].stream));
+            }
+            return LTP_OK;
+        }
         int r = ltp_plan_switch_times_batch(planners[g], c, &shards[g].in, &shards[g].out, shards[g].offsets, shards[g].stream);
         if (r == LTP_OK && end_limit) r = ltp_end_limit_batch(planners[g], 0, c, &shards[g].in, &shards[g].out, shards[g].stream);
         return r;
