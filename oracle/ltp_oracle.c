@@ -810,3 +810,67 @@ long ltpo_plan_batch(const ltpo_planner *P, long first, long count, const double
     free(reuse[0]); free(reuse[1]); free(reuse[2]); free(reuse[3]);
     return n_ok;
 }
+
+/*
+ * Dense comparison for the parity soak (tools/dense_soak.py): plans [first, first+count) of row-major [n][dof] inputs are
+ * planned and sampled by THIS oracle (full cc:7-63) and compared sample by sample with a device's packed rows
+ * (`packed`: host copy of the device tile that starts at element `base`; plan p at offsets[p] - base, laid out
+ * [q,v,a,j][dof][row stride = traj_len rounded up to 32]). Per plan: maxd[4] = max |d| over q, v, a, j (a NaN on one
+ * side only counts as +inf) and flag bits: 1 = one side planned the query and the other rejected it,
+ * 2 = trajectory lengths differ (nothing compared), 4 = end-limit verdicts (cc:59-61) differ, 8 = compared and NOT
+ * bit-identical in every sample (informational: the tolerance test is the caller's).
+ * dev_status: the device's LTP_STATUS_* word (bits 1|2|4|16|64 = rejected before sampling, 8 = end limit).
+ * Returns the number of values compared.
+ */
+long long ltpo_compare_dense(const ltpo_planner *P, long first, long count, const double *q_goal, const double *q_0,
+                             const double *v_0, const double *a_0, const double *packed, const unsigned long long *offsets,
+                             unsigned long long base, const int *dev_len, const int *dev_status, double *maxd, int *flag)
+{
+    int D = P->dof, x, i, k;
+    long p;
+    long long compared = 0;
+    double *t_opt = (double *)malloc(sizeof(double) * 7 * D), *t_sc = (double *)malloc(sizeof(double) * 7 * D);
+    double *dirv = (double *)malloc(sizeof(double) * D), *vd = (double *)malloc(sizeof(double) * D);
+    char *mod = (char *)malloc(D);
+    double *reuse[4] = {NULL, NULL, NULL, NULL};
+    size_t reuse_cap = 0;
+    for (p = first; p < first + count; p++) {
+        double treq;
+        int slow, len = 0, st;
+        double *md = maxd + 4 * (size_t)(p - first);
+        int *fl = flag + (p - first);
+        const int dev_rejected = (dev_status[p] & (1 | 2 | 4 | 16 | 64)) != 0;
+        md[0] = md[1] = md[2] = md[3] = 0.0;
+        *fl = 0;
+        st = plan_trajectory_impl(P, q_goal + (size_t)p * D, q_0 + (size_t)p * D, v_0 + (size_t)p * D, a_0 + (size_t)p * D,
+                                  t_opt, t_sc, dirv, mod, vd, &treq, &slow, &len, NULL, NULL, reuse, &reuse_cap);
+        if ((st == 0) != dev_rejected) { *fl |= 1; continue; }
+        if (st == 0) continue;
+        if (len != dev_len[p]) { *fl |= 2; continue; }
+        if ((st == 2) != ((dev_status[p] & 8) != 0)) *fl |= 4;
+        {
+            const size_t stride = ((size_t)len + 31) / 32 * 32;
+            const double *blk = packed + (offsets[p] - base);
+            for (x = 0; x < 4; x++) {
+                double m = 0.0;
+                for (i = 0; i < D; i++) {
+                    const double *dev = blk + ((size_t)x * D + i) * stride;
+                    const double *ref = reuse[x] + (size_t)i * len;
+                    for (k = 0; k < len; k++) {
+                        double d;
+                        if (dev[k] == ref[k]) d = 0.0;                                  /* includes inf == inf */
+                        else if (dev[k] != dev[k] && ref[k] != ref[k]) d = 0.0;         /* NaN on both sides */
+                        else { d = fabs(dev[k] - ref[k]); if (!(d == d)) d = INFINITY; }
+                        if (d > m) m = d;
+                        if (d != 0.0) *fl |= 8;
+                    }
+                }
+                md[x] = m;
+            }
+            compared += 4ll * D * len;
+        }
+    }
+    free(t_opt); free(t_sc); free(dirv); free(vd); free(mod);
+    free(reuse[0]); free(reuse[1]); free(reuse[2]); free(reuse[3]);
+    return compared;
+}

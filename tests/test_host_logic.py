@@ -117,3 +117,53 @@ def test_bench_in_flight_needs_the_switching_times_workload():
     assert p.returncode != 0 and "{" not in p.stdout and "--switch-only" in p.stderr
     p = _run_bench(["--in-flight", "0", "--switch-only"])
     assert p.returncode != 0 and "{" not in p.stdout
+
+
+def test_dense_comparator_of_the_soak_tool(oracle_mod):
+    """oracle/ltp_oracle.c: ltpo_compare_dense (tools/dense_soak.py) — rows packed from the oracle's own trajectories compare
+    equal; a perturbed sample, a wrong length and a wrong verdict are each reported."""
+    import ctypes as C
+    from longtermplanner_amd.synthetic import generate_queries, limit_set
+    D, lim = limit_set("ref")
+    Ts = 0.004
+    orc = oracle_mod.Oracle(D, Ts, **lim)
+    n = 12
+    qs = [np.ascontiguousarray(x) for x in generate_queries(n, lim, seed=5)]
+    qs[1][3, 0] = 9.0                                        # rejected by checkInputs
+    lens, status, blocks, off = np.zeros(n, dtype=np.int32), np.zeros(n, dtype=np.int32), [], [0]
+    for p in range(n):
+        r = orc.plan_trajectory(*[x[p] for x in qs])
+        if r["status"] == 0:
+            status[p] = 1
+            off.append(off[-1])
+            continue
+        L = r["length"]
+        lens[p] = L
+        status[p] = 8 if r["status"] == 2 else 0
+        stride = (L + 31) // 32 * 32
+        blk = np.zeros((4, D, stride))
+        for x, key in enumerate("qvaj"):
+            blk[x, :, :L] = r[key]
+        blocks.append(blk.reshape(-1))
+        off.append(off[-1] + blk.size)
+    packed = np.concatenate(blocks)
+    off = np.asarray(off, dtype=np.uint64)
+    lib = oracle_mod.lib()
+    lib.ltpo_compare_dense.restype = C.c_longlong
+    dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int)
+
+    def run():
+        maxd, flag = np.zeros((n, 4)), np.zeros(n, dtype=np.int32)
+        cnt = lib.ltpo_compare_dense(orc._ref, C.c_long(0), C.c_long(n), *[x.ctypes.data_as(dp) for x in qs], packed.ctypes.data_as(dp),
+                                     off.ctypes.data_as(C.POINTER(C.c_ulonglong)), C.c_ulonglong(0), lens.ctypes.data_as(ip),
+                                     status.ctypes.data_as(ip), maxd.ctypes.data_as(dp), flag.ctypes.data_as(ip))
+        return cnt, maxd, flag
+    cnt, maxd, flag = run()
+    assert cnt == 4 * D * int(lens.sum()) and not maxd.any() and not flag.any()
+    packed[int(off[5]) + 7] += 1e-6                          # q of joint 0, sample 7 of plan 5
+    status[6] ^= 8
+    lens[7] += 1
+    status[3] = 0                                            # the device "planned" a query the oracle rejects
+    cnt, maxd, flag = run()
+    assert abs(maxd[5, 0] - 1e-6) < 1e-12 and not maxd[5, 1:].any() and flag[5] == 8 and flag[6] == 4 and flag[7] == 2 and flag[3] == 1
+    assert np.count_nonzero(maxd) == 1 and np.count_nonzero(flag) == 4

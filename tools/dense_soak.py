@@ -1,0 +1,177 @@
+"""Dense-trajectory parity soak: EVERY sample of q/v/a/j of the HIP path against the CPU oracle, on ~10^6 plans.
+
+For each limit set the batch is planned and sampled on the device chunk by chunk (a reused tile, as bench.py does), each
+chunk's rows are copied to pinned host memory, and 16 host threads run the oracle's full planTrajectory (cc:7-63) on the
+same queries and compare sample by sample (oracle/ltp_oracle.c: ltpo_compare_dense). Plans beyond the tolerance are listed
+with a cause class, as SURVEY.md §8(d) asks: root-classification, window-test flip, sample-index flip, else rounding.
+
+  python tools/dense_soak.py [panda_plans] [ref_plans] [ref30_plans] [fuzz_sets] [plans_per_fuzz_set] [out.json]
+"""
+import ctypes as C
+import json
+import os
+import sys
+import time
+from concurrent.futures import ThreadPoolExecutor
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+import longtermplanner_amd as amd
+import oracle
+
+TOL = 1e-9
+argv = sys.argv[1:]
+n_panda = int(argv[0]) if len(argv) > 0 else 600_000
+n_ref = int(argv[1]) if len(argv) > 1 else 300_000
+n_ref30 = int(argv[2]) if len(argv) > 2 else 50_000
+n_fuzz_sets = int(argv[3]) if len(argv) > 3 else 24
+n_fuzz = int(argv[4]) if len(argv) > 4 else 2_500
+out_path = argv[5] if len(argv) > 5 else "gpurun_out/dense_soak.json"
+THREADS = max(1, min(len(os.sched_getaffinity(0)), 16))
+CHUNK_BYTES = 3 << 30                       # per host buffer; two buffers in flight
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int)
+_up = C.POINTER(C.c_ulonglong)
+olib = oracle.lib()
+olib.ltpo_compare_dense.restype = C.c_longlong
+
+
+def cause(ltp, orc, q):
+    """Why this query differs: compare the device's records with the oracle's (SURVEY.md §8(d) classes)."""
+    dev = ltp.planBatchHost(*q, sample=False)
+    o = orc.plan_batch(*q, sample=False)
+    if np.any(dev["mod"][0] != o["mod"][0]) or np.any(dev["dir"][0] != o["dir"][0]) or dev["slowest"][0] != o["slowest"][0]:
+        dv = np.abs(dev["v_drive"][0] - o["v_drive"][0])
+        return "root-classification" if np.any(np.isfinite(dv) & (dv > 1e-6)) else "window-test flip"
+    if dev["traj_len"][0] != o["traj_len"][0]:
+        return "sample-index flip (trajectory length)"
+    Ts = ltp.t_sample
+    a, b = dev["t_scaled"][0] / Ts, o["t_scaled"][0] / Ts
+    if np.any(np.floor(a) != np.floor(b)) or np.any(np.ceil(a) != np.ceil(b)):
+        return "sample-index flip"
+    dt = float(np.nanmax(np.abs(dev["t_scaled"][0] - o["t_scaled"][0])))
+    gain = float(np.max(orc.j_max)) / Ts
+    if dt > 0.0:
+        # cc:771-807: a fractional jerk sample is (t - Ts floor(t / Ts)) / Ts * j_max — a last-bit difference of a switching time
+        # (pow's last bit, which also differs between libm builds) reaches that ONE jerk sample multiplied by j_max / Ts
+        return (f"rounding: switching times differ by {dt:.2e} (last bits); the fractional jerk samples (cc:771-807) carry that "
+                f"times j_max / Ts = {gain:.1e}")
+    return "rounding"
+
+
+def soak(name, D, lim, Ts, n, seed, bufs):
+    ltp = amd.LongTermPlanner(D, Ts, device=0, **lim)
+    orc = oracle.Oracle(D, Ts, **lim)
+    t0 = time.time()
+    dq = ltp.generateQueries(n, seed=seed)
+    b = ltp.planSwitchTimesBatch(*dq)
+    torch.cuda.synchronize()
+    host = [np.ascontiguousarray(x.cpu().numpy()) for x in dq]
+    off = b.offsets.cpu().numpy().view(np.uint64)
+    cap = CHUNK_BYTES // 8
+    tile = torch.empty(cap, dtype=torch.float64, device="cuda")
+    maxd = np.zeros((n, 4))
+    flag = np.zeros(n, dtype=np.int32)
+    compared = [0]
+    pending = [None, None]
+    bounds, first = [], 0
+    while first < n:
+        end = int(np.searchsorted(off, off[first] + np.uint64(cap), side="right")) - 1
+        assert end > first, "one trajectory does not fit the chunk buffer"
+        bounds.append((first, min(end, n)))
+        first = min(end, n)
+    with ThreadPoolExecutor(THREADS) as ex:
+        # the device's lengths / status words are complete only after a chunk's sampler ran (END_LIMIT bits): per chunk copies
+        for ci, (f, e) in enumerate(bounds):
+            slot = ci & 1
+            if pending[slot] is not None:
+                for fut in pending[slot]:
+                    compared[0] += fut.result()
+            used = int(off[e] - off[f])
+            tile[:used].zero_()
+            ltp.sampleBatch(b, f, e - f, tile)
+            hb = bufs[slot]
+            hb[:used].copy_(tile[:used], non_blocking=True)
+            torch.cuda.synchronize()
+            dev_len = np.ascontiguousarray(b.traj_len[f:e].cpu().numpy())
+            dev_st = np.ascontiguousarray(b.status[f:e].cpu().numpy())
+            hnp = hb.numpy()
+            step = -(-(e - f) // THREADS)
+
+            def work(t, f=f, e=e, hnp=hnp, dev_len=dev_len, dev_st=dev_st):
+                lo = f + t * step
+                cnt = min(step, e - lo)
+                if cnt <= 0:
+                    return 0
+                # the comparator indexes inputs / offsets / device records by absolute plan number: shift the chunk-local arrays
+                return int(olib.ltpo_compare_dense(orc._ref, C.c_long(lo), C.c_long(cnt), *[x.ctypes.data_as(_dp) for x in host],
+                                                   hnp.ctypes.data_as(_dp), off.ctypes.data_as(_up), C.c_ulonglong(int(off[f])),
+                                                   C.cast(dev_len.ctypes.data - 4 * f, _ip), C.cast(dev_st.ctypes.data - 4 * f, _ip),
+                                                   maxd[lo:].ctypes.data_as(_dp), flag[lo:].ctypes.data_as(_ip)))
+            pending[slot] = [ex.submit(work, t) for t in range(THREADS)]
+        for slot in (0, 1):
+            if pending[slot] is not None:
+                for fut in pending[slot]:
+                    compared[0] += fut.result()
+    worst = maxd.max(axis=0)
+    beyond = np.nonzero((maxd.max(axis=1) > TOL) | ((flag & 7) != 0))[0]
+    outliers = []
+    for p in beyond[:40]:
+        q = [x[p:p + 1] for x in host]
+        outliers.append({"query": int(p), "max_abs_d": [float(x) for x in maxd[p]], "flags": int(flag[p]), "cause": cause(ltp, orc, q)})
+    st = b.status.cpu().numpy()
+    res = {"dof": D, "t_sample": Ts, "seed": seed, "dense_plans": int(n), "sampled": int(np.sum((st & 0x57) == 0)),
+           "values_compared": int(compared[0]), "bytes_compared": int(compared[0]) * 8,
+           "max_abs_d": {k: float(worst[i]) for i, k in enumerate("qvaj")},
+           "plans_beyond_tolerance": int(np.sum(maxd.max(axis=1) > TOL)),
+           "verdict_mismatches": int(np.sum((flag & 1) != 0)), "length_mismatches": int(np.sum((flag & 2) != 0)),
+           "end_limit_flag_mismatches": int(np.sum((flag & 4) != 0)), "end_limit_false": int(np.sum((st & 8) != 0)),
+           "plans_bit_identical_in_every_sample": int(np.sum(((flag & 8) == 0) & ((flag & 3) == 0) & ((st & 0x57) == 0))),
+           "fraction_within_tolerance": float(1.0 - beyond.size / n), "outliers": outliers,
+           "seconds": round(time.time() - t0, 1)}
+    del tile
+    torch.cuda.empty_cache()
+    print(name, json.dumps(res), flush=True)
+    return res
+
+
+def main():
+    bufs = [torch.empty(CHUNK_BYTES // 8, dtype=torch.float64, pin_memory=True) for _ in range(2)]
+    report = {"tolerance": TOL, "host_threads": THREADS, "what": "every q/v/a/j sample of the device's dense rows vs the oracle's planTrajectory", "sets": {}}
+    for name, n in (("panda", n_panda), ("ref", n_ref), ("ref30", n_ref30)):
+        if n > 0:
+            D, lim = amd.limit_set(name)
+            report["sets"][name] = soak(name, D, lim, 0.001, n, 4242, bufs)
+    rng = np.random.default_rng(2027)
+    fuzz = {"sets": [], "dense_plans": 0, "values_compared": 0, "plans_beyond_tolerance": 0, "max_abs_d": {k: 0.0 for k in "qvaj"},
+            "verdict_mismatches": 0, "length_mismatches": 0, "end_limit_flag_mismatches": 0, "plans_bit_identical_in_every_sample": 0, "outliers": []}
+    for trial in range(n_fuzz_sets):
+        D = int(rng.integers(1, 13))
+        ts = float(rng.choice([0.001, 0.002, 0.004, 0.01]))
+        v_max = rng.uniform(0.5, 3.0, D)
+        a_max = rng.uniform(1.0, 20.0, D)
+        j_max = a_max * rng.uniform(5.0, 600.0, D)
+        q_hi = rng.uniform(1.0, 3.5, D)
+        lim = dict(q_min=list(-q_hi), q_max=list(q_hi), v_max=list(v_max), a_max=list(a_max), j_max=list(j_max))
+        r = soak(f"fuzz{trial}", D, lim, ts, n_fuzz, 5000 + trial, bufs)
+        fuzz["sets"].append({"dof": D, "t_sample": ts, "max_abs_d": r["max_abs_d"], "plans_beyond_tolerance": r["plans_beyond_tolerance"]})
+        for k in ("dense_plans", "values_compared", "plans_beyond_tolerance", "verdict_mismatches", "length_mismatches", "end_limit_flag_mismatches",
+                  "plans_bit_identical_in_every_sample"):
+            fuzz[k] += r[k]
+        for k in "qvaj":
+            fuzz["max_abs_d"][k] = max(fuzz["max_abs_d"][k], r["max_abs_d"][k])
+        fuzz["outliers"] += [dict(o, set=trial) for o in r["outliers"]]
+    if n_fuzz_sets:
+        report["sets"]["fuzzed limit sets (dof 1-12, Ts 1-10 ms, random per-joint limits)"] = fuzz
+    report["total_dense_plans"] = sum(v["dense_plans"] for v in report["sets"].values())
+    report["total_values_compared"] = sum(v["values_compared"] for v in report["sets"].values())
+    os.makedirs(os.path.dirname(os.path.abspath(out_path)), exist_ok=True)
+    with open(out_path, "w") as f:
+        json.dump(report, f, indent=1)
+    print("wrote", out_path, "-", report["total_dense_plans"], "dense plans,", report["total_values_compared"], "values")
+
+
+if __name__ == "__main__":
+    main()
