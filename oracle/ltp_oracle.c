@@ -817,8 +817,8 @@ long ltpo_plan_batch(const ltpo_planner *P, long first, long count, const double
  * (`packed`: host copy of the device tile that starts at element `base`; plan p at offsets[p] - base, laid out
  * [q,v,a,j][dof][row stride = traj_len rounded up to 32]). Per plan: maxd[4] = max |d| over q, v, a, j (a NaN on one
  * side only counts as +inf) and flag bits: 1 = one side planned the query and the other rejected it,
- * 2 = trajectory lengths differ (nothing compared), 4 = end-limit verdicts (cc:59-61) differ, 8 = compared and NOT
- * bit-identical in every sample (informational: the tolerance test is the caller's).
+ * 2 = trajectory lengths differ (nothing compared), 4 = end-limit verdicts (cc:59-61) differ, 8 = compared and the JERK
+ * rows are not bit-identical (informational; q, v, a come from a different but equivalent summation order on the device).
  * dev_status: the device's LTP_STATUS_* word (bits 1|2|4|16|64 = rejected before sampling, 8 = end limit).
  * Returns the number of values compared.
  */
@@ -862,7 +862,7 @@ long long ltpo_compare_dense(const ltpo_planner *P, long first, long count, cons
                         else if (dev[k] != dev[k] && ref[k] != ref[k]) d = 0.0;         /* NaN on both sides */
                         else { d = fabs(dev[k] - ref[k]); if (!(d == d)) d = INFINITY; }
                         if (d > m) m = d;
-                        if (d != 0.0) *fl |= 8;
+                        if (d != 0.0 && x == 3) *fl |= 8;
                     }
                 }
                 md[x] = m;

@@ -161,9 +161,10 @@ def test_dense_comparator_of_the_soak_tool(oracle_mod):
     cnt, maxd, flag = run()
     assert cnt == 4 * D * int(lens.sum()) and not maxd.any() and not flag.any()
     packed[int(off[5]) + 7] += 1e-6                          # q of joint 0, sample 7 of plan 5
+    packed[int(off[8]) + 3 * D * ((int(lens[8]) + 31) // 32 * 32) + 2] += 1e-13      # a jerk sample of plan 8, below any tolerance
     status[6] ^= 8
     lens[7] += 1
     status[3] = 0                                            # the device "planned" a query the oracle rejects
     cnt, maxd, flag = run()
-    assert abs(maxd[5, 0] - 1e-6) < 1e-12 and not maxd[5, 1:].any() and flag[5] == 8 and flag[6] == 4 and flag[7] == 2 and flag[3] == 1
-    assert np.count_nonzero(maxd) == 1 and np.count_nonzero(flag) == 4
+    assert abs(maxd[5, 0] - 1e-6) < 1e-12 and not maxd[5, 1:].any() and flag[5] == 0 and flag[6] == 4 and flag[7] == 2 and flag[3] == 1 and flag[8] == 8
+    assert np.count_nonzero(maxd) == 2 and np.count_nonzero(flag) == 4

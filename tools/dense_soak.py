@@ -128,7 +128,7 @@ def soak(name, D, lim, Ts, n, seed, bufs):
            "plans_beyond_tolerance": int(np.sum(maxd.max(axis=1) > TOL)),
            "verdict_mismatches": int(np.sum((flag & 1) != 0)), "length_mismatches": int(np.sum((flag & 2) != 0)),
            "end_limit_flag_mismatches": int(np.sum((flag & 4) != 0)), "end_limit_false": int(np.sum((st & 8) != 0)),
-           "plans_bit_identical_in_every_sample": int(np.sum(((flag & 8) == 0) & ((flag & 3) == 0) & ((st & 0x57) == 0))),
+           "plans_with_bit_identical_jerk_rows": int(np.sum(((flag & 8) == 0) & ((flag & 3) == 0) & ((st & 0x57) == 0))),
            "fraction_within_tolerance": float(1.0 - beyond.size / n), "outliers": outliers,
            "seconds": round(time.time() - t0, 1)}
     del tile
@@ -146,7 +146,7 @@ def main():
             report["sets"][name] = soak(name, D, lim, 0.001, n, 4242, bufs)
     rng = np.random.default_rng(2027)
     fuzz = {"sets": [], "dense_plans": 0, "values_compared": 0, "plans_beyond_tolerance": 0, "max_abs_d": {k: 0.0 for k in "qvaj"},
-            "verdict_mismatches": 0, "length_mismatches": 0, "end_limit_flag_mismatches": 0, "plans_bit_identical_in_every_sample": 0, "outliers": []}
+            "verdict_mismatches": 0, "length_mismatches": 0, "end_limit_flag_mismatches": 0, "plans_with_bit_identical_jerk_rows": 0, "outliers": []}
     for trial in range(n_fuzz_sets):
         D = int(rng.integers(1, 13))
         ts = float(rng.choice([0.001, 0.002, 0.004, 0.01]))
@@ -158,7 +158,7 @@ def main():
         r = soak(f"fuzz{trial}", D, lim, ts, n_fuzz, 5000 + trial, bufs)
         fuzz["sets"].append({"dof": D, "t_sample": ts, "max_abs_d": r["max_abs_d"], "plans_beyond_tolerance": r["plans_beyond_tolerance"]})
         for k in ("dense_plans", "values_compared", "plans_beyond_tolerance", "verdict_mismatches", "length_mismatches", "end_limit_flag_mismatches",
-                  "plans_bit_identical_in_every_sample"):
+                  "plans_with_bit_identical_jerk_rows"):
             fuzz[k] += r[k]
         for k in "qvaj":
             fuzz["max_abs_d"][k] = max(fuzz["max_abs_d"][k], r["max_abs_d"][k])
