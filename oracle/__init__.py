@@ -28,7 +28,7 @@ _LIB_PATH = os.path.join(_HERE, "libltp_oracle.so")
 
 def build(force=False):
     """Compile the C restatement (gcc). Building the checker is not using it."""
-    src_time = max(os.path.getmtime(os.path.join(_HERE, f)) for f in ("ltp_oracle.c", "kat_grid.c", "companion_roots.inc", "Makefile"))
+    src_time = max(os.path.getmtime(os.path.join(_HERE, f)) for f in ("ltp_oracle.c", "kat_grid.c", "companion_roots.inc", "matlab_roots.inc", "Makefile"))
     if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < src_time:
         subprocess.check_call(["make", "-C", _HERE, "-s", "clean", "all"])
     return _LIB_PATH
@@ -38,7 +38,7 @@ class _Planner(C.Structure):
     _fields_ = [("dof", C.c_int), ("t_sample", C.c_double),
                 ("q_min", C.POINTER(C.c_double)), ("q_max", C.POINTER(C.c_double)),
                 ("v_max", C.POINTER(C.c_double)), ("a_max", C.POINTER(C.c_double)),
-                ("j_max", C.POINTER(C.c_double))]
+                ("j_max", C.POINTER(C.c_double)), ("semantics", C.c_int)]
 
 
 _lib = None
@@ -95,9 +95,12 @@ def smallest_root(poly):
 class Oracle:
     """Mirror of the reference class (ctor args as long_term_planner.h:118-131)."""
 
-    def __init__(self, dof, t_sample, q_min, q_max, v_max, a_max, j_max):
+    def __init__(self, dof, t_sample, q_min, q_max, v_max, a_max, j_max, semantics="cpp"):
+        """semantics: "cpp" = src/long_term_planner.cc (the parity reference), "matlab" = LTPlanner.m where it diverges
+        (LTPlanner.m has no position limits: q_min / q_max are ignored then)."""
         self.dof = int(dof)
         self.t_sample = float(t_sample)
+        self.semantics = {"cpp": 0, "matlab": 1}[semantics]
         self.set_limits(q_min, q_max, v_max, a_max, j_max)
 
     def set_limits(self, q_min, q_max, v_max, a_max, j_max):
@@ -111,7 +114,8 @@ class Oracle:
         self._sync()
 
     def _sync(self):
-        self._p = _Planner(self.dof, self.t_sample, _d(self.q_min), _d(self.q_max), _d(self.v_max), _d(self.a_max), _d(self.j_max))
+        self._p = _Planner(self.dof, self.t_sample, _d(self.q_min), _d(self.q_max), _d(self.v_max), _d(self.a_max), _d(self.j_max),
+                           getattr(self, "semantics", 0))
 
     @property
     def _ref(self):
@@ -181,6 +185,10 @@ class Oracle:
                                      g("status", _ip), g("checksum"))
         del null_d
         r["n_ok"] = int(n_ok)
+        if want_records and self.semantics == 1:
+            # MATLAB semantics: bits 4 / 5 of the C status word = LTPlanner.m would have carried a complex value / raised an error
+            r["matlab_flags"] = r["status"] >> 4
+            r["status"] = r["status"] & 15
         return r
 
     def plan_trajectory(self, q_goal, q_0, v_0, a_0):
@@ -199,6 +207,15 @@ class Oracle:
                 break
         out.update(status=st, length=n, q=q, v=v, a=a, j=j)
         return out
+
+
+def matlab_roots(poly):
+    """MATLAB's roots() as LTPlanner.m sees it (oracle/matlab_roots.inc): complex array in MATLAB's output order."""
+    p = _arr(poly)
+    n = p.size - 1
+    re = np.empty(n); im = np.empty(n); nr = C.c_int()
+    st = lib().ltpm_roots(_d(p), C.c_int(n), _d(re), _d(im), C.byref(nr))
+    return (re + 1j * im)[:nr.value], st
 
 
 def poly_log(fn, cap=200000):

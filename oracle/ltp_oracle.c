@@ -72,7 +72,44 @@ typedef struct {
     int dof;
     double t_sample;
     const double *q_min, *q_max, *v_max, *a_max, *j_max;
+    int semantics;   /* 0 = the C++ reference (src/long_term_planner.cc), 1 = the MATLAB original (LTPlanner.m), see below */
 } ltpo_planner;
+
+/*
+ * MATLAB-semantics mode. With P->semantics == 1 the functions below follow LTPlanner.m wherever
+ * it diverges from the C++ translation; every such branch cites the .m lines. What MATLAB does that plain real arithmetic
+ * cannot is DEFINED here, identically to the HIP product, and reported through ltpo_matlab_flags():
+ *   LTPM_COMPLEX  MATLAB's sqrt of a negative number is a complex value that then flows through the formulas (and a
+ *                 filtered polynomial root may carry an imaginary part below eps, LTPlanner.m:247-249). This restatement
+ *                 continues with the REAL PART (sqrt -> 0) and applies the safety test |imag(t_rel)| > eps
+ *                 (LTPlanner.m:294-297) to the imaginary part where it arose; the plan is delivered and flagged.
+ *   LTPM_ERROR    LTPlanner.m would have raised an error: checkInputs (LTPlanner.m:92-103), an index past the filtered
+ *                 roots (:250), a vector assigned to t_rel(1) (:275: the filter must leave exactly one root), NaN / Inf
+ *                 polynomial coefficients. The query is rejected (status 0, no trajectory).
+ * PARITY PIN STATUS of this mode: the three MATLAB unit tables (tests/unittests/ *.m, all seven switching times) and the
+ * end-error bounds of the two MATLAB grid tests (tests/gridTestOneJoint.m, gridTestTimeScaling.m), held in
+ * tests/golden/reference_kat.json; the eigenvalue ORDER that the positional root picks depend on is pinned against
+ * numpy.roots (same LAPACK driver), against MATLAB itself it is unpinned (no MATLAB or Octave in this image).
+ */
+#define LTPM_COMPLEX 1
+#define LTPM_ERROR 2
+static _Thread_local int ltpm_flags = 0;
+static _Thread_local double ltpm_imag = 0.0;   /* largest imaginary part that entered t_rel in the current optSwitchTimes */
+int ltpo_matlab_flags(int clear) { int f = ltpm_flags; if (clear) ltpm_flags = 0; return f; }
+
+#include "matlab_roots.inc"
+
+/* sqrt as LTPlanner.m's arithmetic sees it: MATLAB returns i*sqrt(-x) for x < 0 (C++: NaN) */
+static double sem_sqrt(const ltpo_planner *P, double x)
+{
+    if (P->semantics == 1 && x < 0.0) {
+        const double im = sqrt(-x);
+        ltpm_flags |= LTPM_COMPLEX;
+        if (im > ltpm_imag) ltpm_imag = im;
+        return 0.0;
+    }
+    return sqrt(x);
+}
 
 /* exported: eigenvalues in Eigen's order (roots.h:22-34); status as in the .inc */
 int ltpo_roots_f64(const double *p, int degree, double *re, double *im)
@@ -110,6 +147,65 @@ static double solve_poly(const double *p, int degree)
     return r;
 }
 
+/*
+ * LTPlanner.m:247-250 / 272-275: root = root(abs(imag(root)) < eps); root = root(root >= 0) — MATLAB compares the real
+ * parts — then root(1) (site A) or the whole filtered vector assigned to the scalar t_rel(1) (site B: an error unless
+ * exactly one root is left). The real part is used; an imaginary part below eps is recorded (sem_sqrt's convention).
+ */
+static double matlab_filtered_root(const double *c, int deg, double eps, int must_be_single)
+{
+    double re[MR_MAXN], im[MR_MAXN], pick = NAN, pick_im = 0.0;
+    int nr = 0, i, kept = 0;
+    const int st = ltpm_roots(c, deg, re, im, &nr);
+    if (st != 0) { ltpm_flags |= LTPM_ERROR; return NAN; }
+    for (i = 0; i < nr; i++) {
+        if (fabs(im[i]) < eps && re[i] >= 0.0) {
+            if (kept == 0) { pick = re[i]; pick_im = fabs(im[i]); }
+            kept++;
+        }
+    }
+    if (kept == 0 || (must_be_single && kept != 1)) { ltpm_flags |= LTPM_ERROR; return NAN; }
+    if (pick_im != 0.0) {
+        ltpm_flags |= LTPM_COMPLEX;
+        if (pick_im > ltpm_imag) ltpm_imag = pick_im;
+    }
+    if (g_poly_log && g_poly_n < g_poly_cap) {
+        double *row = g_poly_log + 9 * g_poly_n++;
+        row[0] = deg;
+        for (i = 0; i < 7; i++) row[1 + i] = (i <= deg) ? c[i] : 0.0;
+        row[8] = pick;
+    }
+    return pick;
+}
+
+/*
+ * The square of the root a timeScaling candidate uses. C++ (cc:467-627): the smallest positive exactly-real root.
+ * LTPlanner.m:345-416: root(k) BY POSITION in the output of roots(); v_drive is then tested with ~imag(v_drive), i.e. the
+ * square of a complex root must be exactly real, else the candidate is skipped (NaN here has the same effect).
+ */
+static double root_squared(const ltpo_planner *P, const double *c, int deg, int k)
+{
+    if (P->semantics == 1) {
+        double re[MR_MAXN], im[MR_MAXN], rr, ri;
+        int nr = 0, i;
+        const int st = ltpm_roots(c, deg, re, im, &nr);
+        if (st != 0 || k > nr) { ltpm_flags |= LTPM_ERROR; return NAN; }   /* roots() error / index exceeds the number of elements */
+        rr = re[k - 1] * re[k - 1] - im[k - 1] * im[k - 1];
+        ri = 2.0 * (re[k - 1] * im[k - 1]);
+        if (g_poly_log && g_poly_n < g_poly_cap) {
+            double *row = g_poly_log + 9 * g_poly_n++;
+            row[0] = deg;
+            for (i = 0; i < 7; i++) row[1 + i] = (i <= deg) ? c[i] : 0.0;
+            row[8] = im[k - 1] == 0.0 ? re[k - 1] : NAN;
+        }
+        return ri != 0.0 ? NAN : rr;
+    }
+    {
+        const double root = solve_poly(c, deg);
+        return pow(root, 2);
+    }
+}
+
 /* long_term_planner.h:54-56 */
 static int sgn(double v) { return (0.0 < v) - (v < 0.0); }
 
@@ -123,7 +219,9 @@ int ltpo_check_inputs(const ltpo_planner *P, const double *q_0, const double *v_
 {
     int i;
     for (i = 0; i < P->dof; i++) {
-        if (q_0[i] < P->q_min[i] || q_0[i] > P->q_max[i] || fabs(v_0[i]) > P->v_max[i] || fabs(a_0[i]) > P->a_max[i]) return 0;
+        /* LTPlanner.m:92-103 has no position limits at all; its three tests raise error() */
+        if (P->semantics != 1 && (q_0[i] < P->q_min[i] || q_0[i] > P->q_max[i])) return 0;
+        if (fabs(v_0[i]) > P->v_max[i] || fabs(a_0[i]) > P->a_max[i]) return 0;
         if (fabs(v_0[i] + 0.5 * a_0[i] * fabs(a_0[i]) / P->j_max[i]) > P->v_max[i]) return 0;
     }
     return 1;
@@ -147,7 +245,7 @@ int ltpo_opt_braking(const ltpo_planner *P, int joint, double v_0, double a_0, d
     t_rel[2] = am / jm;
     t_rel[1] = (-v_0 - 1.0 / 2.0 * t_rel[0] * a_0) / am - 1.0 / 2.0 * (t_rel[0] + t_rel[2]);
     if (t_rel[1] < -P->t_sample) {
-        t_rel[0] = -a_0 / jm + sqrt(P2(a_0) / (2 * P2(jm)) - v_0 / jm);
+        t_rel[0] = -a_0 / jm + sem_sqrt(P, P2(a_0) / (2 * P2(jm)) - v_0 / jm);   /* LTPlanner.m:476: complex for a negative argument */
         t_rel[2] = t_rel[0] + a_0 / jm;
         t_rel[1] = 0;
     }
@@ -178,7 +276,18 @@ int ltpo_opt_switch_times(const ltpo_planner *P, int joint, double q_goal, doubl
     double r[7] = {0, 0, 0, 0, 0, 0, 0};
     double q_stop = 0, q_diff, q_brake = 0.0, emp, q_part1 = 0, q_part2;
     int i;
+    const int matlab = P->semantics == 1;
     *mod = 0;
+    if (matlab) {
+        /* LTPlanner.m:131 -> :92-103: checkInputs inside optSwitchTimes, error() on violation */
+        ltpm_imag = 0.0;
+        if (fabs(v_0) > P->v_max[joint] || fabs(a_0) > P->a_max[joint] ||
+            fabs(v_0 + 1.0 / 2.0 * a_0 * fabs(a_0) / jm) > P->v_max[joint]) {
+            ltpm_flags |= LTPM_ERROR;
+            zero7(t);
+            return 0;
+        }
+    }
 
     ltpo_opt_braking(P, joint, v_0, a_0, &q_stop, r, dir);
     q_diff = q_goal - (q_0 + q_stop);
@@ -249,7 +358,7 @@ int ltpo_opt_switch_times(const ltpo_planner *P, int joint, double q_goal, doubl
         double root;
         if (*mod == 1) {
             zero7(t);
-            return 0;
+            return matlab ? 1 : 0;   /* LTPlanner.m:222-227 returns the zeros like any other result; cc:195-200 returns false */
         }
         root = (P2(jm) * P4(r[0])) / 2 -
                (P2(jm) * P4(r[2])) / 4 +
@@ -300,9 +409,10 @@ int ltpo_opt_switch_times(const ltpo_planner *P, int joint, double q_goal, doubl
                    48 * *dir * P2(jm) * q_goal +
                    16 * P3(a_0) - 48 * a_0 * jm * v_0;
             c[4] = -3 * P4(a_0) + 12.0 * P2(a_0) * jm * v_0 - 12.0 * P2(jm) * P2(v_0);
-            root = solve_poly(c, 4);
+            root = matlab ? matlab_filtered_root(c, 4, eps, 0) : solve_poly(c, 4);   /* LTPlanner.m:247-250: first root that passes the filter */
+            if (matlab && (ltpm_flags & LTPM_ERROR)) { zero7(t); return 0; }
             r[0] = (2.0 * P2(root) - 4 * a_0 * root + P2(a_0) - 2.0 * v_0 * jm) / (4 * jm * root);
-            r[6] = sqrt(4 * P2(jm) * P2(r[0]) +
+            r[6] = sem_sqrt(P, 4 * P2(jm) * P2(r[0]) +
                         8 * a_0 * jm * r[0] +
                         2.0 * P2(a_0) +
                         4 * jm * v_0) / (2.0 * jm);
@@ -312,8 +422,8 @@ int ltpo_opt_switch_times(const ltpo_planner *P, int joint, double q_goal, doubl
 
             if (a_0 + r[0] * jm > am) {
                 r[0] = (am - a_0) / jm;
-                r[6] = 1.0 / jm * (am / 2 + sqrt(
-                           9 * P2(am) + 6 * sqrt(
+                r[6] = 1.0 / jm * (am / 2 + sem_sqrt(P,
+                           9 * P2(am) + 6 * sem_sqrt(P,
                                -12.0 * am * P3(jm) * P3(r[0]) +
                                9 * P2(a_0) * P2(jm) * P2(r[0]) -
                                18 * a_0 * am * P2(jm) * P2(r[0]) +
@@ -349,7 +459,8 @@ int ltpo_opt_switch_times(const ltpo_planner *P, int joint, double q_goal, doubl
                        24 * a_0 * jm * v_0 * am -
                        12.0 * P2(am) * jm * v_0 +
                        12.0 * P2(jm) * P2(v_0);
-                root = solve_poly(c, 4);
+                root = matlab ? matlab_filtered_root(c, 4, eps, 1) : solve_poly(c, 4);   /* LTPlanner.m:272-275: the filter must leave exactly one root */
+                if (matlab && (ltpm_flags & LTPM_ERROR)) { zero7(t); return 0; }
                 r[0] = (root - a_0 - am) / jm;
                 r[4] = (a_0 + am) / jm + r[0];
                 r[5] = (P2(jm) * P2(r[0]) +
@@ -364,6 +475,16 @@ int ltpo_opt_switch_times(const ltpo_planner *P, int joint, double q_goal, doubl
             r[2] = 0;
             r[3] = 0;
         }
+    }
+    if (matlab) {
+        /* LTPlanner.m:288-303: any(t_rel < -eps) or any(|imag(t_rel)| > eps) zeroes t_rel (no failure); then
+         * t_rel = max(0, real(t_rel)), which also turns NaN into 0 (MATLAB's max ignores NaN) */
+        int bad = 0;
+        for (i = 0; i < 7; i++) if (r[i] < -eps) bad = 1;
+        if (ltpm_imag > eps) bad = 1;
+        for (i = 0; i < 7; i++) r[i] = (bad || !(r[i] > 0.0)) ? 0.0 : r[i];
+        cumsum7(r, t);
+        return 1;
     }
     /* cc:340-348 (the std::cerr diagnostic is not reproduced) */
     for (i = 0; i < 7; i++) {
@@ -396,7 +517,7 @@ int ltpo_time_scaling_ex(const ltpo_planner *P, int joint, double q_goal, double
 {
     const double am = P->a_max[joint], jm = P->j_max[joint];
     const double tr = t_required;
-    double c[7], root;
+    double c[7], root2;
     int dummy;
     if (!case_out) case_out = &dummy;
     if (dir < 0) {
@@ -474,8 +595,8 @@ int ltpo_time_scaling_ex(const ltpo_planner *P, int joint, double q_goal, double
            48 * P2(a_0) * jm * v_0 +
            48 * P2(am) * jm * v_0 +
            48 * P2(jm) * P2(v_0);
-    root = solve_poly(c, 4);
-    *v_drive = (-2.0 * P2(a_0) + 4 * jm * v_0 + P2(root)) / (4 * jm);
+    root2 = root_squared(P, c, 4, 3);      /* LTPlanner.m:346 root(3) */
+    *v_drive = (-2.0 * P2(a_0) + 4 * jm * v_0 + root2) / (4 * jm);
     *case_out = 3;
     if (try_v_drive(P, joint, q_goal, q_0, v_0, a_0, dir, tr, *v_drive, scaled_t, mod)) return 1;
 
@@ -500,8 +621,8 @@ int ltpo_time_scaling_ex(const ltpo_planner *P, int joint, double q_goal, double
            12.0 * am * jm * v_0 +
            4 * a_0 * am -
            4 * P2(am);
-    root = solve_poly(c, 4);
-    *v_drive = P2(root) / jm;
+    root2 = root_squared(P, c, 4, 3);      /* LTPlanner.m:360 root(3) */
+    *v_drive = root2 / jm;
     *case_out = 4;
     if (try_v_drive(P, joint, q_goal, q_0, v_0, a_0, dir, tr, *v_drive, scaled_t, mod)) return 1;
 
@@ -512,8 +633,8 @@ int ltpo_time_scaling_ex(const ltpo_planner *P, int joint, double q_goal, double
     c[3] = (-144 * dir * P3(jm) * q_0 * tr + 144 * dir * P3(jm) * q_goal * tr - 48 * P3(a_0) * jm * tr - 144 * a_0 * dir * P2(jm) * q_0 + 144 * a_0 * dir * P2(jm) * q_goal + 144 * a_0 * P2(jm) * v_0 * tr + 6 * P4(a_0) - 72.0 * P2(a_0) * jm * v_0 + 216 * P2(jm) * P2(v_0));
     c[4] = 0;
     c[5] = -72.0 * P2(dir) * P4(jm) * P2(q_0) + 144 * P2(dir) * P4(jm) * q_0 * q_goal - 72.0 * P2(dir) * P4(jm) * P2(q_goal) - 48 * P3(a_0) * dir * P2(jm) * q_0 + 48 * P3(a_0) * dir * P2(jm) * q_goal + 144 * a_0 * dir * P3(jm) * q_0 * v_0 - 144 * a_0 * dir * P3(jm) * q_goal * v_0 + P6(a_0) - 6 * P4(a_0) * jm * v_0 + 36 * P2(a_0) * P2(jm) * P2(v_0) - 72.0 * P3(jm) * P3(v_0);
-    root = solve_poly(c, 5);
-    *v_drive = P2(root) / jm;
+    root2 = root_squared(P, c, 5, 2);      /* LTPlanner.m:374 root(2) */
+    *v_drive = root2 / jm;
     *case_out = 5;
     if (try_v_drive(P, joint, q_goal, q_0, v_0, a_0, dir, tr, *v_drive, scaled_t, mod)) return 1;
 
@@ -523,8 +644,8 @@ int ltpo_time_scaling_ex(const ltpo_planner *P, int joint, double q_goal, double
     c[2] = (12.0 * am * jm * tr - 6 * P2(a_0) - 12.0 * a_0 * am - 6 * P2(am) - 12.0 * jm * v_0);
     c[3] = 0;
     c[4] = -12.0 * P2(a_0) * am * jm * tr - 24 * dir * P2(jm) * am * q_0 + 24 * dir * P2(jm) * am * q_goal - 24 * am * P2(jm) * v_0 * tr + 3 * P4(a_0) + 4 * P3(a_0) * am + 6 * P2(a_0) * P2(am) + 12.0 * P2(a_0) * jm * v_0 + 12.0 * P2(am) * jm * v_0 + 12.0 * P2(jm) * P2(v_0);
-    root = solve_poly(c, 4);
-    *v_drive = -(P2(root) - P2(a_0) - 2.0 * jm * v_0) / (2.0 * jm);
+    root2 = root_squared(P, c, 4, 3);      /* LTPlanner.m:388 root(3) */
+    *v_drive = -(root2 - P2(a_0) - 2.0 * jm * v_0) / (2.0 * jm);
     *case_out = 6;
     if (try_v_drive(P, joint, q_goal, q_0, v_0, a_0, dir, tr, *v_drive, scaled_t, mod)) return 1;
 
@@ -534,8 +655,8 @@ int ltpo_time_scaling_ex(const ltpo_planner *P, int joint, double q_goal, double
     c[2] = (24 * am * jm * tr - 12.0 * P2(a_0) - 24 * a_0 * am - 12.0 * P2(am) - 24 * jm * v_0);
     c[3] = 0;
     c[4] = 24 * dir * P2(jm) * am * q_0 - 24 * dir * P2(jm) * am * q_goal + 3 * P4(a_0) + 8 * P3(a_0) * am + 6 * P2(a_0) * P2(am) + 12.0 * P2(a_0) * jm * v_0 + 24 * a_0 * am * jm * v_0 + 12.0 * P2(am) * jm * v_0 + 12.0 * P2(jm) * P2(v_0);
-    root = solve_poly(c, 4);
-    *v_drive = P2(root) / jm;
+    root2 = root_squared(P, c, 4, 3);      /* LTPlanner.m:402 root(3) */
+    *v_drive = root2 / jm;
     *case_out = 7;
     if (try_v_drive(P, joint, q_goal, q_0, v_0, a_0, dir, tr, *v_drive, scaled_t, mod)) return 1;
 
@@ -556,8 +677,8 @@ int ltpo_time_scaling_ex(const ltpo_planner *P, int joint, double q_goal, double
            6 * P4(a_0) * jm * v_0 -
            36 * P2(a_0) * P2(jm) * P2(v_0) -
            72.0 * P3(jm) * P3(v_0);
-    root = solve_poly(c, 6);
-    *v_drive = P2(root) / jm;
+    root2 = root_squared(P, c, 6, 4);      /* LTPlanner.m:416 root(4); the C++ notes "WAS root(4) --> Debug this" (cc:628) */
+    *v_drive = root2 / jm;
     *case_out = 8;
     if (try_v_drive(P, joint, q_goal, q_0, v_0, a_0, dir, tr, *v_drive, scaled_t, mod)) return 1;
 
@@ -589,6 +710,103 @@ int ltpo_traj_len(const ltpo_planner *P, const double *t /* [dof][7] */)
     return len;
 }
 
+
+/*
+ * MATLAB's mod(x, y) for y > 0 as LTPlanner.m:531 uses it: x - floor(x./y).*y, except that "if y is not an integer and the
+ * quotient x./y is within roundoff error of an integer, then n is that integer" (MATLAB documentation of mod), i.e. the
+ * result is 0. The round-off test is restated with GNU Octave's published rule (|q - round(q)| / |round(q)| < eps): MATLAB's
+ * own constant is not documented. The C++ translation computes t - Ts*floor(t/Ts) without that rule (cc:747).
+ */
+static double matlab_mod(double x, double y)
+{
+    double q, n;
+    if (y == 0.0) return x;
+    q = x / y;
+    n = nearbyint(q);
+    if (nearbyint(y) != y && fabs((q - n) / n) < DBL_EPSILON) return 0.0;
+    {
+        volatile double tmp = y * floor(q);
+        return x - tmp;
+    }
+}
+
+/*
+ * LTPlanner.m:486-625 getTrajectories, 1-based there, 0-based here (index k of MATLAB is k-1). Differences to cc:706-841:
+ *   - the fractional corrections land one sample EARLIER (the C++ kept MATLAB's index expressions in 0-based arrays);
+ *   - a = Ts*cumsum(j) + a_0, v = Ts*cumsum(a) + v_0, q = Ts*cumsum(v) + q_0 (:604, :610, :624): the sums run over the
+ *     arrays as they stand, so v continues from the un-snapped sum after the constant-velocity samples;
+ *   - the constant-velocity samples are S3+1 .. S4-1 (1-based, :616) and the tail starts at S7+1 (:607, :620), one sample
+ *     earlier than in the C++;
+ *   - :607 "a_traj(joint, sampled_t(joint,7)+1:end) = 0" stands AFTER the joint loop: only the LAST joint's acceleration
+ *     tail is zeroed (reproduced as is);
+ *   - sample fractions come from mod() (:531).
+ * j is returned as well (LTPlanner.m does not return it).
+ */
+static void matlab_get_trajectories(const ltpo_planner *P, const double *t, const double *dir, const char *mod,
+                                    const double *q_0, const double *v_0, const double *a_0, const double *v_drive,
+                                    int len, double *q, double *v, double *a, double *j)
+{
+    const double Ts = P->t_sample;
+    int joint;
+    memset(j, 0, sizeof(double) * (size_t)P->dof * len);
+#define JADDM(idx1, val) do { int ix_ = (idx1) - 1; if (ix_ >= 0 && ix_ < len) jt[ix_] = jt[ix_] + (val); } while (0)
+    for (joint = 0; joint < P->dof; joint++) {
+        const double *tj = t + 7 * joint;
+        double *jt = j + (size_t)joint * len, *at = a + (size_t)joint * len;
+        double *vt = v + (size_t)joint * len, *qt = q + (size_t)joint * len;
+        double fr[7], jp[7], cs;
+        int s[7], prof[7], k, i, const_v;
+        if (mod[joint]) { int m[7] = {-1, 0, 1, 0, -1, 0, 1}; memcpy(prof, m, sizeof m); }
+        else { int m[7] = {1, 0, -1, 0, -1, 0, 1}; memcpy(prof, m, sizeof m); }
+        for (k = 0; k < 7; k++) jp[k] = dir[joint] * P->j_max[joint] * prof[k];
+        for (k = 0; k < 7; k++) fr[k] = matlab_mod(tj[k], Ts);
+        s[0] = (int)floor(tj[0] / Ts);
+        s[1] = (int)ceil(tj[1] / Ts);
+        s[2] = (int)floor(tj[2] / Ts);
+        s[3] = (int)ceil(tj[3] / Ts);
+        s[4] = (int)floor(tj[4] / Ts);
+        s[5] = (int)ceil(tj[5] / Ts);
+        s[6] = (int)floor(tj[6] / Ts);
+        /* :544-551, 1-based 1..S1 and S(k-1)+1..S(k) */
+        if (s[0] > 0) for (i = 0; i < s[0] && i < len; i++) jt[i] = jp[0];
+        for (k = 1; k < 7; k++)
+            if (s[k] - s[k - 1] > 0) for (i = s[k - 1]; i < s[k] && i < len; i++) jt[i] = jp[k];
+        /* :554-597 */
+        if (s[2] >= s[1]) {
+            JADDM(s[0] + 1, fr[0] / Ts * jp[0]);
+            if (s[1] > 0) JADDM(s[1], (1 - fr[1] / Ts) * jp[2]);
+            JADDM(s[2] + 1, fr[2] / Ts * jp[2]);
+        } else {
+            if (s[1] > 0) { JADDM(s[1], fr[0] / Ts * jp[0]); JADDM(s[1], (fr[2] - fr[0]) / Ts * jp[2]); }
+        }
+        if (s[3] > 0) JADDM(s[3], (1 - fr[3] / Ts) * jp[4]);
+        if (s[2] - s[0] > 0) {
+            JADDM(s[4] + 1, fr[4] / Ts * jp[4]);
+        } else {
+            if (s[4] > 0) { JADDM(s[4], fr[4] / Ts * jp[4]); JADDM(s[4], fr[0] / Ts * jp[0]); JADDM(s[4], (fr[2] - fr[0]) / Ts * jp[2]); }
+        }
+        if (s[5] > 0) JADDM(s[5], (1 - fr[5] / Ts) * jp[6]);
+        JADDM(s[6] + 1, fr[6] / Ts * jp[6]);
+        const_v = s[3] - s[2] > 2;                                            /* :600-602 */
+        /* :604 */
+        cs = 0.0;
+        for (i = 0; i < len; i++) { cs = cs + jt[i]; at[i] = Ts * cs + a_0[joint]; }
+        /* :607, outside the joint loop in LTPlanner.m: `joint` is DoF there */
+        if (joint == P->dof - 1) for (i = s[6]; i < len; i++) if (i >= 0) at[i] = 0.0;
+        /* :610 */
+        cs = 0.0;
+        for (i = 0; i < len; i++) { cs = cs + at[i]; vt[i] = Ts * cs + v_0[joint]; }
+        /* :615-617, 1-based S3+1 .. S4-1 */
+        if (const_v) for (i = s[2]; i <= s[3] - 2 && i < len; i++) if (i >= 0) vt[i] = v_drive[joint] * dir[joint];
+        /* :620 */
+        for (i = s[6]; i < len; i++) if (i >= 0) vt[i] = 0.0;
+        /* :624 */
+        cs = 0.0;
+        for (i = 0; i < len; i++) { cs = cs + vt[i]; qt[i] = Ts * cs + q_0[joint]; }
+    }
+#undef JADDM
+}
+
 /*
  * cc:706-841. Caller provides q,v,a,j as [dof][len] row-major, len = ltpo_traj_len().
  * Writes with an index >= len are dropped (DEFINED; reference UB).
@@ -600,6 +818,10 @@ void ltpo_get_trajectory(const ltpo_planner *P, const double *t /* [dof][7] */, 
     const double Ts = P->t_sample;
     int joint;
     if (len <= 0) return;
+    if (P->semantics == 1) {
+        matlab_get_trajectories(P, t, dir, mod, q_0, v_0, a_0, v_drive, len, q, v, a, j);
+        return;
+    }
     memset(q, 0, sizeof(double) * (size_t)P->dof * len);
     memset(v, 0, sizeof(double) * (size_t)P->dof * len);
     memset(a, 0, sizeof(double) * (size_t)P->dof * len);
@@ -677,9 +899,11 @@ int ltpo_plan_switch_times(const ltpo_planner *P, const double *q_goal, const do
         for (k = 0; k < 7; k++) { t_opt[7 * i + k] = 0; t_scaled[7 * i + k] = 0; }
         dirv[i] = 0; mod[i] = 0; v_drive[i] = P->v_max[i];
     }
-    if (!ltpo_check_inputs(P, q_0, v_0, a_0)) return 0;
+    if (P->semantics == 1) ltpm_flags &= ~LTPM_ERROR;
+    if (!ltpo_check_inputs(P, q_0, v_0, a_0)) { if (P->semantics == 1) ltpm_flags |= LTPM_ERROR; return 0; }
     for (i = 0; i < D; i++) {
         if (!ltpo_opt_switch_times(P, i, q_goal[i], q_0[i], v_0[i], a_0[i], P->v_max[i], t_opt + 7 * i, dirv + i, mod + i)) return 0;
+        if (P->semantics == 1) mod[i] = 0;   /* LTPlanner.m:64 discards optSwitchTimes' third output: mod_jerk_profile stays false */
     }
     for (i = 0; i < D; i++) {
         if (t_opt[7 * i + 6] > *t_required) {
@@ -692,7 +916,15 @@ int ltpo_plan_switch_times(const ltpo_planner *P, const double *q_goal, const do
         if (i == *slowest) continue;
         ltpo_time_scaling(P, i, q_goal[i], q_0[i], v_0[i], a_0[i], dirv[i], *t_required, t_scaled + 7 * i, v_drive + i, mod + i);
     }
+    if (P->semantics == 1 && (ltpm_flags & LTPM_ERROR)) return 0;   /* an error() inside timeScaling ends LTPlanner.m's trajectory() */
     for (i = 0; i < D; i++) {
+        if (P->semantics == 1) {
+            /* LTPlanner.m:82 ~any(t_scaled(joint,:)): every entry exactly zero (NaN counts as non-zero) */
+            int any = 0;
+            for (k = 0; k < 7; k++) if (t_scaled[7 * i + k] != 0.0) any = 1;
+            if (!any) for (k = 0; k < 7; k++) t_scaled[7 * i + k] = t_opt[7 * i + k];
+            continue;
+        }
         double mx = t_scaled[7 * i];
         for (k = 1; k < 7; k++) if (mx < t_scaled[7 * i + k]) mx = t_scaled[7 * i + k]; /* std::max_element */
         if (mx <= 0.0) for (k = 0; k < 7; k++) t_scaled[7 * i + k] = t_opt[7 * i + k];
@@ -736,7 +968,7 @@ static int plan_trajectory_impl(const ltpo_planner *P, const double *q_goal, con
         j = (double *)malloc(sizeof(double) * (size_t)D * len);
     }
     ltpo_get_trajectory(P, t_scaled, dirv, mod, q_0, v_0, a_0, v_drive, len, q, v, a, j);
-    for (i = 0; i < D; i++) {
+    for (i = 0; i < D && P->semantics != 1; i++) {   /* LTPlanner.m has no position limits: no end-limit check */
         double qe = q[(size_t)i * len + len - 1];
         if (qe < P->q_min[i] || qe > P->q_max[i]) { status = 2; break; }
     }
@@ -785,6 +1017,7 @@ long ltpo_plan_batch(const ltpo_planner *P, long first, long count, const double
     for (p = first; p < first + count; p++) {
         double treq, cs = 0;
         int slow, len = 0, st;
+        if (P->semantics == 1) ltpm_flags = 0;
         double *o_topt = t_opt ? t_opt + (size_t)p * 7 * D : b_topt;
         double *o_tsc = t_scaled ? t_scaled + (size_t)p * 7 * D : b_tsc;
         double *o_dir = dirv ? dirv + (size_t)p * D : b_dir;
@@ -802,7 +1035,8 @@ long ltpo_plan_batch(const ltpo_planner *P, long first, long count, const double
         if (t_required) t_required[p] = treq;
         if (slowest) slowest[p] = slow;
         if (traj_len) traj_len[p] = len;
-        if (status) status[p] = st;
+        /* MATLAB semantics: bits 4 / 5 of the status word carry LTPM_COMPLEX / LTPM_ERROR of this plan */
+        if (status) status[p] = P->semantics == 1 ? (st | (ltpm_flags << 4)) : st;
         if (checksum) checksum[p] = cs;
         if (st == 1) n_ok++;
     }
