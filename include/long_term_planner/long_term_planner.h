@@ -114,6 +114,7 @@ class LongTermPlanner {
   int max_samples_ = 0;
   int sample_stride_ = 1;
   bool goal_check_ = false;
+  int semantics_ = LTP_SEMANTICS_CPP;
 
   static void raise(const ltp_planner* h, int rc, const char* what) {
     throw std::runtime_error(std::string("long_term_planner (MI355X): ") + what + " failed with code " + std::to_string(rc) +
@@ -143,6 +144,7 @@ class LongTermPlanner {
       if ((rc = ltp_set_max_samples(t.h, max_samples_)) != LTP_OK) raise(t.h, rc, "ltp_set_max_samples");
       if ((rc = ltp_set_sample_stride(t.h, sample_stride_)) != LTP_OK) raise(t.h, rc, "ltp_set_sample_stride");
       if ((rc = ltp_set_goal_check(t.h, goal_check_ ? 1 : 0)) != LTP_OK) raise(t.h, rc, "ltp_set_goal_check");
+      if ((rc = ltp_set_semantics(t.h, semantics_)) != LTP_OK) raise(t.h, rc, "ltp_set_semantics");
       t.dirty = false;
     }
     return t.h;
@@ -199,12 +201,12 @@ class LongTermPlanner {
   LongTermPlanner(const LongTermPlanner& o)
       : dof_(o.dof_), t_sample_(o.t_sample_), q_min_(o.q_min_), q_max_(o.q_max_), v_max_(o.v_max_), a_max_(o.a_max_),
         j_max_(o.j_max_), device_(o.device_), max_samples_(o.max_samples_), sample_stride_(o.sample_stride_),
-        goal_check_(o.goal_check_) {}
+        goal_check_(o.goal_check_), semantics_(o.semantics_) {}
   LongTermPlanner& operator=(const LongTermPlanner& o) {
     if (this != &o) {
       dof_ = o.dof_; t_sample_ = o.t_sample_; q_min_ = o.q_min_; q_max_ = o.q_max_; v_max_ = o.v_max_; a_max_ = o.a_max_;
       j_max_ = o.j_max_; device_ = o.device_; max_samples_ = o.max_samples_; sample_stride_ = o.sample_stride_;
-      goal_check_ = o.goal_check_; markDirty();
+      goal_check_ = o.goal_check_; semantics_ = o.semantics_; markDirty();
     }
     return *this;
   }
@@ -217,10 +219,11 @@ class LongTermPlanner {
     planTrajectoryBatch(1, q_goal.data(), q_0.data(), v_0.data(), a_0.data(), b);
     const int st = b.status[0];
     // the reference leaves `traj` untouched when it returns false before sampling (cc:14-39)
-    if (st & (LTP_STATUS_INVALID_INPUT | LTP_STATUS_OPT_FAILED | LTP_STATUS_NO_SLOWEST | LTP_STATUS_NONFINITE | LTP_STATUS_GOAL_OUTSIDE))
+    if (st & (LTP_STATUS_INVALID_INPUT | LTP_STATUS_OPT_FAILED | LTP_STATUS_NO_SLOWEST | LTP_STATUS_NONFINITE | LTP_STATUS_GOAL_OUTSIDE |
+              LTP_STATUS_MATLAB_ERROR))
       return false;
     traj = b.trajectory(0);
-    return st == 0;   // LTP_STATUS_END_LIMIT: false with the trajectory filled (cc:59-61)
+    return (st & ~LTP_STATUS_MATLAB_COMPLEX) == 0;   // LTP_STATUS_END_LIMIT: false with the trajectory filled (cc:59-61)
   }
 
   /**
@@ -360,6 +363,11 @@ class LongTermPlanner {
   /** @brief NEW, off by default: reject a q_goal outside [q_min, q_max] before planning (LTP_STATUS_GOAL_OUTSIDE;
    * planTrajectory then returns false with traj untouched). The reference leaves q_goal unchecked (cc:68-77). */
   inline void setGoalCheck(bool enabled) { goal_check_ = enabled; markDirty(); }
+
+  /** @brief NEW, default false: follow the MATLAB original LTPlanner.m where the C++ translation diverges
+   * from it (positional root picks, zeros instead of failures, no position limits, 1-based sampler; ltp_hip.h
+   * LTP_SEMANTICS_MATLAB). BatchTrajectory::status may then carry LTP_STATUS_MATLAB_ERROR / LTP_STATUS_MATLAB_COMPLEX. */
+  inline void setMatlabSemantics(bool enabled) { semantics_ = enabled ? LTP_SEMANTICS_MATLAB : LTP_SEMANTICS_CPP; markDirty(); }
 
   /** @brief NEW: HIP device ordinal used by this planner (default 0). */
   inline void setDevice(int device) { if (device != device_) { device_ = device; markDirty(); } }

@@ -55,6 +55,23 @@ typedef enum {
                                     /* range; traj_len = 0, not sampled (reference: undefined behaviour)  */
 #define LTP_STATUS_OVERFLOW     32  /* trajectory did not fit the output tile passed to ltp_sample_batch  */
 #define LTP_STATUS_GOAL_OUTSIDE 64  /* only with ltp_set_goal_check(p, 1): q_goal outside [q_min,q_max]   */
+#define LTP_STATUS_MATLAB_ERROR 128 /* only with LTP_SEMANTICS_MATLAB: LTPlanner.m would have raised an error */
+                                    /* (checkInputs, index past / vector of filtered roots); traj_len = 0     */
+#define LTP_STATUS_MATLAB_COMPLEX 256 /* only with LTP_SEMANTICS_MATLAB, informational: LTPlanner.m would have */
+                                    /* carried a complex intermediate; real parts used, the plan IS delivered */
+
+/* Which source the arithmetic follows where the two references diverge:
+ * LTP_SEMANTICS_CPP     src/long_term_planner.cc — the parity reference, the default.
+ * LTP_SEMANTICS_MATLAB  the MATLAB original LTPlanner.m: polynomial roots picked by POSITION in the output of roots()
+ *                       (:346-416) or first-through-a-filter (:247-250, 272-275); optSwitchTimes returns zeros where the C++
+ *                       returns false (:222-227, 288-303); fallback rule ~any(t_scaled) (:82); no position limits (no q_0
+ *                       check, no end-limit verdict); the slowest joint's jerk-profile flag stays false (:64); sampler with
+ *                       1-based correction indices, mod(), cumsum-then-overwrite integration and the acceleration tail zeroed
+ *                       for the LAST joint only (:531-624). Rows still carry j as the fourth array. The order of MATLAB's
+ *                       roots() is restated from LAPACK's DGEEV path and checked against numpy.roots; against MATLAB itself
+ *                       this mode is pinned only by the MATLAB unit tables and grid tests the reference holds. */
+#define LTP_SEMANTICS_CPP 0
+#define LTP_SEMANTICS_MATLAB 1
 
 /* Queries: element (query p, joint j) of each array is ptr[p*query_stride + j*joint_stride].
  * Row-major [n][dof] (the reference's vector-per-query view): query_stride = dof, joint_stride = 1.
@@ -120,6 +137,11 @@ int ltp_get_sample_stride(const ltp_planner* p);
  * other query is planned exactly as before. */
 int ltp_set_goal_check(ltp_planner* p, int enabled);
 int ltp_get_goal_check(const ltp_planner* p);
+/* LTP_SEMANTICS_CPP (default) or LTP_SEMANTICS_MATLAB, see above. Captured with the batch geometry: the
+ * calls that consume a planned batch refuse a handle whose semantics changed in between. With MATLAB semantics rows and
+ * envelopes always take the table pass, single calls the staged path; ltp_end_limit_batch does nothing. */
+int ltp_set_semantics(ltp_planner* p, int semantics);
+int ltp_get_semantics(const ltp_planner* p);
 
 /* Table pass. A sampler / envelope item (one plan x <= 8 joints) needs the joint's run tables (<= 20 runs of constant jerk
  * with 10 closed-form coefficients each). They are either built inside the sampler kernel by the item's block (no extra
@@ -308,6 +330,11 @@ int ltp_roots_f64_host(ltp_planner* p, long long n, int degree, const double* co
 int ltp_roots_f32_host(ltp_planner* p, long long n, int degree, const float* coef, float* re, float* im);
 
 /* ---- diagnostics used by the parity tests ---------------------------------------------------- */
+/* MATLAB semantics: flags of the latest one-lane call (ltp_opt_*_host, ltp_time_scaling_host): 1 = complex intermediate, 2 = LTPlanner.m would have raised an error */
+int ltp_debug_last_matlab_flags(const ltp_planner* p);
+/* MATLAB's roots() as the MATLAB-semantics kernels compute it, n polynomials of degree 1..6: re, im [n][degree] in MATLAB's
+ * output order, nroots [n] (degree minus stripped leading zeros), status [n] (0 ok, 1 no convergence, 2 NaN / Inf) */
+int ltp_debug_roots_matlab_host(ltp_planner* p, long long n, int degree, const double* coef, double* re, double* im, int* nroots, int* status);
 /* device_buffer (3 x count u64, or NULL to switch off): k_sample block start / run tables ready / end on the
  * 100 MHz wall clock; ltp_envelope_batch writes 16 u64 per (plan, joint group) item instead: loop top, item drawn,
  * traj_len read, after each of the seven table-build barriers, reduction done */

@@ -20,6 +20,10 @@ STATUS_END_LIMIT = 8
 STATUS_NONFINITE = 16
 STATUS_OVERFLOW = 32
 STATUS_GOAL_OUTSIDE = 64
+STATUS_MATLAB_ERROR = 128
+STATUS_MATLAB_COMPLEX = 256
+SEMANTICS_CPP = 0
+SEMANTICS_MATLAB = 1
 
 ERROR_NAMES = {1: "LTP_ERR_INVALID_ARGUMENT", 2: "LTP_ERR_NO_DEVICE", 3: "LTP_ERR_OUT_OF_MEMORY", 4: "LTP_ERR_HIP"}
 
@@ -93,6 +97,10 @@ _SIGNATURES = {
     "ltp_plan_envelope_host": (C.c_int, [C.c_void_p, C.c_longlong, _dp, _dp, _dp, _dp, C.c_int, C.c_int, C.POINTER(Records), _dp]),
     "ltp_state_at_batch": (C.c_int, [C.c_void_p, C.c_longlong, C.c_longlong, C.POINTER(Queries), C.POINTER(Records), C.c_void_p, C.c_int,
                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_longlong, C.c_void_p]),
+    "ltp_set_semantics": (C.c_int, [C.c_void_p, C.c_int]),
+    "ltp_get_semantics": (C.c_int, [C.c_void_p]),
+    "ltp_debug_last_matlab_flags": (C.c_int, [C.c_void_p]),
+    "ltp_debug_roots_matlab_host": (C.c_int, [C.c_void_p, C.c_longlong, C.c_int, _dp, _dp, _dp, _ip, _ip]),
     "ltp_set_goal_check": (C.c_int, [C.c_void_p, C.c_int]),
     "ltp_get_goal_check": (C.c_int, [C.c_void_p]),
     "ltp_set_table_pass": (C.c_int, [C.c_void_p, C.c_int]),

@@ -58,26 +58,31 @@ k_generate(long long n, int dof, Limits lim, unsigned long long seed, long long 
 // One-lane mirrors of the protected member functions (for the reference's KAT-style tests).
 // ---------------------------------------------------------------------------------------
 // LongTermPlanner::checkInputs (cc:68-77) for one query
+template <int SEM>
 __global__ void k_check_inputs(int dof, Limits lim, const double* q_0, const double* v_0, const double* a_0, int* ok)
 {
     int good = 1;
     for (int j = 0; j < dof; ++j)
-        if (!check_inputs_joint(load_limits(lim, j), q_0[j], v_0[j], a_0[j])) good = 0;
+        if (!check_inputs_joint<SEM>(load_limits(lim, j), q_0[j], v_0[j], a_0[j])) good = 0;
     *ok = good;
 }
 
+template <int SEM>
 __global__ void k_single_opt_braking(int joint, double t_sample, Limits lim, double v_0, double a_0, double* out)
 {
     const JointLimits L = load_limits(lim, joint);
     double r[7] = {out[0], out[1], out[2], out[3], out[4], out[5], out[6]};
     double q, dir;
-    opt_braking(L.a_max, L.j_max, t_sample, v_0, a_0, q, r, dir);
+    MatlabCtx mc;
+    opt_braking<SEM>(L.a_max, L.j_max, t_sample, v_0, a_0, q, r, dir, mc);
 #pragma unroll
     for (int k = 0; k < 7; ++k) out[k] = r[k];
     out[7] = q;
     out[8] = dir;
+    out[11] = (double)mc.flags;
 }
 
+template <int SEM>
 __global__ void k_single_opt_switch(int joint, double t_sample, Limits lim, double q_goal, double q_0, double v_0, double a_0,
                                     double v_drive, double* io)
 {
@@ -85,14 +90,17 @@ __global__ void k_single_opt_switch(int joint, double t_sample, Limits lim, doub
     double t[7] = {io[0], io[1], io[2], io[3], io[4], io[5], io[6]};
     double dir = 0.0;
     int mod = 0;
-    const bool ok = opt_switch_times<true>(L.a_max, L.j_max, t_sample, q_goal, q_0, v_0, a_0, v_drive, t, dir, mod) == kOptTrue;
+    MatlabCtx mc;
+    const bool ok = opt_switch_times<true, SEM>(L.a_max, L.j_max, L.v_max, t_sample, q_goal, q_0, v_0, a_0, v_drive, t, dir, mod, mc) == kOptTrue;
 #pragma unroll
     for (int k = 0; k < 7; ++k) io[k] = t[k];
     io[7] = dir;
     io[8] = (double)mod;
     io[9] = ok ? 1.0 : 0.0;
+    io[11] = (double)mc.flags;
 }
 
+template <int SEM>
 __global__ void k_single_time_scaling(int joint, double t_sample, Limits lim, double q_goal, double q_0, double v_0, double a_0,
                                       double dir, double tr, double* io)
 {
@@ -100,13 +108,30 @@ __global__ void k_single_time_scaling(int joint, double t_sample, Limits lim, do
     double ts[7] = {io[0], io[1], io[2], io[3], io[4], io[5], io[6]};
     double vd;
     int mod = 0, which = 0;
-    const bool acc = time_scaling_full(L, t_sample, q_goal, q_0, v_0, a_0, dir, tr, vd, ts, mod, which);
+    MatlabCtx mc;
+    const bool acc = time_scaling_full<SEM>(L, t_sample, q_goal, q_0, v_0, a_0, dir, tr, vd, ts, mod, which, mc);
 #pragma unroll
     for (int k = 0; k < 7; ++k) io[k] = ts[k];
     io[7] = vd;
     io[8] = (double)mod;
     io[9] = acc ? 1.0 : 0.0;
     io[10] = (double)which;
+    io[11] = (double)mc.flags;
+}
+
+// MATLAB's roots() (ltp_roots_matlab.hpp) for the tests of the MATLAB-semantics mode
+__global__ void __launch_bounds__(64)
+k_roots_matlab(long long n, int degree, const double* __restrict__ coef, double* __restrict__ re, double* __restrict__ im,
+               int* __restrict__ nroots, int* __restrict__ status)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double c[mr::kMaxN + 1], r[mr::kMaxN], m[mr::kMaxN];
+    for (int k = 0; k <= degree; ++k) c[k] = coef[i * (degree + 1) + k];
+    int nr = 0;
+    status[i] = mr::roots(c, degree, r, m, nr);
+    nroots[i] = nr;
+    for (int k = 0; k < degree; ++k) { re[i * degree + k] = r[k]; im[i * degree + k] = m[k]; }
 }
 
 // device arithmetic probes: tests compare these with the host's libm bit for bit
@@ -200,24 +225,38 @@ void launch_generate(hipStream_t s, long long n, int dof, Limits lim, unsigned l
                        q_goal, q_0, v_0, a_0, sq, sj);
 }
 
-void launch_check_inputs(hipStream_t s, int dof, Limits lim, const double* q_0, const double* v_0, const double* a_0, int* ok)
+void launch_check_inputs(hipStream_t s, int dof, Limits lim, const double* q_0, const double* v_0, const double* a_0, int* ok, int semantics)
 {
-    hipLaunchKernelGGL(k_check_inputs, dim3(1), dim3(1), 0, s, dof, lim, q_0, v_0, a_0, ok);
+    if (semantics == kSemMatlab) hipLaunchKernelGGL(k_check_inputs<kSemMatlab>, dim3(1), dim3(1), 0, s, dof, lim, q_0, v_0, a_0, ok);
+    else hipLaunchKernelGGL(k_check_inputs<kSemCpp>, dim3(1), dim3(1), 0, s, dof, lim, q_0, v_0, a_0, ok);
 }
-void launch_single_opt_braking(hipStream_t s, int joint, double t_sample, Limits lim, double v_0, double a_0, double* out10)
+void launch_single_opt_braking(hipStream_t s, int joint, double t_sample, Limits lim, double v_0, double a_0, double* out10, int semantics)
 {
-    hipLaunchKernelGGL(k_single_opt_braking, dim3(1), dim3(1), 0, s, joint, t_sample, lim, v_0, a_0, out10);
+    if (semantics == kSemMatlab) hipLaunchKernelGGL(k_single_opt_braking<kSemMatlab>, dim3(1), dim3(1), 0, s, joint, t_sample, lim, v_0, a_0, out10);
+    else hipLaunchKernelGGL(k_single_opt_braking<kSemCpp>, dim3(1), dim3(1), 0, s, joint, t_sample, lim, v_0, a_0, out10);
+}
+void launch_roots_matlab(hipStream_t s, long long n, int degree, const double* coef, double* re, double* im, int* nroots, int* status)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_roots_matlab, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, n, degree, coef, re, im, nroots, status);
 }
 void launch_single_opt_switch(hipStream_t s, int joint, double t_sample, Limits lim, double q_goal, double q_0, double v_0,
-                              double a_0, double v_drive, double* io10)
+                              double a_0, double v_drive, double* io10, int semantics)
 {
-    hipLaunchKernelGGL(k_single_opt_switch, dim3(1), dim3(1), 0, s, joint, t_sample, lim, q_goal, q_0, v_0, a_0, v_drive, io10);
+    if (semantics == kSemMatlab)
+        hipLaunchKernelGGL(k_single_opt_switch<kSemMatlab>, dim3(1), dim3(1), 0, s, joint, t_sample, lim, q_goal, q_0, v_0, a_0, v_drive, io10);
+    else
+        hipLaunchKernelGGL(k_single_opt_switch<kSemCpp>, dim3(1), dim3(1), 0, s, joint, t_sample, lim, q_goal, q_0, v_0, a_0, v_drive, io10);
 }
 void launch_single_time_scaling(hipStream_t s, int joint, double t_sample, Limits lim, double q_goal, double q_0, double v_0,
-                                double a_0, double dir, double t_required, double* out11)
+                                double a_0, double dir, double t_required, double* out11, int semantics)
 {
-    hipLaunchKernelGGL(k_single_time_scaling, dim3(1), dim3(1), 0, s, joint, t_sample, lim, q_goal, q_0, v_0, a_0, dir,
-                       t_required, out11);
+    if (semantics == kSemMatlab)
+        hipLaunchKernelGGL(k_single_time_scaling<kSemMatlab>, dim3(1), dim3(1), 0, s, joint, t_sample, lim, q_goal, q_0, v_0, a_0, dir,
+                           t_required, out11);
+    else
+        hipLaunchKernelGGL(k_single_time_scaling<kSemCpp>, dim3(1), dim3(1), 0, s, joint, t_sample, lim, q_goal, q_0, v_0, a_0, dir,
+                           t_required, out11);
 }
 void launch_math_probe(hipStream_t s, long long n, const double* x, const double* y, double* out)
 {

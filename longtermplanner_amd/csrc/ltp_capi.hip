@@ -43,6 +43,7 @@ struct ltp_planner {
     bool small_dirty = false;              // a fused small-batch call failed: k_plan_small's arrival word may be non-zero
     const char* last_kernel = "";          // row / envelope kernel of the latest ltp_sample_batch* / ltp_envelope_batch
     int semantics = 0;                     // LTP_SEMANTICS_CPP (the reference's C++, default) or LTP_SEMANTICS_MATLAB
+    int last_matlab_flags = 0;             // MATLAB semantics: flags of the latest one-lane call (1 = complex intermediate, 2 = error)
     unsigned long long* dbg_stamps = nullptr; // diagnostic: per-block start/end stamps of k_sample (caller-owned)
     // persistent buffers of the small synchronous host-pointer calls (no hipMalloc per call)
     std::mutex host_mu;
@@ -58,7 +59,7 @@ struct ltp_planner {
     hipEvent_t ws_event = nullptr;
     bool ws_used = false;
     // geometry of the batches planned by this handle (include/ltp_hip.h, "Batch geometry")
-    struct Geometry { bool valid = false; int dof = 0; double t_sample = 0.0; int max_samples = 0; int stride = 1; } planned;
+    struct Geometry { bool valid = false; int dof = 0; double t_sample = 0.0; int max_samples = 0; int stride = 1; int semantics = 0; } planned;
     std::mutex mu;
     std::string err;
 };
@@ -219,15 +220,16 @@ void capture_geometry(ltp_planner* p)
     p->planned.t_sample = p->t_sample;
     p->planned.max_samples = p->max_samples;
     p->planned.stride = p->sample_stride;
+    p->planned.semantics = p->semantics;
 }
 
 // consumers of a planned batch: the handle must still have the geometry the batch was planned with
 int check_geometry(ltp_planner* p)
 {
     const auto& g = p->planned;
-    if (g.valid && (g.dof != p->dof || g.t_sample != p->t_sample || g.max_samples != p->max_samples || g.stride != p->sample_stride))
+    if (g.valid && (g.dof != p->dof || g.t_sample != p->t_sample || g.max_samples != p->max_samples || g.stride != p->sample_stride || g.semantics != p->semantics))
         return fail(p, LTP_ERR_INVALID_ARGUMENT,
-                    "dof, t_sample, max_samples or sample_stride changed since the batch was planned; plan it again");
+                    "dof, t_sample, max_samples, sample_stride or the semantics changed since the batch was planned; plan it again");
     return LTP_OK;
 }
 
@@ -411,6 +413,14 @@ int ltp_set_goal_check(ltp_planner* p, int enabled)
     return LTP_OK;
 }
 int ltp_get_goal_check(const ltp_planner* p) { return p ? p->goal_check : -1; }
+int ltp_set_semantics(ltp_planner* p, int semantics)
+{
+    if (!p || (semantics != LTP_SEMANTICS_CPP && semantics != LTP_SEMANTICS_MATLAB)) return fail(p, LTP_ERR_INVALID_ARGUMENT, "semantics must be LTP_SEMANTICS_CPP or LTP_SEMANTICS_MATLAB");
+    std::lock_guard<std::mutex> g(p->mu);
+    p->semantics = semantics;
+    return LTP_OK;
+}
+int ltp_get_semantics(const ltp_planner* p) { return p ? p->semantics : -1; }
 int ltp_set_table_pass(ltp_planner* p, int mode)
 {
     if (!p || mode < -1 || mode > 1) return fail(p, LTP_ERR_INVALID_ARGUMENT, "table pass mode must be -1, 0 or 1");
@@ -497,7 +507,7 @@ int ltp_plan_switch_times_batch(ltp_planner* p, long long n, const ltp_queries* 
     const ltp::Queries q = to_dev(in);
     const ltp::Records r = to_dev(out);
     LTP_HIP_TRY(p, hipMemsetAsync(p->d_queue_count, 0, 16 * sizeof(unsigned long long), s));
-    ltp::launch_switch_times(s, n, p->dof, p->t_sample, p->goal_check, L, q, r, p->d_lane_flags, p->d_queue, p->d_queue_count);
+    ltp::launch_switch_times(s, n, p->dof, p->t_sample, p->goal_check, L, q, r, p->d_lane_flags, p->d_queue, p->d_queue_count, p->semantics);
     ltp::launch_offsets(s, n, p->dof, p->t_sample, r, p->d_block_sums, offsets ? offsets : p->d_offsets_scratch, true, ltp::RowSpec{p->max_samples, p->sample_stride});
     LTP_HIP_TRY(p, hipGetLastError());
     return workspace_release(p, s, capturing);
@@ -510,6 +520,7 @@ int ltp_end_limit_batch(ltp_planner* p, long long first, long long count, const 
     int rc = check_config(p);
     if (rc == LTP_OK) rc = check_geometry(p);
     if (rc != LTP_OK) return rc;
+    if (p->semantics == LTP_SEMANTICS_MATLAB) return LTP_OK;   // LTPlanner.m has no position limits: there is no end-limit verdict
     LTP_HIP_TRY(p, hipSetDevice(p->device));
     ltp::launch_end_limit((hipStream_t)stream, first, count, p->dof, p->t_sample, dev_limits(p), to_dev(in), to_dev(rec));
     LTP_HIP_TRY(p, hipGetLastError());
@@ -534,7 +545,10 @@ static int sample_batch_any(ltp_planner* p, long long first, long long count, co
     const int blocks = p->sample_blocks_override > 0 ? p->sample_blocks_override : p->sample_blocks[f32 ? 1 : 0];
     // bytes of one joint's four rows when the cap applies (a cap is the only way rows are known to be short up front)
     const unsigned long long row_bytes = p->max_samples > 0 ? 4ull * (f32 ? 4 : 8) * (unsigned long long)p->max_samples : 0ull;
-    if (!(flags & 2) && (!p->dbg_stamps || (flags & 4)) && ((flags & 4) || (!(flags & 8) && want_table_pass(p, row_bytes, f32)))) {
+    // MATLAB semantics: the run tables always come from the table pass (k_build_tables<MATLAB>); the sampler kernels that read
+    // tables do not depend on the semantics, the fused build of k_sample exists for the C++ semantics only
+    const bool matlab = p->semantics == LTP_SEMANTICS_MATLAB;
+    if (matlab || (!(flags & 2) && (!p->dbg_stamps || (flags & 4)) && ((flags & 4) || (!(flags & 8) && want_table_pass(p, row_bytes, f32))))) {
         // table pass: per piece of the range, k_build_tables then the sampler variant that reads the tables
         bool capturing = false;
         if ((rc = workspace_acquire(p, s, capturing)) != LTP_OK) return rc;
@@ -544,8 +558,8 @@ static int sample_batch_any(ltp_planner* p, long long first, long long count, co
             const long long c = first + count - f < piece ? first + count - f : piece;
             unsigned long long* head = p->d_sample_next + (p->sample_next_slot++ & 63u);
             LTP_HIP_TRY(p, hipMemsetAsync(head, 0, sizeof(unsigned long long), s));
-            ltp::launch_build_tables(s, f, c, p->dof, p->t_sample, dev_limits(p), to_dev(in), to_dev(rec), rows, false, offsets, first, p->d_tables);
-            ltp::launch_sample_tab(s, f, c, first, p->dof, to_dev(rec), offsets, out, f32, capacity, flags, rows, head,
+            ltp::launch_build_tables(s, f, c, p->dof, p->t_sample, dev_limits(p), to_dev(in), to_dev(rec), rows, false, offsets, first, p->d_tables, p->semantics);
+            ltp::launch_sample_tab(s, f, c, first, p->dof, to_dev(rec), offsets, out, f32, capacity, flags & ~2, rows, head,
                                    p->sample_blocks_override > 0 ? p->sample_blocks_override : p->sample_blocks[f32 ? 4 : 3], p->d_tables, p->dbg_stamps);
         }
         LTP_HIP_TRY(p, hipGetLastError());
@@ -588,7 +602,7 @@ int ltp_envelope_batch(ltp_planner* p, long long first, long long count, const l
     if ((rc = reserve(p, 0)) != LTP_OK) return rc;
     const hipStream_t s = (hipStream_t)stream;
     const int blocks = p->sample_blocks_override > 0 ? p->sample_blocks_override : p->sample_blocks[2];
-    if (!p->dbg_stamps && (p->table_pass > 0 || (p->table_pass == 0 && kEnvelopeTablePassByDefault))) {
+    if (p->semantics == LTP_SEMANTICS_MATLAB || (!p->dbg_stamps && (p->table_pass > 0 || (p->table_pass == 0 && kEnvelopeTablePassByDefault)))) {
         bool capturing = false;
         if ((rc = workspace_acquire(p, s, capturing)) != LTP_OK) return rc;
         long long piece = 0;
@@ -597,7 +611,7 @@ int ltp_envelope_batch(ltp_planner* p, long long first, long long count, const l
             const long long c = first + count - f < piece ? first + count - f : piece;
             unsigned long long* head = p->d_sample_next + (p->sample_next_slot++ & 63u);
             LTP_HIP_TRY(p, hipMemsetAsync(head, 0, sizeof(unsigned long long), s));
-            ltp::launch_build_tables(s, f, c, p->dof, p->t_sample, dev_limits(p), to_dev(in), to_dev(rec), ltp::RowSpec{0, 1}, true, nullptr, f, p->d_tables);
+            ltp::launch_build_tables(s, f, c, p->dof, p->t_sample, dev_limits(p), to_dev(in), to_dev(rec), ltp::RowSpec{0, 1}, true, nullptr, f, p->d_tables, p->semantics);
             ltp::launch_envelope(s, f, c, first, p->dof, p->t_sample, dev_limits(p), to_dev(in), to_dev(rec), window, n_windows, env, head,
                                  blocks, nullptr, p->d_tables);
         }
@@ -644,7 +658,7 @@ int ltp_state_at_batch(ltp_planner* p, long long first, long long count, const l
     if (rc != LTP_OK) return rc;
     LTP_HIP_TRY(p, hipSetDevice(p->device));
     ltp::launch_state_at((hipStream_t)stream, first, count, p->dof, p->t_sample, dev_limits(p), to_dev(in), to_dev(rec), sample_index,
-                         uniform_index, q_0, v_0, a_0, query_stride, joint_stride);
+                         uniform_index, q_0, v_0, a_0, query_stride, joint_stride, p->semantics);
     LTP_HIP_TRY(p, hipGetLastError());
     return LTP_OK;
 }
@@ -1025,6 +1039,7 @@ int run_one_lane(ltp_planner* p, double (&buf)[16], Launch launch)
     LTP_HIP_TRY(p, hipGetLastError());
     LTP_HIP_TRY(p, hipStreamSynchronize(nullptr));
     memcpy(buf, p->h_arena, sizeof(buf));
+    p->last_matlab_flags = (int)buf[11];
     return LTP_OK;
 }
 }  // extern "C++"
@@ -1046,7 +1061,7 @@ int ltp_plan_batch_host(ltp_planner* p, long long n, const double* q_goal, const
     const double* const h_in[4] = {q_goal, q_0, v_0, a_0};
     if (n > 0 && dof > 0 && arena_layout(n, dof).end <= kSmallHostBytes) {
         std::lock_guard<std::mutex> hg(p->host_mu);
-        if (nd <= (size_t)ltp::small_batch_pairs()) {
+        if (nd <= (size_t)ltp::small_batch_pairs() && p->semantics == LTP_SEMANTICS_CPP) {   // k_plan_small exists for the C++ semantics only
             bool handled = false;
             rc = plan_batch_host_fused(p, n, h_in, host_records, nullptr, offsets, packed, &handled);
             if (rc != LTP_OK || handled) return rc;
@@ -1360,7 +1375,7 @@ int ltp_get_trajectory_host(ltp_planner* p, long long n, const double* t, const 
     if (n > 0 && dof > 0 && arena_layout(n, dof).end <= kSmallHostBytes) {
         // staged path: persistent arena + pinned mirror, one upload, one download
         std::lock_guard<std::mutex> hg(p->host_mu);
-        if (nd <= (size_t)ltp::small_batch_pairs()) {
+        if (nd <= (size_t)ltp::small_batch_pairs() && p->semantics == LTP_SEMANTICS_CPP) {
             // fused path: one launch, rows written straight into the pinned result buffer
             const double* const h_in[4] = {nullptr, q_0, v_0, a_0};
             const ltp_records given{nullptr, const_cast<double*>(t), const_cast<double*>(dir), const_cast<double*>(v_drive),
@@ -1459,7 +1474,7 @@ int ltp_check_inputs_host(ltp_planner* p, const double* q_0, const double* v_0, 
     memcpy(p->h_arena + row, v_0, sizeof(double) * dof);
     memcpy(p->h_arena + 2 * row, a_0, sizeof(double) * dof);
     ltp::launch_check_inputs(nullptr, dof, dev_limits(p), (const double*)p->h_arena, (const double*)(p->h_arena + row),
-                             (const double*)(p->h_arena + 2 * row), (int*)(p->h_arena + 3 * row));   // pinned: no copies
+                             (const double*)(p->h_arena + 2 * row), (int*)(p->h_arena + 3 * row), p->semantics);   // pinned: no copies
     LTP_HIP_TRY(p, hipGetLastError());
     LTP_HIP_TRY(p, hipStreamSynchronize(nullptr));
     *ok = *(const int*)(p->h_arena + 3 * row);
@@ -1474,7 +1489,7 @@ int ltp_opt_braking_host(ltp_planner* p, int joint, double v_0, double a_0, doub
     LTP_HIP_TRY(p, hipSetDevice(p->device));
     double buf[16] = {0};
     memcpy(buf, t_rel, sizeof(double) * 7);
-    const int rc = run_one_lane(p, buf, [&](double* io) { ltp::launch_single_opt_braking(nullptr, joint, p->t_sample, dev_limits(p), v_0, a_0, io); });
+    const int rc = run_one_lane(p, buf, [&](double* io) { ltp::launch_single_opt_braking(nullptr, joint, p->t_sample, dev_limits(p), v_0, a_0, io, p->semantics); });
     if (rc != LTP_OK) return rc;
     memcpy(t_rel, buf, sizeof(double) * 7);
     *q = buf[7];
@@ -1491,7 +1506,7 @@ int ltp_opt_switch_times_host(ltp_planner* p, int joint, double q_goal, double q
     LTP_HIP_TRY(p, hipSetDevice(p->device));
     double buf[16] = {0};
     memcpy(buf, t, sizeof(double) * 7);
-    const int rc = run_one_lane(p, buf, [&](double* io) { ltp::launch_single_opt_switch(nullptr, joint, p->t_sample, dev_limits(p), q_goal, q_0, v_0, a_0, v_drive, io); });
+    const int rc = run_one_lane(p, buf, [&](double* io) { ltp::launch_single_opt_switch(nullptr, joint, p->t_sample, dev_limits(p), q_goal, q_0, v_0, a_0, v_drive, io, p->semantics); });
     if (rc != LTP_OK) return rc;
     memcpy(t, buf, sizeof(double) * 7);
     *dir = buf[7];
@@ -1509,7 +1524,7 @@ int ltp_time_scaling_host(ltp_planner* p, int joint, double q_goal, double q_0, 
     LTP_HIP_TRY(p, hipSetDevice(p->device));
     double buf[16] = {0};
     memcpy(buf, scaled_t, sizeof(double) * 7);
-    const int rc = run_one_lane(p, buf, [&](double* io) { ltp::launch_single_time_scaling(nullptr, joint, p->t_sample, dev_limits(p), q_goal, q_0, v_0, a_0, dir, t_required, io); });
+    const int rc = run_one_lane(p, buf, [&](double* io) { ltp::launch_single_time_scaling(nullptr, joint, p->t_sample, dev_limits(p), q_goal, q_0, v_0, a_0, dir, t_required, io, p->semantics); });
     if (rc != LTP_OK) return rc;
     memcpy(scaled_t, buf, sizeof(double) * 7);
     *v_drive = buf[7];
@@ -1561,6 +1576,30 @@ int ltp_roots_f64_host(ltp_planner* p, long long n, int degree, const double* co
 int ltp_roots_f32_host(ltp_planner* p, long long n, int degree, const float* coef, float* re, float* im)
 {
     return roots_host_any(p, n, degree, true, coef, re, im);
+}
+
+int ltp_debug_last_matlab_flags(const ltp_planner* p) { return p ? p->last_matlab_flags : -1; }
+
+int ltp_debug_roots_matlab_host(ltp_planner* p, long long n, int degree, const double* coef, double* re, double* im, int* nroots, int* status)
+{
+    if (!p || n < 0 || degree < 1 || degree > 6 || !coef || !re || !im || !nroots || !status) return fail(p, LTP_ERR_INVALID_ARGUMENT, "bad argument (degree 1..6)");
+    LTP_HIP_TRY(p, hipSetDevice(p->device));
+    double *dc = nullptr, *dr = nullptr, *di = nullptr;
+    int *dn = nullptr, *ds = nullptr;
+    DevRecords holder;
+    LTP_HIP_TRY(p, holder.alloc(&dc, (size_t)n * (degree + 1)));
+    LTP_HIP_TRY(p, holder.alloc(&dr, (size_t)n * degree));
+    LTP_HIP_TRY(p, holder.alloc(&di, (size_t)n * degree));
+    LTP_HIP_TRY(p, holder.alloc(&dn, (size_t)n));
+    LTP_HIP_TRY(p, holder.alloc(&ds, (size_t)n));
+    LTP_HIP_TRY(p, hipMemcpy(dc, coef, sizeof(double) * (size_t)n * (degree + 1), hipMemcpyHostToDevice));
+    ltp::launch_roots_matlab(nullptr, n, degree, dc, dr, di, dn, ds);
+    LTP_HIP_TRY(p, hipGetLastError());
+    LTP_HIP_TRY(p, hipMemcpy(re, dr, sizeof(double) * (size_t)n * degree, hipMemcpyDeviceToHost));
+    LTP_HIP_TRY(p, hipMemcpy(im, di, sizeof(double) * (size_t)n * degree, hipMemcpyDeviceToHost));
+    LTP_HIP_TRY(p, hipMemcpy(nroots, dn, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost));
+    LTP_HIP_TRY(p, hipMemcpy(status, ds, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost));
+    return LTP_OK;
 }
 
 int ltp_debug_set_sample_stamps(ltp_planner* p, unsigned long long* device_buffer)

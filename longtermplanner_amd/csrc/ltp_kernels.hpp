@@ -26,6 +26,9 @@ enum : int {
     kStatusNonFinite = 16,     // DEFINED: non-finite switching times -> traj_len 0 (reference: UB)
     kStatusOverflow = 32,      // trajectory does not fit the caller's output tile; not sampled
     kStatusGoalOutside = 64,   // NEW, opt-in: q_goal outside [q_min,q_max]; rejected before planning (reference: unchecked)
+    kStatusMatlabError = 128,  // MATLAB semantics only: LTPlanner.m would have raised an error; rejected, traj_len 0
+    kStatusMatlabComplex = 256,// MATLAB semantics only, informational: LTPlanner.m would have carried a complex intermediate
+                               // value; the plan continues with the real part and IS delivered
 };
 
 constexpr int kQueriesPerBlock = 64;   // one wave = 64 queries of one joint
@@ -77,7 +80,8 @@ struct Records {           // query-major outputs of stages 1-3
 
 long long queue_segment(long long n, int dof);   // entries per queue shard; a batch needs 2 * 8 * this many u64
 void launch_switch_times(hipStream_t s, long long n, int dof, double t_sample, int goal_check, Limits lim, Queries in,
-                         Records out, signed char* lane_flags, unsigned long long* queue_items, unsigned long long* counts);
+                         Records out, signed char* lane_flags, unsigned long long* queue_items, unsigned long long* counts,
+                         int semantics = 0 /* 0 = the C++ reference, 1 = LTPlanner.m (ltp_profile.hpp) */);
 void launch_offsets(hipStream_t s, long long n, int dof, double t_sample, Records rec,
                     unsigned long long* block_sums, unsigned long long* offsets, bool lens_ready, RowSpec rows);
 // Run tables: built inside the sampler / envelope kernel by the item's block, or by the table pass —
@@ -88,7 +92,7 @@ unsigned long long table_bytes(long long lanes /* plans * dof */);
 void launch_build_tables(hipStream_t s, long long first, long long count, int dof, double t_sample, Limits lim, Queries in, Records rec,
                          RowSpec rows, bool whole_trajectory /* false: only the runs capped rows touch */,
                          const unsigned long long* offsets /* or nullptr */, long long base_first /* row offsets relative to this plan */,
-                         unsigned long long* tables);
+                         unsigned long long* tables, int semantics = 0);
 void launch_sample(hipStream_t s, long long first, long long count, int dof, double t_sample, Limits lim, Queries in,
                    Records rec, const unsigned long long* offsets, void* out, bool f32, unsigned long long capacity,
                    int flags, RowSpec rows, unsigned long long* next_item /* zeroed on the same stream */,
@@ -110,7 +114,7 @@ void launch_replan_states(hipStream_t s, long long first, long long count, int d
 void launch_end_limit(hipStream_t s, long long first, long long count, int dof, double t_sample, Limits lim, Queries in, Records rec);
 void launch_state_at(hipStream_t s, long long first, long long count, int dof, double t_sample, Limits lim, Queries in,
                      Records rec, const int* sample_index, int uniform_index, double* q_0, double* v_0, double* a_0,
-                     long long sq, long long sj);
+                     long long sq, long long sj, int semantics = 0);
 // planTrajectory for n queries with n * dof <= small_batch_pairs() in one launch of one block; every pointer may be host
 // memory the device can address (pinned). rows == nullptr: no sampling (status still carries the end-limit verdict).
 // *done becomes 1 when all results are visible to the host, 2 if the rows did not fit `capacity` (then nothing was sampled).
@@ -125,13 +129,16 @@ void launch_plan_small(hipStream_t s, int n, int dof, double t_sample, int goal_
 void launch_generate(hipStream_t s, long long n, int dof, Limits lim, unsigned long long seed, long long first_query,
                      double* q_goal, double* q_0, double* v_0, double* a_0, long long sq, long long sj);
 
-void launch_check_inputs(hipStream_t s, int dof, Limits lim, const double* q_0, const double* v_0, const double* a_0, int* ok);
-// single-joint mirrors of the protected methods (one lane)
-void launch_single_opt_braking(hipStream_t s, int joint, double t_sample, Limits lim, double v_0, double a_0, double* out10);
+void launch_check_inputs(hipStream_t s, int dof, Limits lim, const double* q_0, const double* v_0, const double* a_0, int* ok, int semantics = 0);
+// single-joint mirrors of the protected methods (one lane); io[11] receives the lane's MATLAB flags (kMatlabComplex | kMatlabError)
+void launch_single_opt_braking(hipStream_t s, int joint, double t_sample, Limits lim, double v_0, double a_0, double* out10, int semantics = 0);
 void launch_single_opt_switch(hipStream_t s, int joint, double t_sample, Limits lim, double q_goal, double q_0, double v_0,
-                              double a_0, double v_drive, double* io10);
+                              double a_0, double v_drive, double* io10, int semantics = 0);
 void launch_single_time_scaling(hipStream_t s, int joint, double t_sample, Limits lim, double q_goal, double q_0, double v_0,
-                                double a_0, double dir, double t_required, double* out11);
+                                double a_0, double dir, double t_required, double* out11, int semantics = 0);
+// MATLAB's roots() on the device (ltp_roots_matlab.hpp): n polynomials of `degree` <= 6, [n][degree+1] coefficients; re, im
+// [n][degree] in MATLAB's output order, nroots [n], status [n] (0 ok, 1 no convergence, 2 NaN / Inf)
+void launch_roots_matlab(hipStream_t s, long long n, int degree, const double* coef, double* re, double* im, int* nroots, int* status);
 void launch_math_probe(hipStream_t s, long long n, const double* x, const double* y, double* out);
 void launch_roots_probe(hipStream_t s, long long n, int degree, const double* coef, double* root);
 void launch_roots_all(hipStream_t s, long long n, int degree, bool f32, const void* coef, void* re, void* im);

@@ -24,6 +24,7 @@ namespace ltp {
 // ---------------------------------------------------------------------------------------
 constexpr int kModeTail = 1;    // i > s6: a = 0, v = 0 (cc:815-829)
 constexpr int kModeVSnap = 2;   // phase 4 interior: v = v_drive*dir (cc:822-823)
+constexpr int kModeKeepA = 4;   // MATLAB semantics, tail of every joint but the last: a keeps following the jerk sums (LTPlanner.m:607)
 
 // Inside one run, with m = 1-based position in the run, S1 = m(m+1)/2 and S2 = m(m+1)(m+2)/6:
 //   q(m) = q0 + (q1*m + (q2*S1 + q3*S2))   {q_s, Ts*v_s, Ts*Ts*a_s, Ts*Ts*Ts*J}
@@ -80,6 +81,7 @@ __device__ const signed char kCutDelta[kCutSlots] = {0, 0, 1, 2, 0, 1, 0, 1, 2, 
 // to eight "+=" fractional corrections (cc:768-807), applied in the reference's order and association (cc:781 and
 // cc:798 add two / three terms to the element one after the other). s = sampled switch indices,
 // Jp = jerk of the seven phases, corr = the correction terms, all in LDS.
+template <int SEM = kSemCpp>
 LTP_DEV double jerk_at(const int* s, const double* Jp, const double* corr, int i)
 {
     const int s0 = s[0], s1 = s[1], s2 = s[2], s3 = s[3], s4 = s[4], s5 = s[5], s6 = s[6];
@@ -91,25 +93,29 @@ LTP_DEV double jerk_at(const int* s, const double* Jp, const double* corr, int i
     if (s4 - s3 > 0 && i >= s3 && i < s4) val = Jp[4];
     if (s5 - s4 > 0 && i >= s4 && i < s5) val = Jp[5];
     if (s6 - s5 > 0 && i >= s5 && i < s6) val = Jp[6];
+    // LTPlanner.m:558-597 addresses the same elements in a 1-BASED array: every correction lands one sample earlier than in
+    // the C++, which kept the index expressions for its 0-based arrays
+    constexpr int o = SEM == kSemMatlab ? 1 : 0;
     if (s2 >= s1) {
-        if (i == s0 + 1) val = val + corr[0];
-        if (s1 > 0 && i == s1) val = val + corr[1];
-        if (i == s2 + 1) val = val + corr[2];
+        if (i == s0 + 1 - o) val = val + corr[0];
+        if (s1 > 0 && i == s1 - o) val = val + corr[1];
+        if (i == s2 + 1 - o) val = val + corr[2];
     } else {
-        if (s1 > 0 && i == s1) val = (val + corr[0]) + corr[3];             // cc:781: j + A + B, left to right
+        if (s1 > 0 && i == s1 - o) val = (val + corr[0]) + corr[3];             // cc:781: j + A + B, left to right
     }
-    if (s3 > 0 && i == s3) val = val + corr[4];
+    if (s3 > 0 && i == s3 - o) val = val + corr[4];
     if (s2 - s0 > 0) {
-        if (i == s4 + 1) val = val + corr[5];
+        if (i == s4 + 1 - o) val = val + corr[5];
     } else {
-        if (s4 > 0 && i == s4) val = ((val + corr[5]) + corr[0]) + corr[3]; // cc:798: j + A + B + C, left to right
+        if (s4 > 0 && i == s4 - o) val = ((val + corr[5]) + corr[0]) + corr[3]; // cc:798: j + A + B + C, left to right
     }
-    if (s5 > 0 && i == s5) val = val + corr[7];
-    if (i == s6 + 1) val = val + corr[8];
+    if (s5 > 0 && i == s5 - o) val = val + corr[7];
+    if (i == s6 + 1 - o) val = val + corr[8];
     return val;
 }
 
 // coefficients of a run that starts after state (a_s, v_s, q_s)
+template <int SEM = kSemCpp>
 LTP_DEV RunCoef run_coef(int mode, double J, double a_s, double v_s, double q_s, double vsnap, double Ts)
 {
     RunCoef r;
@@ -117,7 +123,7 @@ LTP_DEV RunCoef run_coef(int mode, double J, double a_s, double v_s, double q_s,
     for (int x = 0; x < kRunCoefs; ++x) r.c[x] = 0.0;
     const double tj = Ts * J;
     r.c[9] = J;
-    if (!(mode & kModeTail)) { r.c[7] = a_s; r.c[8] = tj; }
+    if (!(mode & kModeTail) || (SEM == kSemMatlab && (mode & kModeKeepA))) { r.c[7] = a_s; r.c[8] = tj; }
     r.c[0] = q_s;
     if (mode & kModeVSnap) {
         r.c[4] = vsnap;
@@ -1225,16 +1231,28 @@ k_replan_states(long long first, long long count, int dof, RowSpec rows, Queries
 // 26.8 vs 20.0 ms per 1 M plans: lanes of a wave sit in runs of different lengths.) visit(b, e, rc) is called for every run [b, e) with its
 // coefficients and returns true to stop; (a, v, q) hold the state before the run and are advanced to its last sample
 // (exactly the value the sampler stores there) after each call that returns false.
-template <class Visit>
+// MATLAB's mod(x, y) for y > 0 as LTPlanner.m:531 uses it: x - floor(x./y).*y, except that "if y is not an integer and the
+// quotient x./y is within roundoff error of an integer, then n is that integer" (MATLAB documentation), i.e. the result is 0;
+// the round-off test is GNU Octave's published rule, as in the test suite's CPU twin. (cc:747 has no such rule.)
+LTP_DEV double matlab_mod(double x, double y)
+{
+    if (y == 0.0) return x;
+    const double q = x / y;
+    const double n = __builtin_rint(q);
+    if (__builtin_rint(y) != y && dabs((q - n) / n) < kDblEps) return 0.0;
+    return x - y * dfloor(q);
+}
+
+template <int SEM = kSemCpp, class Visit>
 LTP_DEV void for_each_run(const Limits& lim, const Records& rec, long long rj, int j, int len, double Ts, double& q, double& v,
-                          double& a, Visit&& visit)
+                          double& a, Visit&& visit, bool last_joint = true)
 {
     int sw[7];                                                                        // sampled switch indices (cc:751-757)
     double fr[7], frts[7];
 #pragma unroll
     for (int x = 0; x < 7; ++x) {
         const double tk = rec.t_scaled[rj * 7 + x];
-        fr[x] = tk - Ts * dfloor(tk / Ts);                                            // cc:747
+        fr[x] = SEM == kSemMatlab ? matlab_mod(tk, Ts) : tk - Ts * dfloor(tk / Ts);   // cc:747 / LTPlanner.m:531
         frts[x] = fr[x] / Ts;
         sw[x] = (x & 1) ? (int)dceil(tk / Ts) : (int)dfloor(tk / Ts);
     }
@@ -1248,12 +1266,15 @@ LTP_DEV void for_each_run(const Limits& lim, const Records& rec, long long rj, i
     const double d20 = (fr[2] - fr[0]) / Ts;
     const double corr[9] = {frts[0] * J0, (1 - frts[1]) * J2, frts[2] * J2, d20 * J2, (1 - frts[3]) * J4,
                             frts[4] * J4, 0.0, (1 - frts[5]) * J6, frts[6] * J6};
-    // candidate cut points (slot 0 = index 0 starts the first run and is not needed here)
+    // candidate cut points (slot 0 = index 0 starts the first run and is not needed here). MATLAB semantics: the corrections
+    // sit one sample earlier, the constant-velocity samples are s2 .. s3-2 and the tail starts at s6 (LTPlanner.m:616, 620)
     constexpr int cut_base[kCutSlots] = {0, 0, 0, 0, 1, 1, 2, 2, 2, 3, 3, 3, 4, 4, 4, 5, 5, 6, 6, 6};
     constexpr int cut_delta[kCutSlots] = {0, 0, 1, 2, 0, 1, 0, 1, 2, -1, 0, 1, 0, 1, 2, 0, 1, 0, 1, 2};
+    constexpr int mcut_base[kCutSlots] = {0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 4, 5, 5, 6, 6, 6, 6, 6, 6};
+    constexpr int mcut_delta[kCutSlots] = {0, 0, 1, -1, 0, 0, 1, -1, 0, -1, 0, 1, -1, 0, 0, 1, 1, 1, 1, 1};
     int cand[kCutSlots];
 #pragma unroll
-    for (int c = 1; c < kCutSlots; ++c) cand[c] = sw[cut_base[c]] + cut_delta[c];
+    for (int c = 1; c < kCutSlots; ++c) cand[c] = SEM == kSemMatlab ? sw[mcut_base[c]] + mcut_delta[c] : sw[cut_base[c]] + cut_delta[c];
     const bool phase4 = sw[3] - sw[2] > 2;                                            // cc:813
     int b = 0;
     for (int run = 0; run < kMaxSegments && b < len; ++run) {
@@ -1261,12 +1282,31 @@ LTP_DEV void for_each_run(const Limits& lim, const Records& rec, long long rj, i
 #pragma unroll
         for (int c = 1; c < kCutSlots; ++c) e = (cand[c] > b && cand[c] < e) ? cand[c] : e;
         int mode = 0;
-        if (b > sw[6]) mode |= kModeTail;
-        if (phase4 && b >= sw[2] + 1 && b < sw[3] - 1) mode |= kModeVSnap;
-        const RunCoef rc = run_coef(mode, jerk_at(sw, Jp, corr, b), a, v, q, vsnap, Ts);
+        if constexpr (SEM == kSemMatlab) {
+            if (b >= sw[6]) mode |= last_joint ? kModeTail : (kModeTail | kModeKeepA);
+            if (phase4 && b >= sw[2] && b < sw[3] - 1) mode |= kModeVSnap;
+        } else {
+            if (b > sw[6]) mode |= kModeTail;
+            if (phase4 && b >= sw[2] + 1 && b < sw[3] - 1) mode |= kModeVSnap;
+        }
+        const double J = jerk_at<SEM>(sw, Jp, corr, b);
+        const RunCoef rc = run_coef<SEM>(mode, J, a, v, q, vsnap, Ts);
         if (visit(b, e, rc)) return;
-        double jj;
-        run_eval(rc.c, e - b, q, v, a, jj);
+        if constexpr (SEM == kSemMatlab) {
+            // LTPlanner.m:604-624: a, v, q are cumulative sums over the arrays as they stand — behind the constant-velocity
+            // samples (and in the tail) v continues from the UN-snapped sum, the acceleration sum never stops
+            const double md = (double)(e - b);
+            const double s1 = 0.5 * (md * (md + 1.0));
+            const double v_cum = v + ((Ts * a) * md + (Ts * (Ts * J)) * s1);
+            const double a_cum = a + (Ts * J) * md;
+            double vv, aa, jj;
+            run_eval(rc.c, e - b, q, vv, aa, jj);
+            v = v_cum;
+            a = a_cum;
+        } else {
+            double jj;
+            run_eval(rc.c, e - b, q, v, a, jj);
+        }
         b = e;
     }
 }
@@ -1275,6 +1315,7 @@ LTP_DEV void for_each_run(const Limits& lim, const Records& rec, long long rj, i
 // the switching-time records. A caller that only needs the restart state pays neither the table build of a sampler
 // item (~15 us of latency per plan) nor a byte of trajectory traffic. The result has the bits of the row element the
 // sampler would have stored at k.
+template <int SEM>
 __global__ void __launch_bounds__(256)
 k_state_at(long long first, long long count, int dof, double t_sample, Limits lim, Queries in, Records rec,
            const int* __restrict__ sample_index, int uniform_index,
@@ -1292,12 +1333,12 @@ k_state_at(long long first, long long count, int dof, double t_sample, Limits li
     if (len > 0) {
         int k = sample_index ? sample_index[local] : uniform_index;
         k = k < 0 ? 0 : (k >= len ? len - 1 : k);             // beyond the end: the last state
-        for_each_run(lim, rec, p * dof + j, j, len, t_sample, q, v, a, [&](int b, int e, const RunCoef& rc) {
+        for_each_run<SEM>(lim, rec, p * dof + j, j, len, t_sample, q, v, a, [&](int b, int e, const RunCoef& rc) {
             if (k >= e) return false;
             double jj;
             run_eval(rc.c, k + 1 - b, q, v, a, jj);
             return true;
-        });
+        }, j == dof - 1);
     }
     q_0[dst] = q;
     v_0[dst] = v;
@@ -1328,6 +1369,7 @@ k_end_limit(long long first, long long count, int dof, double t_sample, Limits l
 // (prefetched) table read instead of a cooperative build of ~8 us of latency — what short rows, the envelope consumer and
 // receding-horizon rows are bound by. 1 696 bytes per joint: worth it when a plan's rows are not much longer than that.
 // Also applies the end-limit check of cc:59-61 (the sampler variants that read tables no longer do).
+template <int SEM>
 __global__ void __launch_bounds__(256)
 k_build_tables(long long first, long long count, int dof, double t_sample, Limits lim, Queries in, Records rec,
                int needed_end /* runs that start at or after this sample are not stored (capped rows) */,
@@ -1347,7 +1389,7 @@ k_build_tables(long long first, long long count, int dof, double t_sample, Limit
     double q = in.q_0[ix], v = in.v_0[ix], a = in.a_0[ix];
     int run = 0;
     int last_b = len;
-    for_each_run(lim, rec, p * dof + j, j, len, t_sample, q, v, a, [&](int b, int, const RunCoef& rc) {
+    for_each_run<SEM>(lim, rec, p * dof + j, j, len, t_sample, q, v, a, [&](int b, int, const RunCoef& rc) {
         if (b < needed_end) {
             reinterpret_cast<int*>(word(1 + (run >> 1)))[run & 1] = b;
             // coefficients as whole word pairs: 16 bytes per lane, a full 1 KiB line per wave instruction
@@ -1365,7 +1407,7 @@ k_build_tables(long long first, long long count, int dof, double t_sample, Limit
             last_b = b;                                        // first run that is not stored: it ends the last stored one
         }
         return false;                                          // the walk still goes to the last sample: end-limit check
-    });
+    }, j == dof - 1);
     reinterpret_cast<int*>(word(1 + (run >> 1)))[run & 1] = last_b;
     *word(0) = (unsigned long long)(unsigned)run | ((unsigned long long)(unsigned)len << 32);
     // where the plan's rows start inside the range the sampler is called for: what k_sample_tab's loader would otherwise
@@ -1375,7 +1417,9 @@ k_build_tables(long long first, long long count, int dof, double t_sample, Limit
         const unsigned long long rel = (offsets[p] - offsets[base_first]) / kRowAlign;
         reinterpret_cast<unsigned*>(word(1 + (kMaxSegments + 1) / 2))[(kMaxSegments + 1) & 1] = rel > 0xffffffffull ? 0xffffffffu : (unsigned)rel;
     }
-    if (q < lim.q_min[j] || q > lim.q_max[j]) atomicOr(&rec.status[p], kStatusEndLimit);   // cc:59-61: q is sample len-1
+    if constexpr (SEM == kSemCpp) {                            // LTPlanner.m has no position limits, hence no end-limit check
+        if (q < lim.q_min[j] || q > lim.q_max[j]) atomicOr(&rec.status[p], kStatusEndLimit);   // cc:59-61: q is sample len-1
+    }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1453,7 +1497,8 @@ k_plan_small(int n, int dof, double t_sample, int goal_check, RowSpec rows, Limi
         double tt[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
         double dir = 0.0;
         int mod = 0;
-        if (opt_switch_times<true>(L.a_max, L.j_max, t_sample, qg, q0, v0, a0, L.v_max, tt, dir, mod) == kOptFalse) flags |= kStatusOptFailed;
+        MatlabCtx mc;
+        if (opt_switch_times<true>(L.a_max, L.j_max, L.v_max, t_sample, qg, q0, v0, a0, L.v_max, tt, dir, mod, mc) == kOptFalse) flags |= kStatusOptFailed;
 #pragma unroll
         for (int k = 0; k < 7; ++k) s_t_opt[t][k] = tt[k];
         s_dir[t] = dir;
@@ -1487,7 +1532,8 @@ k_plan_small(int n, int dof, double t_sample, int goal_check, RowSpec rows, Limi
             mod = s_mod[t];
             if (j != s_slowest[q]) {
                 int which = 0;
-                time_scaling_full(L, t_sample, qg, q0, v0, a0, s_dir[t], s_treq[q], vd, ts, mod, which);
+                MatlabCtx mc;
+                time_scaling_full(L, t_sample, qg, q0, v0, a0, s_dir[t], s_treq[q], vd, ts, mod, which, mc);
             }
             double mx = ts[0];
 #pragma unroll
@@ -1647,7 +1693,8 @@ unsigned long long table_bytes(long long lanes)
 }
 
 void launch_build_tables(hipStream_t s, long long first, long long count, int dof, double t_sample, Limits lim, Queries in, Records rec,
-                         RowSpec rows, bool whole_trajectory, const unsigned long long* offsets, long long base_first, unsigned long long* tables)
+                         RowSpec rows, bool whole_trajectory, const unsigned long long* offsets, long long base_first, unsigned long long* tables,
+                         int semantics)
 {
     if (count <= 0 || dof <= 0) return;
     const long long total = count * dof;
@@ -1655,8 +1702,12 @@ void launch_build_tables(hipStream_t s, long long first, long long count, int do
     long long needed = 0x7fffffffll;
     if (!whole_trajectory && rows.max_samples > 0) needed = (long long)rows.max_samples * (rows.stride > 1 ? rows.stride : 1);
     if (needed > 0x7fffffffll) needed = 0x7fffffffll;
-    hipLaunchKernelGGL(k_build_tables, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, first, count, dof, t_sample, lim, in, rec,
-                       (int)needed, offsets, base_first, tables);
+    if (semantics == kSemMatlab)
+        hipLaunchKernelGGL(k_build_tables<kSemMatlab>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, first, count, dof, t_sample, lim, in, rec,
+                           (int)needed, offsets, base_first, tables);
+    else
+        hipLaunchKernelGGL(k_build_tables<kSemCpp>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, first, count, dof, t_sample, lim, in, rec,
+                           (int)needed, offsets, base_first, tables);
 }
 
 int sample_tab_resident_blocks(int device, bool f32)
@@ -1771,12 +1822,16 @@ void launch_end_limit(hipStream_t s, long long first, long long count, int dof, 
 
 void launch_state_at(hipStream_t s, long long first, long long count, int dof, double t_sample, Limits lim, Queries in,
                      Records rec, const int* sample_index, int uniform_index, double* q_0, double* v_0, double* a_0,
-                     long long sq, long long sj)
+                     long long sq, long long sj, int semantics)
 {
     if (count <= 0 || dof <= 0) return;
     const long long total = count * dof;
-    hipLaunchKernelGGL(k_state_at, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, first, count, dof, t_sample, lim, in, rec,
-                       sample_index, uniform_index, q_0, v_0, a_0, sq, sj);
+    if (semantics == kSemMatlab)
+        hipLaunchKernelGGL(k_state_at<kSemMatlab>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, first, count, dof, t_sample, lim, in, rec,
+                           sample_index, uniform_index, q_0, v_0, a_0, sq, sj);
+    else
+        hipLaunchKernelGGL(k_state_at<kSemCpp>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, first, count, dof, t_sample, lim, in, rec,
+                           sample_index, uniform_index, q_0, v_0, a_0, sq, sj);
 }
 
 }  // namespace ltp

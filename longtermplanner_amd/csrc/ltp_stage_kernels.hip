@@ -21,6 +21,17 @@ namespace ltp {
 // ---------------------------------------------------------------------------------------
 constexpr int kLaneGoalOutside = 128; // lane_flags bit: q_goal outside [q_min, q_max] (only with the opt-in goal check)
 constexpr int kLaneDeferred = 64;   // lane_flags bit: optSwitchTimes of this lane is still pending in queue A
+// MATLAB semantics only: the lane's MatlabCtx flags (complex intermediate / LTPlanner.m would have raised an error), mapped to
+// kStatusMatlabComplex / kStatusMatlabError when the per-query status is formed
+constexpr int kLaneMatlabComplex = 16, kLaneMatlabError = 32;
+LTP_DEV int matlab_lane_bits(const MatlabCtx& mc)
+{
+    return ((mc.flags & kMatlabComplex) ? kLaneMatlabComplex : 0) | ((mc.flags & kMatlabError) ? kLaneMatlabError : 0);
+}
+LTP_DEV int matlab_status_bits(const MatlabCtx& mc)
+{
+    return ((mc.flags & kMatlabComplex) ? kStatusMatlabComplex : 0) | ((mc.flags & kMatlabError) ? kStatusMatlabError : 0);
+}
 
 // Compaction queues. A single device-scope counter saturates near 90 atomics/us on MI355X, which a kernel that
 // pushes from ~10^5 waves would run into; so a queue has kQueueShards segments with one counter each (shard =
@@ -76,6 +87,24 @@ LTP_DEV unsigned long long queue_total(const Queue& Q, unsigned long long (&cnt)
     return total;
 }
 
+// cc:50-55: max_element(t_scaled) <= 0 (a NaN in the first place wins every comparison of the scan, as in std::max_element);
+// LTPlanner.m:82: ~any(t_scaled), i.e. every entry exactly zero (NaN counts as non-zero)
+template <int SEM>
+LTP_DEV bool needs_fallback(const double (&ts)[7])
+{
+    if constexpr (SEM == kSemMatlab) {
+        bool any = false;
+#pragma unroll
+        for (int k = 0; k < 7; ++k) any = any || ts[k] != 0.0;
+        return !any;
+    } else {
+        double mx = ts[0];
+#pragma unroll
+        for (int k = 1; k < 7; ++k) if (mx < ts[k]) mx = ts[k];
+        return mx <= 0.0;
+    }
+}
+
 LTP_DEV void store_opt_record(const Records& out, long long rj, const double (&t)[7], double dir, int mod)
 {
 #pragma unroll
@@ -84,6 +113,7 @@ LTP_DEV void store_opt_record(const Records& out, long long rj, const double (&t
     out.mod[rj] = (signed char)mod;
 }
 
+template <int SEM>
 __global__ void __launch_bounds__(kQueriesPerBlock* kMaxJointSlots)
 k_opt_fast(long long n, int dof, double t_sample, int goal_check, Limits lim, Queries in, Records out,
            signed char* __restrict__ lane_flags, Queue queue)
@@ -102,18 +132,23 @@ k_opt_fast(long long n, int dof, double t_sample, int goal_check, Limits lim, Qu
         if (active) {
             const long long ix = q * in.sq + (long long)j * in.sj;
             const double qg = in.q_goal[ix], q0 = in.q_0[ix], v0 = in.v_0[ix], a0 = in.a_0[ix];
-            int flags = check_inputs_joint(L, q0, v0, a0) ? 0 : kStatusInvalidInput;
+            int flags = check_inputs_joint<SEM>(L, q0, v0, a0) ? 0 : kStatusInvalidInput;
             // NEW, opt-in: the reference never checks q_goal (cc:68-77), only the last sample (cc:59-61)
             if (goal_check && !(qg >= L.q_min && qg <= L.q_max)) flags |= kLaneGoalOutside;
             double t[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
             double dir = 0.0;
             int mod = 0;
-            const int rc = opt_switch_times<false>(L.a_max, L.j_max, t_sample, qg, q0, v0, a0, L.v_max, t, dir, mod);
+            MatlabCtx mc;
+            const int rc = opt_switch_times<false, SEM>(L.a_max, L.j_max, L.v_max, t_sample, qg, q0, v0, a0, L.v_max, t, dir, mod, mc);
             if (rc == kOptDefer) {
                 defer = true;
                 flags |= kLaneDeferred;
             } else {
                 if (rc == kOptFalse) flags |= kStatusOptFailed;
+                if constexpr (SEM == kSemMatlab) {
+                    flags |= matlab_lane_bits(mc);
+                    mod = 0;   // LTPlanner.m:64 discards optSwitchTimes' third output: mod_jerk_profile stays false after stage 1
+                }
                 store_opt_record(out, rj, t, dir, mod);
             }
             lane_flags[rj] = (signed char)flags;
@@ -122,6 +157,7 @@ k_opt_fast(long long n, int dof, double t_sample, int goal_check, Limits lim, Qu
     }
 }
 
+template <int SEM>
 __global__ void __launch_bounds__(64)
 k_opt_slow(int dof, double t_sample, Limits lim, Queries in, Records out, signed char* __restrict__ lane_flags, Queue queue)
 {
@@ -137,15 +173,19 @@ k_opt_slow(int dof, double t_sample, Limits lim, Queries in, Records out, signed
         double t[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
         double dir = 0.0;
         int mod = 0;
-        const int rc = opt_switch_times<true>(L.a_max, L.j_max, t_sample, in.q_goal[ix], in.q_0[ix], in.v_0[ix], in.a_0[ix],
-                                              L.v_max, t, dir, mod);
+        MatlabCtx mc;
+        const int rc = opt_switch_times<true, SEM>(L.a_max, L.j_max, L.v_max, t_sample, in.q_goal[ix], in.q_0[ix], in.v_0[ix], in.a_0[ix],
+                                                   L.v_max, t, dir, mod, mc);
+        if constexpr (SEM == kSemMatlab) mod = 0;   // LTPlanner.m:64
         store_opt_record(out, rj, t, dir, mod);
         int flags = lane_flags[rj] & ~kLaneDeferred;
         if (rc == kOptFalse) flags |= kStatusOptFailed;
+        if constexpr (SEM == kSemMatlab) flags |= matlab_lane_bits(mc);
         lane_flags[rj] = (signed char)flags;
     }
 }
 
+template <int SEM>
 __global__ void __launch_bounds__(kQueriesPerBlock* kMaxJointSlots)
 k_reduce_scale(long long n, int dof, double t_sample, Limits lim, Queries in, Records out,
                const signed char* __restrict__ lane_flags, Queue queue)
@@ -193,6 +233,14 @@ k_reduce_scale(long long n, int dof, double t_sample, Limits lim, Queries in, Re
     }
     if (slowest < 0) flags |= kStatusNoSlowest;
     if (flags & kLaneGoalOutside) flags = (flags & ~kLaneGoalOutside) | kStatusGoalOutside;
+    if constexpr (SEM == kSemMatlab) {
+        // lane bits -> status bits, after the goal-outside bit has moved (its lane number is kStatusMatlabError's; the two MATLAB
+        // lane bits share numbers with NONFINITE / OVERFLOW, which nothing has set yet)
+        const int mb = ((flags & kLaneMatlabComplex) ? kStatusMatlabComplex : 0) | ((flags & kLaneMatlabError) ? kStatusMatlabError : 0);
+        flags = (flags & ~(kLaneMatlabComplex | kLaneMatlabError)) | mb;
+    }
+    // whether the query is planned at all: kStatusMatlabComplex is informational (the plan is delivered)
+    const bool planned = (flags & ~kStatusMatlabComplex) == 0;
     if (y == 0) {
         s_treq[x] = t_required;
         s_len[x] = 0;
@@ -210,10 +258,7 @@ k_reduce_scale(long long n, int dof, double t_sample, Limits lim, Queries in, Re
     auto finish = [&](long long rj, int col, bool valid, double (&ts)[7], double vd, int mod) {
         if (valid) {
             // cc:50-55: no scaled solution (or the slowest joint) -> optimal times
-            double mx = ts[0];
-#pragma unroll
-            for (int k = 1; k < 7; ++k) if (mx < ts[k]) mx = ts[k];
-            if (mx <= 0.0) {
+            if (needs_fallback<SEM>(ts)) {
 #pragma unroll
                 for (int k = 0; k < 7; ++k) ts[k] = out.t_opt[rj * 7 + k];
             }
@@ -242,7 +287,8 @@ k_reduce_scale(long long n, int dof, double t_sample, Limits lim, Queries in, Re
             double vd = L.v_max;
             int mod = 0;   // failed query: zero record, never sampled
             int acc = kOptTrue;
-            if (flags == 0) {
+            MatlabCtx mc;
+            if (planned) {
                 mod = out.mod[rj];
                 if (j != slowest) {
                     const long long ix = q * in.sq + (long long)j * in.sj;
@@ -250,11 +296,14 @@ k_reduce_scale(long long n, int dof, double t_sample, Limits lim, Queries in, Re
                     double v0 = in.v_0[ix], a0 = in.a_0[ix];
                     const double dir = out.dir[rj];
                     if (dir < 0.0) { v0 = -v0; a0 = -a0; }
-                    vd = v_drive_candidate<1>(L.a_max, L.j_max, qg, q0, v0, a0, dir, t_required);
-                    acc = try_v_drive<false>(L.a_max, L.j_max, t_sample, qg, q0, v0, a0, dir, t_required, vd, ts, mod);
+                    vd = v_drive_candidate<1, SEM>(L.a_max, L.j_max, qg, q0, v0, a0, dir, t_required, mc);
+                    acc = try_v_drive<false, SEM>(L.a_max, L.j_max, L.v_max, t_sample, qg, q0, v0, a0, dir, t_required, vd, ts, mod, mc);
                 }
             }
-            if (acc == kOptTrue) finish(rj, x, flags == 0, ts, vd, mod);
+            if constexpr (SEM == kSemMatlab) {
+                if (mc.flags && acc != kOptDefer) atomicOr(&out.status[q], matlab_status_bits(mc));
+            }
+            if (acc == kOptTrue) finish(rj, x, planned, ts, vd, mod);
             else if (acc == kOptFalse) s_second[atomicAdd(&s_nsecond, 1)] = (unsigned short)tid;
             else s_slow[atomicAdd(&s_nslow, 1)] = (unsigned long long)rj;      // c1 reached a quartic site: all of it in queue B
         }
@@ -274,8 +323,12 @@ k_reduce_scale(long long n, int dof, double t_sample, Limits lim, Queries in, Re
             if (dir < 0.0) { v0 = -v0; a0 = -a0; }
             double ts[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
             int mod = 0;
-            const double vd = v_drive_candidate<2>(L2.a_max, L2.j_max, qg, q0, v0, a0, dir, tr);
-            const int acc = try_v_drive<false>(L2.a_max, L2.j_max, t_sample, qg, q0, v0, a0, dir, tr, vd, ts, mod);
+            MatlabCtx mc;
+            const double vd = v_drive_candidate<2, SEM>(L2.a_max, L2.j_max, qg, q0, v0, a0, dir, tr, mc);
+            const int acc = try_v_drive<false, SEM>(L2.a_max, L2.j_max, L2.v_max, t_sample, qg, q0, v0, a0, dir, tr, vd, ts, mod, mc);
+            if constexpr (SEM == kSemMatlab) {
+                if (mc.flags && acc != kOptDefer) atomicOr(&out.status[q2], matlab_status_bits(mc));
+            }
             if (acc == kOptTrue) finish(rj2, x2, true, ts, vd, mod);
             else s_slow[atomicAdd(&s_nslow, 1)] = (unsigned long long)rj2;
         }
@@ -293,8 +346,8 @@ k_reduce_scale(long long n, int dof, double t_sample, Limits lim, Queries in, Re
         __syncthreads();
     }
     if (live && y == 0) {
-        out.traj_len[q] = flags == 0 ? s_len[x] : 0;
-        if (s_bad[x]) out.status[q] = flags | kStatusNonFinite;
+        out.traj_len[q] = planned ? s_len[x] : 0;
+        if (s_bad[x]) atomicOr(&out.status[q], kStatusNonFinite);
     }
 }
 
@@ -302,6 +355,7 @@ k_reduce_scale(long long n, int dof, double t_sample, Limits lim, Queries in, Re
 // the eight candidates of cc:378-638 (independent computations) run side by side and the kernel's latency is the
 // slowest candidate (the degree-6 solve) instead of their sum. The reference's "first accepted in order" is then a
 // lookup over eight flags in LDS.
+template <int SEM>
 __global__ void __launch_bounds__(kQueriesPerBlock * 8)
 k_scaling_slow(int dof, double t_sample, Limits lim, Queries in, Records out, Queue queue)
 {
@@ -320,6 +374,7 @@ k_scaling_slow(int dof, double t_sample, Limits lim, Queries in, Records out, Qu
         int mod = 0, j = 0;
         long long rj = 0, q = 0;
         JointLimits L = {0.0, 0.0, 0.0, 0.0, 0.0};
+        MatlabCtx mc;
         if (live) {
             rj = (long long)queue_item(queue, cnt, it);
             q = rj / dof;
@@ -331,14 +386,14 @@ k_scaling_slow(int dof, double t_sample, Limits lim, Queries in, Records out, Qu
             const double dir = out.dir[rj], tr = out.t_required[q];
             if (dir < 0.0) { v0 = -v0; a0 = -a0; }   // cc:372-375
             switch (c) {
-            case 0: acc = scaling_case<1>(L, t_sample, qg, q0, v0, a0, dir, tr, vd, ts, mod); break;
-            case 1: acc = scaling_case<2>(L, t_sample, qg, q0, v0, a0, dir, tr, vd, ts, mod); break;
-            case 2: acc = scaling_case<3>(L, t_sample, qg, q0, v0, a0, dir, tr, vd, ts, mod); break;
-            case 3: acc = scaling_case<4>(L, t_sample, qg, q0, v0, a0, dir, tr, vd, ts, mod); break;
-            case 4: acc = scaling_case<5>(L, t_sample, qg, q0, v0, a0, dir, tr, vd, ts, mod); break;
-            case 5: acc = scaling_case<6>(L, t_sample, qg, q0, v0, a0, dir, tr, vd, ts, mod); break;
-            case 6: acc = scaling_case<7>(L, t_sample, qg, q0, v0, a0, dir, tr, vd, ts, mod); break;
-            default: acc = scaling_case<8>(L, t_sample, qg, q0, v0, a0, dir, tr, vd, ts, mod); break;
+            case 0: acc = scaling_case<1, SEM>(L, t_sample, qg, q0, v0, a0, dir, tr, vd, ts, mod, mc); break;
+            case 1: acc = scaling_case<2, SEM>(L, t_sample, qg, q0, v0, a0, dir, tr, vd, ts, mod, mc); break;
+            case 2: acc = scaling_case<3, SEM>(L, t_sample, qg, q0, v0, a0, dir, tr, vd, ts, mod, mc); break;
+            case 3: acc = scaling_case<4, SEM>(L, t_sample, qg, q0, v0, a0, dir, tr, vd, ts, mod, mc); break;
+            case 4: acc = scaling_case<5, SEM>(L, t_sample, qg, q0, v0, a0, dir, tr, vd, ts, mod, mc); break;
+            case 5: acc = scaling_case<6, SEM>(L, t_sample, qg, q0, v0, a0, dir, tr, vd, ts, mod, mc); break;
+            case 6: acc = scaling_case<7, SEM>(L, t_sample, qg, q0, v0, a0, dir, tr, vd, ts, mod, mc); break;
+            default: acc = scaling_case<8, SEM>(L, t_sample, qg, q0, v0, a0, dir, tr, vd, ts, mod, mc); break;
             }
         }
         s_acc[c][x] = acc ? 1 : 0;
@@ -354,11 +409,13 @@ k_scaling_slow(int dof, double t_sample, Limits lim, Queries in, Records out, Qu
                 zero7(ts);
                 vd = L.v_max;
             }
+            if constexpr (SEM == kSemMatlab) {
+                // LTPlanner.m tries the candidates one after the other: what a candidate BEHIND the accepted one would have
+                // raised or flagged never happens there
+                if (mc.flags && (first < 0 || c <= first)) atomicOr(&out.status[q], matlab_status_bits(mc));
+            }
             if (winner || reset) {
-                double mx = ts[0];
-#pragma unroll
-                for (int k = 1; k < 7; ++k) if (mx < ts[k]) mx = ts[k];
-                if (mx <= 0.0) {   // cc:50-55
+                if (needs_fallback<SEM>(ts)) {   // cc:50-55
 #pragma unroll
                     for (int k = 0; k < 7; ++k) ts[k] = out.t_opt[rj * 7 + k];
                 }
@@ -390,7 +447,7 @@ k_finalize(long long n, int dof, double t_sample, RowSpec rows, Records rec, uns
         const long long q = base + e * 256 + threadIdx.x;
         if (q < n) {
             int len = 0, st = rec.status[q];
-            if (st == 0) {
+            if ((st & ~kStatusMatlabComplex) == 0) {
                 bool finite = true;
                 for (int j = 0; j < dof; ++j) {
                     const double* t = rec.t_scaled + (q * dof + j) * 7;
@@ -425,7 +482,7 @@ k_finalize_lens(long long n, int dof, RowSpec rows, Records rec, unsigned long l
         const long long q = base + e * 256 + threadIdx.x;
         if (q < n) {
             int len = rec.traj_len[q];
-            if (rec.status[q] != 0) { len = 0; rec.traj_len[q] = 0; }   // failed or non-finite: nothing to sample
+            if ((rec.status[q] & ~kStatusMatlabComplex) != 0) { len = 0; rec.traj_len[q] = 0; }   // failed or non-finite: nothing to sample
             local += plan_size(stored_len(len, rows), dof);
         }
     }
@@ -510,7 +567,7 @@ long long queue_segment(long long n, int dof)
 
 void launch_switch_times(hipStream_t s, long long n, int dof, double t_sample, int goal_check, Limits lim, Queries in,
                          Records out, signed char* lane_flags, unsigned long long* queue_items /* 2 * 8 * queue_segment(n, dof) */,
-                         unsigned long long* counts /* [16], zeroed by the caller on the same stream */)
+                         unsigned long long* counts /* [16], zeroed by the caller on the same stream */, int semantics)
 {
     if (n <= 0) return;
     const int jb = dof < kMaxJointSlots ? dof : kMaxJointSlots;
@@ -524,10 +581,17 @@ void launch_switch_times(hipStream_t s, long long n, int dof, double t_sample, i
     if (a_blocks > 4096) a_blocks = 4096;
     long long b_blocks = (n * dof + kQueriesPerBlock - 1) / kQueriesPerBlock;
     if (b_blocks > 1024) b_blocks = 1024;
-    hipLaunchKernelGGL(k_opt_fast, grid, block, 0, s, n, dof, t_sample, goal_check, lim, in, out, lane_flags, qa);
-    hipLaunchKernelGGL(k_opt_slow, dim3((unsigned)a_blocks), dim3(64), 0, s, dof, t_sample, lim, in, out, lane_flags, qa);
-    hipLaunchKernelGGL(k_reduce_scale, grid, block, 0, s, n, dof, t_sample, lim, in, out, lane_flags, qb);
-    hipLaunchKernelGGL(k_scaling_slow, dim3((unsigned)b_blocks), dim3(kQueriesPerBlock, 8), 0, s, dof, t_sample, lim, in, out, qb);
+    if (semantics == kSemMatlab) {
+        hipLaunchKernelGGL(k_opt_fast<kSemMatlab>, grid, block, 0, s, n, dof, t_sample, goal_check, lim, in, out, lane_flags, qa);
+        hipLaunchKernelGGL(k_opt_slow<kSemMatlab>, dim3((unsigned)a_blocks), dim3(64), 0, s, dof, t_sample, lim, in, out, lane_flags, qa);
+        hipLaunchKernelGGL(k_reduce_scale<kSemMatlab>, grid, block, 0, s, n, dof, t_sample, lim, in, out, lane_flags, qb);
+        hipLaunchKernelGGL(k_scaling_slow<kSemMatlab>, dim3((unsigned)b_blocks), dim3(kQueriesPerBlock, 8), 0, s, dof, t_sample, lim, in, out, qb);
+        return;
+    }
+    hipLaunchKernelGGL(k_opt_fast<kSemCpp>, grid, block, 0, s, n, dof, t_sample, goal_check, lim, in, out, lane_flags, qa);
+    hipLaunchKernelGGL(k_opt_slow<kSemCpp>, dim3((unsigned)a_blocks), dim3(64), 0, s, dof, t_sample, lim, in, out, lane_flags, qa);
+    hipLaunchKernelGGL(k_reduce_scale<kSemCpp>, grid, block, 0, s, n, dof, t_sample, lim, in, out, lane_flags, qb);
+    hipLaunchKernelGGL(k_scaling_slow<kSemCpp>, dim3((unsigned)b_blocks), dim3(kQueriesPerBlock, 8), 0, s, dof, t_sample, lim, in, out, qb);
 }
 
 void launch_offsets(hipStream_t s, long long n, int dof, double t_sample, Records rec,

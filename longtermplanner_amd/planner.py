@@ -117,6 +117,26 @@ class LongTermPlanner:
         LTP_STATUS_GOAL_OUTSIDE (64) instead of planning them and failing the end-limit check (cc:59-61)."""
         self._check(self._lib.ltp_set_goal_check(self._h, 1 if enabled else 0))
 
+    def setSemantics(self, semantics):
+        """NEW: "cpp" (default: src/long_term_planner.cc, the parity reference) or "matlab" (the MATLAB original
+        LTPlanner.m where it diverges: positional root picks, zeros instead of failures, no position limits, 1-based sampler with
+        cumsum integration; include/ltp_hip.h LTP_SEMANTICS_MATLAB)."""
+        code = {"cpp": _abi.SEMANTICS_CPP, "matlab": _abi.SEMANTICS_MATLAB}.get(semantics, semantics)
+        self._check(self._lib.ltp_set_semantics(self._h, int(code)))
+
+    def lastMatlabFlags(self):
+        """MATLAB semantics: flags of the latest one-lane call (optBraking / optSwitchTimes / timeScaling): 1 = complex intermediate, 2 = error."""
+        return self._lib.ltp_debug_last_matlab_flags(self._h)
+
+    def matlabRoots(self, poly):
+        """MATLAB's roots() as the MATLAB-semantics kernels compute it (device): (complex roots [n][degree] in MATLAB's order, nroots, status)."""
+        poly = np.ascontiguousarray(np.atleast_2d(np.asarray(poly, dtype=np.float64)))
+        n, deg = poly.shape[0], poly.shape[1] - 1
+        re = np.zeros((n, deg)); im = np.zeros((n, deg)); nr = np.zeros(n, dtype=np.int32); st = np.zeros(n, dtype=np.int32)
+        ip = C.POINTER(C.c_int)
+        self._check(self._lib.ltp_debug_roots_matlab_host(self._h, n, deg, _ptr(poly), _ptr(re), _ptr(im), nr.ctypes.data_as(ip), st.ctypes.data_as(ip)))
+        return re + 1j * im, nr, st
+
     def setTablePass(self, mode, workspace_bytes=None):
         """NEW: where the sampler's run tables are built — 0 automatic, 1 always by the table pass (a kernel of its own,
         1 696 B per joint through the workspace), -1 always inside the sampler kernel. Rows are bit-identical either way."""
@@ -146,7 +166,7 @@ class LongTermPlanner:
         reference would have overwritten it (status has none of the pre-sampling failure bits)."""
         r = self.planBatchHost(q_goal, q_0, v_0, a_0, sample=True)
         st = int(r["status"][0])
-        if st & (_abi.STATUS_INVALID_INPUT | _abi.STATUS_OPT_FAILED | _abi.STATUS_NO_SLOWEST | _abi.STATUS_NONFINITE | _abi.STATUS_GOAL_OUTSIDE):
+        if st & (_abi.STATUS_INVALID_INPUT | _abi.STATUS_OPT_FAILED | _abi.STATUS_NO_SLOWEST | _abi.STATUS_NONFINITE | _abi.STATUS_GOAL_OUTSIDE | _abi.STATUS_MATLAB_ERROR):
             return False
         n = int(r["traj_len"][0])
         q, v, a, j = unpack_trajectory(r["packed"], int(r["offsets"][0]), self.dof, n)

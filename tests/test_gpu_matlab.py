@@ -1,0 +1,203 @@
+"""the MATLAB-semantics mode on the device (ltp_set_semantics(p, LTP_SEMANTICS_MATLAB)) against its CPU twin
+(oracle.Oracle(..., semantics="matlab"), itself pinned by the MATLAB unit tables, the MATLAB grid tests and numpy.roots in
+tests/test_matlab_twin.py) — bit-exact on integers and flags, 1e-9 on times and samples, through the C ABI."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-9
+
+
+@pytest.fixture(scope="module")
+def amd():
+    import longtermplanner_amd
+    return longtermplanner_amd
+
+
+def _pair(amd, oracle_mod, name, ts=0.001):
+    D, lim = amd.limit_set(name)
+    ltp = amd.LongTermPlanner(D, ts, device=0, **lim)
+    ltp.setSemantics("matlab")
+    orc = oracle_mod.Oracle(D, ts, semantics="matlab", **lim)
+    return D, lim, ltp, orc
+
+
+def test_matlab_roots_on_the_device(amd, oracle_mod):
+    """ltp_roots_matlab.hpp vs oracle/matlab_roots.inc: the same restated LAPACK path -> same order, same classification."""
+    D, lim = amd.limit_set("ref")
+    ltp = amd.LongTermPlanner(D, 0.001, device=0, **lim)
+    rng = np.random.default_rng(3)
+    rows = np.load(__import__("os").path.join(__import__("os").path.dirname(__file__), "golden", "planner_polynomials.npz"))["rows"]
+    for deg in (1, 2, 3, 4, 5, 6):
+        polys = [r[1:2 + deg] for r in rows if int(r[0]) == deg]
+        for trial in range(4000):
+            c = rng.normal(size=deg + 1) * 10.0 ** rng.uniform(-2, 3, size=deg + 1)
+            if trial % 7 == 0 and deg > 1:
+                c[rng.integers(1, deg)] = 0.0
+            if trial % 11 == 0 and deg > 2:
+                c[-1] = 0.0                                   # a zero root, placed first
+            if trial % 13 == 0 and deg > 2:
+                c[0] = 0.0                                    # a stripped leading coefficient: fewer roots
+            polys.append(c)
+        polys = np.array(polys)
+        got, nr, st = ltp.matlabRoots(polys)
+        worst = 0.0
+        for i, c in enumerate(polys):
+            want, wst = oracle_mod.matlab_roots(c)
+            assert st[i] == wst and nr[i] == want.size, (deg, i)
+            g = got[i, :nr[i]]
+            assert np.array_equal(g.imag == 0, want.imag == 0), (deg, i)
+            den = np.maximum(np.abs(want), 1e-300)
+            worst = max(worst, float(np.max(np.abs(g - want) / den)) if want.size else 0.0)
+        assert worst < 1e-12, (deg, worst)
+    bad, nr, st = ltp.matlabRoots(np.array([[1.0, np.nan, 2.0, 3.0]]))
+    assert st[0] == 2 and nr[0] == 0
+
+
+def test_matlab_unit_tables_on_the_device(amd, kat):
+    """tests/unittests/*.m through the one-lane entry points in MATLAB semantics (all seven switching times)."""
+    m = kat["matlab_twins"]
+    mm = m["opt_switch_times"]
+    t_all = np.cumsum(np.array(mm["t_rel_rows"]).T, axis=1)
+    for i in range(len(mm["q_goal"])):
+        ltp = amd.LongTermPlanner(1, 0.001, [0.0], [0.0], [mm["v_max"][i]], [mm["a_max"][i]], [mm["j_max"][i]], device=0)
+        ltp.setSemantics("matlab")
+        for sgn in ((1, -1) if i else (1,)):
+            ok, t, d, mod = ltp.optSwitchTimes(0, sgn * mm["q_goal"][i], sgn * mm["q_0"], sgn * mm["v_0"][i], sgn * mm["a_0"][i], mm["v_max"][i])
+            assert ok and np.all(np.abs(t - t_all[i]) < mm["eps"]) and ltp.lastMatlabFlags() == 0, (i, sgn, t)
+    mm = m["time_scaling"]
+    t_all = np.cumsum(np.array(mm["t_rel_rows"]).T, axis=1)
+    cases = set()
+    for i in range(len(mm["q_goal"])):
+        ltp = amd.LongTermPlanner(1, 0.001, [0.0], [0.0], [mm["v_max"][i]], [mm["a_max"][i]], [mm["j_max"][i]], device=0)
+        ltp.setSemantics("matlab")
+        for sgn in ((1, -1) if i else (1,)):
+            ok, t, vd, mod, case = ltp.timeScaling(0, sgn * mm["q_goal"][i], sgn * mm["q_0"], sgn * mm["v_0"][i], sgn * mm["a_0"][i],
+                                                   sgn * mm["dir"][i], t_all[i, -1])
+            cases.add(case)
+            assert np.all(np.abs(t - t_all[i]) < mm["eps"]), (i, sgn, case, t)
+    assert cases - {0, 1, 2}, "polynomial cases (positional root picks) are reached"
+    mm = m["opt_braking"]
+    for i in range(len(mm["v_0"])):
+        ltp = amd.LongTermPlanner(1, 0.001, [0.0], [0.0], [mm["v_max"]], [mm["a_max"][i]], [mm["j_max"][i]], device=0)
+        ltp.setSemantics("matlab")
+        for sgn in ((1, -1) if i else (1,)):
+            ok, q, t, d = ltp.optBraking(0, sgn * mm["v_0"][i], sgn * mm["a_0"][i])
+            assert np.all(np.abs(t[:3] - np.array(mm["t_rel_rows"])[:, i]) < mm["eps"]) and abs(q - sgn * mm["q_goal"][i]) < mm["eps"]
+
+
+@pytest.mark.parametrize("name,n,ts", [("panda", 200_000, 0.001), ("ref", 200_000, 0.001), ("ref30", 20_000, 0.001), ("ref", 50_000, 0.004)])
+def test_matlab_records_parity(amd, oracle_mod, name, n, ts):
+    from concurrent.futures import ThreadPoolExecutor
+    D, lim, ltp, orc = _pair(amd, oracle_mod, name, ts)
+    qg, q0, v0, a0 = amd.generate_queries(n, lim, seed=909)
+    q0[5] = q0[5] + 50.0                  # far outside [q_min, q_max]: LTPlanner.m has no position limits, the query is planned
+    v0[9, 0] = 2.0 * lim["v_max"][0]      # LTPlanner.m:93-95 error()
+    r = ltp.planBatchHost(qg, q0, v0, a0, sample=False)
+    parts = 16
+    with ThreadPoolExecutor(parts) as ex:
+        outs = list(ex.map(lambda i: orc.plan_batch(qg[i::parts], q0[i::parts], v0[i::parts], a0[i::parts], sample=False), range(parts)))
+    o = {k: np.empty_like(outs[0][k], shape=(n,) + outs[0][k].shape[1:]) for k in outs[0] if isinstance(outs[0][k], np.ndarray)}
+    for i, part in enumerate(outs):
+        for k in o:
+            o[k][i::parts] = part[k]
+    planned = o["status"] != 0
+    assert planned[5] and not planned[9] and (o["matlab_flags"][9] & 2)
+    dev_planned = (r["status"] & ~amd.STATUS_MATLAB_COMPLEX) == 0
+    assert np.array_equal(dev_planned, planned)
+    assert np.array_equal((r["status"] & amd.STATUS_MATLAB_ERROR) != 0, (o["matlab_flags"] & 2) != 0)
+    assert np.array_equal((r["status"] & amd.STATUS_MATLAB_COMPLEX) != 0, (o["matlab_flags"] & 1) != 0)
+    assert not np.any(r["status"] & amd.STATUS_END_LIMIT)
+    for k in ("slowest", "traj_len", "mod", "dir"):
+        assert np.array_equal(r[k][planned], o[k][planned]), k
+    worst = 0.0
+    for k in ("t_opt", "t_scaled", "v_drive", "t_required"):
+        a, b = r[k][planned], o[k][planned]
+        d = np.where((a == b) | (np.isnan(a) & np.isnan(b)), 0.0, np.abs(a - b))
+        assert np.all(np.isfinite(d)), k
+        worst = max(worst, float(d.max()))
+    print(f"MATLAB semantics {name}: {int(planned.sum())} plans, worst |dt| {worst:.3e}, complex flags {int(np.sum(o['matlab_flags'] & 1))}, "
+          f"errors {int(np.sum((o['matlab_flags'] & 2) != 0))}, mod joints {float(np.mean(o['mod'][planned])):.3f}")
+    assert worst <= TOL
+    # the two semantics really differ on this batch: other switching times for some joints
+    c = amd.LongTermPlanner(D, ts, device=0, **lim).planBatchHost(qg, q0, v0, a0, sample=False)
+    both = planned & ((c["status"] & 7) == 0)
+    assert np.any(np.abs(c["t_scaled"][both] - r["t_scaled"][both]) > 1e-6) or name == "panda"
+
+
+@pytest.mark.parametrize("name,n,ts", [("panda", 600, 0.001), ("ref", 300, 0.001), ("ref30", 40, 0.001), ("ref", 400, 0.004)])
+def test_matlab_dense_trajectory_parity(amd, oracle_mod, name, n, ts):
+    import torch
+    D, lim, ltp, orc = _pair(amd, oracle_mod, name, ts)
+    qg, q0, v0, a0 = amd.generate_queries(n, lim, seed=31337)
+    r = ltp.planBatchHost(qg, q0, v0, a0, sample=True)
+    o = orc.plan_batch(qg, q0, v0, a0, sample=False)
+    assert np.array_equal(r["traj_len"], o["traj_len"])
+    worst = {k: 0.0 for k in "qvaj"}
+    for p in range(n):
+        if o["status"][p] == 0:
+            continue
+        L, q, v, a, j = orc.get_trajectory(o["t_scaled"][p], o["dir"][p], o["mod"][p], q0[p], v0[p], a0[p], o["v_drive"][p])
+        g = amd.unpack_trajectory(r["packed"], int(r["offsets"][p]), D, L)
+        for key, got, want in zip("qvaj", g, (q, v, a, j)):
+            worst[key] = max(worst[key], float(np.max(np.abs(got - want))))
+    print(f"MATLAB semantics dense {name}: {worst}")
+    # j: a last-bit difference of a switching time reaches the fractional jerk sample times j_max / Ts
+    assert worst["q"] <= TOL and worst["v"] <= TOL and worst["a"] <= 1e-8 and worst["j"] <= 1e-5
+    # the consumers share the tables: restart states and envelopes are the bits of the rows
+    dq = [torch.from_numpy(x).cuda() for x in (qg, q0, v0, a0)]
+    b = ltp.planSwitchTimesBatch(*dq)
+    k = 37
+    sq, sv, sa = ltp.stateAt(b, 0, n, k)
+    env = ltp.envelopeBatch(b, 0, n, 64, 8).cpu().numpy()
+    torch.cuda.synchronize()
+    for p in range(0, n, max(1, n // 60)):
+        L = int(r["traj_len"][p])
+        if L <= 0:
+            continue
+        g = amd.unpack_trajectory(r["packed"], int(r["offsets"][p]), D, L)
+        kk = min(k, L - 1)
+        assert np.array_equal(sq[p].cpu().numpy(), g[0][:, kk]) and np.array_equal(sv[p].cpu().numpy(), g[1][:, kk])
+        assert np.array_equal(sa[p].cpu().numpy(), g[2][:, kk])
+        for w in range(8):
+            lo, hi = min(w * 64, L - 1), min(w * 64 + 64, L)
+            seg = g[0][:, lo:max(hi, lo + 1)]
+            assert np.array_equal(env[p, :, w, 0], seg.min(axis=1)) and np.array_equal(env[p, :, w, 1], seg.max(axis=1))
+    # float32 rows and capped rows go through the same tables
+    ltp.setMaxSamples(100)
+    m = min(n, 50)
+    r2 = ltp.planBatchHost(qg[:m], q0[:m], v0[:m], a0[:m], sample=True)
+    for p in range(m):
+        L = int(r["traj_len"][p])
+        if L <= 0:
+            continue
+        S = min(L, 100)
+        g = amd.unpack_trajectory(r["packed"], int(r["offsets"][p]), D, L)
+        g2 = amd.unpack_trajectory(r2["packed"], int(r2["offsets"][p]), D, S)
+        for x in range(4):
+            assert np.array_equal(g2[x], g[x][:, :S])
+
+
+def test_matlab_mode_single_call_and_misuse(amd, oracle_mod):
+    D, lim, ltp, orc = _pair(amd, oracle_mod, "ref", 0.004)
+    qg, q0, v0, a0 = amd.generate_queries(4, lim, seed=5)
+    tr = amd.Trajectory()
+    ok = ltp.planTrajectory(qg[0], q0[0], v0[0], a0[0], tr)
+    o = orc.plan_trajectory(qg[0], q0[0], v0[0], a0[0])
+    assert ok and tr.length == o["length"]
+    for got, want in ((tr.q, o["q"]), (tr.v, o["v"]), (tr.a, o["a"])):
+        assert np.max(np.abs(np.asarray(got) - want)) <= TOL
+    assert np.all(np.asarray(tr.v)[:, -1] == 0.0) and np.max(np.abs(np.asarray(tr.q)[:, -1] - qg[0])) < 0.03
+    assert ltp.checkInputs(q0[0] + 100.0, v0[0], a0[0]) and not ltp.checkInputs(q0[0], v0[0] * 0 + 5.0, a0[0])
+    # a batch planned with one semantics cannot be sampled with the other
+    import torch
+    dq = [torch.from_numpy(x).cuda() for x in (qg, q0, v0, a0)]
+    b = ltp.planSwitchTimesBatch(*dq)
+    tile = torch.zeros(int(b.offsets[-1].item()) + 64, dtype=torch.float64, device="cuda")
+    ltp.setSemantics("cpp")
+    with pytest.raises(amd.LtpError):
+        ltp.sampleBatch(b, 0, 4, tile)
+    ltp.setSemantics("matlab")
+    ltp.sampleBatch(b, 0, 4, tile)
+    assert ltp.lastSamplerKernel().startswith("k_sample_tab")
+    torch.cuda.synchronize()
