@@ -26,13 +26,16 @@ constexpr int kModeTail = 1;    // i > s6: a = 0, v = 0 (cc:815-829)
 constexpr int kModeVSnap = 2;   // phase 4 interior: v = v_drive*dir (cc:822-823)
 constexpr int kModeKeepA = 4;   // MATLAB semantics, tail of every joint but the last: a keeps following the jerk sums (LTPlanner.m:607)
 
-// Inside one run, with m = 1-based position in the run, S1 = m(m+1)/2 and S2 = m(m+1)(m+2)/6:
-//   q(m) = q0 + (q1*m + (q2*S1 + q3*S2))   {q_s, Ts*v_s, Ts*Ts*a_s, Ts*Ts*Ts*J}
-//   v(m) = v0 + (v1*m + v2*S1)             {v_s, Ts*a_s, Ts*Ts*J}
-//   a(m) = a0 + a1*m                       {a_s, Ts*J}
-//   j(m) = J
-// and the three snap rules of cc:815-829 only change coefficients, so evaluating a sample has no branches.
-constexpr int kRunCoefs = 10;   // q0..q3, v0..v2, a0, a1, J
+// Inside one run, with m = 1-based position in the run, the reference's recurrence forms
+//   a(m) = a_s + m Ts J,   v(m) = v_s + Ts (m a_s + Ts J m(m+1)/2),   q(m) = q_s + Ts (m v_s + Ts (a_s m(m+1)/2 + Ts J m(m+1)(m+2)/6)),
+// i.e. polynomials of degree 1, 2 and 3 in m. They are stored in the monomial basis and evaluated by Horner's rule with fused
+// multiply-adds,
+//   q(m) = fma(fma(fma(q3, m, q2), m, q1), m, q0),   v(m) = fma(fma(v2, m, v1), m, v0),   a(m) = fma(a1, m, a0),   j(m) = J
+// — 6 arithmetic instructions per sample. That is what bounds the rows that carry more samples per byte (float32 rows: round 2
+// measured 75 % VALU-busy at 0.74 of the HBM peak with 19 instructions per sample) and the envelope consumer. The stage kernels
+// keep the reference's unfused operation order (branch decisions hang on it); here any rounding order is ~1e-12 from the
+// sequential sums (bar 1e-9). The three snap rules of cc:815-829 only change coefficients, so evaluating a sample has no branches.
+constexpr int kRunCoefs = 10;   // q0..q3, v0..v2, a0, a1, J (monomial basis in m)
 struct RunCoef {
     double c[kRunCoefs];
 };
@@ -129,8 +132,11 @@ LTP_DEV RunCoef run_coef(int mode, double J, double a_s, double v_s, double q_s,
         r.c[4] = vsnap;
         r.c[1] = Ts * vsnap;
     } else if (!(mode & kModeTail)) {
-        r.c[4] = v_s; r.c[5] = Ts * a_s; r.c[6] = Ts * tj;
-        r.c[1] = Ts * v_s; r.c[2] = Ts * (Ts * a_s); r.c[3] = Ts * (Ts * tj);
+        // binomial-sum form -> monomial basis: m(m+1)/2 = (m^2 + m)/2, m(m+1)(m+2)/6 = (m^3 + 3 m^2 + 2 m)/6
+        const double v1 = Ts * a_s, v2 = 0.5 * (Ts * tj);
+        const double q1 = Ts * v_s, q2 = 0.5 * (Ts * (Ts * a_s)), q3 = (Ts * (Ts * tj)) * (1.0 / 6.0);
+        r.c[4] = v_s; r.c[5] = v1 + v2; r.c[6] = v2;
+        r.c[1] = q1 + (q2 + 2.0 * q3); r.c[2] = q2 + 3.0 * q3; r.c[3] = q3;
     }
     return r;
 }
@@ -139,11 +145,9 @@ LTP_DEV RunCoef run_coef(int mode, double J, double a_s, double v_s, double q_s,
 LTP_DEV void run_eval(const double (&c)[kRunCoefs], int m, double& q, double& v, double& a, double& j)
 {
     const double md = (double)m;
-    const double s1 = 0.5 * (md * (md + 1.0));
-    const double s2 = s1 * (md + 2.0) * (1.0 / 3.0);
-    q = c[0] + (c[1] * md + (c[2] * s1 + c[3] * s2));
-    v = c[4] + (c[5] * md + c[6] * s1);
-    a = c[7] + c[8] * md;
+    q = __builtin_fma(__builtin_fma(__builtin_fma(c[3], md, c[2]), md, c[1]), md, c[0]);
+    v = __builtin_fma(__builtin_fma(c[6], md, c[5]), md, c[4]);
+    a = __builtin_fma(c[8], md, c[7]);
     j = c[9];
 }
 
@@ -310,8 +314,8 @@ LTP_DEV void build_run_tables(SegTable& tab, long long p, int j0, int nj, int le
     }
     wave_sync();
     if constexpr (PROBE) { if (threadIdx.x == 0) probe[6] = wall_clock64(); }
-    // (4) lane k < ns: mode and jerk of run k, and everything of the run's end-state update that does not depend
-    //     on the state (parked in tab.jt[.].c[k][0..5] until step (6) overwrites it with the coefficients)
+    // (4) lane k < ns: mode, jerk and length of run k (the length parked in tab.jt[.].c[k][0] until step (6) overwrites it
+    //     with the coefficients)
     const int ns = jact ? tab.jt[jl].nseg : 0;
     if (k < ns) {
         const int b = tab.jt[jl].start[k];
@@ -323,50 +327,29 @@ LTP_DEV void build_run_tables(SegTable& tab, long long p, int j0, int nj, int le
         const double J = jerk_at(sj, tab.w.Jp[jl], tab.w.corr[jl], b);
         tab.w.runMode[jl][k] = mode;
         tab.w.runJ[jl][k] = J;
-        const double md = (double)(tab.jt[jl].start[k + 1] - b);     // samples in the run
-        const double s1 = 0.5 * (md * (md + 1.0));
-        const double tj = Ts * J;
-        double* pre = tab.jt[jl].c[k];
-        pre[0] = md;
-        pre[1] = s1;
-        pre[2] = s1 * (md + 2.0) * (1.0 / 3.0);
-        pre[3] = tj;
-        pre[4] = Ts * tj;
-        pre[5] = Ts * (Ts * tj);
+        // samples in the run (as an int in the low half of pre[0]: step (5) evaluates the run at its last sample)
+        reinterpret_cast<int*>(tab.jt[jl].c[k])[0] = tab.jt[jl].start[k + 1] - b;
     }
     wave_sync();
     if constexpr (PROBE) { if (threadIdx.x == 0) probe[7] = wall_clock64(); }
     // (5) lane 0 of the joint: the state before each run — the only serial part. Each step is run_eval(run_coef(..))
-    //     at the run's last sample, i.e. exactly what the streaming loop will store there, with the state-independent
-    //     factors taken from step (4).
+    //     at the run's last sample, i.e. exactly what the streaming loop will store there (same functions, same bits).
     if (jact && k == 0) {
         const double vsnap = tab.w.misc[jl][1];
         double q = tab.w.misc[jl][2], v = tab.w.misc[jl][3], a = tab.w.misc[jl][4];   // state "before sample 0" (cc:810-812)
-        // software-pipelined by hand: the state-independent factors of run m+1 are fetched from LDS while the
-        // dependent chain of run m executes (the chain is ~5 binary64 operations, an LDS round trip is longer)
-        const double* pre = tab.jt[jl].c[0];
-        double md = pre[0], s1 = pre[1], s2 = pre[2], p3 = pre[3], p4 = pre[4], p5 = pre[5];
-        int mode = tab.w.runMode[jl][0];
+        // software-pipelined by hand: the next run's mode, jerk and length are fetched from LDS while the dependent chain of
+        // the current run executes (the chain is a handful of binary64 operations, an LDS round trip is longer)
+        int mode = tab.w.runMode[jl][0], cnt = reinterpret_cast<const int*>(tab.jt[jl].c[0])[0];
+        double J = tab.w.runJ[jl][0];
         for (int m = 0; m < ns; ++m) {
             const int mn = m + 1 < ns ? m + 1 : m;
-            const double* nx = tab.jt[jl].c[mn];
-            const double md_n = nx[0], s1_n = nx[1], s2_n = nx[2], p3_n = nx[3], p4_n = nx[4], p5_n = nx[5];
-            const int mode_n = tab.w.runMode[jl][mn];
+            const int mode_n = tab.w.runMode[jl][mn], cnt_n = reinterpret_cast<const int*>(tab.jt[jl].c[mn])[0];
+            const double J_n = tab.w.runJ[jl][mn];
             tab.w.state[jl][m][0] = a; tab.w.state[jl][m][1] = v; tab.w.state[jl][m][2] = q;
-            double qn, vn, an;
-            if (mode & kModeVSnap) {
-                vn = vsnap + (0.0 * md + 0.0 * s1);
-                qn = q + ((Ts * vsnap) * md + (0.0 * s1 + 0.0 * s2));
-            } else if (mode & kModeTail) {
-                vn = 0.0 + (0.0 * md + 0.0 * s1);
-                qn = q + (0.0 * md + (0.0 * s1 + 0.0 * s2));
-            } else {
-                vn = v + ((Ts * a) * md + p4 * s1);
-                qn = q + ((Ts * v) * md + ((Ts * (Ts * a)) * s1 + p5 * s2));
-            }
-            an = (mode & kModeTail) ? 0.0 + 0.0 * md : a + p3 * md;
-            q = qn; v = vn; a = an;
-            md = md_n; s1 = s1_n; s2 = s2_n; p3 = p3_n; p4 = p4_n; p5 = p5_n; mode = mode_n;
+            const RunCoef rc = run_coef(mode, J, a, v, q, vsnap, Ts);
+            double jj;
+            run_eval(rc.c, cnt, q, v, a, jj);
+            mode = mode_n; cnt = cnt_n; J = J_n;
         }
         // cc:59-61: q now holds sample len-1
         if (q < lim.q_min[j] || q > lim.q_max[j]) atomicOr(&rec.status[p], kStatusEndLimit);
@@ -1083,9 +1066,7 @@ LTP_TAB_KERNEL(k_sample_tab_f32_nt, true, float, 4)
 LTP_DEV double run_eval_q(const double* c, int m)
 {
     const double md = (double)m;
-    const double s1 = 0.5 * (md * (md + 1.0));
-    const double s2 = s1 * (md + 2.0) * (1.0 / 3.0);
-    return c[0] + (c[1] * md + (c[2] * s1 + c[3] * s2));   // the q line of run_eval
+    return __builtin_fma(__builtin_fma(__builtin_fma(c[3], md, c[2]), md, c[1]), md, c[0]);   // the q line of run_eval
 }
 
 template <bool PROBE, bool TABLES>
@@ -1296,9 +1277,9 @@ LTP_DEV void for_each_run(const Limits& lim, const Records& rec, long long rj, i
             // LTPlanner.m:604-624: a, v, q are cumulative sums over the arrays as they stand — behind the constant-velocity
             // samples (and in the tail) v continues from the UN-snapped sum, the acceleration sum never stops
             const double md = (double)(e - b);
-            const double s1 = 0.5 * (md * (md + 1.0));
-            const double v_cum = v + ((Ts * a) * md + (Ts * (Ts * J)) * s1);
-            const double a_cum = a + (Ts * J) * md;
+            const double v2 = 0.5 * (Ts * (Ts * J));
+            const double v_cum = __builtin_fma(__builtin_fma(v2, md, Ts * a + v2), md, v);   // run_eval's v of an ordinary run
+            const double a_cum = __builtin_fma(Ts * J, md, a);
             double vv, aa, jj;
             run_eval(rc.c, e - b, q, vv, aa, jj);
             v = v_cum;
