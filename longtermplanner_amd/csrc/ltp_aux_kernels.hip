@@ -160,16 +160,15 @@ LTP_DEV double probe_root(const double* c)
     return smallest_positive_real_root<N>(p);
 }
 
-__global__ void k_roots_probe(long long n, int degree, const double* coef, double* root)
+// one kernel per degree: with the three solvers in one kernel its register allocation is the largest solver's plus the others'
+// live ranges, and the probe would not time what a candidate wave of k_scaling_slow runs
+template <int N>
+__global__ void __launch_bounds__(64)
+k_roots_probe(long long n, const double* coef, double* root)
 {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const double* c = coef + i * 7;
-    double r;
-    if (degree == 4) r = probe_root<4>(c);
-    else if (degree == 5) r = probe_root<5>(c);
-    else r = probe_root<6>(c);
-    root[i] = r;
+    root[i] = probe_root<N>(coef + i * 7);
 }
 
 // roots<T>() of the reference's long_term_planner/roots.h:22-34 for polynomial i: all eigenvalues of the companion matrix,
@@ -266,7 +265,10 @@ void launch_math_probe(hipStream_t s, long long n, const double* x, const double
 void launch_roots_probe(hipStream_t s, long long n, int degree, const double* coef, double* root)
 {
     if (n <= 0) return;
-    hipLaunchKernelGGL(k_roots_probe, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, n, degree, coef, root);
+    const dim3 grid((unsigned)((n + 63) / 64)), block(64);
+    if (degree == 4) hipLaunchKernelGGL(k_roots_probe<4>, grid, block, 0, s, n, coef, root);
+    else if (degree == 5) hipLaunchKernelGGL(k_roots_probe<5>, grid, block, 0, s, n, coef, root);
+    else hipLaunchKernelGGL(k_roots_probe<6>, grid, block, 0, s, n, coef, root);
 }
 
 }  // namespace ltp

@@ -102,6 +102,123 @@ LTP_DEV void givens(R p, R q, R& c, R& s)
     }
 }
 
+
+// One Francis double-shift step on the active window rows / columns 0..3 (il == 0, iu == 3), every subscript a compile-time
+// constant and no lane predicates except the start row im in {0, 1}: what the general step below does for such a window,
+// element for element and in the same order — minus the entries right of column 3, which no eigenvalue ever reads (a step only
+// feeds on the window itself: diagonal, sub-diagonal and the three columns / rows of the bulge; the columns beyond iu are the
+// coupling block of the Schur form, which Eigen carries along for its eigenvectors). Measured on the polynomials the planner
+// solves (tools/schur_iters.py): 92 % of all Francis steps of the degree-6 solves, 77 % of degree 5 and all of degree 4 are
+// taken on exactly this window — after the first step the two bottom roots of a degree-6 polynomial split off and the
+// remaining 4 x 4 block is what converges slowly (the slowest lane of a 100 k batch: 75 of its 76 steps).
+template <int N, typename R>
+LTP_DEV void francis_step_window4(R (&T)[N][N], R sh0, R sh1, R sh2)
+{
+    static_assert(N >= 4, "needs a 4 x 4 window");
+    // initFrancisQRStep: m = 1, then m = 0
+    int im;
+    R v0, v1, v2;
+    {
+        const R Tmm = T[1][1];
+        const R r = sh0 - Tmm, s = sh1 - Tmm;
+        v0 = (r * s - sh2) / T[2][1] + T[1][2];
+        v1 = T[2][2] - Tmm - r - s;
+        v2 = T[3][2];
+        im = 1;
+        const R lhs = T[1][0] * (rabs(v1) + rabs(v2));
+        const R rhs = v0 * (rabs(T[0][0]) + rabs(Tmm) + rabs(T[2][2]));
+        if (!(rabs(lhs) < RealTraits<R>::eps() * rhs)) {
+            const R T00 = T[0][0];
+            const R r0 = sh0 - T00, s0 = sh1 - T00;
+            v0 = (r0 * s0 - sh2) / T[1][0] + T[0][1];
+            v1 = T[1][1] - T00 - r0 - s0;
+            v2 = T[2][1];
+            im = 0;
+        }
+    }
+    // performFrancisQRStep, k = 0 (only when the step starts at row 0)
+    if (im == 0) {
+        R e0, e1, tau, beta;
+        householder3(v0, v1, v2, e0, e1, tau, beta);
+        if (beta != R(0) && tau != R(0)) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                R tmp = e0 * T[1][j] + e1 * T[2][j];
+                tmp += T[0][j];
+                T[0][j] -= tau * tmp;
+                T[1][j] -= (tau * e0) * tmp;
+                T[2][j] -= (tau * e1) * tmp;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                R tmp = T[i][1] * e0 + T[i][2] * e1;
+                tmp += T[i][0];
+                T[i][0] -= tau * tmp;
+                T[i][1] -= (tau * tmp) * e0;
+                T[i][2] -= (tau * tmp) * e1;
+            }
+        }
+    }
+    // k = 1
+    {
+        const bool first = im == 1;
+        R w0, w1, w2;
+        if (first) { w0 = v0; w1 = v1; w2 = v2; }
+        else { w0 = T[1][0]; w1 = T[2][0]; w2 = T[3][0]; }
+        R e0, e1, tau, beta;
+        householder3(w0, w1, w2, e0, e1, tau, beta);
+        if (beta != R(0)) {
+            if (first) T[1][0] = -T[1][0];      // k = 1 > il = 0
+            else T[1][0] = beta;
+            if (tau != R(0)) {
+#pragma unroll
+                for (int j = 1; j < 4; ++j) {
+                    R tmp = e0 * T[2][j] + e1 * T[3][j];
+                    tmp += T[1][j];
+                    T[1][j] -= tau * tmp;
+                    T[2][j] -= (tau * e0) * tmp;
+                    T[3][j] -= (tau * e1) * tmp;
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    R tmp = T[i][2] * e0 + T[i][3] * e1;
+                    tmp += T[i][1];
+                    T[i][1] -= tau * tmp;
+                    T[i][2] -= (tau * tmp) * e0;
+                    T[i][3] -= (tau * tmp) * e1;
+                }
+            }
+        }
+    }
+    // last 2-vector reflector at (2, 1)
+    {
+        R e0, tau, beta;
+        householder2(T[2][1], T[3][1], e0, tau, beta);
+        if (beta != R(0)) {
+            T[2][1] = beta;
+            if (tau != R(0)) {
+#pragma unroll
+                for (int j = 2; j < 4; ++j) {
+                    R tmp = e0 * T[3][j];
+                    tmp += T[2][j];
+                    T[2][j] -= tau * tmp;
+                    T[3][j] -= (tau * e0) * tmp;
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    R tmp = T[i][3] * e0;
+                    tmp += T[i][2];
+                    T[i][2] -= tau * tmp;
+                    T[i][3] -= (tau * tmp) * e0;
+                }
+            }
+        }
+    }
+    // clean up pollution due to round-off errors
+    if (im == 0) { T[2][0] = R(0); T[3][0] = R(0); }
+    T[3][1] = R(0);
+}
+
 // RealSchur::compute on the monic companion matrix of p (highest coefficient first): T is left quasi-triangular, in the
 // scaled units (multiply by scale_out). false: non-finite matrix or no convergence within 40 N iterations.
 template <int N, typename R>
@@ -259,6 +376,15 @@ __device__ bool real_schur_companion(const R (&p)[N + 1], R (&T)[N][N], R& scale
             iter += 1;
             total_iter += 1;
             if (total_iter > max_iters) { converged = false; break; }
+
+            if constexpr (N >= 4) {
+                // every lane that takes a step now is on the window rows 0..3: the specialised step (same arithmetic, far fewer
+                // instructions: no lane predicates, no columns beyond the window)
+                if (__builtin_amdgcn_ballot_w64(!(il == 0 && iu == 3)) == 0ull) {
+                    francis_step_window4<N, R>(T, sh0, sh1, sh2);
+                    continue;
+                }
+            }
 
             // initFrancisQRStep
             int im = il;

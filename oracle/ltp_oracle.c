@@ -44,6 +44,11 @@
 /* ---------- root finder, instantiated for double and float ---------- */
 static int ltpo_schur_iterations = 0;
 int ltpo_last_schur_iterations(void) { return ltpo_schur_iterations; }
+/* diagnostic: Francis steps of the last solve by size of the active window iu - il + 1 (tools/schur_iters.py) */
+static int ltpo_schur_window_steps[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+static int ltpo_schur_iliu_steps[81];   /* [il][iu] */
+void ltpo_last_schur_window_steps(int *out9) { int i; for (i = 0; i < 9; i++) out9[i] = ltpo_schur_window_steps[i]; }
+void ltpo_last_schur_iliu_steps(int *out81) { int i; for (i = 0; i < 81; i++) out81[i] = ltpo_schur_iliu_steps[i]; }
 #define REAL double
 #define REAL_MIN DBL_MIN
 #define REAL_EPS DBL_EPSILON
