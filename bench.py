@@ -143,6 +143,8 @@ def parse_args(argv=None):
     ap.add_argument("--table-gib", type=float, default=0.0, help="upper bound of the table-pass workspace (default: library default, 1/16 of device memory)")
     ap.add_argument("--sample-blocks", type=int, default=0, help="TUNING: size of the sampler's persistent grid (0 = library default)")
     ap.add_argument("--gather", action="store_true", help="also all_gather t_required over RCCL each step (optional path)")
+    ap.add_argument("--semantics", default="cpp", choices=["cpp", "matlab"],
+                    help="VARIANT (SURVEY §8(f).4): 'matlab' follows LTPlanner.m where the C++ translation diverges (ltp_set_semantics); rows then take the table pass")
     ap.add_argument("--one-process", action="store_true",
                     help="--gpus N from ONE process: one planner handle, stream and host thread per device, device-resident shards "
                          "(ltp_plan_switch_times_multi / ltp_envelope_multi / ltp_state_at_multi), no torch.distributed. Workloads without dense "
@@ -200,6 +202,7 @@ class Workload:
         self.table_pass, self.table_gib = args.table_pass, args.table_gib
         self.end_limit = args.end_limit
         self.in_flight = args.in_flight
+        self.semantics = args.semantics
         self.name = "primary"
         for k, v in over.items():
             setattr(self, k, v)
@@ -215,6 +218,8 @@ def run_workload(wl, ctx):
     world, rank, dev, cdev, local_rank = ctx["world"], ctx["rank"], ctx["dev"], ctx["cdev"], ctx["local_rank"]
     dof, lim = limit_set(wl.limits)
     ltp = LongTermPlanner(dof, wl.t_sample, device=local_rank, **lim)
+    if wl.semantics != "cpp":
+        ltp.setSemantics(wl.semantics)
     if wl.global_batch:
         first_query, n = shard_range(wl.global_batch, rank, world)
         total_queries = wl.global_batch
@@ -254,6 +259,9 @@ def run_workload(wl, ctx):
             pool.append(torch.cuda.Stream())
         lanes = [{"ltp": ltp if i == 0 else LongTermPlanner(dof, wl.t_sample, device=local_rank, **lim), "stream": pool[i], "batch": None}
                  for i in range(wl.in_flight)]
+        for lane in lanes[1:]:
+            if wl.semantics != "cpp":
+                lane["ltp"].setSemantics(wl.semantics)
     step_no = 0
     gather_buf = [torch.empty(n, dtype=torch.float64, device=cdev) for _ in range(world)] if (wl.gather and world > 1 and not wl.global_batch) else None
     ev_pairs = []
@@ -393,7 +401,7 @@ def run_workload(wl, ctx):
         return None
     replans = rec_spec[0] if rec_spec else 1
     out = {
-        "metric": "7-DoF trajectory plans/sec (batch 1M)" if dof == 7 else f"{dof}-DoF trajectory plans/sec",
+        "metric": ("7-DoF trajectory plans/sec (batch 1M)" if dof == 7 else f"{dof}-DoF trajectory plans/sec") + (" [MATLAB semantics]" if wl.semantics == "matlab" else ""),
         "value": round(total_queries * wl.steps * replans / elapsed, 1),
         "unit": "plans/s",
         "n_gpus": world,
@@ -417,7 +425,7 @@ def run_workload(wl, ctx):
                              f"q/v/a/j rows: every {wl.sample_stride}-th sample" + (f", first {wl.max_samples} stored" if wl.max_samples else ""))
                             + f" into a reused {tile_gib} GiB tile ({n_chunks} chunks per step)")),
             "batch_per_gpu": n if not wl.global_batch else None, "global_batch": total_queries, "dof": dof, "t_sample": wl.t_sample,
-            "limits": wl.limits, "input_layout": wl.layout, "table_pass": wl.table_pass, "batches_in_flight": wl.in_flight,
+            "limits": wl.limits, "input_layout": wl.layout, "table_pass": wl.table_pass, "batches_in_flight": wl.in_flight, "semantics": wl.semantics,
             "sharding": "contiguous query ranges per rank, no data-path collective" + (", RCCL all_gather of t_required" if gather_buf else ""),
             "plans_ok_frac": round(ok_total / total_queries, 5),
             "plans_ok_is": ("planTrajectory's bool" if (wl.end_limit or not (wl.switch_only or rec_direct)) else
@@ -599,7 +607,7 @@ def main():
     out = run_workload(primary, ctx)
 
     variant = (args.switch_only or args.end_limit or args.f32 or args.max_samples or args.sample_stride > 1 or args.envelope or args.receding or args.dry_sampler
-               or args.in_flight > 1 or args.table_pass != "auto" or args.limits != "panda" or args.batch != 1_000_000 or args.global_batch or args.window_gib or args.layout != "query_major")
+               or args.in_flight > 1 or args.semantics != "cpp" or args.table_pass != "auto" or args.limits != "panda" or args.batch != 1_000_000 or args.global_batch or args.window_gib or args.layout != "query_major")
     secondary = []
     if not args.no_secondary and not variant:
         few = max(1, min(args.steps, 2))

@@ -377,9 +377,11 @@ __device__ bool real_schur_companion(const R (&p)[N + 1], R (&T)[N][N], R& scale
             total_iter += 1;
             if (total_iter > max_iters) { converged = false; break; }
 
-            if constexpr (N >= 4) {
+            if constexpr (N >= 5) {
                 // every lane that takes a step now is on the window rows 0..3: the specialised step (same arithmetic, far fewer
-                // instructions: no lane predicates, no columns beyond the window)
+                // instructions: no lane predicates, no columns beyond the window). Degree 4 keeps the general step: its whole
+                // matrix is that window, its solves are 3-5 steps long, and the second code path costs registers in every kernel
+                // that carries a quartic site.
                 if (__builtin_amdgcn_ballot_w64(!(il == 0 && iu == 3)) == 0ull) {
                     francis_step_window4<N, R>(T, sh0, sh1, sh2);
                     continue;

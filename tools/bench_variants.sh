@@ -12,6 +12,11 @@ run --envelope 64:32
 run --receding 10:100 --max-samples 128
 run --receding 10:100
 run --limits ref --f32 --steps 2 --warmup 1
+run --semantics matlab --steps 2 --warmup 1
+run --semantics matlab --switch-only --batch 100000 --steps 30 --warmup 3
+run --semantics matlab --limits ref --switch-only --batch 100000 --steps 30 --warmup 3
+run --switch-only --batch 100000 --steps 50 --warmup 5
+run --switch-only --batch 100000 --limits ref --steps 50 --warmup 5
 python - "$out" <<'PY'
 import json, sys
 for ln in open(sys.argv[1]):
