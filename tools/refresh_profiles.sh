@@ -2,11 +2,14 @@
 # Runs on the GPU box (gpurun -- bash tools/refresh_profiles.sh [tag]): headline bench, workload variants and the rocprofv3
 # passes whose summaries are kept under profiles/. Everything lands in gpurun_out/; profiles/summarize.py condenses it.
 set -o pipefail
-TAG=${1:-r02}
+TAG=${1:-r03}
+PART=${2:-all}      # all | bench (the bench lines) | prof (the rocprofv3 passes): two gpurun calls when one would run out of time
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$R/gpurun_out
-mkdir -p $O && rm -rf $O/prof_stats $O/prof_write $O/prof_fetch $O/prof_tab_stats $O/prof_switch_100000 $O/prof_switch_1000000 $O/prof_sq_first256 $O/prof_sq_switch100k
+mkdir -p $O
+if [ "$PART" != bench ]; then rm -rf $O/prof_stats $O/prof_write $O/prof_fetch $O/prof_tab_stats $O/prof_switch_100000 $O/prof_switch_1000000 $O/prof_sq_first256 $O/prof_sq_switch100k $O/prof_sq_f32 $O/prof_sq_envelope $O/prof_f32_stats; fi
 cd $R
+if [ "$PART" != prof ]; then
 timeout -k 10 400 python bench.py > $O/bench_default.json 2> $O/bench_default.err || exit 1
 echo "default done"; cut -c1-300 $O/bench_default.json
 : > $O/bench_variants.jsonl
@@ -16,7 +19,13 @@ for a in "--limits ref" "--limits ref30 --batch 200000" "--switch-only --batch 1
          "--max-samples 256" "--max-samples 256 --table-pass off" "--max-samples 64" "--sample-stride 4" "--f32" "--f32 --limits ref" \
          "--f32 --max-samples 256" "--f32 --max-samples 256 --table-pass off" "--f32 --max-samples 1024" "--envelope 64:32" \
          "--envelope 64:32 --table-pass off" "--envelope 64:32 --limits ref" "--receding 10:100" "--receding 10:100 --end-limit" \
-         "--receding 10:100 --max-samples 128" "--receding 10:100 --max-samples 128 --table-pass off" "--tile-gib 64" "--layout joint_major"; do
+         "--receding 10:100 --max-samples 128" "--receding 10:100 --max-samples 128 --table-pass off" "--tile-gib 64" "--layout joint_major" \
+         "--semantics matlab --steps 3" "--semantics matlab --limits ref --steps 2" "--semantics matlab --switch-only --batch 100000 --steps 30 --warmup 3" \
+         "--semantics matlab --switch-only --batch 100000 --limits ref --steps 30 --warmup 3" "--semantics matlab --envelope 64:32" \
+         "--gpus 8 --one-process --device 0 --global-batch 10000000 --switch-only --end-limit --checksum --steps 5" \
+         "--gpus 8 --one-process --device 0 --global-batch 10000000 --envelope 64:32 --steps 2" \
+         "--gpus 8 --one-process --device 0 --global-batch 10000000 --receding 10:100 --steps 2" \
+         "--gpus 1 --global-batch 10000000 --switch-only --end-limit --checksum --steps 5"; do
   timeout -k 10 300 python bench.py --no-cpu-baseline $a >> $O/bench_variants.jsonl 2>> $O/bench_variants.err || exit 1
   echo "variant $a done"
 done
@@ -29,7 +38,11 @@ done
 # N ranks rehearsed on this one GPU (gloo for the barrier; every rank on device 0): the launch path the 8-GPU node uses
 timeout -k 10 300 python bench.py --gpus 2 --backend gloo --device 0 --no-cpu-baseline --steps 3 > $O/bench_2ranks_gloo.json 2>> $O/bench_variants.err || exit 1
 timeout -k 10 300 python bench.py --gpus 4 --backend gloo --device 0 --no-cpu-baseline --no-secondary --global-batch 1000000 --steps 3 > $O/bench_4ranks_gloo_global.json 2>> $O/bench_variants.err || exit 1
+# BASELINE.json configs[3] at its real size, as far as one GPU goes: 10 M queries, four ranks (a box allows six GPU processes) sharing the device
+timeout -k 10 400 python bench.py --gpus 4 --backend gloo --device 0 --no-cpu-baseline --no-secondary --global-batch 10000000 --checksum --tile-gib 96 --steps 2 > $O/bench_config4_4ranks_gloo.json 2>> $O/bench_variants.err || exit 1
 echo "rank rehearsal done"
+fi
+if [ "$PART" = bench ]; then exit 0; fi
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_stats -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary > $O/prof_stats.log 2>&1 || exit 1
 echo "stats pass done"
@@ -46,6 +59,9 @@ echo "switching-times stats passes done"
 SQ="SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU"
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d $O/prof_sq_first256 -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary --max-samples 256 > $O/prof_sq_first256.log 2>&1 || exit 1
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d $O/prof_sq_switch100k -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary --switch-only --batch 100000 > $O/prof_sq_switch100k.log 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d $O/prof_sq_f32 -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-secondary --f32 > $O/prof_sq_f32.log 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d $O/prof_sq_envelope -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-secondary --envelope 64:32 > $O/prof_sq_envelope.log 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_f32_stats -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary --f32 > $O/prof_f32_stats.log 2>&1 || exit 1
 echo "SQ counter passes done"
 # keep only the small CSVs
-find $O/prof_stats $O/prof_write $O/prof_fetch $O/prof_tab_stats $O/prof_switch_100000 $O/prof_switch_1000000 $O/prof_sq_first256 $O/prof_sq_switch100k -type f ! -name "*_kernel_stats.csv" ! -name "*_counter_collection.csv" -delete
+find $O/prof_stats $O/prof_write $O/prof_fetch $O/prof_tab_stats $O/prof_switch_100000 $O/prof_switch_1000000 $O/prof_sq_first256 $O/prof_sq_switch100k $O/prof_sq_f32 $O/prof_sq_envelope $O/prof_f32_stats -type f ! -name "*_kernel_stats.csv" ! -name "*_counter_collection.csv" -delete
