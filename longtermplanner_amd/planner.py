@@ -172,7 +172,7 @@ class LongTermPlanner:
         q, v, a, j = unpack_trajectory(r["packed"], int(r["offsets"][0]), self.dof, n)
         traj.dof, traj.t_sample, traj.length = self.dof, self.t_sample, n
         traj.q, traj.v, traj.a, traj.j = q.copy(), v.copy(), a.copy(), j.copy()
-        return st == 0
+        return (st & ~_abi.STATUS_MATLAB_COMPLEX) == 0   # the informational MATLAB bit does not make a plan fail
 
     # ---- the reference's protected methods (exposed to tests through a subclass there) ----
     def optBraking(self, joint, v_0, a_0, t_rel=None):
