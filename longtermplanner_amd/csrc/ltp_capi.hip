@@ -44,6 +44,13 @@ struct ltp_planner {
     const char* last_kernel = "";          // row / envelope kernel of the latest ltp_sample_batch* / ltp_envelope_batch
     int semantics = 0;                     // LTP_SEMANTICS_CPP (the reference's C++, default) or LTP_SEMANTICS_MATLAB
     int last_matlab_flags = 0;             // MATLAB semantics: flags of the latest one-lane call (1 = complex intermediate, 2 = error)
+    // resident single-call service (ltp_set_service_idle_us): mailbox in pinned host memory, two device words, its own stream
+    int service_idle_us = 0;               // 0 = off: every small call launches k_plan_small
+    void* svc_mailbox = nullptr;
+    unsigned* d_svc = nullptr;
+    hipStream_t svc_stream = nullptr;
+    unsigned svc_seq = 0;                  // last command posted
+    bool svc_started = false;              // an instance was launched and not yet known to have ended
     unsigned long long* dbg_stamps = nullptr; // diagnostic: per-block start/end stamps of k_sample (caller-owned)
     // persistent buffers of the small synchronous host-pointer calls (no hipMalloc per call)
     std::mutex host_mu;
@@ -67,6 +74,7 @@ struct ltp_planner {
 namespace {
 
 constexpr bool kEnvelopeTablePassByDefault = true;   // measured: see DESIGN.md "Table pass"
+int service_stop(ltp_planner* p);                    // resident single-call service, below
 
 int fail(ltp_planner* p, int code, const std::string& msg)
 {
@@ -344,6 +352,10 @@ void ltp_destroy(ltp_planner* p)
 {
     if (!p) return;
     (void)hipSetDevice(p->device);
+    (void)service_stop(p);
+    if (p->svc_stream) (void)hipStreamDestroy(p->svc_stream);
+    if (p->d_svc) (void)hipFree(p->d_svc);
+    if (p->svc_mailbox) (void)hipHostFree(p->svc_mailbox);
     if (p->d_lim) (void)hipFree(p->d_lim);
     if (p->d_queue) (void)hipFree(p->d_queue);
     if (p->d_lane_flags) (void)hipFree(p->d_lane_flags);
@@ -369,6 +381,11 @@ int ltp_set_limits(ltp_planner* p, int n_limits, const double* q_min, const doub
     const double* src[5] = {q_min, q_max, v_max, a_max, j_max};
     for (int k = 0; k < 5; ++k) p->h_lim[k].assign(src[k], src[k] + n_limits);
     LTP_HIP_TRY(p, hipSetDevice(p->device));
+    {
+        std::lock_guard<std::mutex> hg(p->host_mu);
+        const int rc = service_stop(p);       // a resident service instance reads the limits too (and would outlast the synchronisation below)
+        if (rc != LTP_OK) return rc;
+    }
     LTP_HIP_TRY(p, hipDeviceSynchronize());   // limits are read by in-flight kernels
     return upload_limits(p);
 }
@@ -421,6 +438,22 @@ int ltp_set_semantics(ltp_planner* p, int semantics)
     return LTP_OK;
 }
 int ltp_get_semantics(const ltp_planner* p) { return p ? p->semantics : -1; }
+int ltp_set_service_idle_us(ltp_planner* p, int idle_us)
+{
+    if (!p || idle_us < 0 || idle_us > 1000000) return fail(p, LTP_ERR_INVALID_ARGUMENT, "the idle time must be 0 (off) .. 1 000 000 us");
+    std::lock_guard<std::mutex> hg(p->host_mu);
+    const int rc = service_stop(p);       // a running instance carries the old idle time
+    if (rc != LTP_OK) return rc;
+    p->service_idle_us = idle_us;
+    return LTP_OK;
+}
+int ltp_get_service_idle_us(const ltp_planner* p) { return p ? p->service_idle_us : -1; }
+int ltp_debug_service_ticks(ltp_planner* p, unsigned long long out[7])
+{
+    if (!p || !out || !p->svc_mailbox) return LTP_ERR_INVALID_ARGUMENT;
+    ltp::service_ticks(p->svc_mailbox, out);
+    return LTP_OK;
+}
 int ltp_set_table_pass(ltp_planner* p, int mode)
 {
     if (!p || mode < -1 || mode > 1) return fail(p, LTP_ERR_INVALID_ARGUMENT, "table pass mode must be -1, 0 or 1");
@@ -713,8 +746,8 @@ static int run_sample_to_host(ltp_planner* p, long long n, const ltp_queries& dq
     if (e != hipSuccess) rc = hip_fail(p, e, "hipMemset");
     if (rc == LTP_OK) rc = ltp_sample_batch(p, 0, n, &dq, &dr, d_offsets, d_out, total, 0, nullptr);
     if (rc == LTP_OK) {
-        e = hipDeviceSynchronize();
-        if (e != hipSuccess) rc = hip_fail(p, e, "hipDeviceSynchronize");
+        e = hipStreamSynchronize(nullptr);   // (not the whole device: a resident single-call service of some handle may be polling)
+        if (e != hipSuccess) rc = hip_fail(p, e, "hipStreamSynchronize");
     }
     if (rc == LTP_OK) {
         double* h = (double*)malloc(sizeof(double) * (size_t)(total ? total : 1));
@@ -801,6 +834,46 @@ int wait_done(ltp_planner* p, volatile int* done)
 #endif
     }
     std::atomic_thread_fence(std::memory_order_acquire);   // the result buffers are read after the flag
+    return LTP_OK;
+}
+
+}  // namespace
+
+// ---- resident single-call service (k_plan_service). Caller holds host_mu. ----
+namespace {
+
+constexpr unsigned long long kServiceHardSeconds = 20;      // an instance never lives longer than this, whatever happens
+
+// makes sure no instance is running (returns when the leader has left): before anything that synchronises the whole device,
+// changes the limits' device array or frees the handle
+int service_stop(ltp_planner* p)
+{
+    if (!p->svc_started) return LTP_OK;
+    ltp::service_stop_request(p->svc_mailbox);
+    LTP_HIP_TRY(p, hipSetDevice(p->device));
+    LTP_HIP_TRY(p, hipStreamSynchronize(p->svc_stream));
+    p->svc_started = false;
+    return LTP_OK;
+}
+
+int service_start(ltp_planner* p)
+{
+    LTP_HIP_TRY(p, hipSetDevice(p->device));
+    if (!p->svc_mailbox) {
+        LTP_HIP_TRY(p, hipHostMalloc(&p->svc_mailbox, (size_t)ltp::service_mailbox_bytes(), hipHostMallocPortable | hipHostMallocCoherent));
+        memset(p->svc_mailbox, 0, (size_t)ltp::service_mailbox_bytes());
+        LTP_HIP_TRY(p, hipMalloc((void**)&p->d_svc, 2 * sizeof(unsigned)));
+        LTP_HIP_TRY(p, hipStreamCreateWithFlags(&p->svc_stream, hipStreamNonBlocking));
+    }
+    // stream order: a previous instance (which has cleared `alive`, or is about to) is over before the words are re-armed
+    const unsigned words[2] = {p->svc_seq, 0u};
+    LTP_HIP_TRY(p, hipMemcpyAsync(p->d_svc, words, sizeof(words), hipMemcpyHostToDevice, p->svc_stream));
+    LTP_HIP_TRY(p, hipStreamSynchronize(p->svc_stream));   // `words` is a stack array; this also ends the wait for an instance on its way out
+    ltp::service_set(p->svc_mailbox, 1u, 0u);
+    ltp::launch_plan_service(p->svc_stream, p->svc_mailbox, p->d_svc, dev_limits(p), p->svc_seq, (unsigned long long)p->service_idle_us * 100ull,
+                             kServiceHardSeconds * 100000000ull);   // wall_clock64 ticks at 100 MHz
+    LTP_HIP_TRY(p, hipGetLastError());
+    p->svc_started = true;
     return LTP_OK;
 }
 
@@ -909,7 +982,7 @@ int plan_batch_host_fused(ltp_planner* p, long long n, const double* const (&h_i
     const size_t nd = (size_t)n * dof;
     const ArenaLayout L = arena_layout(n, dof);
     const size_t flag_at = (L.end + 63) & ~(size_t)63;
-    const int blocks = ltp::small_batch_blocks(dof, packed != nullptr);
+    const int blocks = p->service_idle_us > 0 ? ltp::service_blocks() : ltp::small_batch_blocks(dof, packed != nullptr);
     const size_t ends_at = flag_at + 64;                         // [blocks][n] end-limit bits
     int rc = ensure_arena(p, ends_at + sizeof(int) * (size_t)blocks * (size_t)n);
     if (rc != LTP_OK) return rc;
@@ -938,6 +1011,47 @@ int plan_batch_host_fused(ltp_planner* p, long long n, const double* const (&h_i
     *done = 0;
     const double* in[4] = {(const double*)(p->h_arena + L.in[0]), (const double*)(p->h_arena + L.in[1]),
                            (const double*)(p->h_arena + L.in[2]), (const double*)(p->h_arena + L.in[3])};
+    if (p->service_idle_us > 0) {
+        // resident service: post the command to the mailbox; start an instance if none is running, and again if the one that
+        // was running left (idle timeout) before it saw the command
+        {
+            std::lock_guard<std::mutex> g(p->mu);
+            capture_geometry(p);
+        }
+        if (!p->svc_started || ltp::service_alive(p->svc_mailbox) == 0u) {
+            p->svc_started = false;
+            if ((rc = service_start(p)) != LTP_OK) { if (rows) g_pinned.release(rows); return rc; }
+        }
+        const unsigned prev_seq = p->svc_seq;
+        p->svc_seq = prev_seq + 1u == 0xffffffffu ? 0u : prev_seq + 1u;    // (0xffffffff is the kernel's "leave" word)
+        ltp::service_post(p->svc_mailbox, p->svc_seq, (int)n, dof, p->t_sample, p->goal_check, ltp::RowSpec{p->max_samples, p->sample_stride}, in,
+                          to_dev(&hr), (unsigned long long*)(p->h_arena + L.offsets), rows, kFusedRowsBytes / sizeof(double),
+                          (int*)(p->h_arena + ends_at), p->d_svc + 1, done, given != nullptr);
+        rc = LTP_OK;
+        int restarts = 0;
+        for (long spins = 0; *done == 0; ++spins) {
+            if ((spins & 255) == 255 && ltp::service_alive(p->svc_mailbox) == 0u && *done == 0) {
+                // the instance ended without serving this command (it was on its way out when the command arrived): the new
+                // instance starts with the previous command as the last one seen, so it takes this one at once
+                if (++restarts > 3) { rc = fail(p, LTP_ERR_HIP, "the single-call service keeps ending before it serves the command"); break; }
+                const unsigned posted = p->svc_seq;
+                p->svc_seq = prev_seq;
+                rc = service_start(p);
+                p->svc_seq = posted;
+                if (rc != LTP_OK) break;
+            }
+            if (spins > 400000000l) { rc = fail(p, LTP_ERR_HIP, "the single-call service did not answer"); break; }
+#if defined(__x86_64__)
+            __builtin_ia32_pause();
+#endif
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+        if (rc != LTP_OK) {
+            (void)service_stop(p);               // whatever is left of it must be gone before the buffers are reused
+            if (rows) g_pinned.release(rows);
+            return rc;
+        }
+    } else {
     {
         std::lock_guard<std::mutex> g(p->mu);
         capture_geometry(p);
@@ -948,6 +1062,7 @@ int plan_batch_host_fused(ltp_planner* p, long long n, const double* const (&h_i
         if (e != hipSuccess) { if (rows) g_pinned.release(rows); return hip_fail(p, e, "k_plan_small"); }   // nothing was launched
     }
     rc = wait_done(p, done);
+    }
     if (rc != LTP_OK) {
         // the kernel may still be running (or have died half way): its arrival word is suspect, and `rows` goes back to the
         // pool only once the stream is known to be idle — otherwise it stays allocated (leaked) rather than be written behind a later owner's back
@@ -1081,7 +1196,7 @@ int ltp_plan_batch_host(ltp_planner* p, long long n, const double* q_goal, const
     rc = ltp_plan_switch_times_batch(p, n, &dq, &dr.r, d_off, nullptr);
     if (rc == LTP_OK && !packed) rc = ltp_end_limit_batch(p, 0, n, &dq, &dr.r, nullptr);   // cc:59-61 without the sampler
     if (rc != LTP_OK) return rc;
-    LTP_HIP_TRY(p, hipDeviceSynchronize());
+    LTP_HIP_TRY(p, hipStreamSynchronize(nullptr));
     if (packed) {
         rc = run_sample_to_host(p, n, dq, dr.r, d_off, offsets, packed);
         if (rc != LTP_OK) return rc;
@@ -1355,7 +1470,7 @@ int ltp_plan_envelope_host(ltp_planner* p, long long n, const double* q_goal, co
     if (rc == LTP_OK) rc = ltp_envelope_batch(p, 0, n, &dq, &dr.r, window, n_windows, d_env, nullptr);
     if (rc != LTP_OK) return rc;
     if (env_doubles) LTP_HIP_TRY(p, hipMemcpy(env, d_env, sizeof(double) * env_doubles, hipMemcpyDeviceToHost));   // synchronises
-    else LTP_HIP_TRY(p, hipDeviceSynchronize());
+    else LTP_HIP_TRY(p, hipStreamSynchronize(nullptr));
     return download_records(p, n, dof, dr.r, host_records);   // after the consumer: status carries END_LIMIT
 }
 
@@ -1443,7 +1558,7 @@ int ltp_get_trajectory_host(ltp_planner* p, long long n, const double* t, const 
         ltp::launch_offsets(nullptr, n, dof, p->t_sample, to_dev(&dr.r), p->d_block_sums, d_off, false, ltp::RowSpec{p->max_samples, p->sample_stride});
         LTP_HIP_TRY(p, hipGetLastError());
     }
-    LTP_HIP_TRY(p, hipDeviceSynchronize());
+    LTP_HIP_TRY(p, hipStreamSynchronize(nullptr));
     rc = run_sample_to_host(p, n, dq, dr.r, d_off, offsets, packed);
     if (rc != LTP_OK) return rc;
     if (traj_len) LTP_HIP_TRY(p, hipMemcpy(traj_len, dr.r.traj_len, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost));

@@ -1432,23 +1432,47 @@ struct SmallHost {               // device-addressable host memory (or device me
     volatile int* done;          // set to 1 (2: rows did not fit `capacity`, nothing sampled) when everything above is visible
 };
 
+struct SmallShared {             // LDS of one small-batch block
+    SegTable tab;
+    double t_opt[kSmallPairs][7], t_scaled[kSmallPairs][7], dir[kSmallPairs], vd[kSmallPairs];
+    double treq[kSmallPairs];
+    signed char mod[kSmallPairs];
+    int flags[kSmallPairs], slowest[kSmallPairs], len[kSmallPairs], status[kSmallPairs];
+    unsigned long long off[kSmallPairs + 1];
+    int fit;
+    unsigned long long tick[8];     // diagnostic: wall clock of thread 0 at the phase boundaries
+};
+
 // GIVEN: the switching-time records are inputs (LongTermPlanner::getTrajectory, cc:706-841: t_scaled, dir, mod, v_drive
 // from io.rec, start states from io.in[1..3]); stages 1-3 are skipped, lengths are those of k_finalize.
+// Every thread of every block of the grid calls this (it contains block barriers); on return the block's part is done and,
+// in the last block to finish, *io.done has been set.
 template <bool GIVEN>
-__global__ void __launch_bounds__(kSampleThreads)
-k_plan_small(int n, int dof, double t_sample, int goal_check, RowSpec rows, Limits lim, SmallHost io)
+LTP_DEV void plan_small_body(int n, int dof, double t_sample, int goal_check, RowSpec rows, const Limits& lim, const SmallHost& io,
+                             SmallShared& sh)
 {
-    __shared__ SegTable tab;
-    __shared__ double s_t_opt[kSmallPairs][7], s_t_scaled[kSmallPairs][7], s_dir[kSmallPairs], s_vd[kSmallPairs];
-    __shared__ double s_treq[kSmallPairs];
-    __shared__ signed char s_mod[kSmallPairs];
-    __shared__ int s_flags[kSmallPairs], s_slowest[kSmallPairs], s_len[kSmallPairs], s_status[kSmallPairs];
-    __shared__ unsigned long long s_off[kSmallPairs + 1];
-    __shared__ int s_fit;
+    SegTable& tab = sh.tab;
+    double (&s_t_opt)[kSmallPairs][7] = sh.t_opt;
+    double (&s_t_scaled)[kSmallPairs][7] = sh.t_scaled;
+    double (&s_dir)[kSmallPairs] = sh.dir;
+    double (&s_vd)[kSmallPairs] = sh.vd;
+    double (&s_treq)[kSmallPairs] = sh.treq;
+    signed char (&s_mod)[kSmallPairs] = sh.mod;
+    int (&s_flags)[kSmallPairs] = sh.flags;
+    int (&s_slowest)[kSmallPairs] = sh.slowest;
+    int (&s_len)[kSmallPairs] = sh.len;
+    int (&s_status)[kSmallPairs] = sh.status;
+    unsigned long long (&s_off)[kSmallPairs + 1] = sh.off;
+    int& s_fit = sh.fit;
     const int t = threadIdx.x;
     const int pairs = n * dof;
-    const bool pair = t < pairs;
-    const int q = pair ? t / dof : 0, j = pair ? t - q * dof : 0;
+    // (query, joint) pair `pid` of stages 1-3: lane pid. Spreading the pairs of a single call over the four waves of the block
+    // (so that joints in different branches of optSwitchTimes / timeScaling run side by side) was measured and is SLOWER by 1.8x:
+    // the kernel is ~530 KB of straight-line code behind a 64 KB instruction cache, and four waves in four places of it wait for
+    // instruction fetches more than one wave walking through it (single call)
+    const int pid = t;
+    const bool pair = pid < pairs;
+    const int q = pair ? pid / dof : 0, j = pair ? pid - q * dof : 0;
     JointLimits L = {0.0, 0.0, 0.0, 0.0, 0.0};
     double qg = 0.0, q0 = 0.0, v0 = 0.0, a0 = 0.0;
     if constexpr (GIVEN) {
@@ -1456,23 +1480,24 @@ k_plan_small(int n, int dof, double t_sample, int goal_check, RowSpec rows, Limi
         __syncthreads();
         if (pair) {
             L = load_limits(lim, j);
-            q0 = io.in[1][t]; v0 = io.in[2][t]; a0 = io.in[3][t];
+            q0 = io.in[1][pid]; v0 = io.in[2][pid]; a0 = io.in[3][pid];
             double ts[7];
 #pragma unroll
-            for (int k = 0; k < 7; ++k) { ts[k] = io.rec.t_scaled[t * 7 + k]; s_t_scaled[t][k] = ts[k]; s_t_opt[t][k] = 0.0; }
-            s_dir[t] = io.rec.dir[t];
-            s_vd[t] = io.rec.v_drive[t];
-            s_mod[t] = io.rec.mod[t];
+            for (int k = 0; k < 7; ++k) { ts[k] = io.rec.t_scaled[pid * 7 + k]; s_t_scaled[pid][k] = ts[k]; s_t_opt[pid][k] = 0.0; }
+            s_dir[pid] = io.rec.dir[pid];
+            s_vd[pid] = io.rec.v_drive[pid];
+            s_mod[pid] = io.rec.mod[pid];
             const int l = joint_len(ts, t_sample);
             if (l < 0) atomicOr(&s_status[q], kStatusNonFinite);
             else atomicMax(&s_len[q], l);
         }
         __syncthreads();
     } else {
+    if (t == 0) sh.tick[0] = (unsigned long long)wall_clock64();
     // ---- stage 1 ----
     if (pair) {
         L = load_limits(lim, j);
-        qg = io.in[0][t]; q0 = io.in[1][t]; v0 = io.in[2][t]; a0 = io.in[3][t];
+        qg = io.in[0][pid]; q0 = io.in[1][pid]; v0 = io.in[2][pid]; a0 = io.in[3][pid];
         int flags = check_inputs_joint(L, q0, v0, a0) ? 0 : kStatusInvalidInput;
         if (goal_check && !(qg >= L.q_min && qg <= L.q_max)) flags |= kStatusGoalOutside;
         double tt[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
@@ -1481,12 +1506,13 @@ k_plan_small(int n, int dof, double t_sample, int goal_check, RowSpec rows, Limi
         MatlabCtx mc;
         if (opt_switch_times<true>(L.a_max, L.j_max, L.v_max, t_sample, qg, q0, v0, a0, L.v_max, tt, dir, mod, mc) == kOptFalse) flags |= kStatusOptFailed;
 #pragma unroll
-        for (int k = 0; k < 7; ++k) s_t_opt[t][k] = tt[k];
-        s_dir[t] = dir;
-        s_mod[t] = (signed char)mod;
-        s_flags[t] = flags;
+        for (int k = 0; k < 7; ++k) s_t_opt[pid][k] = tt[k];
+        s_dir[pid] = dir;
+        s_mod[pid] = (signed char)mod;
+        s_flags[pid] = flags;
     }
     __syncthreads();
+    if (t == 0) sh.tick[1] = (unsigned long long)wall_clock64();
     // ---- slowest joint (cc:31-39: strict '>', first index wins, NaN never wins, init -1) ----
     if (t < n) {
         double best_t = -1.0;
@@ -1510,29 +1536,30 @@ k_plan_small(int n, int dof, double t_sample, int goal_check, RowSpec rows, Limi
         double vd = L.v_max;
         int mod = 0;                                   // failed query: zero record, never sampled
         if (flags == 0) {
-            mod = s_mod[t];
+            mod = s_mod[pid];
             if (j != s_slowest[q]) {
                 int which = 0;
                 MatlabCtx mc;
-                time_scaling_full(L, t_sample, qg, q0, v0, a0, s_dir[t], s_treq[q], vd, ts, mod, which, mc);
+                time_scaling_full(L, t_sample, qg, q0, v0, a0, s_dir[pid], s_treq[q], vd, ts, mod, which, mc);
             }
             double mx = ts[0];
 #pragma unroll
             for (int k = 1; k < 7; ++k) if (mx < ts[k]) mx = ts[k];
             if (mx <= 0.0) {
 #pragma unroll
-                for (int k = 0; k < 7; ++k) ts[k] = s_t_opt[t][k];
+                for (int k = 0; k < 7; ++k) ts[k] = s_t_opt[pid][k];
             }
             const int l = joint_len(ts, t_sample);
             if (l < 0) atomicOr(&s_status[q], kStatusNonFinite);
             else atomicMax(&s_len[q], l);
         }
 #pragma unroll
-        for (int k = 0; k < 7; ++k) s_t_scaled[t][k] = ts[k];
-        s_vd[t] = vd;
-        s_mod[t] = (signed char)mod;
+        for (int k = 0; k < 7; ++k) s_t_scaled[pid][k] = ts[k];
+        s_vd[pid] = vd;
+        s_mod[pid] = (signed char)mod;
     }
     __syncthreads();
+    if (t == 0) sh.tick[2] = (unsigned long long)wall_clock64();
     }   // !GIVEN
     // ---- lengths and packed offsets ----
     if (t == 0) {
@@ -1585,16 +1612,18 @@ k_plan_small(int n, int dof, double t_sample, int goal_check, RowSpec rows, Limi
         }
         if (t < n) io.end_flags[blockIdx.x * n + t] = s_status[t] & kStatusEndLimit;
     } else if (pair && s_len[q] > 0) {
-        // no rows wanted: the end-limit check alone (k_end_limit)
+        // no rows wanted: the end-limit check alone (k_end_limit). (For a single call the cooperative table build — 32 lanes per
+        // joint, the verdict from its step (5) — was measured in this place: 9.9 us against 10.7 us for this walk; not kept.)
         double qq = q0, vv = v0, aa = a0;
-        for_each_run(lim, lrec, t, j, s_len[q], t_sample, qq, vv, aa, [](int, int, const RunCoef&) { return false; });
+        for_each_run(lim, lrec, pid, j, s_len[q], t_sample, qq, vv, aa, [](int, int, const RunCoef&) { return false; });
         if (qq < L.q_min || qq > L.q_max) atomicOr(&s_status[q], kStatusEndLimit);
     }
     __syncthreads();
+    if (t == 0) sh.tick[3] = (unsigned long long)wall_clock64();
     // ---- records out (block 0; the other blocks computed the same values) ----
     if (blockIdx.x == 0) {
     if constexpr (!GIVEN) {
-        if (pair) {
+        if (t < pairs) {
 #pragma unroll
             for (int k = 0; k < 7; ++k) { io.rec.t_opt[t * 7 + k] = s_t_opt[t][k]; io.rec.t_scaled[t * 7 + k] = s_t_scaled[t][k]; }
             io.rec.dir[t] = s_dir[t];
@@ -1614,6 +1643,7 @@ k_plan_small(int n, int dof, double t_sample, int goal_check, RowSpec rows, Limi
     }
     __threadfence_system();
     __syncthreads();
+    if (t == 0) sh.tick[4] = (unsigned long long)wall_clock64();
     if (t == 0) {
         // the last block to get here has seen every other block's fence: it reports, and re-arms the counter
         if (atomicAdd(io.arrivals, 1u) == gridDim.x - 1) {
@@ -1623,9 +1653,149 @@ k_plan_small(int n, int dof, double t_sample, int goal_check, RowSpec rows, Limi
             __threadfence_system();
         }
     }
+    __syncthreads();   // the LDS of this block is free for the next call (k_plan_service)
+}
+
+template <bool GIVEN>
+__global__ void __launch_bounds__(kSampleThreads)
+k_plan_small(int n, int dof, double t_sample, int goal_check, RowSpec rows, Limits lim, SmallHost io)
+{
+    __shared__ SmallShared sh;
+    plan_small_body<GIVEN>(n, dof, t_sample, goal_check, rows, lim, io, sh);
+}
+
+// ---------------------------------------------------------------------------------------
+// Resident service for single calls (opt-in: ltp_set_service_idle_us). k_plan_small costs a launch per call: ~25 of the 37 us of
+// a single planTrajectory call are launch and completion, not work. Here kServiceBlocks blocks stay resident and poll a mailbox
+// in pinned host memory: the host writes a command (the same SmallHost a k_plan_small launch would get) and bumps `seq`; block
+// 0 sees it, hands it to the other blocks through a word in device memory, every block runs plan_small_body, the last one
+// sets the caller's completion word. No launch, no stream operation per call.
+// Lifetime is bounded three ways, so that nothing can hold CUs for long: the leader ends the service when no command arrived for
+// idle_ticks (the next call then starts a new instance), when the host sets `stop` (ltp_destroy, setters, library paths that
+// synchronise the device), or when hard_ticks have passed since the launch whatever happens. On the way out it clears `alive`;
+// a host that posted a command to an instance that was just leaving sees that and starts a new one.
+// ---------------------------------------------------------------------------------------
+constexpr int kServiceBlocks = 8;
+constexpr unsigned kServiceExit = 0xffffffffu;
+struct ServiceCmd {
+    int n, dof, goal_check, given;
+    double t_sample;
+    RowSpec rows;
+    SmallHost io;
+};
+struct ServiceMailbox {              // pinned, coherent host memory
+    unsigned seq;                    // host: bumped after `cmd` is complete
+    unsigned stop;                   // host: 1 = leave now
+    unsigned alive;                  // host sets 1 before a launch, the leader clears it when the instance ends
+    unsigned pad;
+    unsigned long long ticks[8];     // leader, last command: 100 MHz ticks from "seq seen" to command fetched / body done (diagnostic)
+    ServiceCmd cmd;
+};
+static_assert(sizeof(ServiceCmd) % 8 == 0, "copied as 8-byte words");
+
+__global__ void __launch_bounds__(kSampleThreads)
+k_plan_service(ServiceMailbox* mb, unsigned* dev_words /* [0] command seen by the leader, [1] arrivals */, Limits lim, unsigned start_seq,
+               unsigned long long idle_ticks, unsigned long long hard_ticks)
+{
+    __shared__ SmallShared sh;
+    __shared__ ServiceCmd s_cmd;
+    __shared__ unsigned s_got;
+    unsigned seen = start_seq;
+    const unsigned long long t_start = (unsigned long long)wall_clock64();
+    unsigned long long t_last = t_start;
+    for (;;) {
+        if (threadIdx.x == 0) {
+            unsigned got = seen;
+            if (blockIdx.x == 0) {
+                for (;;) {
+                    got = __hip_atomic_load(&mb->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    if (got != seen) break;
+                    const unsigned long long now = (unsigned long long)wall_clock64();
+                    if (now - t_last > idle_ticks || now - t_start > hard_ticks ||
+                        __hip_atomic_load(&mb->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) {
+                        got = kServiceExit;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(4);
+                }
+                __hip_atomic_store(&dev_words[0], got, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                for (;;) {
+                    got = __hip_atomic_load(&dev_words[0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                    if (got != seen) break;
+                    if ((unsigned long long)wall_clock64() - t_start > hard_ticks + hard_ticks / 4) { got = kServiceExit; break; }   // the leader never came
+                    __builtin_amdgcn_s_sleep(8);
+                }
+            }
+            s_got = got;
+        }
+        __syncthreads();
+        const unsigned got = s_got;
+        if (got == kServiceExit) break;
+        seen = got;
+        const unsigned long long tk0 = (unsigned long long)wall_clock64();
+        // the command was complete in host memory before `seq` changed: fetch it past every cache, then make the plain loads of the
+        // inputs that follow see host memory as it is now
+        {
+            const unsigned long long* src = reinterpret_cast<const unsigned long long*>(&mb->cmd);
+            unsigned long long* dst = reinterpret_cast<unsigned long long*>(&s_cmd);
+            for (int w = threadIdx.x; w < (int)(sizeof(ServiceCmd) / 8); w += kSampleThreads)
+                dst[w] = __hip_atomic_load(src + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        __threadfence_system();
+        __syncthreads();
+        const unsigned long long tk1 = (unsigned long long)wall_clock64();
+        if (s_cmd.given) plan_small_body<true>(s_cmd.n, s_cmd.dof, s_cmd.t_sample, s_cmd.goal_check, s_cmd.rows, lim, s_cmd.io, sh);
+        else plan_small_body<false>(s_cmd.n, s_cmd.dof, s_cmd.t_sample, s_cmd.goal_check, s_cmd.rows, lim, s_cmd.io, sh);
+        t_last = (unsigned long long)wall_clock64();
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            mb->ticks[0] = tk1 - tk0; mb->ticks[1] = t_last - tk0;
+            for (int k = 0; k < 5; ++k) mb->ticks[2 + k] = sh.tick[k] - tk0;
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        __hip_atomic_store(&mb->alive, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 int small_batch_pairs() { return kSmallPairs; }
+int service_blocks() { return kServiceBlocks; }
+unsigned long long service_mailbox_bytes() { return sizeof(ServiceMailbox); }
+
+void launch_plan_service(hipStream_t s, void* mailbox, unsigned* dev_words, Limits lim, unsigned start_seq, unsigned long long idle_ticks,
+                         unsigned long long hard_ticks)
+{
+    hipLaunchKernelGGL(k_plan_service, dim3(kServiceBlocks), dim3(kSampleThreads), 0, s, (ServiceMailbox*)mailbox, dev_words, lim, start_seq,
+                       idle_ticks, hard_ticks);
+}
+
+// host side of the mailbox protocol: the command is written first, then `seq`
+void service_post(void* mailbox, unsigned seq, int n, int dof, double t_sample, int goal_check, RowSpec rows, const double* const in[4],
+                  Records rec, unsigned long long* offsets, double* out_rows, unsigned long long capacity, int* end_flags,
+                  unsigned int* arrivals, volatile int* done, bool records_given)
+{
+    ServiceMailbox* mb = (ServiceMailbox*)mailbox;
+    ServiceCmd c;
+    c.n = n; c.dof = dof; c.goal_check = goal_check; c.given = records_given ? 1 : 0; c.t_sample = t_sample; c.rows = rows;
+    for (int k = 0; k < 4; ++k) c.io.in[k] = in[k];
+    c.io.rec = rec; c.io.offsets = offsets; c.io.rows = out_rows; c.io.capacity = capacity; c.io.end_flags = end_flags;
+    c.io.arrivals = arrivals; c.io.done = done;
+    mb->cmd = c;
+    __atomic_thread_fence(__ATOMIC_RELEASE);
+    __atomic_store_n(&mb->seq, seq, __ATOMIC_RELEASE);
+}
+void service_ticks(const void* mailbox, unsigned long long out[7])
+{
+    for (int k = 0; k < 7; ++k) out[k] = ((const ServiceMailbox*)mailbox)->ticks[k];
+}
+unsigned service_alive(const void* mailbox) { return __atomic_load_n(&((const ServiceMailbox*)mailbox)->alive, __ATOMIC_ACQUIRE); }
+void service_set(void* mailbox, unsigned alive, unsigned stop)
+{
+    ServiceMailbox* mb = (ServiceMailbox*)mailbox;
+    __atomic_store_n(&mb->stop, stop, __ATOMIC_RELEASE);
+    __atomic_store_n(&mb->alive, alive, __ATOMIC_RELEASE);
+}
+void service_stop_request(void* mailbox) { __atomic_store_n(&((ServiceMailbox*)mailbox)->stop, 1u, __ATOMIC_RELEASE); }
 int small_batch_blocks(int dof, bool with_rows) { return !with_rows ? 1 : (dof < kSmallBlocks ? (dof > 0 ? dof : 1) : kSmallBlocks); }
 
 void launch_plan_small(hipStream_t s, int n, int dof, double t_sample, int goal_check, RowSpec rows, Limits lim, const double* const in[4],

@@ -778,6 +778,66 @@ def test_fused_small_batch_path_has_the_bits_of_the_batched_path(amd, limits, ts
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("limits,ts", [("ref", 0.004), ("panda", 0.001), ("ref30", 0.002)])
+def test_resident_service_has_the_bits_of_the_launched_single_call(amd, limits, ts):
+    """ltp_set_service_idle_us: small calls are posted to a resident kernel instead of launching one. Same records, rows and
+    statuses as the launched path; the instance ends by itself after the idle time (the next call starts another), is stopped by
+    setLimits, coexists with a second handle's instance and with torch work on the device, and is gone after the handle is."""
+    import time
+    import torch
+    D, lim = amd.limit_set(limits)
+    ltp = amd.LongTermPlanner(D, ts, device=0, **lim)
+    other = amd.LongTermPlanner(D, ts, device=0, **lim)
+    qg, q0, v0, a0 = amd.generate_queries(60, lim, seed=11)
+    q0[3, 0] = 99.0                                             # rejected by checkInputs
+    qg[4] = q0[4]; v0[4] = 0.0; a0[4] = 0.0                     # the all-zero plan
+    small_n = max(1, min(128 // D, 9))
+    cases = [(first, cnt, rows) for first in (0, 3, 4, 17) for cnt in sorted({1, small_n}) for rows in (True, False)]
+    want = [ltp.planBatchHost(qg[f:f + c], q0[f:f + c], v0[f:f + c], a0[f:f + c], sample=r) for f, c, r in cases]
+    keys = ("t_opt", "t_scaled", "dir", "v_drive", "mod", "t_required", "slowest", "traj_len", "status", "offsets")
+
+    def check(planner, tag):
+        for (f, c, r), w in zip(cases, want):
+            g = planner.planBatchHost(qg[f:f + c], q0[f:f + c], v0[f:f + c], a0[f:f + c], sample=r)
+            for key in keys:
+                assert g[key].tobytes() == w[key].tobytes(), (tag, f, c, r, key)
+            if r:
+                assert g["packed"].tobytes() == w["packed"].tobytes(), (tag, f, c)
+
+    ltp.setServiceIdle(2000)
+    check(ltp, "first instance")
+    time.sleep(0.02)                                            # the instance has left by now
+    check(ltp, "second instance")
+    other.setServiceIdle(2000)                                  # two handles, two resident instances
+    check(other, "other handle")
+    check(ltp, "next to the other handle")
+    x = torch.arange(1 << 20, device="cuda", dtype=torch.float64)
+    assert float((x * 2).sum().item()) == float((1 << 20) * ((1 << 20) - 1))      # torch work while an instance is resident
+    check(ltp, "after torch work")
+    # the one-joint getTrajectory entry goes the same way
+    f, c = 17, 1
+    w = want[cases.index((17, 1, True))]
+    g = ltp.getTrajectoryBatchHost(w["t_scaled"], w["dir"], w["mod"], q0[f:f + c], v0[f:f + c], a0[f:f + c], w["v_drive"])
+    if int(w["status"][0]) & 0x37 == 0:
+        assert g["packed"].tobytes() == w["packed"].tobytes()
+    # new limits while resident
+    half = dict(lim); half["v_max"] = [0.5 * v for v in lim["v_max"]]
+    ltp.setLimits(**half)
+    a = ltp.planBatchHost(qg[:1], q0[:1], v0[:1], a0[:1], sample=True)
+    ltp.setServiceIdle(0)
+    b = ltp.planBatchHost(qg[:1], q0[:1], v0[:1], a0[:1], sample=True)
+    assert a["packed"].tobytes() == b["packed"].tobytes() and a["t_scaled"].tobytes() == b["t_scaled"].tobytes()
+    assert a["t_scaled"].tobytes() != want[0]["t_scaled"].tobytes()
+    ltp.setServiceIdle(300000)
+    ltp.planBatchHost(qg[:1], q0[:1], v0[:1], a0[:1], sample=False)
+    t0 = time.perf_counter()
+    del ltp, other                                              # destroys the handles with instances resident
+    import gc; gc.collect()
+    torch.cuda.synchronize()
+    assert time.perf_counter() - t0 < 0.2
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("limits,n,cap", [("panda", 70001, 64), ("ref30", 66000, 16)])
 def test_table_pass_matches_the_fused_sampler_on_a_large_range(amd, limits, n, cap):
     """The short-row sampler on a range of tens of thousands of plans (every resident block draws many items, the table
