@@ -593,7 +593,7 @@ static int sample_batch_any(ltp_planner* p, long long first, long long count, co
             LTP_HIP_TRY(p, hipMemsetAsync(head, 0, sizeof(unsigned long long), s));
             ltp::launch_build_tables(s, f, c, p->dof, p->t_sample, dev_limits(p), to_dev(in), to_dev(rec), rows, false, offsets, first, p->d_tables, p->semantics);
             ltp::launch_sample_tab(s, f, c, first, p->dof, to_dev(rec), offsets, out, f32, capacity, flags & ~2, rows, head,
-                                   p->sample_blocks_override > 0 ? p->sample_blocks_override : p->sample_blocks[f32 ? 4 : 3], p->d_tables, p->dbg_stamps);
+                                   p->sample_blocks_override > 0 ? p->sample_blocks_override : p->sample_blocks[f32 ? 4 : 3], p->d_tables, p->t_sample, p->dbg_stamps);
         }
         LTP_HIP_TRY(p, hipGetLastError());
         p->last_kernel = f32 ? ((flags & 1) ? "k_sample_tab_f32_nt" : "k_sample_tab_f32") : ((flags & 1) ? "k_sample_tab_f64_nt" : "k_sample_tab_f64");

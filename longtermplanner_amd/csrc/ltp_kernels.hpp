@@ -85,8 +85,8 @@ void launch_switch_times(hipStream_t s, long long n, int dof, double t_sample, i
 void launch_offsets(hipStream_t s, long long n, int dof, double t_sample, Records rec,
                     unsigned long long* block_sums, unsigned long long* offsets, bool lens_ready, RowSpec rows);
 // Run tables: built inside the sampler / envelope kernel by the item's block, or by the table pass —
-// launch_build_tables(first, count, ...) leaves table_bytes(count * dof) bytes in `tables` for launch_sample_tab /
-// launch_envelope(tables != nullptr). base_first: the plan whose offset is the origin of out / env (== first unless a
+// launch_build_tables(first, count, ...) leaves table_bytes(count * dof) bytes in `tables` (912 bytes per plan and joint: the
+// packed form, which the consumer expands with run_coef()) for launch_sample_tab / launch_envelope(tables != nullptr). base_first: the plan whose offset is the origin of out / env (== first unless a
 // range is processed in pieces that share one table buffer).
 unsigned long long table_bytes(long long lanes /* plans * dof */);
 void launch_build_tables(hipStream_t s, long long first, long long count, int dof, double t_sample, Limits lim, Queries in, Records rec,
@@ -100,6 +100,7 @@ void launch_sample(hipStream_t s, long long first, long long count, int dof, dou
 void launch_sample_tab(hipStream_t s, long long first, long long count, long long base_first, int dof, Records rec,
                        const unsigned long long* offsets, void* out, bool f32, unsigned long long capacity, int flags, RowSpec rows,
                        unsigned long long* next_item /* zeroed on the same stream */, int resident_blocks, const unsigned long long* tables,
+                       double t_sample /* the one the tables were built with */,
                        unsigned long long* stamps = nullptr /* diagnostic: 8 per (plan, joint group) item */);
 int sample_tab_resident_blocks(int device, bool f32);
 int sample_resident_blocks(int device, int which /* 0 k_sample f64, 1 k_sample f32, 2 k_envelope */);

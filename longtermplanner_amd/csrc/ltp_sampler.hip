@@ -38,6 +38,7 @@ constexpr int kModeKeepA = 4;   // MATLAB semantics, tail of every joint but the
 constexpr int kRunCoefs = 10;   // q0..q3, v0..v2, a0, a1, J (monomial basis in m)
 struct RunCoef {
     double c[kRunCoefs];
+    int mode;                    // the kMode* bits the coefficients were made with (the table pass stores them)
 };
 
 struct SegScratch {              // scratch of the cooperative table build, dead once the coefficients are written
@@ -52,8 +53,8 @@ struct SegScratch {              // scratch of the cooperative table build, dead
     int runMode[kSampleJointGroup][kMaxSegments];
     double state[kSampleJointGroup][kMaxSegments][3];
 };
-// The run table of one joint: kTableWords 8-byte words. This is the layout in LDS and, word for word, what the table
-// pass (k_build_tables) writes to global memory for the sampler variants that do not build tables themselves.
+// The run table of one joint: kTableWords 8-byte words. This is the layout in LDS; the table pass (k_build_tables) keeps a
+// packed form of it in global memory for the sampler variants that do not build tables themselves (below).
 struct JointTable {
     int nseg;                               // word 0 (low half)
     int len;                                // table pass only: traj_len of the plan (the fused build leaves it unset)
@@ -64,7 +65,19 @@ struct JointTable {
 };
 constexpr int kTableWords = 1 + (kMaxSegments + 2) / 2 + kMaxSegments * kRunCoefs;
 static_assert(sizeof(JointTable) == kTableWords * 8, "JointTable must be kTableWords 8-byte words");
-static_assert(kTableWords % 2 == 0, "the table pass stores word pairs");
+// What the table pass keeps in global memory is the PACKED form of a JointTable: the header as it is, then per run the five
+// words run_coef() makes the ten coefficients from — half the bytes to write and to read back; the consumer expands them with
+// the same run_coef() (same operations, same bits):
+//   words 0..11   nseg | len, start[]                       (JointTable words 0..11)
+//   word  12      vsnap = v_drive * dir (cc:823); word 13 unused
+//   words 14 + 5r .. 18 + 5r   a, v, q before run r, its jerk, its mode bits
+// In LDS the packed words land at the END of the JointTable they expand into (unpack order: see expand_packed_tables).
+constexpr int kPackedHeaderWords = 14;
+constexpr int kPackedRunWords = 5;
+constexpr int kPackedWords = kPackedHeaderWords + kMaxSegments * kPackedRunWords;           // 114
+constexpr int kPackedAt = kTableWords - kPackedWords;                                       // first JointTable word of the packed form
+static_assert(kPackedWords % 2 == 0 && kPackedAt % 2 == 0 && kPackedHeaderWords % 2 == 0, "word pairs, 16-byte aligned in LDS");
+static_assert(kPackedWords / 2 <= 64, "one LDS-direct load instruction brings a whole packed table");
 struct SegTable {
     JointTable jt[kSampleJointGroup];
     union {
@@ -125,6 +138,7 @@ LTP_DEV RunCoef run_coef(int mode, double J, double a_s, double v_s, double q_s,
 #pragma unroll
     for (int x = 0; x < kRunCoefs; ++x) r.c[x] = 0.0;
     const double tj = Ts * J;
+    r.mode = mode;
     r.c[9] = J;
     if (!(mode & kModeTail) || (SEM == kSemMatlab && (mode & kModeKeepA))) { r.c[7] = a_s; r.c[8] = tj; }
     r.c[0] = q_s;
@@ -168,7 +182,7 @@ LTP_DEV void wave_sync()
 // offset (the same in every lane).
 // With the table pass (k_build_tables) the lane instead holds up to kTableLoads 8-byte words of the finished tables:
 // word (threadIdx.x >> 3) + 32 r of joint slot threadIdx.x & 7.
-constexpr int kTableLoads = (kTableWords + 31) / 32;
+constexpr int kTableLoads = (kPackedWords + 31) / 32;
 template <bool TABLES>
 struct ItemRegs {
     int len;
@@ -189,7 +203,7 @@ struct ItemRegs<false> {
 // joint's table straight into the JointTable layout
 LTP_DEV unsigned long long table_word_index(unsigned long long lane, int word)
 {
-    return (lane >> 6) * (unsigned long long)(kTableWords * 64) + ((unsigned long long)(word >> 1) * 64ull + (lane & 63ull)) * 2ull + (unsigned long long)(word & 1);
+    return (lane >> 6) * (unsigned long long)(kPackedWords * 64) + ((unsigned long long)(word >> 1) * 64ull + (lane & 63ull)) * 2ull + (unsigned long long)(word & 1);
 }
 
 // Issues the loads of an item (nothing here waits for them). p < 0: no item. tables != nullptr (TABLES): plan p is local
@@ -215,7 +229,7 @@ LTP_DEV ItemRegs<TABLES> fetch_item(long long p, int j0, int nj, int dof, const 
 #pragma unroll
             for (int x = 0; x < kTableLoads; ++x) {
                 const int w = wb + 32 * x;
-                if (w < kTableWords) r.w[x] = tables[table_word_index(lane, w)];
+                if (w < kPackedWords) r.w[x] = tables[table_word_index(lane, w)];
             }
         }
         return r;
@@ -366,19 +380,49 @@ LTP_DEV void build_run_tables(SegTable& tab, long long p, int j0, int nj, int le
     __builtin_amdgcn_s_setprio(0);
 }
 
-// Table-pass form of build_run_tables: the finished tables arrive in registers (fetch_item<true>) and only have to be
-// placed in LDS. The caller must pass a block barrier before any wave reads them.
-LTP_DEV void install_run_tables(SegTable& tab, int nj, const unsigned long long (&w)[kTableLoads])
+// Table-pass form of build_run_tables: the packed tables arrive in registers (fetch_item<true>), are placed at the end of their
+// JointTable and expanded in place. Every thread of the block calls this; it ends with the block barrier after which any wave may
+// read the tables.
+LTP_DEV void install_run_tables(SegTable& tab, int nj, const unsigned long long (&w)[kTableLoads], double Ts)
 {
-    const int jt = threadIdx.x & 7, wb = threadIdx.x >> 3;
-    if (jt < nj) {
-        unsigned long long* dst = reinterpret_cast<unsigned long long*>(&tab.jt[jt]);
+    static_assert(kSampleJointGroup * kMaxSegments <= kSampleThreads && kSampleJointGroup * (kPackedHeaderWords - 2) <= kSampleThreads, "one task per thread");
+    {
+        const int jt = threadIdx.x & 7, wb = threadIdx.x >> 3;
+        if (jt < nj) {
+            unsigned long long* dst = reinterpret_cast<unsigned long long*>(&tab.jt[jt]) + kPackedAt;
 #pragma unroll
-        for (int x = 0; x < kTableLoads; ++x) {
-            const int word = wb + 32 * x;
-            if (word < kTableWords) dst[word] = w[x];
+            for (int x = 0; x < kTableLoads; ++x) {
+                const int word = wb + 32 * x;
+                if (word < kPackedWords) dst[word] = w[x];
+            }
         }
     }
+    __syncthreads();
+    // every thread reads what it expands (the coefficients of run r overwrite packed words of later runs), then all write
+    const int t = threadIdx.x;
+    const int jx = t / kMaxSegments, r = t - jx * kMaxSegments;          // run task
+    const int hx = t / (kPackedHeaderWords - 2), hw = t - hx * (kPackedHeaderWords - 2);   // header word task
+    unsigned long long hdr = 0ull;
+    if (hx < nj) hdr = reinterpret_cast<const unsigned long long*>(&tab.jt[hx])[kPackedAt + hw];
+    bool live = false;
+    RunCoef rc;
+    if (jx < nj) {
+        const unsigned long long* pk = reinterpret_cast<const unsigned long long*>(&tab.jt[jx]) + kPackedAt;
+        const int nseg = (int)(unsigned)pk[0];
+        if (r < nseg) {
+            live = true;
+            const double* st = reinterpret_cast<const double*>(pk + kPackedHeaderWords + r * kPackedRunWords);
+            rc = run_coef<kSemMatlab>((int)(unsigned)pk[kPackedHeaderWords + r * kPackedRunWords + 4], st[3], st[0], st[1], st[2],
+                                      reinterpret_cast<const double*>(pk)[12], Ts);   // (a superset of the C++ modes: same bits)
+        }
+    }
+    __syncthreads();
+    if (hx < nj) reinterpret_cast<unsigned long long*>(&tab.jt[hx])[hw] = hdr;
+    if (live) {
+#pragma unroll
+        for (int x = 0; x < kRunCoefs; ++x) tab.jt[jx].c[r][x] = rc.c[x];
+    }
+    __syncthreads();
 }
 
 // Streams the rows of one item (plan x joint group) from the run tables in LDS. Every thread of the block calls this.
@@ -789,14 +833,73 @@ LTP_DEV unsigned long long lds_peek64(unsigned a)
     asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(a) : "memory");
     return v;
 }
+// several reads, one wait: an LDS round trip is ~150 cycles in a CU full of streaming waves
+LTP_DEV void lds_peek64x4(unsigned a0, unsigned a1, unsigned a2, unsigned a3, unsigned long long (&v)[4])
+{
+    asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %5\n\tds_read_b64 %2, %6\n\tds_read_b64 %3, %7\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]) : "v"(a0), "v"(a1), "v"(a2), "v"(a3) : "memory");
+}
+LTP_DEV void lds_peek64x5(unsigned a, unsigned long long (&v)[5])      // five consecutive 8-byte words
+{
+    asm volatile("ds_read_b64 %0, %5\n\tds_read_b64 %1, %5 offset:8\n\tds_read_b64 %2, %5 offset:16\n\tds_read_b64 %3, %5 offset:24\n\t"
+                 "ds_read_b64 %4, %5 offset:32\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]) : "v"(a) : "memory");
+}
 LTP_DEV void lds_poke32(unsigned a, int v) { asm volatile("ds_write_b32 %0, %1" : : "v"(a), "v"(v) : "memory"); }
 LTP_DEV void lds_poke64(unsigned a, unsigned long long v) { asm volatile("ds_write_b64 %0, %1" : : "v"(a), "v"(v) : "memory"); }
+
+// Loader wave: turns the packed tables that LDS-direct loads left at the end of the item's JointTables into the tables the
+// streaming waves read (header words to the front, ten coefficients per run from its five packed words, by run_coef()).
+// Lane -> (joint lane / 9, run 9 * pass + lane % 9): 63 lanes per pass, one pass for capped rows, three for whole tables.
+// Order matters, because the expanded words overwrite the packed ones: a pass writes JointTable words 12 + 90 k .. 101 + 90 k,
+// the packed header sits in words 98 .. 111 and the packed run r in words 112 + 5 r .. 116 + 5 r — so the header (and vsnap) is
+// read before pass 0 writes, every lane of a pass reads its run before any lane writes (the LDS serves a wave in order and
+// lds_peek waits for its data), and what pass k overwrites is below what the later passes still have to read.
+// The same expansion by the streaming wave that owns the joint (ordinary LDS accesses: a streaming wave has no LDS-direct loads
+// in flight). Lane r < nseg expands run r, lanes 32..43 move the header; every lane has read before any lane writes (one wave,
+// one instruction stream, and the LDS serves it in order).
+template <class Buffer>
+LTP_DEV void expand_packed_tables(Buffer& B, int nj, int max_runs, int lane, double Ts)
+{
+    constexpr int kRunsPerPass = 9;
+    static_assert(kTabJointGroup * kRunsPerPass <= 64, "a pass is one wave");
+    static_assert(12 + kRunCoefs * kRunsPerPass <= kPackedAt + kPackedHeaderWords - 2, "pass 0 stays below vsnap and the packed runs");
+    static_assert(12 + kRunCoefs * 2 * kRunsPerPass <= kPackedAt + kPackedHeaderWords + kPackedRunWords * 2 * kRunsPerPass && kMaxSegments <= 3 * kRunsPerPass,
+                  "pass 1 stays below the packed runs of pass 2, and there is no pass 3");
+    const int x = lane / kRunsPerPass, i = lane - x * kRunsPerPass;
+    const bool joint = x < nj;
+    const unsigned jt = lds_offset(&B.jt[joint ? x : 0]);
+    const unsigned pk = jt + (unsigned)kPackedAt * 8u;
+    unsigned long long hd[4];
+    lds_peek64x4(pk + 8u * (unsigned)i, pk + 8u * (unsigned)(9 + (i < 3 ? i : 0)), pk, pk + 12u * 8u, hd);
+    const int nseg = (int)(unsigned)hd[2];
+    const double vsnap = __builtin_bit_cast(double, hd[3]);
+    if (joint) {
+        lds_poke64(jt + 8u * (unsigned)i, hd[0]);
+        if (i < 3) lds_poke64(jt + 8u * (unsigned)(9 + i), hd[1]);
+    }
+    for (int r0 = 0; r0 < max_runs; r0 += kRunsPerPass) {
+        const int r = r0 + i;
+        const bool live = joint && r < nseg;
+        const unsigned src = pk + (unsigned)(kPackedHeaderWords + kPackedRunWords * (live ? r : 0)) * 8u;
+        unsigned long long st[5];
+        lds_peek64x5(src, st);
+        const RunCoef rc = run_coef<kSemMatlab>((int)(unsigned)st[4], __builtin_bit_cast(double, st[3]), __builtin_bit_cast(double, st[0]),
+                                                __builtin_bit_cast(double, st[1]), __builtin_bit_cast(double, st[2]), vsnap, Ts);   // (a superset of the C++ modes: same bits)
+        if (live) {
+            const unsigned dst = jt + (unsigned)(12 + kRunCoefs * r) * 8u;
+#pragma unroll
+            for (int c = 0; c < kRunCoefs; ++c) lds_poke64(dst + 8u * (unsigned)c, __builtin_bit_cast(unsigned long long, rc.c[c]));
+        }
+    }
+}
 
 template <bool STREAMING, typename T>
 LTP_DEV void sample_tab_body(long long first, long long count, long long base_first, int dof, Records rec,
                              const unsigned long long* __restrict__ offsets, T* __restrict__ out, unsigned long long capacity, int spread,
                              RowSpec rows, unsigned long long* __restrict__ next_item, const unsigned long long* __restrict__ tables,
-                             int draw_chunk, unsigned long long* __restrict__ stamps /* diagnostic: 8 per item, nullptr in product calls */)
+                             int draw_chunk, unsigned long long* __restrict__ stamps /* diagnostic: 8 per item, nullptr in product calls */,
+                             double t_sample)
 {
     // stamps[8 * item + k] (wall clock, tools/tab_probe.py): loader — 0 its iteration starts (a buffer is free), 6 the next
     // item's loads are issued, 1 this item's loads are in, 3 it is published, 7 the previous publication, 2 = 1 if the tables
@@ -819,7 +922,7 @@ LTP_DEV void sample_tab_body(long long first, long long count, long long base_fi
         // ---- streaming waves: LDS reads and row stores only ----
         for (int seq = 0;; ++seq) {
             const int b = seq % kTabBuffers;
-            while (__hip_atomic_load(&s_ready[b], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != seq + 1) __builtin_amdgcn_s_sleep(1);
+            while (__hip_atomic_load(&s_ready[b], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != seq + 1) __builtin_amdgcn_s_sleep(1);   // (longer sleeps: no gain)
             if (buf[b].hdr.done) break;
             const bool stamp = stamps && wave == 0 && (threadIdx.x & 63) == 0;
             const unsigned long long it = buf[b].hdr.item;
@@ -843,15 +946,17 @@ LTP_DEV void sample_tab_body(long long first, long long count, long long base_fi
     // ALU busy: it runs at raised issue priority. ----
     __builtin_amdgcn_s_setprio(3);
     constexpr int kTabAhead = 2;
-    constexpr int kCappedPairs = 46;           // 12 header words + 8 runs x 10 coefficients
+    constexpr int kCappedRuns = 8;
+    constexpr int kCappedPairs = (kPackedHeaderWords + kCappedRuns * kPackedRunWords) / 2;   // 27 word pairs: header + 8 packed runs
+    constexpr unsigned kPackedByte = (unsigned)kPackedAt * 8u;                               // where the packed form lands in a JointTable
     static_assert(kTabAhead + 2 <= kTabBuffers, "buffers: one being streamed, one being published, kTabAhead in flight");
     const int ngroups = (dof + kTabJointGroup - 1) / kTabJointGroup;
     const long long per = (count + spread - 1) / spread;
     const unsigned long long total = (unsigned long long)per * spread * ngroups;
-    constexpr unsigned kTileBytes = (unsigned)kTableWords * 64u * 8u;
+    constexpr unsigned kTileBytes = (unsigned)kPackedWords * 64u * 8u;
     // capped rows mostly touch the first runs only (a switch of the jerk profile cuts up to three runs: 8 runs is what
-    // 256 samples of a 7-DoF plan need in 99.95 % of the items): kCappedPairs word pairs (92 words, 8 runs) per joint — an
-    // item's joints are neighbours in the table tile, so its seven loads fetch 46 lines of 128 bytes; whole tables are 106 pairs
+    // 256 samples of a 7-DoF plan need in 99.95 % of the items): kCappedPairs word pairs (54 words, 8 packed runs) per joint — an
+    // item's joints are neighbours in the table tile, so its seven loads fetch 27 lines of 128 bytes; whole tables are 57 pairs
     const bool whole_tables = rows.max_samples <= 0;
     typedef __attribute__((address_space(3))) void* lds_ptr;
     auto uniform64 = [](unsigned long long x) -> unsigned long long {
@@ -912,22 +1017,17 @@ LTP_DEV void sample_tab_body(long long first, long long count, long long base_fi
         const bool real = local >= 0;
         const int lane = fresh_lane();
         // (the plan's length and row offset come with its tables: JointTable::len, start[kMaxSegments + 1]; holes re-read plan `first`)
-        // tables: per joint slot one (capped rows) or two loads of 64 word pairs; a descriptor over the two tiles the item's
-        // joints can lie in, one 32-bit offset per lane
+        // tables: per joint slot one load of up to 57 word pairs (the packed form, landing at the end of the JointTable it is
+        // expanded into); a descriptor over the two tiles the item's joints can lie in, one 32-bit offset per lane
         const unsigned long long l0 = (unsigned long long)(real ? local : 0) * dof + (real ? j0 : 0);       // wave-uniform
         const __amdgpu_buffer_rsrc_t r_tab = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<unsigned long long*>(tables) + (l0 >> 6) * (unsigned long long)(kTableWords * 64), 0, (int)(2u * kTileBytes), 0x00020000);
+            const_cast<unsigned long long*>(tables) + (l0 >> 6) * (unsigned long long)(kPackedWords * 64), 0, (int)(2u * kTileBytes), 0x00020000);
 #pragma unroll
         for (int x = 0; x < kTabJointGroup; ++x) {
             const unsigned long long li = l0 + (unsigned)((real && x < nj) ? x : 0);
             const unsigned base = (unsigned)((li >> 6) - (l0 >> 6)) * kTileBytes + (unsigned)(li & 63ull) * 16u;
-            if (whole_tables || lane < kCappedPairs)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(r_tab, (lds_ptr)&B.jt[x], 16, base + (unsigned)lane * 1024u, 0, 0, 0);
-            if (whole_tables) {
-                if (lane < kTableWords / 2 - 64)
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(r_tab, (lds_ptr)(reinterpret_cast<char*>(&B.jt[x]) + 1024), 16,
-                                                             base + (unsigned)(64 + lane) * 1024u, 0, 0, 0);
-            }
+            if (lane < (whole_tables ? kPackedWords / 2 : kCappedPairs))
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(r_tab, (lds_ptr)(reinterpret_cast<char*>(&B.jt[x]) + kPackedByte), 16, base + (unsigned)lane * 1024u, 0, 0, 0);
         }
     };
     // header of an item whose loads are in: what the streaming waves read
@@ -943,9 +1043,11 @@ LTP_DEV void sample_tab_body(long long first, long long count, long long base_fi
         unsigned long long rel = 0ull;
         if (local >= 0) {
             // everything the header needs from what the loads brought, in one LDS round trip: lanes 0..6 read the joints' run
-            // counts, lane 7 the trajectory length, lane 8 the plan's row offset (both written by the table pass)
-            const unsigned peek_at = lane < kTabJointGroup ? lds_offset(&B.jt[lane].nseg)
-                                     : (lane == kTabJointGroup ? lds_offset(&B.jt[0].len) : lds_offset(&B.jt[0].start[kMaxSegments + 1]));
+            // counts, lane 7 the trajectory length, lane 8 the plan's row offset (all written by the table pass; packed word 0 =
+            // nseg | len, the row offset is the upper half of packed word 11)
+            const unsigned pk0 = lds_offset(&B.jt[0]) + kPackedByte;
+            const unsigned peek_at = lane < kTabJointGroup ? lds_offset(&B.jt[lane]) + kPackedByte
+                                     : (lane == kTabJointGroup ? pk0 + 4u : pk0 + (unsigned)(1 + (kMaxSegments + 1) / 2) * 8u + 4u * ((kMaxSegments + 1) & 1));
             const int peeked = lds_peek32(peek_at);
             const int len = __builtin_amdgcn_readlane(peeked, kTabJointGroup);
             slen = stored_len(len, rows);
@@ -955,27 +1057,33 @@ LTP_DEV void sample_tab_body(long long first, long long count, long long base_fi
                 if (lane == 0 && j0 == 0) atomicOr(&rec.status[first + local], kStatusOverflow);
                 slen = 0;
             }
-            if (slen > 0 && !whole_tables) {
-                // a capped row whose joint has more than 8 runs inside the cap (short trajectories): fetch the rest now
-                const bool long_table = __builtin_amdgcn_ballot_w64(lane < nj && 1 + (kMaxSegments + 2) / 2 + peeked * kRunCoefs > 2 * kCappedPairs) != 0ull;
-                if (stamps && lane == 0) stamps[8 * item + 2] = (unsigned long long)long_table;
-                if (long_table) {
-                    const unsigned long long l0 = (unsigned long long)local * dof + j0;
-                    const __amdgpu_buffer_rsrc_t r_tab = __builtin_amdgcn_make_buffer_rsrc(
-                        const_cast<unsigned long long*>(tables) + (l0 >> 6) * (unsigned long long)(kTableWords * 64), 0, (int)(2u * kTileBytes), 0x00020000);
+            // the largest run count among the item's joints (wave-uniform): how many passes the expansion needs
+            int max_runs = 0;
 #pragma unroll
-                    for (int x = 0; x < kTabJointGroup; ++x) {
-                        const unsigned long long li = l0 + (unsigned)(x < nj ? x : 0);
-                        const unsigned base = (unsigned)((li >> 6) - (l0 >> 6)) * kTileBytes + (unsigned)(li & 63ull) * 16u;
-                        if (lane >= kCappedPairs)
-                            __builtin_amdgcn_raw_ptr_buffer_load_lds(r_tab, (lds_ptr)&B.jt[x], 16, base + (unsigned)lane * 1024u, 0, 0, 0);
-                        if (lane < kTableWords / 2 - 64)
-                            __builtin_amdgcn_raw_ptr_buffer_load_lds(r_tab, (lds_ptr)(reinterpret_cast<char*>(&B.jt[x]) + 1024), 16,
-                                                                     base + (unsigned)(64 + lane) * 1024u, 0, 0, 0);
-                    }
-                    LTP_WAIT_VMCNT(0);                          // rare: drain everything (later waits only get easier)
-                }
+            for (int x = 0; x < kTabJointGroup; ++x) {
+                const int n_x = __builtin_amdgcn_readlane(peeked, x);
+                max_runs = (x < nj && n_x > max_runs) ? n_x : max_runs;
             }
+            if (slen > 0 && !whole_tables && max_runs > kCappedRuns) {
+                // a capped row whose joint has more than 8 runs inside the cap (short trajectories): fetch the rest now
+                if (stamps && lane == 0) stamps[8 * item + 2] = 1ull;
+                const unsigned long long l0 = (unsigned long long)local * dof + j0;
+                const __amdgpu_buffer_rsrc_t r_tab = __builtin_amdgcn_make_buffer_rsrc(
+                    const_cast<unsigned long long*>(tables) + (l0 >> 6) * (unsigned long long)(kPackedWords * 64), 0, (int)(2u * kTileBytes), 0x00020000);
+#pragma unroll
+                for (int x = 0; x < kTabJointGroup; ++x) {
+                    const unsigned long long li = l0 + (unsigned)(x < nj ? x : 0);
+                    const unsigned base = (unsigned)((li >> 6) - (l0 >> 6)) * kTileBytes + (unsigned)(li & 63ull) * 16u;
+                    if (lane >= kCappedPairs && lane < kPackedWords / 2)
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(r_tab, (lds_ptr)(reinterpret_cast<char*>(&B.jt[x]) + kPackedByte), 16, base + (unsigned)lane * 1024u, 0, 0, 0);
+                }
+                LTP_WAIT_VMCNT(0);                          // rare: drain everything (later waits only get easier)
+            } else if (stamps && lane == 0 && slen > 0 && !whole_tables) {
+                stamps[8 * item + 2] = 0ull;
+            }
+            // (expanding in the streaming wave that owns the joint instead — seven waves in parallel — was measured: the sampler
+            // of 64-sample rows went from 4.1 to 4.9 ms; the streaming waves are the longer side of an item already)
+            if (slen > 0) expand_packed_tables(B, nj, max_runs, lane, t_sample);
         }
         if (lane == 0) {
             lds_poke64(lds_offset(&B.hdr.rel), rel);
@@ -1017,8 +1125,7 @@ LTP_DEV void sample_tab_body(long long first, long long count, long long base_fi
         request(buf[(seq + kTabAhead) % kTabBuffers], ids[kTabAhead]);
         const unsigned long long t_req = stamps ? wall_clock64() : 0ull;
         // item seq is in when at most the loads of the kTabAhead younger items are outstanding
-        if (whole_tables) LTP_WAIT_VMCNT(kTabAhead * 2 * kTabJointGroup);
-        else LTP_WAIT_VMCNT(kTabAhead * kTabJointGroup);
+        LTP_WAIT_VMCNT(kTabAhead * kTabJointGroup);
         TabBuffer& B = buf[seq % kTabBuffers];
         const unsigned long long item = ids[0];
         if (stamps && fresh_lane() == 0 && item < total) stamps[8 * item + 1] = wall_clock64();
@@ -1043,9 +1150,9 @@ LTP_DEV void sample_tab_body(long long first, long long count, long long base_fi
     __global__ void __launch_bounds__(kTabThreads) __attribute__((amdgpu_waves_per_eu(WAVES, 8)))                                    \
     NAME(long long first, long long count, long long base_first, int dof, Records rec, const unsigned long long* __restrict__ offsets, \
          TY* __restrict__ out, unsigned long long capacity, int spread, RowSpec rows, unsigned long long* __restrict__ next_item,     \
-         const unsigned long long* __restrict__ tables, int draw_chunk, unsigned long long* __restrict__ stamps)                      \
+         const unsigned long long* __restrict__ tables, int draw_chunk, unsigned long long* __restrict__ stamps, double t_sample)     \
     {                                                                                                                                 \
-        sample_tab_body<ST, TY>(first, count, base_first, dof, rec, offsets, out, capacity, spread, rows, next_item, tables, draw_chunk, stamps); \
+        sample_tab_body<ST, TY>(first, count, base_first, dof, rec, offsets, out, capacity, spread, rows, next_item, tables, draw_chunk, stamps, t_sample); \
     }
 LTP_TAB_KERNEL(k_sample_tab_f64, false, double, 6)
 LTP_TAB_KERNEL(k_sample_tab_f64_nt, true, double, 6)
@@ -1115,9 +1222,11 @@ k_envelope(long long first, long long count, long long base_first, int dof, doub
         }
         if constexpr (PROBE) { if (threadIdx.x == 0) probe[2] = wall_clock64(); }
         const ItemRegs<TABLES> regs = fetch_item<TABLES>(p, j0, nj, dof, lim, in, rec, nullptr, tables, first);
-        if constexpr (TABLES) install_run_tables(tab, nj, regs.w);
-        else build_run_tables<PROBE>(tab, p, j0, nj, len, t_sample, lim, rec, regs.pa, regs.pb, probe);
-        __syncthreads();
+        if constexpr (TABLES) install_run_tables(tab, nj, regs.w, t_sample);
+        else {
+            build_run_tables<PROBE>(tab, p, j0, nj, len, t_sample, lim, rec, regs.pa, regs.pb, probe);
+            __syncthreads();
+        }
         if constexpr (PROBE) { if (threadIdx.x == 0) probe[9] = wall_clock64(); }
         // g lanes share one (joint, window) task (g = 2^lg divides 64, chosen by the host so that the block has
         // work for all its lanes); lane r of the task takes samples b + r, b + r + g, ... and the g partial results
@@ -1365,30 +1474,50 @@ k_build_tables(long long first, long long count, int dof, double t_sample, Limit
     const unsigned long long lane_id = (unsigned long long)idx;
     auto word = [&](int w) -> unsigned long long* { return tables + table_word_index(lane_id, w); };
     const int len = rec.traj_len[p];
+    typedef double pair_t __attribute__((ext_vector_type(2)));
+    auto store_pair = [&](int w, double lo, double hi) {        // 16 bytes per lane: a full 1 KiB line per wave instruction
+        pair_t v2;
+        v2[0] = lo;
+        v2[1] = hi;
+        __builtin_nontemporal_store(v2, reinterpret_cast<pair_t*>(word(w)));
+    };
     if (len <= 0) { *word(0) = 0ull; return; }                 // nseg 0: the sampler skips such plans anyway
     const long long ix = p * in.sq + (long long)j * in.sj;
     double q = in.q_0[ix], v = in.v_0[ix], a = in.a_0[ix];
-    int run = 0;
+    store_pair(12, rec.v_drive[p * dof + j] * rec.dir[p * dof + j], 0.0);   // vsnap, as for_each_run forms it (cc:823)
+    // Packed runs: five words each, stored as word pairs two runs at a time. A lane whose runs are past the cap stores zeros as
+    // long as a neighbour still stores: the lanes of a wave are the lanes of one table tile, and a 1 KiB line written whole costs
+    // HBM half of what the same line written by some of its lanes does (measured: 1.53 -> 1.1 ms for the same tables).
+    int run = 0, slots = 0;
     int last_b = len;
+    double ha = 0.0, hv = 0.0, hq = 0.0, hj = 0.0, hm = 0.0;     // the even run of a pair, until its odd partner arrives
+    auto as_word = [](int mode) { return __builtin_bit_cast(double, (unsigned long long)(unsigned)mode); };
     for_each_run<SEM>(lim, rec, p * dof + j, j, len, t_sample, q, v, a, [&](int b, int, const RunCoef& rc) {
-        if (b < needed_end) {
-            reinterpret_cast<int*>(word(1 + (run >> 1)))[run & 1] = b;
-            // coefficients as whole word pairs: 16 bytes per lane, a full 1 KiB line per wave instruction
-            static_assert((1 + (kMaxSegments + 2) / 2) % 2 == 0 && kRunCoefs % 2 == 0, "a run's coefficients start on a word pair");
-            typedef double pair_t __attribute__((ext_vector_type(2)));
-#pragma unroll
-            for (int x = 0; x < kRunCoefs; x += 2) {
-                pair_t v2;
-                v2[0] = rc.c[x];
-                v2[1] = rc.c[x + 1];
-                __builtin_nontemporal_store(v2, reinterpret_cast<pair_t*>(word(1 + (kMaxSegments + 2) / 2 + run * kRunCoefs + x)));
+        const bool mine = b < needed_end;
+        if (__builtin_amdgcn_ballot_w64(mine) != 0ull) {
+            // q, v, a still hold the state before this run: for_each_run advances them after the visit
+            const double sa = mine ? a : 0.0, sv = mine ? v : 0.0, sq = mine ? q : 0.0, sj = mine ? rc.c[9] : 0.0;
+            const double sm = mine ? as_word(rc.mode) : 0.0;
+            if (mine) {
+                reinterpret_cast<int*>(word(1 + (run >> 1)))[run & 1] = b;
+                ++run;
             }
-            ++run;
-        } else if (last_b == len) {
-            last_b = b;                                        // first run that is not stored: it ends the last stored one
+            if (slots & 1) {
+                const int w0 = kPackedHeaderWords + (slots - 1) * kPackedRunWords;   // even: a pair boundary
+                store_pair(w0, ha, hv); store_pair(w0 + 2, hq, hj); store_pair(w0 + 4, hm, sa); store_pair(w0 + 6, sv, sq); store_pair(w0 + 8, sj, sm);
+            } else {
+                ha = sa; hv = sv; hq = sq; hj = sj; hm = sm;
+            }
+            ++slots;
         }
+        if (!mine && last_b == len) last_b = b;                  // first run that is not stored: it ends the last stored one
         return false;                                          // the walk still goes to the last sample: end-limit check
     }, j == dof - 1);
+    if (slots & 1) {
+        const int w0 = kPackedHeaderWords + (slots - 1) * kPackedRunWords;
+        store_pair(w0, ha, hv); store_pair(w0 + 2, hq, hj); store_pair(w0 + 4, hm, 0.0);
+    }
+    static_assert(kPackedHeaderWords % 2 == 0 && (2 * kPackedRunWords) % 2 == 0, "two runs start on a word pair");
     reinterpret_cast<int*>(word(1 + (run >> 1)))[run & 1] = last_b;
     *word(0) = (unsigned long long)(unsigned)run | ((unsigned long long)(unsigned)len << 32);
     // where the plan's rows start inside the range the sampler is called for: what k_sample_tab's loader would otherwise
@@ -1840,7 +1969,7 @@ int sample_resident_blocks(int device, int which)
 
 unsigned long long table_bytes(long long lanes)
 {
-    return (unsigned long long)((lanes + 63) / 64) * (unsigned long long)kTableWords * 64ull * 8ull;
+    return (unsigned long long)((lanes + 63) / 64) * (unsigned long long)kPackedWords * 64ull * 8ull;
 }
 
 void launch_build_tables(hipStream_t s, long long first, long long count, int dof, double t_sample, Limits lim, Queries in, Records rec,
@@ -1873,7 +2002,8 @@ int sample_tab_resident_blocks(int device, bool f32)
 
 void launch_sample_tab(hipStream_t s, long long first, long long count, long long base_first, int dof, Records rec,
                        const unsigned long long* offsets, void* out, bool f32, unsigned long long capacity, int flags, RowSpec rows,
-                       unsigned long long* next_item, int resident_blocks, const unsigned long long* tables, unsigned long long* stamps)
+                       unsigned long long* next_item, int resident_blocks, const unsigned long long* tables, double t_sample,
+                       unsigned long long* stamps)
 {
     if (count <= 0) return;
     int spread = (flags >> 8) & 0xFFFF;
@@ -1885,7 +2015,7 @@ void launch_sample_tab(hipStream_t s, long long first, long long count, long lon
     const dim3 grid((unsigned)blocks), block(kTabThreads);
     // (the loader pays one exposed atomic round trip per draw: larger chunks than k_sample's)
     const int draw_chunk = 2 * queue_draw_chunk(rows, f32, dof < kTabJointGroup ? dof : kTabJointGroup);
-#define LTP_TAB_CASE(K, TY) hipLaunchKernelGGL(K, grid, block, 0, s, first, count, base_first, dof, rec, offsets, (TY*)out, capacity, spread, rows, next_item, tables, draw_chunk, stamps)
+#define LTP_TAB_CASE(K, TY) hipLaunchKernelGGL(K, grid, block, 0, s, first, count, base_first, dof, rec, offsets, (TY*)out, capacity, spread, rows, next_item, tables, draw_chunk, stamps, t_sample)
     switch ((flags & 1) | (f32 ? 2 : 0)) {
     case 0: LTP_TAB_CASE(k_sample_tab_f64, double); break;
     case 1: LTP_TAB_CASE(k_sample_tab_f64_nt, double); break;

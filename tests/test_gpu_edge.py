@@ -700,7 +700,7 @@ def test_table_pass_gives_the_bits_of_the_fused_build(amd, limits, n):
         ltp.setMaxSamples(cap); ltp.setSampleStride(stride)
         res = {}
         for mode in ("fused", "tables", "tables_small_workspace"):
-            ltp.setTablePass(0, (1 << 32) if mode != "tables_small_workspace" else 40 * D * 1696)
+            ltp.setTablePass(0, (1 << 32) if mode != "tables_small_workspace" else 40 * D * 912)
             b = ltp.planSwitchTimesBatch(*qm)
             total = int(b.offsets[-1].item())
             t64 = torch.full((total,), 3.0, dtype=torch.float64, device="cuda")
@@ -725,7 +725,7 @@ def test_table_pass_gives_the_bits_of_the_fused_build(amd, limits, n):
     b = ltp.planSwitchTimesBatch(*qm)
     env = {}
     for mode, flag in (("fused", -1), ("tables", 1), ("pieces", 1)):
-        ltp.setTablePass(flag, (1 << 32) if mode != "pieces" else 40 * D * 1696)
+        ltp.setTablePass(flag, (1 << 32) if mode != "pieces" else 40 * D * 912)
         env[mode] = (ltp.envelopeBatch(b, 0, n, 48, 24).clone(), ltp.envelopeBatch(b, 30, n - 60, 100, 7).clone())
     torch.cuda.synchronize()
     for mode in ("tables", "pieces"):
