@@ -725,80 +725,92 @@ LTP_DEV void tab_stream(const TabBuffer& B, int dof, T* __restrict__ out, int ss
     const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
     const int slen = B.hdr.slen, j0 = B.hdr.j0, nj = B.hdr.nj;
     if (slen <= 0) return;
-    const int wpr = nj >= 4 ? 1 : (nj == 3 ? 2 : (nj == 2 ? 3 : 7));     // waves per joint
-    const int jl2 = wave / wpr, sub = wave - jl2 * wpr;
-    if (jl2 >= nj) return;
     const unsigned long long stride = ((unsigned long long)slen + (kRowAlign - 1)) / kRowAlign * kRowAlign;
     const unsigned long long arr_stride = (unsigned long long)dof * stride;
     const int nslots = (slen + N - 1) / N;
+    // Lanes per joint: a row of at most 32 (16) slots leaves half (three quarters) of a wave without a slot, and what a
+    // streaming wave costs is the instructions it issues, not the lanes that execute them: such rows share a wave between
+    // two (four) joints — 64-sample rows of a 7-joint item take four waves' worth of instructions instead of seven.
+    const int lg = nslots > 32 ? 6 : (nslots > 16 ? 5 : 4);
+    int jl2, first_slot, step;
+    if (lg == 6) {
+        const int wpr = nj >= 4 ? 1 : (nj == 3 ? 2 : (nj == 2 ? 3 : 7));     // waves per joint
+        jl2 = wave / wpr;
+        first_slot = (wave - jl2 * wpr) * 64 + lane;
+        step = 64 * wpr;
+    } else {
+        jl2 = (wave << (6 - lg)) + (lane >> lg);
+        first_slot = lane & ((1 << lg) - 1);
+        step = 64;                                                         // (one slot per lane)
+    }
+    const bool mine = jl2 < nj;
+    if (__builtin_amdgcn_ballot_w64(mine) == 0ull) return;
+    const JointTable& jt = B.jt[mine ? jl2 : 0];
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-    constexpr int kWindowSlots = 1 << 26;
-    constexpr bool kBufferStores = STREAMING && sizeof(T) == 8;
-    T* const row = out + B.hdr.rel + (unsigned long long)(j0 + jl2) * stride;
-    const int* st = B.jt[jl2].start;
-    const int nruns = B.jt[jl2].nseg;
+    // one buffer descriptor over the item's rows (all four arrays of all its joints), a 32-bit offset per lane; items beyond
+    // 4 GB of rows (trajectories of millions of samples) take ordinary stores
+    const unsigned long long item_bytes = 4ull * arr_stride * sizeof(T);
+    const bool buffer_stores = STREAMING && sizeof(T) == 8 && item_bytes <= 0xffffff00ull;
+    T* const item = out + B.hdr.rel;
+    const unsigned long long row_at = (unsigned long long)(j0 + (mine ? jl2 : 0)) * stride;     // element offset of the joint's q row
+    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(item, 0, buffer_stores ? (int)(unsigned)item_bytes : 0, 0x00020000);
+    const int* st = jt.start;
+    const int nruns = jt.nseg;
     int kr = 0, cur = 0, nxt = nruns > 1 ? st[1] : 0x7fffffff;
-    for (int wbase = 0; wbase < nslots; wbase += kWindowSlots) {
-        const int wend = nslots - wbase < kWindowSlots ? nslots : wbase + kWindowSlots;
-        __amdgpu_buffer_rsrc_t rsrc[4];
-        if constexpr (kBufferStores) {
-#pragma unroll
-            for (int x = 0; x < 4; ++x)
-                rsrc[x] = __builtin_amdgcn_make_buffer_rsrc(row + x * arr_stride + (unsigned long long)wbase * N, 0,
-                                                            (wend - wbase) * (int)sizeof(V), 0x00020000);
+    for (int slot = mine ? first_slot : nslots; slot < nslots; slot += step) {
+        const int i0 = N * slot;
+        V o[4];
+        const int t0 = i0 * sstride;
+        while (nxt <= t0) {
+            ++kr;
+            cur = nxt;
+            nxt = kr + 1 < nruns ? st[kr + 1] : 0x7fffffff;
         }
-        for (int slot = wbase + sub * 64 + lane; slot < wend; slot += 64 * wpr) {
-            const int i0 = N * slot;
-            V o[4];
-            const int t0 = i0 * sstride;
-            while (nxt <= t0) {
-                ++kr;
-                cur = nxt;
-                nxt = kr + 1 < nruns ? st[kr + 1] : 0x7fffffff;
-            }
-            const bool straddles = t0 + (N - 1) * sstride >= nxt;
-            if (straddles || i0 + N > slen) {
-                // a run boundary or the end of the row inside the slot: sample by sample (the tail of the last slot is
-                // row padding and stays zero)
-                int kh = kr, ch = cur, nh = nxt;
+        const bool straddles = t0 + (N - 1) * sstride >= nxt;
+        if (straddles || i0 + N > slen) {
+            // a run boundary or the end of the row inside the slot: sample by sample (the tail of the last slot is
+            // row padding and stays zero)
+            int kh = kr, ch = cur, nh = nxt;
 #pragma unroll
-                for (int h = 0; h < N; ++h) {
-                    const int i = t0 + h * sstride;
-                    while (nh <= i) {
-                        ++kh;
-                        ch = nh;
-                        nh = kh + 1 < nruns ? st[kh + 1] : 0x7fffffff;
-                    }
-                    const bool pad = i0 + h >= slen;
-                    double x4[4];
-                    run_eval(B.jt[jl2].c[kh], i - ch + 1, x4[0], x4[1], x4[2], x4[3]);
-#pragma unroll
-                    for (int x = 0; x < 4; ++x) o[x][h] = pad ? (T)0 : (T)x4[x];
+            for (int h = 0; h < N; ++h) {
+                const int i = t0 + h * sstride;
+                while (nh <= i) {
+                    ++kh;
+                    ch = nh;
+                    nh = kh + 1 < nruns ? st[kh + 1] : 0x7fffffff;
                 }
-            } else {
-                double c[kRunCoefs];
+                const bool pad = i0 + h >= slen;
+                double x4[4];
+                run_eval(jt.c[kh], i - ch + 1, x4[0], x4[1], x4[2], x4[3]);
 #pragma unroll
-                for (int x = 0; x < kRunCoefs; ++x) c[x] = B.jt[jl2].c[kr][x];
-#pragma unroll
-                for (int h = 0; h < N; ++h) {
-                    double x4[4];
-                    run_eval(c, t0 + h * sstride - cur + 1, x4[0], x4[1], x4[2], x4[3]);
-#pragma unroll
-                    for (int x = 0; x < 4; ++x) o[x][h] = (T)x4[x];
-                }
+                for (int x = 0; x < 4; ++x) o[x][h] = pad ? (T)0 : (T)x4[x];
             }
-            if constexpr (kBufferStores) {
-                const unsigned voff = (unsigned)(slot - wbase) * (unsigned)sizeof(V);
+        } else {
+            double c[kRunCoefs];
+#pragma unroll
+            for (int x = 0; x < kRunCoefs; ++x) c[x] = jt.c[kr][x];
+#pragma unroll
+            for (int h = 0; h < N; ++h) {
+                double x4[4];
+                run_eval(c, t0 + h * sstride - cur + 1, x4[0], x4[1], x4[2], x4[3]);
+#pragma unroll
+                for (int x = 0; x < 4; ++x) o[x][h] = (T)x4[x];
+            }
+        }
+        if (buffer_stores) {
+            if constexpr (STREAMING && sizeof(T) == 8) {
+                const unsigned voff = (unsigned)((row_at + (unsigned long long)i0) * sizeof(T));
+                const unsigned arr_bytes = (unsigned)(arr_stride * sizeof(T));
 #pragma unroll
                 for (int x = 0; x < 4; ++x)
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o[x]), rsrc[x], voff, 0, /*nt | sc1*/ 2 | 16);
-            } else if constexpr (STREAMING) {
-#pragma unroll
-                for (int x = 0; x < 4; ++x) __builtin_nontemporal_store(o[x], reinterpret_cast<V*>(row + x * arr_stride + i0));
-            } else {
-#pragma unroll
-                for (int x = 0; x < 4; ++x) *reinterpret_cast<V*>(row + x * arr_stride + i0) = o[x];
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o[x]), rsrc, voff + (unsigned)x * arr_bytes, 0, /*nt | sc1*/ 2 | 16);
             }
+        } else if constexpr (STREAMING) {
+#pragma unroll
+            for (int x = 0; x < 4; ++x) __builtin_nontemporal_store(o[x], reinterpret_cast<V*>(item + row_at + x * arr_stride + i0));
+        } else {
+#pragma unroll
+            for (int x = 0; x < 4; ++x) *reinterpret_cast<V*>(item + row_at + x * arr_stride + i0) = o[x];
         }
     }
 }
