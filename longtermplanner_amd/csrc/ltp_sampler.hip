@@ -716,14 +716,14 @@ static_assert(sizeof(JointTable) % 16 == 0, "LDS-direct loads land 16 bytes per 
 // stream_rows' pass B, instead of being picked up from LDS: rows this kernel is meant for are one or two wave steps long, and a
 // pass B costs the wave ~2 us per item in which it issues no store.
 template <bool STREAMING, typename T>
-LTP_DEV void tab_stream(const TabBuffer& B, int dof, T* __restrict__ out, int sstride, int wave)
+LTP_DEV void tab_stream(const TabBuffer& B, const TabItem& hdr /* B.hdr, already in registers */, int dof, T* __restrict__ out, int sstride, int wave)
 {
     typedef typename OutVec<T>::type V;
     constexpr int N = OutVec<T>::N;
     // the lane id is recomputed per item: kept in a register across the kernel it ends up spilled (the loader branch needs
     // the registers), and a scratch reload here would wait for every row store the wave has in flight
     const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-    const int slen = B.hdr.slen, j0 = B.hdr.j0, nj = B.hdr.nj;
+    const int slen = hdr.slen, j0 = hdr.j0, nj = hdr.nj;
     if (slen <= 0) return;
     const unsigned long long stride = ((unsigned long long)slen + (kRowAlign - 1)) / kRowAlign * kRowAlign;
     const unsigned long long arr_stride = (unsigned long long)dof * stride;
@@ -735,7 +735,7 @@ LTP_DEV void tab_stream(const TabBuffer& B, int dof, T* __restrict__ out, int ss
     int jl2, first_slot, step;
     if (lg == 6) {
         const int wpr = nj >= 4 ? 1 : (nj == 3 ? 2 : (nj == 2 ? 3 : 7));     // waves per joint
-        jl2 = wave / wpr;
+        jl2 = wpr == 1 ? wave : (wpr == 2 ? wave >> 1 : (wpr == 3 ? (wave >= 3) + (wave >= 6) : 0));   // wave / wpr without a division
         first_slot = (wave - jl2 * wpr) * 64 + lane;
         step = 64 * wpr;
     } else {
@@ -751,7 +751,7 @@ LTP_DEV void tab_stream(const TabBuffer& B, int dof, T* __restrict__ out, int ss
     // 4 GB of rows (trajectories of millions of samples) take ordinary stores
     const unsigned long long item_bytes = 4ull * arr_stride * sizeof(T);
     const bool buffer_stores = STREAMING && sizeof(T) == 8 && item_bytes <= 0xffffff00ull;
-    T* const item = out + B.hdr.rel;
+    T* const item = out + hdr.rel;
     const unsigned long long row_at = (unsigned long long)(j0 + (mine ? jl2 : 0)) * stride;     // element offset of the joint's q row
     __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(item, 0, buffer_stores ? (int)(unsigned)item_bytes : 0, 0x00020000);
     const int* st = jt.start;
@@ -935,11 +935,20 @@ LTP_DEV void sample_tab_body(long long first, long long count, long long base_fi
         for (int seq = 0;; ++seq) {
             const int b = seq % kTabBuffers;
             while (__hip_atomic_load(&s_ready[b], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != seq + 1) __builtin_amdgcn_s_sleep(1);   // (longer sleeps: no gain)
-            if (buf[b].hdr.done) break;
+            // the header in one LDS round trip (two 16-byte reads), wave-uniform
+            typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+            static_assert(sizeof(TabItem) == 32 && offsetof(TabItem, slen) == 8 && offsetof(TabItem, nj) == 16 && offsetof(TabBuffer, hdr) % 16 == 0, "read as two u32x4");
+            const u32x4 h0 = reinterpret_cast<const u32x4*>(&buf[b].hdr)[0], h1 = reinterpret_cast<const u32x4*>(&buf[b].hdr)[1];
+            if (__builtin_amdgcn_readfirstlane((int)h1[1])) break;                       // done
+            TabItem hdr;
+            hdr.rel = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)h0[1]) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)h0[0]);
+            hdr.slen = __builtin_amdgcn_readfirstlane((int)h0[2]);
+            hdr.j0 = __builtin_amdgcn_readfirstlane((int)h0[3]);
+            hdr.nj = __builtin_amdgcn_readfirstlane((int)h1[0]);
             const bool stamp = stamps && wave == 0 && (threadIdx.x & 63) == 0;
-            const unsigned long long it = buf[b].hdr.item;
+            const unsigned long long it = stamp ? ((unsigned long long)h1[3] << 32) | h1[2] : 0ull;
             if (stamp) stamps[8 * it + 4] = wall_clock64();
-            tab_stream<STREAMING, T>(buf[b], dof, out, sstride, wave);
+            tab_stream<STREAMING, T>(buf[b], hdr, dof, out, sstride, wave);
             if (stamp) stamps[8 * it + 5] = wall_clock64();
             // the wave's reads of buf[b] are complete (release orders its LDS traffic; row stores need not be: they carry
             // their data in registers)
@@ -1034,12 +1043,17 @@ LTP_DEV void sample_tab_body(long long first, long long count, long long base_fi
         const unsigned long long l0 = (unsigned long long)(real ? local : 0) * dof + (real ? j0 : 0);       // wave-uniform
         const __amdgpu_buffer_rsrc_t r_tab = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<unsigned long long*>(tables) + (l0 >> 6) * (unsigned long long)(kPackedWords * 64), 0, (int)(2u * kTileBytes), 0x00020000);
+        // where joint slot x starts inside the descriptor, for all slots at once in lanes 0..6 (as scalar code this is the
+        // larger part of the loader's instructions, and the scalar unit is what a CU full of these blocks runs out of)
+        const unsigned in_tile = (unsigned)(l0 & 63ull) + ((real && lane < nj) ? (unsigned)lane : 0u);
+        const unsigned slot_base = (in_tile >> 6) * kTileBytes + (in_tile & 63u) * 16u;
+        const unsigned lane_off = (unsigned)lane * 1024u;
+        const bool wanted = lane < (whole_tables ? kPackedWords / 2 : kCappedPairs);
 #pragma unroll
         for (int x = 0; x < kTabJointGroup; ++x) {
-            const unsigned long long li = l0 + (unsigned)((real && x < nj) ? x : 0);
-            const unsigned base = (unsigned)((li >> 6) - (l0 >> 6)) * kTileBytes + (unsigned)(li & 63ull) * 16u;
-            if (lane < (whole_tables ? kPackedWords / 2 : kCappedPairs))
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(r_tab, (lds_ptr)(reinterpret_cast<char*>(&B.jt[x]) + kPackedByte), 16, base + (unsigned)lane * 1024u, 0, 0, 0);
+            const unsigned base = (unsigned)__builtin_amdgcn_readlane((int)slot_base, x);
+            if (wanted)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(r_tab, (lds_ptr)(reinterpret_cast<char*>(&B.jt[x]) + kPackedByte), 16, base + lane_off, 0, 0, 0);
         }
     };
     // header of an item whose loads are in: what the streaming waves read
@@ -1070,11 +1084,12 @@ LTP_DEV void sample_tab_body(long long first, long long count, long long base_fi
                 slen = 0;
             }
             // the largest run count among the item's joints (wave-uniform): how many passes the expansion needs
+            const int runs_of_mine = lane < nj ? peeked : 0;
             int max_runs = 0;
 #pragma unroll
             for (int x = 0; x < kTabJointGroup; ++x) {
-                const int n_x = __builtin_amdgcn_readlane(peeked, x);
-                max_runs = (x < nj && n_x > max_runs) ? n_x : max_runs;
+                const int n_x = __builtin_amdgcn_readlane(runs_of_mine, x);
+                max_runs = n_x > max_runs ? n_x : max_runs;
             }
             if (slen > 0 && !whole_tables && max_runs > kCappedRuns) {
                 // a capped row whose joint has more than 8 runs inside the cap (short trajectories): fetch the rest now
