@@ -123,3 +123,38 @@ def test_full_size_batch(oracle_mod, name, N, gib1, gib2):
     assert checks[0] == checks[1], "every byte of every trajectory must be independent of chunking, block order and store flavour"
     end_limit = ((b.status & amd.STATUS_END_LIMIT) != 0).float().mean().item()
     assert end_limit < 0.01
+
+
+@pytest.mark.parametrize("name,N,cap,f32", [("panda", 1_000_000, 64, False), ("panda", 1_000_000, 256, True), ("ref30", 300_000, 128, False)])
+def test_full_size_short_rows_table_pass_equals_fused_sampler(name, N, cap, f32):
+    """The short-row sampler (packed run tables from the table pass, expanded by the loader wave; several joints per streaming
+    wave for rows of at most 32 slots) against the fused sampler at BASELINE's batch size: every stored byte and every status
+    must be equal, and so must the envelopes, whose tables take the same packed route."""
+    import torch
+    import longtermplanner_amd as amd
+    D, lim = amd.limit_set(name)
+    ltp = amd.LongTermPlanner(D, 0.001, device=0, **lim)
+    q = ltp.generateQueries(N, seed=777)
+    q[1][123456 % N, 0] = 99.0                                   # a rejected plan
+    ltp.setMaxSamples(cap)
+    got = {}
+    for mode in ("fused", "tables"):
+        b = ltp.planSwitchTimesBatch(*q)
+        total = int(b.offsets[-1].item())
+        tile = torch.full((total,), 7.0, dtype=torch.float32 if f32 else torch.float64, device="cuda")
+        ltp.sampleBatch(b, 0, N, tile, tables=(mode == "tables"))
+        torch.cuda.synchronize()
+        assert ltp.lastSamplerKernel().startswith("k_sample_tab") == (mode == "tables")
+        got[mode] = (tile, b.status.clone(), b.traj_len.clone())
+    for a, w in zip(got["tables"], got["fused"]):
+        assert torch.equal(a, w)
+    assert int((got["fused"][1] == 0).sum().item()) > 0.99 * N
+    del got
+    ltp.setMaxSamples(0)
+    b = ltp.planSwitchTimesBatch(*q)
+    env = {}
+    for mode, flag in (("fused", -1), ("tables", 1)):
+        ltp.setTablePass(flag)
+        env[mode] = ltp.envelopeBatch(b, 0, N, 64, 16).clone()
+    torch.cuda.synchronize()
+    assert torch.equal(env["tables"].nan_to_num(5.0), env["fused"].nan_to_num(5.0))
