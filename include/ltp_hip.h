@@ -159,7 +159,7 @@ int ltp_debug_service_ticks(ltp_planner* p, unsigned long long out[7]);
 /* Table pass. A sampler / envelope item (one plan x <= 8 joints) needs the joint's run tables (<= 20 runs of constant jerk
  * with 10 closed-form coefficients each). They are either built inside the sampler kernel by the item's block (no extra
  * memory traffic, ~8 us of latency per item: right for long rows, which hide it) or by a kernel of their own before the
- * sampler (lane = (plan, joint); 1 696 bytes per joint written and read back through the handle's workspace; an item then
+ * sampler (lane = (plan, joint); 912 bytes per joint written and read back through the handle's workspace; an item then
  * costs one prefetched read: right for short rows — first-N-samples rows, receding-horizon rows, envelopes). Both give
  * bit-identical rows. mode 0 = automatic (the pass for ltp_envelope_batch and when max_samples is at most 256 for float64 /
  * 1024 for float32 rows), 1 = always, -1 = never. ltp_sample_batch's flags bits 2 / 3 force the pass / the fused build per call. */

@@ -241,7 +241,7 @@ int check_geometry(ltp_planner* p)
     return LTP_OK;
 }
 
-// Table pass or fused build? (DESIGN.md "Table pass".) The pass writes and re-reads up to 1 696 bytes per joint and runs
+// Table pass or fused build? (DESIGN.md "Table pass".) The pass writes and re-reads up to 912 bytes per joint and runs
 // the sampler with streaming waves that never wait; the fused build costs every item ~8 us of latency, three barriers and
 // a drain of its own stores: the pass pays when a joint's rows are short (measured crossover: a cap between 256 and 512
 // float64 samples, and beyond 1024 float32 samples, whose fused kernel only holds 16 waves per CU). `row_bytes` = bytes of one joint's four rows under the cap (0 = no cap).

@@ -1484,7 +1484,7 @@ k_end_limit(long long first, long long count, int dof, double t_sample, Limits l
 // The table pass: the run tables of plans [first, first + count) as a kernel of its own, lane = (plan, joint), everything
 // in registers (the walk of k_state_at), written word for word in the JointTable layout. A sampler item then costs one
 // (prefetched) table read instead of a cooperative build of ~8 us of latency — what short rows, the envelope consumer and
-// receding-horizon rows are bound by. 1 696 bytes per joint: worth it when a plan's rows are not much longer than that.
+// receding-horizon rows are bound by. 912 bytes per joint (packed): worth it when a plan's rows are not much longer than that.
 // Also applies the end-limit check of cc:59-61 (the sampler variants that read tables no longer do).
 template <int SEM>
 __global__ void __launch_bounds__(256)

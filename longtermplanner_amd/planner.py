@@ -144,7 +144,7 @@ class LongTermPlanner:
 
     def setTablePass(self, mode, workspace_bytes=None):
         """NEW: where the sampler's run tables are built — 0 automatic, 1 always by the table pass (a kernel of its own,
-        1 696 B per joint through the workspace), -1 always inside the sampler kernel. Rows are bit-identical either way."""
+        912 B per joint through the workspace), -1 always inside the sampler kernel. Rows are bit-identical either way."""
         self._check(self._lib.ltp_set_table_pass(self._h, int(mode)))
         if workspace_bytes is not None:
             self._check(self._lib.ltp_set_table_workspace(self._h, int(workspace_bytes)))
