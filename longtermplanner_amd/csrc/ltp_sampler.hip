@@ -1383,21 +1383,28 @@ LTP_DEV void for_each_run(const Limits& lim, const Records& rec, long long rj, i
     const double d20 = (fr[2] - fr[0]) / Ts;
     const double corr[9] = {frts[0] * J0, (1 - frts[1]) * J2, frts[2] * J2, d20 * J2, (1 - frts[3]) * J4,
                             frts[4] * J4, 0.0, (1 - frts[5]) * J6, frts[6] * J6};
-    // candidate cut points (slot 0 = index 0 starts the first run and is not needed here). MATLAB semantics: the corrections
-    // sit one sample earlier, the constant-velocity samples are s2 .. s3-2 and the tail starts at s6 (LTPlanner.m:616, 620)
-    constexpr int cut_base[kCutSlots] = {0, 0, 0, 0, 1, 1, 2, 2, 2, 3, 3, 3, 4, 4, 4, 5, 5, 6, 6, 6};
-    constexpr int cut_delta[kCutSlots] = {0, 0, 1, 2, 0, 1, 0, 1, 2, -1, 0, 1, 0, 1, 2, 0, 1, 0, 1, 2};
-    constexpr int mcut_base[kCutSlots] = {0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 4, 5, 5, 6, 6, 6, 6, 6, 6};
-    constexpr int mcut_delta[kCutSlots] = {0, 0, 1, -1, 0, 0, 1, -1, 0, -1, 0, 1, -1, 0, 0, 1, 1, 1, 1, 1};
-    int cand[kCutSlots];
+    // Candidate cut points: every index where the jerk array or a snap rule (cc:815-829) can change — the same set as kCutBase /
+    // kCutDelta of the cooperative build: per sampled switch index s_g a few CONSECUTIVE integers s_g + lo_g .. s_g + hi_g. The next
+    // cut after b inside group g is therefore max(s_g + lo_g, b + 1) if that is <= s_g + hi_g: three operations per group instead of
+    // four per candidate. MATLAB semantics: the corrections sit one sample earlier, the constant-velocity samples are s2 .. s3-2
+    // and the tail starts at s6 (LTPlanner.m:616, 620).
+    constexpr int cut_lo[7] = {0, 0, 0, -1, 0, 0, 0}, cut_hi[7] = {2, 1, 2, 1, 2, 1, 2};
+    constexpr int mcut_lo[7] = {0, -1, 0, -1, -1, -1, 0}, mcut_hi[7] = {1, 0, 1, 0, 1, 0, 1};
+    int glo[7], ghi[7];
 #pragma unroll
-    for (int c = 1; c < kCutSlots; ++c) cand[c] = SEM == kSemMatlab ? sw[mcut_base[c]] + mcut_delta[c] : sw[cut_base[c]] + cut_delta[c];
+    for (int g = 0; g < 7; ++g) {
+        glo[g] = sw[g] + (SEM == kSemMatlab ? mcut_lo[g] : cut_lo[g]);
+        ghi[g] = sw[g] + (SEM == kSemMatlab ? mcut_hi[g] : cut_hi[g]);
+    }
     const bool phase4 = sw[3] - sw[2] > 2;                                            // cc:813
     int b = 0;
     for (int run = 0; run < kMaxSegments && b < len; ++run) {
         int e = len;                                                                  // next cut point after b
 #pragma unroll
-        for (int c = 1; c < kCutSlots; ++c) e = (cand[c] > b && cand[c] < e) ? cand[c] : e;
+        for (int g = 0; g < 7; ++g) {
+            const int c = glo[g] > b ? glo[g] : b + 1;
+            e = (c <= ghi[g] && c < e) ? c : e;
+        }
         int mode = 0;
         if constexpr (SEM == kSemMatlab) {
             if (b >= sw[6]) mode |= last_joint ? kModeTail : (kModeTail | kModeKeepA);
