@@ -5,7 +5,7 @@ chunk's rows are copied to pinned host memory, and 16 host threads run the oracl
 same queries and compare sample by sample (oracle/ltp_oracle.c: ltpo_compare_dense). Plans beyond the tolerance are listed
 with a cause class, as SURVEY.md §8(d) asks: root-classification, window-test flip, sample-index flip, else rounding.
 
-  python tools/dense_soak.py [panda_plans] [ref_plans] [ref30_plans] [fuzz_sets] [plans_per_fuzz_set] [out.json]
+  python tools/dense_soak.py [panda_plans] [ref_plans] [ref30_plans] [fuzz_sets] [plans_per_fuzz_set] [out.json] [seed_shift]
 """
 import ctypes as C
 import json
@@ -28,6 +28,7 @@ n_ref30 = int(argv[2]) if len(argv) > 2 else 50_000
 n_fuzz_sets = int(argv[3]) if len(argv) > 3 else 24
 n_fuzz = int(argv[4]) if len(argv) > 4 else 2_500
 out_path = argv[5] if len(argv) > 5 else "gpurun_out/dense_soak.json"
+seed_shift = int(argv[6]) if len(argv) > 6 else 0          # other query sets than the committed report's (seeds 4242 / 5000 + trial)
 THREADS = max(1, min(len(os.sched_getaffinity(0)), 16))
 CHUNK_BYTES = 3 << 30                       # per host buffer; two buffers in flight
 
@@ -143,8 +144,8 @@ def main():
     for name, n in (("panda", n_panda), ("ref", n_ref), ("ref30", n_ref30)):
         if n > 0:
             D, lim = amd.limit_set(name)
-            report["sets"][name] = soak(name, D, lim, 0.001, n, 4242, bufs)
-    rng = np.random.default_rng(2027)
+            report["sets"][name] = soak(name, D, lim, 0.001, n, 4242 + seed_shift, bufs)
+    rng = np.random.default_rng(2027 + seed_shift)
     fuzz = {"sets": [], "dense_plans": 0, "values_compared": 0, "plans_beyond_tolerance": 0, "max_abs_d": {k: 0.0 for k in "qvaj"},
             "verdict_mismatches": 0, "length_mismatches": 0, "end_limit_flag_mismatches": 0, "plans_with_bit_identical_jerk_rows": 0, "outliers": []}
     for trial in range(n_fuzz_sets):
@@ -155,7 +156,7 @@ def main():
         j_max = a_max * rng.uniform(5.0, 600.0, D)
         q_hi = rng.uniform(1.0, 3.5, D)
         lim = dict(q_min=list(-q_hi), q_max=list(q_hi), v_max=list(v_max), a_max=list(a_max), j_max=list(j_max))
-        r = soak(f"fuzz{trial}", D, lim, ts, n_fuzz, 5000 + trial, bufs)
+        r = soak(f"fuzz{trial}", D, lim, ts, n_fuzz, 5000 + trial + 100 * seed_shift, bufs)
         fuzz["sets"].append({"dof": D, "t_sample": ts, "max_abs_d": r["max_abs_d"], "plans_beyond_tolerance": r["plans_beyond_tolerance"]})
         for k in ("dense_plans", "values_compared", "plans_beyond_tolerance", "verdict_mismatches", "length_mismatches", "end_limit_flag_mismatches",
                   "plans_with_bit_identical_jerk_rows"):
