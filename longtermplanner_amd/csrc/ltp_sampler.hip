@@ -839,12 +839,6 @@ LTP_DEV int lds_peek32(unsigned a)
     asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(a) : "memory");
     return v;
 }
-LTP_DEV unsigned long long lds_peek64(unsigned a)
-{
-    unsigned long long v;
-    asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(a) : "memory");
-    return v;
-}
 // several reads, one wait: an LDS round trip is ~150 cycles in a CU full of streaming waves
 LTP_DEV void lds_peek64x4(unsigned a0, unsigned a1, unsigned a2, unsigned a3, unsigned long long (&v)[4])
 {
