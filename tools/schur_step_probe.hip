@@ -7,10 +7,10 @@
 #include "ltp_roots.hpp"
 #include "schur_step_probe_polys.inc"
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
-__global__ void __launch_bounds__(64) solve(const double* coef, double* root, unsigned long long* ticks, int mode /* 0: lane 0 only, 1: all lanes lane 0's polynomial, 2: lane i polynomial i */)
+__global__ void __launch_bounds__(64) solve(const double* coef, double* root, unsigned long long* ticks, int mode /* 0: lane 0 only, 1: all lanes lane 0's polynomial, 2: lane i polynomial i, 3: lane 0 the slowest polynomial, the others ordinary ones */)
 {
     const int lane = threadIdx.x;
-    const double* c = coef + (mode == 2 ? lane : 0) * 7;
+    const double* c = coef + ((mode == 2 || (mode == 3 && lane > 0)) ? lane + (mode == 3 ? 64 : 0) : 0) * 7;
     double p[7];
     for (int i = 0; i < 7; ++i) p[i] = c[i];
     __syncthreads();
@@ -24,10 +24,11 @@ __global__ void __launch_bounds__(64) solve(const double* coef, double* root, un
 int main()
 {
     double *dc, *dr; unsigned long long* dt;
-    CK(hipMalloc((void**)&dc, sizeof(kWorst))); CK(hipMalloc((void**)&dr, 64 * 8)); CK(hipMalloc((void**)&dt, 8));
+    CK(hipMalloc((void**)&dc, 2 * sizeof(kWorst))); CK(hipMalloc((void**)&dr, 64 * 8)); CK(hipMalloc((void**)&dt, 8));
     for (int set = 0; set < 2; ++set) {
         CK(hipMemcpy(dc, set == 0 ? kWorst : kTypical, sizeof(kWorst), hipMemcpyHostToDevice));
-        for (int mode = 0; mode < 3; ++mode) {
+        CK(hipMemcpy(dc + 64 * 7, kTypical, sizeof(kTypical), hipMemcpyHostToDevice));
+        for (int mode = 0; mode < (set == 0 ? 4 : 3); ++mode) {
             unsigned long long best = ~0ull, h;
             for (int rep = 0; rep < 5; ++rep) {
                 hipLaunchKernelGGL(solve, dim3(1), dim3(64), 0, nullptr, dc, dr, dt, mode);
