@@ -814,6 +814,29 @@ def test_resident_service_has_the_bits_of_the_launched_single_call(amd, limits, 
     x = torch.arange(1 << 20, device="cuda", dtype=torch.float64)
     assert float((x * 2).sum().item()) == float((1 << 20) * ((1 << 20) - 1))      # torch work while an instance is resident
     check(ltp, "after torch work")
+    # four host threads on one handle: the calls are serialised by the library, every caller gets its own result
+    import threading
+    errors = []
+
+    def hammer(tid):
+        try:
+            for rep in range(25):
+                f, c, r = cases[(tid * 7 + rep) % len(cases)]
+                w = want[(tid * 7 + rep) % len(cases)]
+                g = ltp.planBatchHost(qg[f:f + c], q0[f:f + c], v0[f:f + c], a0[f:f + c], sample=r)
+                for key in keys:
+                    assert g[key].tobytes() == w[key].tobytes(), (tid, rep, key)
+                if r:
+                    assert g["packed"].tobytes() == w["packed"].tobytes(), (tid, rep)
+        except Exception as e:                                   # noqa: BLE001 - reported below
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=hammer, args=(t,)) for t in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors[:3]
     # the one-joint getTrajectory entry goes the same way
     f, c = 17, 1
     w = want[cases.index((17, 1, True))]
