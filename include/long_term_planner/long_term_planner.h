@@ -115,7 +115,6 @@ class LongTermPlanner {
   int sample_stride_ = 1;
   bool goal_check_ = false;
   int semantics_ = LTP_SEMANTICS_CPP;
-  int service_idle_us_ = 0;
 
   static void raise(const ltp_planner* h, int rc, const char* what) {
     throw std::runtime_error(std::string("long_term_planner (MI355X): ") + what + " failed with code " + std::to_string(rc) +
@@ -146,7 +145,6 @@ class LongTermPlanner {
       if ((rc = ltp_set_sample_stride(t.h, sample_stride_)) != LTP_OK) raise(t.h, rc, "ltp_set_sample_stride");
       if ((rc = ltp_set_goal_check(t.h, goal_check_ ? 1 : 0)) != LTP_OK) raise(t.h, rc, "ltp_set_goal_check");
       if ((rc = ltp_set_semantics(t.h, semantics_)) != LTP_OK) raise(t.h, rc, "ltp_set_semantics");
-      if ((rc = ltp_set_service_idle_us(t.h, service_idle_us_)) != LTP_OK) raise(t.h, rc, "ltp_set_service_idle_us");
       t.dirty = false;
     }
     return t.h;
@@ -203,12 +201,12 @@ class LongTermPlanner {
   LongTermPlanner(const LongTermPlanner& o)
       : dof_(o.dof_), t_sample_(o.t_sample_), q_min_(o.q_min_), q_max_(o.q_max_), v_max_(o.v_max_), a_max_(o.a_max_),
         j_max_(o.j_max_), device_(o.device_), max_samples_(o.max_samples_), sample_stride_(o.sample_stride_),
-        goal_check_(o.goal_check_), semantics_(o.semantics_), service_idle_us_(o.service_idle_us_) {}
+        goal_check_(o.goal_check_), semantics_(o.semantics_) {}
   LongTermPlanner& operator=(const LongTermPlanner& o) {
     if (this != &o) {
       dof_ = o.dof_; t_sample_ = o.t_sample_; q_min_ = o.q_min_; q_max_ = o.q_max_; v_max_ = o.v_max_; a_max_ = o.a_max_;
       j_max_ = o.j_max_; device_ = o.device_; max_samples_ = o.max_samples_; sample_stride_ = o.sample_stride_;
-      goal_check_ = o.goal_check_; semantics_ = o.semantics_; service_idle_us_ = o.service_idle_us_; markDirty();
+      goal_check_ = o.goal_check_; semantics_ = o.semantics_; markDirty();
     }
     return *this;
   }
@@ -371,9 +369,6 @@ class LongTermPlanner {
    * LTP_SEMANTICS_MATLAB). BatchTrajectory::status may then carry LTP_STATUS_MATLAB_ERROR / LTP_STATUS_MATLAB_COMPLEX. */
   inline void setMatlabSemantics(bool enabled) { semantics_ = enabled ? LTP_SEMANTICS_MATLAB : LTP_SEMANTICS_CPP; markDirty(); }
 
-  /** @brief NEW, off by default: keep a small kernel resident between planTrajectory calls (ltp_set_service_idle_us) so that a
-   * call costs a mailbox write instead of a kernel launch; it leaves by itself after `idle_us` microseconds without a call. */
-  inline void setServiceIdle(int idle_us) { service_idle_us_ = idle_us; markDirty(); }
 
   /** @brief NEW: HIP device ordinal used by this planner (default 0). */
   inline void setDevice(int device) { if (device != device_) { device_ = device; markDirty(); } }

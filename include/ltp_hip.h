@@ -143,19 +143,6 @@ int ltp_get_goal_check(const ltp_planner* p);
 int ltp_set_semantics(ltp_planner* p, int semantics);
 int ltp_get_semantics(const ltp_planner* p);
 
-/* Resident service for single calls (BASELINE config 1: one planTrajectory at a time), off by default. A call of at most
- * 128 (query, joint) pairs through ltp_plan_batch_host / ltp_get_trajectory_host normally costs one kernel launch — about 25 of
- * its 37 us. With idle_us > 0 the first such call starts a small resident kernel (8 blocks) that polls a mailbox in pinned
- * host memory; the following calls only write a command there and wait for its completion word: no launch, no stream
- * operation. The kernel leaves by itself when no call arrived for idle_us microseconds (the next call starts a new instance),
- * when this function, ltp_set_limits or ltp_destroy is called, and after 20 s in any case; results are the bits of the
- * launched path. While an instance is resident, a hipDeviceSynchronize() issued elsewhere in the process waits for it to leave,
- * i.e. up to idle_us: choose the idle time with that in mind (a controller calling every millisecond: 1500). */
-int ltp_set_service_idle_us(ltp_planner* p, int idle_us);
-int ltp_get_service_idle_us(const ltp_planner* p);
-/* diagnostic: device-side time of the last command served, in 100 MHz ticks: [0] command seen -> command fetched, [1] -> done */
-int ltp_debug_service_ticks(ltp_planner* p, unsigned long long out[7]);
-
 /* Table pass. A sampler / envelope item (one plan x <= 8 joints) needs the joint's run tables (<= 20 runs of constant jerk
  * with 10 closed-form coefficients each). They are either built inside the sampler kernel by the item's block (no extra
  * memory traffic, ~8 us of latency per item: right for long rows, which hide it) or by a kernel of their own before the

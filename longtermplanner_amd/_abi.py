@@ -97,9 +97,6 @@ _SIGNATURES = {
     "ltp_plan_envelope_host": (C.c_int, [C.c_void_p, C.c_longlong, _dp, _dp, _dp, _dp, C.c_int, C.c_int, C.POINTER(Records), _dp]),
     "ltp_state_at_batch": (C.c_int, [C.c_void_p, C.c_longlong, C.c_longlong, C.POINTER(Queries), C.POINTER(Records), C.c_void_p, C.c_int,
                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_longlong, C.c_void_p]),
-    "ltp_set_service_idle_us": (C.c_int, [C.c_void_p, C.c_int]),
-    "ltp_get_service_idle_us": (C.c_int, [C.c_void_p]),
-    "ltp_debug_service_ticks": (C.c_int, [C.c_void_p, C.POINTER(C.c_ulonglong)]),
     "ltp_set_semantics": (C.c_int, [C.c_void_p, C.c_int]),
     "ltp_get_semantics": (C.c_int, [C.c_void_p]),
     "ltp_debug_last_matlab_flags": (C.c_int, [C.c_void_p]),

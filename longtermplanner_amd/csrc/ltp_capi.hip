@@ -44,13 +44,6 @@ struct ltp_planner {
     const char* last_kernel = "";          // row / envelope kernel of the latest ltp_sample_batch* / ltp_envelope_batch
     int semantics = 0;                     // LTP_SEMANTICS_CPP (the reference's C++, default) or LTP_SEMANTICS_MATLAB
     int last_matlab_flags = 0;             // MATLAB semantics: flags of the latest one-lane call (1 = complex intermediate, 2 = error)
-    // resident single-call service (ltp_set_service_idle_us): mailbox in pinned host memory, two device words, its own stream
-    int service_idle_us = 0;               // 0 = off: every small call launches k_plan_small
-    void* svc_mailbox = nullptr;
-    unsigned* d_svc = nullptr;
-    hipStream_t svc_stream = nullptr;
-    unsigned svc_seq = 0;                  // last command posted
-    bool svc_started = false;              // an instance was launched and not yet known to have ended
     unsigned long long* dbg_stamps = nullptr; // diagnostic: per-block start/end stamps of k_sample (caller-owned)
     // persistent buffers of the small synchronous host-pointer calls (no hipMalloc per call)
     std::mutex host_mu;
@@ -74,7 +67,6 @@ struct ltp_planner {
 namespace {
 
 constexpr bool kEnvelopeTablePassByDefault = true;   // measured: see DESIGN.md "Table pass"
-int service_stop(ltp_planner* p);                    // resident single-call service, below
 
 int fail(ltp_planner* p, int code, const std::string& msg)
 {
@@ -352,10 +344,6 @@ void ltp_destroy(ltp_planner* p)
 {
     if (!p) return;
     (void)hipSetDevice(p->device);
-    (void)service_stop(p);
-    if (p->svc_stream) (void)hipStreamDestroy(p->svc_stream);
-    if (p->d_svc) (void)hipFree(p->d_svc);
-    if (p->svc_mailbox) (void)hipHostFree(p->svc_mailbox);
     if (p->d_lim) (void)hipFree(p->d_lim);
     if (p->d_queue) (void)hipFree(p->d_queue);
     if (p->d_lane_flags) (void)hipFree(p->d_lane_flags);
@@ -377,15 +365,14 @@ int ltp_set_limits(ltp_planner* p, int n_limits, const double* q_min, const doub
                    const double* a_max, const double* j_max)
 {
     if (!p || n_limits < 0 || (n_limits > 0 && (!q_min || !q_max || !v_max || !a_max || !j_max))) return fail(p, LTP_ERR_INVALID_ARGUMENT, "bad limits");
+    // Lock order of the library: host_mu (the synchronous host-pointer calls and their arena) BEFORE mu (configuration and the
+    // device workspace), everywhere. Both are held here: no host-pointer call launches between the synchronisation and the
+    // upload, and no batched call enqueues a kernel that would read the limits while they change.
+    std::lock_guard<std::mutex> hg(p->host_mu);
     std::lock_guard<std::mutex> g(p->mu);
     const double* src[5] = {q_min, q_max, v_max, a_max, j_max};
     for (int k = 0; k < 5; ++k) p->h_lim[k].assign(src[k], src[k] + n_limits);
     LTP_HIP_TRY(p, hipSetDevice(p->device));
-    {
-        std::lock_guard<std::mutex> hg(p->host_mu);
-        const int rc = service_stop(p);       // a resident service instance reads the limits too (and would outlast the synchronisation below)
-        if (rc != LTP_OK) return rc;
-    }
     LTP_HIP_TRY(p, hipDeviceSynchronize());   // limits are read by in-flight kernels
     return upload_limits(p);
 }
@@ -438,22 +425,6 @@ int ltp_set_semantics(ltp_planner* p, int semantics)
     return LTP_OK;
 }
 int ltp_get_semantics(const ltp_planner* p) { return p ? p->semantics : -1; }
-int ltp_set_service_idle_us(ltp_planner* p, int idle_us)
-{
-    if (!p || idle_us < 0 || idle_us > 1000000) return fail(p, LTP_ERR_INVALID_ARGUMENT, "the idle time must be 0 (off) .. 1 000 000 us");
-    std::lock_guard<std::mutex> hg(p->host_mu);
-    const int rc = service_stop(p);       // a running instance carries the old idle time
-    if (rc != LTP_OK) return rc;
-    p->service_idle_us = idle_us;
-    return LTP_OK;
-}
-int ltp_get_service_idle_us(const ltp_planner* p) { return p ? p->service_idle_us : -1; }
-int ltp_debug_service_ticks(ltp_planner* p, unsigned long long out[7])
-{
-    if (!p || !out || !p->svc_mailbox) return LTP_ERR_INVALID_ARGUMENT;
-    ltp::service_ticks(p->svc_mailbox, out);
-    return LTP_OK;
-}
 int ltp_set_table_pass(ltp_planner* p, int mode)
 {
     if (!p || mode < -1 || mode > 1) return fail(p, LTP_ERR_INVALID_ARGUMENT, "table pass mode must be -1, 0 or 1");
@@ -746,7 +717,7 @@ static int run_sample_to_host(ltp_planner* p, long long n, const ltp_queries& dq
     if (e != hipSuccess) rc = hip_fail(p, e, "hipMemset");
     if (rc == LTP_OK) rc = ltp_sample_batch(p, 0, n, &dq, &dr, d_offsets, d_out, total, 0, nullptr);
     if (rc == LTP_OK) {
-        e = hipStreamSynchronize(nullptr);   // (not the whole device: a resident single-call service of some handle may be polling)
+        e = hipStreamSynchronize(nullptr);
         if (e != hipSuccess) rc = hip_fail(p, e, "hipStreamSynchronize");
     }
     if (rc == LTP_OK) {
@@ -834,46 +805,6 @@ int wait_done(ltp_planner* p, volatile int* done)
 #endif
     }
     std::atomic_thread_fence(std::memory_order_acquire);   // the result buffers are read after the flag
-    return LTP_OK;
-}
-
-}  // namespace
-
-// ---- resident single-call service (k_plan_service). Caller holds host_mu. ----
-namespace {
-
-constexpr unsigned long long kServiceHardSeconds = 20;      // an instance never lives longer than this, whatever happens
-
-// makes sure no instance is running (returns when the leader has left): before anything that synchronises the whole device,
-// changes the limits' device array or frees the handle
-int service_stop(ltp_planner* p)
-{
-    if (!p->svc_started) return LTP_OK;
-    ltp::service_stop_request(p->svc_mailbox);
-    LTP_HIP_TRY(p, hipSetDevice(p->device));
-    LTP_HIP_TRY(p, hipStreamSynchronize(p->svc_stream));
-    p->svc_started = false;
-    return LTP_OK;
-}
-
-int service_start(ltp_planner* p)
-{
-    LTP_HIP_TRY(p, hipSetDevice(p->device));
-    if (!p->svc_mailbox) {
-        LTP_HIP_TRY(p, hipHostMalloc(&p->svc_mailbox, (size_t)ltp::service_mailbox_bytes(), hipHostMallocPortable | hipHostMallocCoherent));
-        memset(p->svc_mailbox, 0, (size_t)ltp::service_mailbox_bytes());
-        LTP_HIP_TRY(p, hipMalloc((void**)&p->d_svc, 2 * sizeof(unsigned)));
-        LTP_HIP_TRY(p, hipStreamCreateWithFlags(&p->svc_stream, hipStreamNonBlocking));
-    }
-    // stream order: a previous instance (which has cleared `alive`, or is about to) is over before the words are re-armed
-    const unsigned words[2] = {p->svc_seq, 0u};
-    LTP_HIP_TRY(p, hipMemcpyAsync(p->d_svc, words, sizeof(words), hipMemcpyHostToDevice, p->svc_stream));
-    LTP_HIP_TRY(p, hipStreamSynchronize(p->svc_stream));   // `words` is a stack array; this also ends the wait for an instance on its way out
-    ltp::service_set(p->svc_mailbox, 1u, 0u);
-    ltp::launch_plan_service(p->svc_stream, p->svc_mailbox, p->d_svc, dev_limits(p), p->svc_seq, (unsigned long long)p->service_idle_us * 100ull,
-                             kServiceHardSeconds * 100000000ull);   // wall_clock64 ticks at 100 MHz
-    LTP_HIP_TRY(p, hipGetLastError());
-    p->svc_started = true;
     return LTP_OK;
 }
 
@@ -982,7 +913,7 @@ int plan_batch_host_fused(ltp_planner* p, long long n, const double* const (&h_i
     const size_t nd = (size_t)n * dof;
     const ArenaLayout L = arena_layout(n, dof);
     const size_t flag_at = (L.end + 63) & ~(size_t)63;
-    const int blocks = p->service_idle_us > 0 ? ltp::service_blocks() : ltp::small_batch_blocks(dof, packed != nullptr);
+    const int blocks = ltp::small_batch_blocks(dof, packed != nullptr);
     const size_t ends_at = flag_at + 64;                         // [blocks][n] end-limit bits
     int rc = ensure_arena(p, ends_at + sizeof(int) * (size_t)blocks * (size_t)n);
     if (rc != LTP_OK) return rc;
@@ -1011,47 +942,6 @@ int plan_batch_host_fused(ltp_planner* p, long long n, const double* const (&h_i
     *done = 0;
     const double* in[4] = {(const double*)(p->h_arena + L.in[0]), (const double*)(p->h_arena + L.in[1]),
                            (const double*)(p->h_arena + L.in[2]), (const double*)(p->h_arena + L.in[3])};
-    if (p->service_idle_us > 0) {
-        // resident service: post the command to the mailbox; start an instance if none is running, and again if the one that
-        // was running left (idle timeout) before it saw the command
-        {
-            std::lock_guard<std::mutex> g(p->mu);
-            capture_geometry(p);
-        }
-        if (!p->svc_started || ltp::service_alive(p->svc_mailbox) == 0u) {
-            p->svc_started = false;
-            if ((rc = service_start(p)) != LTP_OK) { if (rows) g_pinned.release(rows); return rc; }
-        }
-        const unsigned prev_seq = p->svc_seq;
-        p->svc_seq = prev_seq + 1u == 0xffffffffu ? 0u : prev_seq + 1u;    // (0xffffffff is the kernel's "leave" word)
-        ltp::service_post(p->svc_mailbox, p->svc_seq, (int)n, dof, p->t_sample, p->goal_check, ltp::RowSpec{p->max_samples, p->sample_stride}, in,
-                          to_dev(&hr), (unsigned long long*)(p->h_arena + L.offsets), rows, kFusedRowsBytes / sizeof(double),
-                          (int*)(p->h_arena + ends_at), p->d_svc + 1, done, given != nullptr);
-        rc = LTP_OK;
-        int restarts = 0;
-        for (long spins = 0; *done == 0; ++spins) {
-            if ((spins & 255) == 255 && ltp::service_alive(p->svc_mailbox) == 0u && *done == 0) {
-                // the instance ended without serving this command (it was on its way out when the command arrived): the new
-                // instance starts with the previous command as the last one seen, so it takes this one at once
-                if (++restarts > 3) { rc = fail(p, LTP_ERR_HIP, "the single-call service keeps ending before it serves the command"); break; }
-                const unsigned posted = p->svc_seq;
-                p->svc_seq = prev_seq;
-                rc = service_start(p);
-                p->svc_seq = posted;
-                if (rc != LTP_OK) break;
-            }
-            if (spins > 400000000l) { rc = fail(p, LTP_ERR_HIP, "the single-call service did not answer"); break; }
-#if defined(__x86_64__)
-            __builtin_ia32_pause();
-#endif
-        }
-        std::atomic_thread_fence(std::memory_order_acquire);
-        if (rc != LTP_OK) {
-            (void)service_stop(p);               // whatever is left of it must be gone before the buffers are reused
-            if (rows) g_pinned.release(rows);
-            return rc;
-        }
-    } else {
     {
         std::lock_guard<std::mutex> g(p->mu);
         capture_geometry(p);
@@ -1062,7 +952,6 @@ int plan_batch_host_fused(ltp_planner* p, long long n, const double* const (&h_i
         if (e != hipSuccess) { if (rows) g_pinned.release(rows); return hip_fail(p, e, "k_plan_small"); }   // nothing was launched
     }
     rc = wait_done(p, done);
-    }
     if (rc != LTP_OK) {
         // the kernel may still be running (or have died half way): its arrival word is suspect, and `rows` goes back to the
         // pool only once the stream is known to be idle — otherwise it stays allocated (leaked) rather than be written behind a later owner's back
@@ -1144,13 +1033,24 @@ int plan_batch_host_small(ltp_planner* p, long long n, const double* const (&h_i
 // device addresses directly): one launch, one synchronisation, no copy engine
 extern "C++" {
 template <class Launch>
-int run_one_lane(ltp_planner* p, double (&buf)[16], Launch launch)
+int run_one_lane(ltp_planner* p, int joint, double (&buf)[16], Launch launch)
 {
-    std::lock_guard<std::mutex> hg(p->host_mu);
+    std::lock_guard<std::mutex> hg(p->host_mu);        // host_mu before mu (see ltp_set_limits)
+    double t_sample;
+    int semantics;
+    ltp::Limits lim;
+    {
+        std::lock_guard<std::mutex> g(p->mu);
+        if (joint < 0 || joint >= p->lim_cap) return fail(p, LTP_ERR_INVALID_ARGUMENT, "joint out of range");
+        t_sample = p->t_sample;
+        semantics = p->semantics;
+        lim = dev_limits(p);                           // stays valid: ltp_set_limits needs host_mu, which this call holds
+    }
+    LTP_HIP_TRY(p, hipSetDevice(p->device));
     int rc = ensure_arena(p, sizeof(buf));
     if (rc != LTP_OK) return rc;
     memcpy(p->h_arena, buf, sizeof(buf));
-    launch((double*)p->h_arena);
+    launch((double*)p->h_arena, t_sample, lim, semantics);
     LTP_HIP_TRY(p, hipGetLastError());
     LTP_HIP_TRY(p, hipStreamSynchronize(nullptr));
     memcpy(buf, p->h_arena, sizeof(buf));
@@ -1599,12 +1499,9 @@ int ltp_check_inputs_host(ltp_planner* p, const double* q_0, const double* v_0, 
 int ltp_opt_braking_host(ltp_planner* p, int joint, double v_0, double a_0, double* q, double* t_rel, double* dir)
 {
     if (!p || !q || !t_rel || !dir) return fail(p, LTP_ERR_INVALID_ARGUMENT, "null argument");
-    std::lock_guard<std::mutex> g(p->mu);
-    if (joint < 0 || joint >= p->lim_cap) return fail(p, LTP_ERR_INVALID_ARGUMENT, "joint out of range");
-    LTP_HIP_TRY(p, hipSetDevice(p->device));
     double buf[16] = {0};
     memcpy(buf, t_rel, sizeof(double) * 7);
-    const int rc = run_one_lane(p, buf, [&](double* io) { ltp::launch_single_opt_braking(nullptr, joint, p->t_sample, dev_limits(p), v_0, a_0, io, p->semantics); });
+    const int rc = run_one_lane(p, joint, buf, [&](double* io, double ts, const ltp::Limits& lim, int sem) { ltp::launch_single_opt_braking(nullptr, joint, ts, lim, v_0, a_0, io, sem); });
     if (rc != LTP_OK) return rc;
     memcpy(t_rel, buf, sizeof(double) * 7);
     *q = buf[7];
@@ -1616,12 +1513,9 @@ int ltp_opt_switch_times_host(ltp_planner* p, int joint, double q_goal, double q
                               double* t, double* dir, char* mod, int* ok)
 {
     if (!p || !t || !dir || !mod || !ok) return fail(p, LTP_ERR_INVALID_ARGUMENT, "null argument");
-    std::lock_guard<std::mutex> g(p->mu);
-    if (joint < 0 || joint >= p->lim_cap) return fail(p, LTP_ERR_INVALID_ARGUMENT, "joint out of range");
-    LTP_HIP_TRY(p, hipSetDevice(p->device));
     double buf[16] = {0};
     memcpy(buf, t, sizeof(double) * 7);
-    const int rc = run_one_lane(p, buf, [&](double* io) { ltp::launch_single_opt_switch(nullptr, joint, p->t_sample, dev_limits(p), q_goal, q_0, v_0, a_0, v_drive, io, p->semantics); });
+    const int rc = run_one_lane(p, joint, buf, [&](double* io, double ts, const ltp::Limits& lim, int sem) { ltp::launch_single_opt_switch(nullptr, joint, ts, lim, q_goal, q_0, v_0, a_0, v_drive, io, sem); });
     if (rc != LTP_OK) return rc;
     memcpy(t, buf, sizeof(double) * 7);
     *dir = buf[7];
@@ -1634,12 +1528,9 @@ int ltp_time_scaling_host(ltp_planner* p, int joint, double q_goal, double q_0, 
                           double t_required, double* scaled_t, double* v_drive, char* mod, int* ok, int* accepted_case)
 {
     if (!p || !scaled_t || !v_drive || !mod || !ok) return fail(p, LTP_ERR_INVALID_ARGUMENT, "null argument");
-    std::lock_guard<std::mutex> g(p->mu);
-    if (joint < 0 || joint >= p->lim_cap) return fail(p, LTP_ERR_INVALID_ARGUMENT, "joint out of range");
-    LTP_HIP_TRY(p, hipSetDevice(p->device));
     double buf[16] = {0};
     memcpy(buf, scaled_t, sizeof(double) * 7);
-    const int rc = run_one_lane(p, buf, [&](double* io) { ltp::launch_single_time_scaling(nullptr, joint, p->t_sample, dev_limits(p), q_goal, q_0, v_0, a_0, dir, t_required, io, p->semantics); });
+    const int rc = run_one_lane(p, joint, buf, [&](double* io, double ts, const ltp::Limits& lim, int sem) { ltp::launch_single_time_scaling(nullptr, joint, ts, lim, q_goal, q_0, v_0, a_0, dir, t_required, io, sem); });
     if (rc != LTP_OK) return rc;
     memcpy(scaled_t, buf, sizeof(double) * 7);
     *v_drive = buf[7];

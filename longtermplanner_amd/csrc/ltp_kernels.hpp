@@ -127,20 +127,6 @@ void launch_plan_small(hipStream_t s, int n, int dof, double t_sample, int goal_
                        Records rec, unsigned long long* offsets, double* out_rows, unsigned long long capacity, int* end_flags,
                        unsigned int* arrivals, volatile int* done,
                        bool records_given = false /* getTrajectory: t_scaled, dir, mod, v_drive of `rec` are inputs */);
-// Resident service for single calls (k_plan_service, ltp_sampler.hip): the mailbox is service_mailbox_bytes() of pinned, coherent
-// host memory (zeroed), dev_words two zeroed device words (the leader's hand-over word, which must hold start_seq when an
-// instance starts, and the arrival counter). service_post = what launch_plan_small is without the service.
-int service_blocks();
-unsigned long long service_mailbox_bytes();
-void launch_plan_service(hipStream_t s, void* mailbox, unsigned* dev_words, Limits lim, unsigned start_seq, unsigned long long idle_ticks,
-                         unsigned long long hard_ticks);
-void service_post(void* mailbox, unsigned seq, int n, int dof, double t_sample, int goal_check, RowSpec rows, const double* const in[4],
-                  Records rec, unsigned long long* offsets, double* out_rows, unsigned long long capacity, int* end_flags,
-                  unsigned int* arrivals, volatile int* done, bool records_given);
-unsigned service_alive(const void* mailbox);
-void service_ticks(const void* mailbox, unsigned long long out[7]);
-void service_set(void* mailbox, unsigned alive, unsigned stop);
-void service_stop_request(void* mailbox);
 void launch_generate(hipStream_t s, long long n, int dof, Limits lim, unsigned long long seed, long long first_query,
                      double* q_goal, double* q_0, double* v_0, double* a_0, long long sq, long long sj);
 

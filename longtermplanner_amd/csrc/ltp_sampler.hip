@@ -1810,7 +1810,6 @@ LTP_DEV void plan_small_body(int n, int dof, double t_sample, int goal_check, Ro
             __threadfence_system();
         }
     }
-    __syncthreads();   // the LDS of this block is free for the next call (k_plan_service)
 }
 
 template <bool GIVEN>
@@ -1821,138 +1820,7 @@ k_plan_small(int n, int dof, double t_sample, int goal_check, RowSpec rows, Limi
     plan_small_body<GIVEN>(n, dof, t_sample, goal_check, rows, lim, io, sh);
 }
 
-// ---------------------------------------------------------------------------------------
-// Resident service for single calls (opt-in: ltp_set_service_idle_us). k_plan_small costs a launch per call: ~25 of the 37 us of
-// a single planTrajectory call are launch and completion, not work. Here kServiceBlocks blocks stay resident and poll a mailbox
-// in pinned host memory: the host writes a command (the same SmallHost a k_plan_small launch would get) and bumps `seq`; block
-// 0 sees it, hands it to the other blocks through a word in device memory, every block runs plan_small_body, the last one
-// sets the caller's completion word. No launch, no stream operation per call.
-// Lifetime is bounded three ways, so that nothing can hold CUs for long: the leader ends the service when no command arrived for
-// idle_ticks (the next call then starts a new instance), when the host sets `stop` (ltp_destroy, setters, library paths that
-// synchronise the device), or when hard_ticks have passed since the launch whatever happens. On the way out it clears `alive`;
-// a host that posted a command to an instance that was just leaving sees that and starts a new one.
-// ---------------------------------------------------------------------------------------
-constexpr int kServiceBlocks = 8;
-constexpr unsigned kServiceExit = 0xffffffffu;
-struct ServiceCmd {
-    int n, dof, goal_check, given;
-    double t_sample;
-    RowSpec rows;
-    SmallHost io;
-};
-struct ServiceMailbox {              // pinned, coherent host memory
-    unsigned seq;                    // host: bumped after `cmd` is complete
-    unsigned stop;                   // host: 1 = leave now
-    unsigned alive;                  // host sets 1 before a launch, the leader clears it when the instance ends
-    unsigned pad;
-    unsigned long long ticks[8];     // leader, last command: 100 MHz ticks from "seq seen" to command fetched / body done (diagnostic)
-    ServiceCmd cmd;
-};
-static_assert(sizeof(ServiceCmd) % 8 == 0, "copied as 8-byte words");
-
-__global__ void __launch_bounds__(kSampleThreads)
-k_plan_service(ServiceMailbox* mb, unsigned* dev_words /* [0] command seen by the leader, [1] arrivals */, Limits lim, unsigned start_seq,
-               unsigned long long idle_ticks, unsigned long long hard_ticks)
-{
-    __shared__ SmallShared sh;
-    __shared__ ServiceCmd s_cmd;
-    __shared__ unsigned s_got;
-    unsigned seen = start_seq;
-    const unsigned long long t_start = (unsigned long long)wall_clock64();
-    unsigned long long t_last = t_start;
-    for (;;) {
-        if (threadIdx.x == 0) {
-            unsigned got = seen;
-            if (blockIdx.x == 0) {
-                for (;;) {
-                    got = __hip_atomic_load(&mb->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                    if (got != seen) break;
-                    const unsigned long long now = (unsigned long long)wall_clock64();
-                    if (now - t_last > idle_ticks || now - t_start > hard_ticks ||
-                        __hip_atomic_load(&mb->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) {
-                        got = kServiceExit;
-                        break;
-                    }
-                    __builtin_amdgcn_s_sleep(4);
-                }
-                __hip_atomic_store(&dev_words[0], got, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-            } else {
-                for (;;) {
-                    got = __hip_atomic_load(&dev_words[0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
-                    if (got != seen) break;
-                    if ((unsigned long long)wall_clock64() - t_start > hard_ticks + hard_ticks / 4) { got = kServiceExit; break; }   // the leader never came
-                    __builtin_amdgcn_s_sleep(8);
-                }
-            }
-            s_got = got;
-        }
-        __syncthreads();
-        const unsigned got = s_got;
-        if (got == kServiceExit) break;
-        seen = got;
-        const unsigned long long tk0 = (unsigned long long)wall_clock64();
-        // the command was complete in host memory before `seq` changed: fetch it past every cache, then make the plain loads of the
-        // inputs that follow see host memory as it is now
-        {
-            const unsigned long long* src = reinterpret_cast<const unsigned long long*>(&mb->cmd);
-            unsigned long long* dst = reinterpret_cast<unsigned long long*>(&s_cmd);
-            for (int w = threadIdx.x; w < (int)(sizeof(ServiceCmd) / 8); w += kSampleThreads)
-                dst[w] = __hip_atomic_load(src + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-        __threadfence_system();
-        __syncthreads();
-        const unsigned long long tk1 = (unsigned long long)wall_clock64();
-        if (s_cmd.given) plan_small_body<true>(s_cmd.n, s_cmd.dof, s_cmd.t_sample, s_cmd.goal_check, s_cmd.rows, lim, s_cmd.io, sh);
-        else plan_small_body<false>(s_cmd.n, s_cmd.dof, s_cmd.t_sample, s_cmd.goal_check, s_cmd.rows, lim, s_cmd.io, sh);
-        t_last = (unsigned long long)wall_clock64();
-        if (blockIdx.x == 0 && threadIdx.x == 0) {
-            mb->ticks[0] = tk1 - tk0; mb->ticks[1] = t_last - tk0;
-            for (int k = 0; k < 5; ++k) mb->ticks[2 + k] = sh.tick[k] - tk0;
-        }
-    }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        __hip_atomic_store(&mb->alive, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-}
-
 int small_batch_pairs() { return kSmallPairs; }
-int service_blocks() { return kServiceBlocks; }
-unsigned long long service_mailbox_bytes() { return sizeof(ServiceMailbox); }
-
-void launch_plan_service(hipStream_t s, void* mailbox, unsigned* dev_words, Limits lim, unsigned start_seq, unsigned long long idle_ticks,
-                         unsigned long long hard_ticks)
-{
-    hipLaunchKernelGGL(k_plan_service, dim3(kServiceBlocks), dim3(kSampleThreads), 0, s, (ServiceMailbox*)mailbox, dev_words, lim, start_seq,
-                       idle_ticks, hard_ticks);
-}
-
-// host side of the mailbox protocol: the command is written first, then `seq`
-void service_post(void* mailbox, unsigned seq, int n, int dof, double t_sample, int goal_check, RowSpec rows, const double* const in[4],
-                  Records rec, unsigned long long* offsets, double* out_rows, unsigned long long capacity, int* end_flags,
-                  unsigned int* arrivals, volatile int* done, bool records_given)
-{
-    ServiceMailbox* mb = (ServiceMailbox*)mailbox;
-    ServiceCmd c;
-    c.n = n; c.dof = dof; c.goal_check = goal_check; c.given = records_given ? 1 : 0; c.t_sample = t_sample; c.rows = rows;
-    for (int k = 0; k < 4; ++k) c.io.in[k] = in[k];
-    c.io.rec = rec; c.io.offsets = offsets; c.io.rows = out_rows; c.io.capacity = capacity; c.io.end_flags = end_flags;
-    c.io.arrivals = arrivals; c.io.done = done;
-    mb->cmd = c;
-    __atomic_thread_fence(__ATOMIC_RELEASE);
-    __atomic_store_n(&mb->seq, seq, __ATOMIC_RELEASE);
-}
-void service_ticks(const void* mailbox, unsigned long long out[7])
-{
-    for (int k = 0; k < 7; ++k) out[k] = ((const ServiceMailbox*)mailbox)->ticks[k];
-}
-unsigned service_alive(const void* mailbox) { return __atomic_load_n(&((const ServiceMailbox*)mailbox)->alive, __ATOMIC_ACQUIRE); }
-void service_set(void* mailbox, unsigned alive, unsigned stop)
-{
-    ServiceMailbox* mb = (ServiceMailbox*)mailbox;
-    __atomic_store_n(&mb->stop, stop, __ATOMIC_RELEASE);
-    __atomic_store_n(&mb->alive, alive, __ATOMIC_RELEASE);
-}
-void service_stop_request(void* mailbox) { __atomic_store_n(&((ServiceMailbox*)mailbox)->stop, 1u, __ATOMIC_RELEASE); }
 int small_batch_blocks(int dof, bool with_rows) { return !with_rows ? 1 : (dof < kSmallBlocks ? (dof > 0 ? dof : 1) : kSmallBlocks); }
 
 void launch_plan_small(hipStream_t s, int n, int dof, double t_sample, int goal_check, RowSpec rows, Limits lim, const double* const in[4],

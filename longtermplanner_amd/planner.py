@@ -124,11 +124,6 @@ class LongTermPlanner:
         code = {"cpp": _abi.SEMANTICS_CPP, "matlab": _abi.SEMANTICS_MATLAB}.get(semantics, semantics)
         self._check(self._lib.ltp_set_semantics(self._h, int(code)))
 
-    def setServiceIdle(self, idle_us):
-        """NEW: resident service for single calls (ltp_set_service_idle_us): with idle_us > 0 small calls (planTrajectory, the
-        protected methods' getTrajectory) post their command to a resident kernel instead of launching one; 0 switches it off."""
-        self._check(self._lib.ltp_set_service_idle_us(self._h, int(idle_us)))
-
     def lastMatlabFlags(self):
         """MATLAB semantics: flags of the latest one-lane call (optBraking / optSwitchTimes / timeScaling): 1 = complex intermediate, 2 = error."""
         return self._lib.ltp_debug_last_matlab_flags(self._h)

@@ -24,12 +24,13 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libltp_oracle.so")
+_EXACT_LIB_PATH = os.path.join(_HERE, "libltp_oracle_exactpow.so")   # diagnostic twin, see lib(exact_pow=True)
 
 
 def build(force=False):
     """Compile the C restatement (gcc). Building the checker is not using it."""
     src_time = max(os.path.getmtime(os.path.join(_HERE, f)) for f in ("ltp_oracle.c", "kat_grid.c", "companion_roots.inc", "matlab_roots.inc", "Makefile"))
-    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < src_time:
+    if force or any(not os.path.exists(p) or os.path.getmtime(p) < src_time for p in (_LIB_PATH, _EXACT_LIB_PATH)):
         subprocess.check_call(["make", "-C", _HERE, "-s", "clean", "all"])
     return _LIB_PATH
 
@@ -42,20 +43,37 @@ class _Planner(C.Structure):
 
 
 _lib = None
+_lib_exact = None
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int)
 _cp = C.POINTER(C.c_char)
 
 
-def lib():
-    global _lib
+def _load(path):
+    if not os.path.exists(path):
+        build()
+    l = C.CDLL(path)
+    l.ltpo_smallest_root.restype = C.c_double
+    l.ltpo_plan_batch.restype = C.c_long
+    l.ltpo_poly_log_end.restype = C.c_long
+    l.ltpo_compare_dense.restype = C.c_longlong
+    return l
+
+
+def lib(exact_pow=False):
+    """The checker library. exact_pow=True: the DIAGNOSTIC twin built with -DLTPO_EXACT_POW, whose pow(x, 3 | 4 | 6) is one
+    rounding of the exact product and whose pow(x, 0.5) is sqrt — the device's rule (csrc/ltp_math.hpp) — instead of libm's
+    pow. It exists to show that libm's pow is the ONLY source of last-bit differences between the device and the default
+    oracle; the parity reference is always the default build."""
+    global _lib, _lib_exact
+    if exact_pow:
+        if _lib_exact is None:
+            _lib_exact = _load(_EXACT_LIB_PATH)
+            assert _lib_exact.ltpo_exact_pow() == 1
+        return _lib_exact
     if _lib is None:
-        if not os.path.exists(_LIB_PATH):
-            build()
-        _lib = C.CDLL(_LIB_PATH)
-        _lib.ltpo_smallest_root.restype = C.c_double
-        _lib.ltpo_plan_batch.restype = C.c_long
-        _lib.ltpo_poly_log_end.restype = C.c_long
+        _lib = _load(_LIB_PATH)
+        assert _lib.ltpo_exact_pow() == 0
     return _lib
 
 
@@ -95,12 +113,14 @@ def smallest_root(poly):
 class Oracle:
     """Mirror of the reference class (ctor args as long_term_planner.h:118-131)."""
 
-    def __init__(self, dof, t_sample, q_min, q_max, v_max, a_max, j_max, semantics="cpp"):
+    def __init__(self, dof, t_sample, q_min, q_max, v_max, a_max, j_max, semantics="cpp", exact_pow=False):
         """semantics: "cpp" = src/long_term_planner.cc (the parity reference), "matlab" = LTPlanner.m where it diverges
         (LTPlanner.m has no position limits: q_min / q_max are ignored then)."""
         self.dof = int(dof)
         self.t_sample = float(t_sample)
         self.semantics = {"cpp": 0, "matlab": 1}[semantics]
+        self.exact_pow = bool(exact_pow)      # diagnostic twin (lib(exact_pow=True)); never the parity reference
+        self._lib = lib(self.exact_pow)
         self.set_limits(q_min, q_max, v_max, a_max, j_max)
 
     def set_limits(self, q_min, q_max, v_max, a_max, j_max):
@@ -122,30 +142,30 @@ class Oracle:
         return C.byref(self._p)
 
     def check_inputs(self, q_0, v_0, a_0):
-        return bool(lib().ltpo_check_inputs(self._ref, _d(_arr(q_0)), _d(_arr(v_0)), _d(_arr(a_0))))
+        return bool(self._lib.ltpo_check_inputs(self._ref, _d(_arr(q_0)), _d(_arr(v_0)), _d(_arr(a_0))))
 
     def opt_braking(self, joint, v_0, a_0):
         q = C.c_double(); d = C.c_double(); t = np.zeros(7)
-        lib().ltpo_opt_braking(self._ref, C.c_int(joint), C.c_double(v_0), C.c_double(a_0), C.byref(q), _d(t), C.byref(d))
+        self._lib.ltpo_opt_braking(self._ref, C.c_int(joint), C.c_double(v_0), C.c_double(a_0), C.byref(q), _d(t), C.byref(d))
         return q.value, t, d.value
 
     def opt_switch_times(self, joint, q_goal, q_0, v_0, a_0, v_drive, t_init=None):
         t = np.zeros(7) if t_init is None else np.array(t_init, dtype=np.float64)
         d = C.c_double(); m = C.c_char()
-        ok = lib().ltpo_opt_switch_times(self._ref, C.c_int(joint), C.c_double(q_goal), C.c_double(q_0), C.c_double(v_0),
+        ok = self._lib.ltpo_opt_switch_times(self._ref, C.c_int(joint), C.c_double(q_goal), C.c_double(q_0), C.c_double(v_0),
                                          C.c_double(a_0), C.c_double(v_drive), _d(t), C.byref(d), C.byref(m))
         return bool(ok), t, d.value, ord(m.value)
 
     def time_scaling(self, joint, q_goal, q_0, v_0, a_0, dir_, t_required):
         t = np.zeros(7); vd = C.c_double(); m = C.c_char(); case = C.c_int()
-        ok = lib().ltpo_time_scaling_ex(self._ref, C.c_int(joint), C.c_double(q_goal), C.c_double(q_0), C.c_double(v_0),
+        ok = self._lib.ltpo_time_scaling_ex(self._ref, C.c_int(joint), C.c_double(q_goal), C.c_double(q_0), C.c_double(v_0),
                                         C.c_double(a_0), C.c_double(dir_), C.c_double(t_required), _d(t), C.byref(vd),
                                         C.byref(m), C.byref(case))
         return bool(ok), t, vd.value, ord(m.value), case.value
 
     def traj_len(self, t):
         t = np.ascontiguousarray(np.asarray(t, dtype=np.float64).reshape(self.dof, 7))
-        return int(lib().ltpo_traj_len(self._ref, _d(t)))
+        return int(self._lib.ltpo_traj_len(self._ref, _d(t)))
 
     def get_trajectory(self, t, dir_, mod, q_0, v_0, a_0, v_drive):
         """Returns (length, q, v, a, j) with arrays [dof][length]."""
@@ -155,7 +175,7 @@ class Oracle:
         out = [np.zeros((D, max(n, 0))) for _ in range(4)]
         modb = np.ascontiguousarray(np.asarray(mod, dtype=np.int8).reshape(D))
         if n > 0:
-            lib().ltpo_get_trajectory(self._ref, _d(t), _d(_arr(dir_)), modb.ctypes.data_as(_cp), _d(_arr(q_0)), _d(_arr(v_0)),
+            self._lib.ltpo_get_trajectory(self._ref, _d(t), _d(_arr(dir_)), modb.ctypes.data_as(_cp), _d(_arr(q_0)), _d(_arr(v_0)),
                                       _d(_arr(a_0)), _d(_arr(v_drive)), C.c_int(n), _d(out[0]), _d(out[1]), _d(out[2]), _d(out[3]))
         return (n, *out)
 
@@ -179,7 +199,7 @@ class Oracle:
 
         def g(k, cast=_dp):
             return r[k].ctypes.data_as(cast) if want_records else C.cast(None, cast)
-        n_ok = lib().ltpo_plan_batch(self._ref, C.c_long(first), C.c_long(count), _d(qg), _d(q0), _d(v0), _d(a0),
+        n_ok = self._lib.ltpo_plan_batch(self._ref, C.c_long(first), C.c_long(count), _d(qg), _d(q0), _d(v0), _d(a0),
                                      C.c_int(2 if sample == "flat" else (1 if sample else 0)), g("t_opt"), g("t_scaled"), g("dir"), g("mod", _cp),
                                      g("v_drive"), g("t_required"), g("slowest", _ip), g("traj_len", _ip),
                                      g("status", _ip), g("checksum"))

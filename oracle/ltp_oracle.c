@@ -133,6 +133,48 @@ double ltpo_smallest_root(const double *p, int degree)
     return smallest_positive_real_root_f64(re, im, degree);
 }
 
+/* ---- test-only build switch -DLTPO_EXACT_POW (oracle/Makefile: libltp_oracle_exactpow.so) ----
+ * The reference calls libm's pow(x, 3 | 4 | 6) and pow(x, 1.0 / 2) (cc:125-331, 378-621). glibc's pow is within
+ * ~0.52 ulp but not correctly rounded, and dispatches between an FMA and a non-FMA variant by CPU, so the
+ * reference's own last bits differ between hosts. The HIP product forms x^3, x^4, x^6 as ONE rounding of the
+ * exact product (csrc/ltp_math.hpp: pw3 / pw4 / pw6, error-free products through fma) and pow(x, 0.5) as sqrt.
+ * This switch restates exactly that rule in C, so that a comparison "device vs this build" isolates libm's pow
+ * as the only source of last-bit differences between the device and the default (libm) oracle
+ * (tools/pow_experiment.py, tests/test_gpu_parity.py). The DEFAULT build stays on libm's pow: it is the
+ * parity reference. gcc already folds pow(x, 2) to x * x in both builds (no -ffast-math needed). */
+#ifdef LTPO_EXACT_POW
+static void ltpo_two_prod(double a, double b, double *hi, double *lo) { *hi = a * b; *lo = fma(a, b, -*hi); }
+static double ltpo_pow_exact(double x, double y)
+{
+    double h, l, p, e, e3;
+    if (y == 2.0) return x * x;
+    if (y == 0.5) return sqrt(x);
+    if (y == 3.0) {                                   /* csrc/ltp_math.hpp: pw3 */
+        ltpo_two_prod(x, x, &h, &l);
+        ltpo_two_prod(h, x, &p, &e);
+        return isfinite(p) ? p + (e + l * x) : h * x;
+    }
+    if (y == 4.0) {                                   /* pw4 */
+        ltpo_two_prod(x, x, &h, &l);
+        ltpo_two_prod(h, h, &p, &e);
+        return isfinite(p) ? p + (e + 2.0 * (h * l)) : h * h;
+    }
+    if (y == 6.0) {                                   /* pw6 */
+        double p3;
+        ltpo_two_prod(x, x, &h, &l);
+        ltpo_two_prod(h, x, &p3, &e3);
+        e3 = e3 + l * x;
+        ltpo_two_prod(p3, p3, &p, &e);
+        return isfinite(p) ? p + (e + 2.0 * (p3 * e3)) : (h * x) * (h * x);
+    }
+    return (pow)(x, y);
+}
+#define pow(x, y) ltpo_pow_exact((x), (y))
+int ltpo_exact_pow(void) { return 1; }
+#else
+int ltpo_exact_pow(void) { return 0; }
+#endif
+
 /* optional polynomial log (tests dump the polynomials a run produced) */
 static double *g_poly_log = NULL;   /* rows of [degree, p0..p6, root] = 9 doubles */
 static long g_poly_cap = 0, g_poly_n = 0;
@@ -232,6 +274,15 @@ int ltpo_check_inputs(const ltpo_planner *P, const double *q_0, const double *v_
     return 1;
 }
 
+/* diagnostic (tools/pow_experiment.py): which branches the LAST ltpo_opt_switch_times call of this thread went through.
+ * 1 optBraking without phase 2 (cc:685-689), 2 modified profile (cc:119-124), 4 phase 2 absent (cc:130-142),
+ * 8 phase 6 absent (cc:150-162), 16 no cruise phase: root + pow(root, 1/2) (cc:192-243), 32 quartic site A (cc:245-270),
+ * 64 acceleration limit after site A (cc:276-304), 128 quartic site B (cc:306-333), 256 |q_diff| < eps early exit */
+static _Thread_local int ltpo_sites = 0;
+static _Thread_local double ltpo_site_root = 0.0, ltpo_site_scale = 0.0;   /* site 16: the radicand and its largest term */
+int ltpo_last_sites(void) { return ltpo_sites; }
+void ltpo_last_site_root(double *out2) { out2[0] = ltpo_site_root; out2[1] = ltpo_site_scale; }
+
 /* cc:650-701. Writes only t_rel[0..2]. */
 int ltpo_opt_braking(const ltpo_planner *P, int joint, double v_0, double a_0, double *q, double *t_rel, double *dir)
 {
@@ -250,6 +301,7 @@ int ltpo_opt_braking(const ltpo_planner *P, int joint, double v_0, double a_0, d
     t_rel[2] = am / jm;
     t_rel[1] = (-v_0 - 1.0 / 2.0 * t_rel[0] * a_0) / am - 1.0 / 2.0 * (t_rel[0] + t_rel[2]);
     if (t_rel[1] < -P->t_sample) {
+        ltpo_sites |= 1;
         t_rel[0] = -a_0 / jm + sem_sqrt(P, P2(a_0) / (2 * P2(jm)) - v_0 / jm);   /* LTPlanner.m:476: complex for a negative argument */
         t_rel[2] = t_rel[0] + a_0 / jm;
         t_rel[1] = 0;
@@ -294,9 +346,11 @@ int ltpo_opt_switch_times(const ltpo_planner *P, int joint, double q_goal, doubl
         }
     }
 
+    ltpo_sites = 0;
     ltpo_opt_braking(P, joint, v_0, a_0, &q_stop, r, dir);
     q_diff = q_goal - (q_0 + q_stop);
     if (fabs(q_diff) < eps) {
+        ltpo_sites |= 256;
         cumsum7(r, t);
         return 1;
     }
@@ -307,6 +361,7 @@ int ltpo_opt_switch_times(const ltpo_planner *P, int joint, double q_goal, doubl
     }
     if (v_0 + 0.5 * a_0 * fabs(a_0) / jm > v_drive) {
         *mod = 1;
+        ltpo_sites |= 2;
         ltpo_opt_braking(P, joint, v_0 - v_drive, a_0, &q_brake, r, &emp);
     } else {
         r[0] = (am - a_0) / jm;
@@ -314,6 +369,7 @@ int ltpo_opt_switch_times(const ltpo_planner *P, int joint, double q_goal, doubl
         r[1] = (v_drive - v_0 - 0.5 * r[0] * a_0) / am - 0.5 * (r[0] + r[2]);
         if (r[1] < -eps) {
             double root = jm * (v_drive - v_0) + 0.5 * P2(a_0);
+            ltpo_sites |= 4;
             if (root > 0) {
                 r[2] = sqrt(root) / jm;
                 r[0] = r[2] - a_0 / jm;
@@ -329,6 +385,7 @@ int ltpo_opt_switch_times(const ltpo_planner *P, int joint, double q_goal, doubl
     r[5] = v_drive / am - 1.0 / 2.0 * (r[4] + r[6]);
     if (r[5] < -eps) {
         double root = v_drive / jm;
+        ltpo_sites |= 8;
         if (root > 0) {
             r[4] = sqrt(root);
             r[6] = r[4];
@@ -387,6 +444,9 @@ int ltpo_opt_switch_times(const ltpo_planner *P, int joint, double q_goal, doubl
                4 * am * v_0 * r[0] +
                4 * *dir * (q_goal - q_0) * am +
                2.0 * P2(v_0);
+        ltpo_sites |= 16;
+        ltpo_site_root = root;
+        ltpo_site_scale = fabs(4 * *dir * (q_goal - q_0) * am) + fabs((P2(jm) * P4(r[0])) / 2) + fabs(2.0 * P2(am) * P2(r[2]));
         if (root > 0) {
             r[5] = -(4 * am * r[4] -
                      2.0 * pow(root, (1.0 / 2)) +
@@ -407,6 +467,7 @@ int ltpo_opt_switch_times(const ltpo_planner *P, int joint, double q_goal, doubl
 
         if (r[5] < -eps || r[1] < -eps) {
             double c[5];
+            ltpo_sites |= 32;
             c[0] = 12;
             c[1] = 0;
             c[2] = -24 * P2(a_0) + 48 * jm * v_0;
@@ -426,6 +487,7 @@ int ltpo_opt_switch_times(const ltpo_planner *P, int joint, double q_goal, doubl
             r[5] = 0;
 
             if (a_0 + r[0] * jm > am) {
+                ltpo_sites |= 64;
                 r[0] = (am - a_0) / jm;
                 r[6] = 1.0 / jm * (am / 2 + sem_sqrt(P,
                            9 * P2(am) + 6 * sem_sqrt(P,
@@ -451,6 +513,7 @@ int ltpo_opt_switch_times(const ltpo_planner *P, int joint, double q_goal, doubl
             }
 
             if (r[6] * jm > am) {
+                ltpo_sites |= 128;
                 r[6] = am / jm;
                 c[0] = 12;
                 c[1] = -24 * am;

@@ -7,15 +7,19 @@
 //   4. the envelope consumer equals min / max over windows of the sampled rows;
 //   6. the table-pass calls (envelopes, capped rows) inside a capture: refused on a handle without a table workspace (nothing
 //      may be allocated while capturing), captured and replayed in pieces after ltp_reserve_tables;
-//   7. the resident single-call service (ltp_set_service_idle_us) returns the bits of the launched path, and ends when it should.
+//   7. several host threads on ONE handle (plans, one-joint calls, checkInputs, ltp_set_limits): own results, no deadlock.
 // Built with g++ against the HIP runtime API only; prints "0 failures" on success.
 #include <hip/hip_runtime_api.h>
 
+#include <unistd.h>
+
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <ctime>
+#include <thread>
 #include <vector>
 
 #include "ltp_hip.h"
@@ -308,8 +312,9 @@ int main()
         }
     }
 
-    // ---- 7. resident single-call service (ltp_set_service_idle_us): same bits as the launched path, survives its own idle
-    //         exit, a device-wide synchronisation, a limits change and ltp_destroy while resident ----
+    // ---- 7. one handle, several host threads: single planTrajectory-sized calls, the one-joint entry points, checkInputs and
+    //         ltp_set_limits (with unchanged limits) at the same time. The library takes its two locks in one order only
+    //         (host_mu before mu); every caller must get its own, unchanged result and nothing may deadlock. ----
     {
         struct Result {
             std::vector<double> t_o, t_s, d, vd, rows;
@@ -318,16 +323,12 @@ int main()
             int slow = 0, ln = 0, stt = 0;
             unsigned long long off[2] = {0, 0};
         };
-        auto call = [&](long long pq, bool with_rows, Result& r, float* us) {
+        auto call = [&](long long pq, bool with_rows, Result& r) {
             r.t_o.assign(dof * 7, -1.0); r.t_s.assign(dof * 7, -1.0); r.d.assign(dof, -1.0); r.vd.assign(dof, -1.0); r.md.assign(dof, 9);
             ltp_records hr{r.t_o.data(), r.t_s.data(), r.d.data(), r.vd.data(), r.md.data(), &r.treq, &r.slow, &r.ln, &r.stt};
             double* packed = nullptr;
-            timespec t0, t1;
-            clock_gettime(CLOCK_MONOTONIC, &t0);
             const int rc3 = ltp_plan_batch_host(h, 1, hq[0].data() + pq * dof, hq[1].data() + pq * dof, hq[2].data() + pq * dof,
                                                 hq[3].data() + pq * dof, &hr, r.off, with_rows ? &packed : nullptr);
-            clock_gettime(CLOCK_MONOTONIC, &t1);
-            if (us) *us = (t1.tv_sec - t0.tv_sec) * 1e6f + (t1.tv_nsec - t0.tv_nsec) * 1e-3f;
             r.rows.clear();
             if (packed) { r.rows.assign(packed, packed + r.off[1]); ltp_free_host(packed); }
             return rc3;
@@ -337,108 +338,53 @@ int main()
                    a.stt == b.stt && std::memcmp(&a.treq, &b.treq, 8) == 0 && a.off[1] == b.off[1] && a.rows.size() == b.rows.size() &&
                    (a.rows.empty() || std::memcmp(a.rows.data(), b.rows.data(), a.rows.size() * 8) == 0);
         };
-        const int cases = 48;
+        const int cases = 24;
         std::vector<Result> want(2 * cases);
-        for (int i = 0; i < 2 * cases; ++i) CHECK(call((i / 2 * 131) % n, i & 1, want[i], nullptr) == LTP_OK);
-        CHECK(ltp_get_service_idle_us(h) == 0);
-        CHECK(ltp_set_service_idle_us(h, -1) == LTP_ERR_INVALID_ARGUMENT);
-        CHECK(ltp_set_service_idle_us(h, 3000) == LTP_OK);
-        CHECK(ltp_get_service_idle_us(h) == 3000);
-        Result got;
-        int differing = 0;
-        for (int i = 0; i < 2 * cases; ++i) {
-            CHECK(call((i / 2 * 131) % n, i & 1, got, nullptr) == LTP_OK);
-            differing += same(got, want[i]) ? 0 : 1;
-        }
-        CHECK(differing == 0);
-        // the instance leaves after 3 ms without a call; the next call starts a new one
-        timespec nap{0, 12 * 1000 * 1000};
-        nanosleep(&nap, nullptr);
-        CHECK(call(0, true, got, nullptr) == LTP_OK);
-        CHECK(same(got, want[1]));
-        // a device-wide synchronisation elsewhere in the process returns once the instance has left (<= idle time)
-        {
-            timespec t0, t1;
-            clock_gettime(CLOCK_MONOTONIC, &t0);
-            HIP(hipDeviceSynchronize());
-            clock_gettime(CLOCK_MONOTONIC, &t1);
-            const double ms = (t1.tv_sec - t0.tv_sec) * 1e3 + (t1.tv_nsec - t0.tv_nsec) * 1e-6;
-            std::printf("hipDeviceSynchronize with a resident service (idle 3 ms): %.2f ms\n", ms);
-            CHECK(ms < 200.0);
-        }
-        CHECK(call(0, false, got, nullptr) == LTP_OK);
-        CHECK(same(got, want[0]));
-        // the batched device path and the service share the handle
-        {
-            CHECK(ltp_plan_switch_times_batch(h, 64, &q, &rec, offsets, s) == LTP_OK);
-            HIP(hipStreamSynchronize(s));
-            CHECK(call(131 % n, true, got, nullptr) == LTP_OK);
-            CHECK(same(got, want[3]));
-        }
-        // latency, back to back
-        for (int with_rows = 0; with_rows < 2; ++with_rows) {
-            float best = 1e30f, sum = 0;
-            std::vector<float> all;
-            const int reps = 400;
-            for (int i = 0; i < reps + 20; ++i) {
-                float us = 0;
-                CHECK(call((i * 37) % n, with_rows, got, &us) == LTP_OK);
-                if (i >= 20) { best = us < best ? us : best; sum += us; all.push_back(us); }
+        for (int i = 0; i < 2 * cases; ++i) CHECK(call((i / 2 * 131) % n, i & 1, want[i]) == LTP_OK);
+        double bq = 0, bt[7] = {0, 0, 0, 0, 0, 0, 0}, bd = 0;
+        CHECK(ltp_opt_braking_host(h, 2, 0.7, -1.5, &bq, bt, &bd) == LTP_OK);
+        std::atomic<int> bad{0}, finished{0};
+        auto planner_thread = [&](int tid) {
+            Result got;
+            for (int rep = 0; rep < 60; ++rep) {
+                const int i = (tid * 7 + rep) % (2 * cases);
+                if (call((i / 2 * 131) % n, i & 1, got) != LTP_OK || !same(got, want[i])) ++bad;
             }
-            std::sort(all.begin(), all.end());
-            std::printf("one 7-DoF call through the resident service, %s: mean %.1f us, median %.1f us, p99 %.1f us, best %.1f us\n",
-                        with_rows ? "switching times + sampled trajectory" : "switching times only", sum / reps, all[all.size() / 2],
-                        all[all.size() * 99 / 100], best);
-            unsigned long long tk[7] = {0, 0, 0, 0, 0, 0, 0};
-            CHECK(ltp_debug_service_ticks(h, tk) == LTP_OK);
-            std::printf("    on the device, last call: command fetched after %.2f us, done after %.2f us (body start %.2f, stage 1 %.2f, scaling %.2f, rows %.2f, records %.2f)\n",
-                        tk[0] * 0.01, tk[1] * 0.01, tk[2] * 0.01, tk[3] * 0.01, tk[4] * 0.01, tk[5] * 0.01, tk[6] * 0.01);
-        }
-        // the same query again and again: the same code path every time
-        {
-            float sum = 0;
-            for (int i = 0; i < 220; ++i) {
-                float us = 0;
-                CHECK(call(37, false, got, &us) == LTP_OK);
-                if (i >= 20) sum += us;
+            ++finished;
+        };
+        auto lane_thread = [&]() {
+            for (int rep = 0; rep < 120; ++rep) {
+                double q2 = 0, t2[7] = {0, 0, 0, 0, 0, 0, 0}, d2 = 0;
+                int ok = 0;
+                if (ltp_opt_braking_host(h, 2, 0.7, -1.5, &q2, t2, &d2) != LTP_OK || std::memcmp(&q2, &bq, 8) != 0 ||
+                    std::memcmp(t2, bt, sizeof(bt)) != 0 || d2 != bd) ++bad;
+                if (ltp_check_inputs_host(h, hq[1].data(), hq[2].data(), hq[3].data(), &ok) != LTP_OK || ok != 1) ++bad;
             }
-            unsigned long long tk[7] = {0, 0, 0, 0, 0, 0, 0};
-            CHECK(ltp_debug_service_ticks(h, tk) == LTP_OK);
-            std::printf("the same query 200 times, switching times only: mean %.1f us; device: done after %.2f us (body start %.2f, stage 1 %.2f, scaling %.2f, rows %.2f, records %.2f)\n",
-                        sum / 200, tk[1] * 0.01, tk[2] * 0.01, tk[3] * 0.01, tk[4] * 0.01, tk[5] * 0.01, tk[6] * 0.01);
+            ++finished;
+        };
+        auto limits_thread = [&]() {
+            for (int rep = 0; rep < 40; ++rep)
+                if (ltp_set_limits(h, dof, q_min, q_max, v_max, a_max, j_max) != LTP_OK) ++bad;
+            ++finished;
+        };
+        std::vector<std::thread> th;
+        th.emplace_back(planner_thread, 0);
+        th.emplace_back(planner_thread, 1);
+        th.emplace_back(lane_thread);
+        th.emplace_back(limits_thread);
+        // a deadlock must fail the test, not hang the box: watch the threads for 60 s, then give up on them
+        for (int waited = 0; finished.load() < 4 && waited < 600; ++waited) {
+            timespec nap{0, 100 * 1000 * 1000};
+            nanosleep(&nap, nullptr);
         }
-        // a 1 kHz caller (the reference's use: one plan per control period)
-        {
-            float sum = 0;
-            const int reps = 50;
-            timespec period{0, 1000 * 1000};
-            for (int i = 0; i < reps; ++i) {
-                nanosleep(&period, nullptr);
-                float us = 0;
-                CHECK(call((i * 37) % n, true, got, &us) == LTP_OK);
-                sum += us;
-            }
-            std::printf("one 7-DoF call per millisecond through the resident service (idle 3 ms): mean %.1f us\n", sum / reps);
+        if (finished.load() < 4) {
+            std::printf("FAILED: host threads on one handle did not finish within 60 s (deadlock)\n1 failures\n");
+            std::fflush(stdout);
+            _exit(1);
         }
-        // new limits while resident: the instance is stopped, the next call starts one with the new limits
-        {
-            double v_half[dof];
-            for (int j = 0; j < dof; ++j) v_half[j] = 0.5 * v_max[j];
-            Result slow_lim, slow_lim_launched;
-            CHECK(ltp_set_limits(h, dof, q_min, q_max, v_half, a_max, j_max) == LTP_OK);
-            CHECK(call(0, true, slow_lim, nullptr) == LTP_OK);
-            CHECK(!same(slow_lim, want[1]));
-            CHECK(ltp_set_service_idle_us(h, 0) == LTP_OK);
-            CHECK(call(0, true, slow_lim_launched, nullptr) == LTP_OK);
-            CHECK(same(slow_lim, slow_lim_launched));
-            CHECK(ltp_set_limits(h, dof, q_min, q_max, v_max, a_max, j_max) == LTP_OK);
-        }
-        CHECK(ltp_set_service_idle_us(h, 0) == LTP_OK);
-        CHECK(call(0, true, got, nullptr) == LTP_OK);
-        CHECK(same(got, want[1]));
-        CHECK(ltp_set_service_idle_us(h, 500000) == LTP_OK);     // resident for half a second: ltp_destroy below must end it
-        CHECK(call(0, true, got, nullptr) == LTP_OK);
-        CHECK(same(got, want[1]));
+        for (auto& t : th) t.join();
+        CHECK(bad.load() == 0);
+        std::printf("4 host threads on one handle (plans, one-joint calls, checkInputs, set_limits): %d wrong results\n", bad.load());
     }
 
     {
@@ -447,7 +393,7 @@ int main()
         ltp_destroy(h);
         clock_gettime(CLOCK_MONOTONIC, &t1);
         const double ms = (t1.tv_sec - t0.tv_sec) * 1e3 + (t1.tv_nsec - t0.tv_nsec) * 1e-6;
-        std::printf("ltp_destroy with a resident service: %.2f ms\n", ms);
+        std::printf("ltp_destroy: %.2f ms\n", ms);
         CHECK(ms < 100.0);
     }
     std::printf("%d failures\n", g_failures);
