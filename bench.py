@@ -58,9 +58,9 @@ def cpu_baseline(dof, lim, t_sample, seed, sample_switch_only):
     import oracle
     from longtermplanner_amd import generate_queries
     affinity = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    # threads actually used: the cores this process may run on, at most 16 (a one-GPU box's CPU share on the pool; the
-    # node's other cores belong to its other GPUs). Both counts are reported.
-    cores = max(1, min(affinity, 16))
+    # threads actually used: one GPU's share of the node's cores — online cores / 8 GPUs per node = 32 on the pool's 256-core hosts
+    # (the node's other cores belong to its other GPUs) — and never more than this process may run on. All counts are reported.
+    cores = max(1, min(affinity, max(1, (os.cpu_count() or 8) // 8), 32))
     per_thread = 49152 if not sample_switch_only else 1000000
     n = per_thread * cores
     qg, q0, v0, a0 = generate_queries(n, lim, seed=seed)
@@ -92,7 +92,8 @@ def cpu_baseline(dof, lim, t_sample, seed, sample_switch_only):
         dtf1 = time.perf_counter() - t3
         flat = {"value": cores * (per_thread // 2) / dtf, "one_thread": n1 / dtf1, "unit": "plans/s",
                 "sample": f"{per_thread // 2} queries per thread on {cores} threads; {n1} on one thread"}
-    return {"value": n / dt, "unit": "plans/s", "cores": cores, "host_cores_affinity": affinity, "host_cores_online": os.cpu_count(), "kind": "port",
+    return {"value": n / dt, "unit": "plans/s", "cores": cores, "cores_rule": "min(affinity, online cores / 8 GPUs per node, 32)",
+            "host_cores_affinity": affinity, "host_cores_online": os.cpu_count(), "kind": "port",
             "one_thread": {"value": n1 / dt1, "unit": "plans/s", "sample": f"first {n1} queries, {dt1:.1f} s"},
             "flat_preallocated": flat,
             "sample": f"first {n} queries of the same synthetic batch, {per_thread} per thread, "
@@ -368,7 +369,8 @@ def run_workload(wl, ctx):
         if world > 1:
             dist.all_reduce(c, op=dist.ReduceOp.SUM)
         checksum = int(c.item()) % M
-    counts = torch.tensor([float((status == 0).sum()), float(traj_len.sum()), float(alg_bytes_per_step)], dtype=torch.float64, device=cdev)
+    # (LTP_STATUS_MATLAB_COMPLEX = 256 is informational: the plan is delivered, planTrajectory returns true)
+    counts = torch.tensor([float(((status & ~256) == 0).sum()), float(traj_len.sum()), float(alg_bytes_per_step)], dtype=torch.float64, device=cdev)
     if world > 1:
         dist.all_reduce(counts, op=dist.ReduceOp.SUM)
     ok_total, len_total, bytes_total = (float(x) for x in counts.tolist())
@@ -427,6 +429,7 @@ def run_workload(wl, ctx):
             "batch_per_gpu": n if not wl.global_batch else None, "global_batch": total_queries, "dof": dof, "t_sample": wl.t_sample,
             "limits": wl.limits, "input_layout": wl.layout, "table_pass": wl.table_pass, "batches_in_flight": wl.in_flight, "semantics": wl.semantics,
             "sharding": "contiguous query ranges per rank, no data-path collective" + (", RCCL all_gather of t_required" if gather_buf else ""),
+            "backend": ctx["backend"], "rank_devices": ctx["rank_devices"],
             "plans_ok_frac": round(ok_total / total_queries, 5),
             "plans_ok_is": ("planTrajectory's bool" if (wl.end_limit or not (wl.switch_only or rec_direct)) else
                             "the pre-sampling verdict (cc:14-39); the end-limit check cc:59-61 was not run"),
@@ -506,7 +509,7 @@ def run_one_process(args):
     ok = lens = 0
     M, acc = 1 << 48, 0
     for b in batches:
-        ok += int((b.status == 0).sum().item())
+        ok += int(((b.status & ~256) == 0).sum().item())
         lens += int(b.traj_len.long().sum().item())
         if args.checksum:
             for x in (b.t_opt, b.t_scaled, b.dir, b.v_drive, b.t_required):
@@ -519,14 +522,15 @@ def run_one_process(args):
             if env_spec else "switching times only (ltp_plan_switch_times_multi" + (" + end-limit check" if args.end_limit else "; status = pre-sampling verdict") + ")")
     out = {
         "metric": "7-DoF trajectory plans/sec (batch 1M)" if dof == 7 else f"{dof}-DoF trajectory plans/sec",
-        "value": round(total * args.steps * replans / elapsed, 1), "unit": "plans/s", "n_gpus": k, "steps": args.steps, "warmup": args.warmup,
+        "value": round(total * args.steps * replans / elapsed, 1), "unit": "plans/s", "n_gpus": len(set(devices)), "n_shards": k,
+        "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
         "scaling": "strong" if args.global_batch else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {
             "workload": f"{total} x {dof}-DoF queries per step in {k} device-resident shard(s) ({counts[0]} in shard 0), limits '{args.limits}', "
                         f"Tsample {args.t_sample} s, {what}, no rows",
             "batch_per_gpu": None if args.global_batch else args.batch, "global_batch": total, "dof": dof, "t_sample": args.t_sample,
-            "limits": args.limits, "input_layout": args.layout, "devices": devices,
+            "limits": args.limits, "input_layout": args.layout, "devices": devices, "backend": "none (one process, no torch.distributed)",
             "sharding": "one process: one handle, stream and host thread per device, contiguous query ranges, device-resident shards, no collective",
             "plans_ok_frac": round(ok / total, 5),
             "plans_ok_is": "planTrajectory's bool" if (args.end_limit or env_spec) else "the pre-sampling verdict (cc:14-39); the end-limit check cc:59-61 was not run",
@@ -602,7 +606,15 @@ def main():
             tile_state["gib"] = gib
         return tile_state["t"], tile_state["gib"]
 
-    ctx = {"world": world, "rank": rank, "dev": dev, "cdev": cdev, "local_rank": local_rank, "tile": get_tile}
+    # which HIP device every rank drives, and what carried the barrier / reductions: stated in every line
+    rank_devices = [local_rank]
+    if world > 1:
+        gathered = [torch.zeros(1, dtype=torch.int64, device=cdev) for _ in range(world)]
+        dist.all_gather(gathered, torch.tensor([local_rank], dtype=torch.int64, device=cdev))
+        rank_devices = [int(x.item()) for x in gathered]
+    backend = "none (single rank)" if world == 1 else ("nccl (RCCL over xGMI)" if args.backend == "nccl" else "gloo (CPU tensors: rehearsal)")
+    ctx = {"world": world, "rank": rank, "dev": dev, "cdev": cdev, "local_rank": local_rank, "tile": get_tile, "backend": backend,
+           "rank_devices": rank_devices}
     primary = Workload(args)
     out = run_workload(primary, ctx)
 
@@ -652,10 +664,13 @@ def main():
     if rank == 0:
         if secondary:
             out["secondary"] = secondary
-        if world == 1 and not args.no_cpu_baseline:
+        if not args.no_cpu_baseline:
+            # rank 0 only, outside every timed region; with N > 1 the other ranks wait in the final barrier meanwhile
             from longtermplanner_amd import limit_set
             dof, lim = limit_set(args.limits)
             out["cpu_baseline"] = cpu_baseline(dof, lim, args.t_sample, args.seed, args.switch_only)
+            if world > 1:
+                out["cpu_baseline"]["measured_on"] = f"rank 0 of {world}, after the timed steps, while the other ranks wait in the final barrier"
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -66,7 +66,7 @@ struct BatchTrajectory {
   std::vector<int> slowest;         ///< [n]
   std::vector<int> length;          ///< [n] Trajectory::length, 0 if the plan failed before sampling
   std::vector<int> stored;          ///< [n] samples stored per row: length, or less when setMaxSamples() is in effect
-  std::vector<int> status;          ///< [n] LTP_STATUS_* bits; planTrajectory's bool is (status == 0)
+  std::vector<int> status;          ///< [n] LTP_STATUS_* bits; planTrajectory's bool is LongTermPlanner::planOk(status)
   std::vector<unsigned long long> offsets;  ///< [n+1] plan p occupies packed[offsets[p], offsets[p+1])
   std::vector<double> packed;       ///< per plan: [q,v,a,j][joint][ltp_row_stride(length)]
   /// pointer to sample 0 of array `arr` (0=q,1=v,2=a,3=j) of joint `joint` of plan `p`
@@ -183,13 +183,17 @@ class LongTermPlanner {
     }
     long long ok = 0;
     for (long long p = 0; p < n; ++p) {
-      ok += out.status[p] == 0;
+      ok += planOk(out.status[p]);
       out.stored[p] = ltp_stored_samples(h, out.length[p]);
     }
     return ok;
   }
 
  public:
+  /** @brief NEW: planTrajectory's bool for a batch status word: every bit but the informational LTP_STATUS_MATLAB_COMPLEX
+   *  (the plan is delivered) must be clear. planTrajectory, the batch counters and bench.py all use this rule. */
+  static inline bool planOk(int status) { return (status & ~LTP_STATUS_MATLAB_COMPLEX) == 0; }
+
   /** @brief Dummy planner (reference long_term_planner.h:103-105). */
   LongTermPlanner() : dof_(0), t_sample_(0.001) {}
 
@@ -291,7 +295,7 @@ class LongTermPlanner {
     const int rc = ltp_plan_envelope_host(h, n, q_goal, q_0, v_0, a_0, window, n_windows, &rec, env.empty() ? &dummy_d : env.data());
     if (rc != LTP_OK) raise(h, rc, "ltp_plan_envelope_host");
     long long ok = 0;
-    for (long long p = 0; p < n; ++p) ok += b.status[p] == 0;
+    for (long long p = 0; p < n; ++p) ok += planOk(b.status[p]);
     return ok;
   }
 
@@ -322,7 +326,7 @@ class LongTermPlanner {
                                                 env.empty() ? &dummy_d : env.data());
     if (rc != LTP_OK) raise(hs[0], rc, "ltp_plan_envelope_multi_host");
     long long ok = 0;
-    for (long long p = 0; p < n; ++p) ok += b.status[p] == 0;
+    for (long long p = 0; p < n; ++p) ok += planOk(b.status[p]);
     return ok;
   }
 

@@ -26,8 +26,8 @@
  *
  * Batch geometry. dof, t_sample, max_samples and sample_stride are captured when a batch is planned
  * (ltp_plan_switch_times_batch) and define its records, offsets and row strides. The calls that consume a planned
- * batch (ltp_sample_batch*, ltp_envelope_batch, ltp_replan_states*_batch, ltp_state_at_batch, ltp_end_limit_batch)
- * return LTP_ERR_INVALID_ARGUMENT if one of them was changed on the handle in between.
+ * batch (ltp_sample_batch*, ltp_envelope_batch, ltp_build_tables_batch, ltp_replan_states*_batch, ltp_state_at_batch,
+ * ltp_end_limit_batch) return LTP_ERR_INVALID_ARGUMENT if one of them was changed on the handle in between.
  */
 #ifndef LTP_HIP_H
 #define LTP_HIP_H
@@ -212,6 +212,20 @@ int ltp_sample_batch_f32(ltp_planner* p, long long first, long long count, const
  * sample_stride do not apply. env: device, count*dof*n_windows*2 doubles, 16-byte aligned. */
 int ltp_envelope_batch(ltp_planner* p, long long first, long long count, const ltp_queries* in, const ltp_records* rec,
                        int window, int n_windows, double* env, void* stream);
+
+/* SURVEY.md §8(f).2 consumer HOOK: the run tables of plans [first, first+count) of a planned batch in a CALLER buffer, for
+ * consumers of the caller's own (include/ltp_run_tables.hpp: the format, run_coef / run_eval, for_each_run / for_each_sample, and
+ * the block-cooperative LDS form — the same single-source device functions ltp_sample_batch and ltp_envelope_batch are built
+ * from). Per (plan, joint) 912 bytes: the <= 20 runs into which getTrajectory's jerk array (cc:735-807) and snap rules
+ * (cc:815-829) cut the trajectory, each with the state before it; every sample is a closed-form polynomial of its position in
+ * its run, with exactly the bits ltp_sample_batch would have stored. Lane index of (plan, joint) = (plan - first) * dof + joint.
+ * tables: device, 16-byte aligned, bytes >= ltp_run_tables_bytes(p, count) (whole tiles of 64 lanes; the lanes of the last tile
+ * beyond count * dof are not written). Plans with traj_len 0 get runs == 0. Applies the end-limit check (cc:59-61,
+ * LTP_STATUS_END_LIMIT) like the samplers do (C++ semantics). max_samples / sample_stride do not apply: tables always cover the
+ * whole trajectory. tests/cpp/example_consumer.hip is a complete user-side consumer. */
+unsigned long long ltp_run_tables_bytes(const ltp_planner* p, long long n_plans);
+int ltp_build_tables_batch(ltp_planner* p, long long first, long long count, const ltp_queries* in, const ltp_records* rec,
+                           unsigned long long* tables, unsigned long long bytes, void* stream);
 
 /* SURVEY.md §8(f).1 receding horizon (reference README.md:10-13): start states of the next plans = sample k of the
  * trajectories sampled into `tile` by ltp_sample_batch(first, count, ...). sample_index: device int[count] or NULL

@@ -80,6 +80,9 @@ _SIGNATURES = {
     "ltp_stored_samples": (C.c_int, [C.c_void_p, C.c_int]),
     "ltp_set_sample_stride": (C.c_int, [C.c_void_p, C.c_int]),
     "ltp_get_sample_stride": (C.c_int, [C.c_void_p]),
+    "ltp_run_tables_bytes": (C.c_ulonglong, [C.c_void_p, C.c_longlong]),
+    "ltp_build_tables_batch": (C.c_int, [C.c_void_p, C.c_longlong, C.c_longlong, C.POINTER(Queries), C.POINTER(Records), C.c_void_p,
+                                        C.c_ulonglong, C.c_void_p]),
     "ltp_envelope_batch": (C.c_int, [C.c_void_p, C.c_longlong, C.c_longlong, C.POINTER(Queries), C.POINTER(Records), C.c_int, C.c_int,
                                      C.c_void_p, C.c_void_p]),
     "ltp_debug_set_sample_blocks": (C.c_int, [C.c_void_p, C.c_int]),

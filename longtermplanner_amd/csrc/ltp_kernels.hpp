@@ -14,6 +14,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "../../include/ltp_run_tables.hpp"   // kMaxSegments, the packed run-table format (public)
 
 namespace ltp {
 
@@ -35,7 +36,6 @@ constexpr int kQueriesPerBlock = 64;   // one wave = 64 queries of one joint
 constexpr int kMaxJointSlots = 8;      // blockDim.y of k_switch_times
 constexpr int kRowAlign = 32;          // trajectory rows padded to 32 elements (256 B of doubles, 128 B of floats)
 constexpr int kSampleJointGroup = 8;   // joints handled by one k_sample block
-constexpr int kMaxSegments = 20;       // runs of constant jerk and mode per joint (1 + 19 cut points)
 constexpr int kSampleThreads = 256;
 #ifndef LTP_SAMPLE_BLOCKS_PER_CU
 #define LTP_SAMPLE_BLOCKS_PER_CU 5
@@ -78,6 +78,17 @@ struct Records {           // query-major outputs of stages 1-3
     int* status;           // [n]
 };
 
+// items per work-queue draw of the persistent samplers: 1 for whole trajectories; for capped rows as many as keep a draw at
+// >= ~256 KB of rows, at most 8
+inline int queue_draw_chunk(RowSpec rows, bool f32, int joints_per_item)
+{
+    if (rows.max_samples <= 0) return 1;
+    const long long item_bytes = 4ll * (f32 ? 4 : 8) * rows.max_samples * joints_per_item;
+    int k = 1;
+    while (k < 8 && item_bytes * (2 * k) <= 262144) k *= 2;
+    return k;
+}
+
 long long queue_segment(long long n, int dof);   // entries per queue shard; a batch needs 2 * 8 * this many u64
 void launch_switch_times(hipStream_t s, long long n, int dof, double t_sample, int goal_check, Limits lim, Queries in,
                          Records out, signed char* lane_flags, unsigned long long* queue_items, unsigned long long* counts,
@@ -104,6 +115,7 @@ void launch_sample_tab(hipStream_t s, long long first, long long count, long lon
                        unsigned long long* stamps = nullptr /* diagnostic: 8 per (plan, joint group) item */);
 int sample_tab_resident_blocks(int device, bool f32);
 int sample_resident_blocks(int device, int which /* 0 k_sample f64, 1 k_sample f32, 2 k_envelope */);
+int envelope_resident_blocks(int device);
 void launch_envelope(hipStream_t s, long long first, long long count, long long base_first, int dof, double t_sample, Limits lim, Queries in,
                      Records rec, int window, int n_windows, double* env, unsigned long long* next_item /* zeroed on the same stream */,
                      int resident_blocks, unsigned long long* probe = nullptr /* diagnostic: 16 stamps per item */,

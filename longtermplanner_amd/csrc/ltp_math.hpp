@@ -12,11 +12,10 @@
 //     which is what a (nearly) correctly rounded libm pow returns.
 #pragma once
 #include <hip/hip_runtime.h>
+#include "../../include/ltp_run_tables.hpp"   // LTP_DEV / LTP_HD, kSemCpp / kSemMatlab
 
 namespace ltp {
 
-#define LTP_DEV __device__ __forceinline__
-#define LTP_HD __host__ __device__ inline
 
 constexpr double kInf = __builtin_huge_val();
 

@@ -30,7 +30,7 @@ constexpr double kTol = 0.1;    // cc:370
 // (LTPlanner.m:294-297) applied to the imaginary part where it arose; where LTPlanner.m would raise an error (checkInputs,
 // an index past the filtered roots, a vector assigned to t_rel(1), NaN / Inf polynomial coefficients) the lane sets
 // kMatlabError and the query is rejected.
-constexpr int kSemCpp = 0, kSemMatlab = 1;
+// (kSemCpp = 0, kSemMatlab = 1: include/ltp_run_tables.hpp)
 constexpr int kMatlabComplex = 1, kMatlabError = 2;
 struct MatlabCtx {
     int flags = 0;        // kMatlabComplex | kMatlabError, accumulated over a lane's calls

@@ -1,0 +1,143 @@
+// ltp_runs.hpp — how a joint's trajectory is cut into runs: the ONE place that restates the jerk array of getTrajectory
+// (cc:735-807) and walks the runs of a joint from its switching-time record. Everything that needs rows or states goes through
+// jerk_at() / for_each_run() here and run_coef() / run_eval() of the public header include/ltp_run_tables.hpp — the cooperative
+// table build of k_sample (ltp_sampler_lds.hpp), k_build_tables, k_state_at, k_end_limit, k_plan_small — which is what keeps
+// their results bit-identical to each other.
+#pragma once
+#include "ltp_device.hpp"
+#include "../../include/ltp_run_tables.hpp"
+
+namespace ltp {
+
+// value of the reference's j_traj[joint][i] after the seven range fills (cc:759-766, last writer wins) and the up
+// to eight "+=" fractional corrections (cc:768-807), applied in the reference's order and association (cc:781 and
+// cc:798 add two / three terms to the element one after the other). s = sampled switch indices,
+// Jp = jerk of the seven phases, corr = the correction terms, all in LDS.
+template <int SEM = kSemCpp>
+LTP_DEV double jerk_at(const int* s, const double* Jp, const double* corr, int i)
+{
+    const int s0 = s[0], s1 = s[1], s2 = s[2], s3 = s[3], s4 = s[4], s5 = s[5], s6 = s[6];
+    double val = 0.0;
+    if (s0 > 0 && i < s0) val = Jp[0];
+    if (s1 - s0 > 0 && i >= s0 && i < s1) val = Jp[1];
+    if (s2 - s1 > 0 && i >= s1 && i < s2) val = Jp[2];
+    if (s3 - s2 > 0 && i >= s2 && i < s3) val = Jp[3];
+    if (s4 - s3 > 0 && i >= s3 && i < s4) val = Jp[4];
+    if (s5 - s4 > 0 && i >= s4 && i < s5) val = Jp[5];
+    if (s6 - s5 > 0 && i >= s5 && i < s6) val = Jp[6];
+    // LTPlanner.m:558-597 addresses the same elements in a 1-BASED array: every correction lands one sample earlier than in
+    // the C++, which kept the index expressions for its 0-based arrays
+    constexpr int o = SEM == kSemMatlab ? 1 : 0;
+    if (s2 >= s1) {
+        if (i == s0 + 1 - o) val = val + corr[0];
+        if (s1 > 0 && i == s1 - o) val = val + corr[1];
+        if (i == s2 + 1 - o) val = val + corr[2];
+    } else {
+        if (s1 > 0 && i == s1 - o) val = (val + corr[0]) + corr[3];             // cc:781: j + A + B, left to right
+    }
+    if (s3 > 0 && i == s3 - o) val = val + corr[4];
+    if (s2 - s0 > 0) {
+        if (i == s4 + 1 - o) val = val + corr[5];
+    } else {
+        if (s4 > 0 && i == s4 - o) val = ((val + corr[5]) + corr[0]) + corr[3]; // cc:798: j + A + B + C, left to right
+    }
+    if (s5 > 0 && i == s5 - o) val = val + corr[7];
+    if (i == s6 + 1 - o) val = val + corr[8];
+    return val;
+}
+
+// One lane walks the runs of one joint in order: the same cut points, jerk_at(), run_coef() and run_eval() as the
+// cooperative table build of k_sample, with everything in registers. A kernel whose work per plan is small
+// (k_state_at) uses this instead of LDS tables: no block-level build, no per-item latency, 64 independent
+// (plan, joint) pairs per wave. (For the envelope consumer the same form is slower than the cooperative kernel,
+// 26.8 vs 20.0 ms per 1 M plans: lanes of a wave sit in runs of different lengths.) visit(b, e, rc) is called for every run [b, e) with its
+// coefficients and returns true to stop; (a, v, q) hold the state before the run and are advanced to its last sample
+// (exactly the value the sampler stores there) after each call that returns false.
+// MATLAB's mod(x, y) for y > 0 as LTPlanner.m:531 uses it: x - floor(x./y).*y, except that "if y is not an integer and the
+// quotient x./y is within roundoff error of an integer, then n is that integer" (MATLAB documentation), i.e. the result is 0;
+// the round-off test is GNU Octave's published rule, as in the test suite's CPU twin. (cc:747 has no such rule.)
+LTP_DEV double matlab_mod(double x, double y)
+{
+    if (y == 0.0) return x;
+    const double q = x / y;
+    const double n = __builtin_rint(q);
+    if (__builtin_rint(y) != y && dabs((q - n) / n) < kDblEps) return 0.0;
+    return x - y * dfloor(q);
+}
+
+template <int SEM = kSemCpp, class Visit>
+LTP_DEV void for_each_run(const Limits& lim, const Records& rec, long long rj, int j, int len, double Ts, double& q, double& v,
+                          double& a, Visit&& visit, bool last_joint = true)
+{
+    int sw[7];                                                                        // sampled switch indices (cc:751-757)
+    double fr[7], frts[7];
+#pragma unroll
+    for (int x = 0; x < 7; ++x) {
+        const double tk = rec.t_scaled[rj * 7 + x];
+        fr[x] = SEM == kSemMatlab ? matlab_mod(tk, Ts) : tk - Ts * dfloor(tk / Ts);   // cc:747 / LTPlanner.m:531
+        frts[x] = fr[x] / Ts;
+        sw[x] = (x & 1) ? (int)dceil(tk / Ts) : (int)dfloor(tk / Ts);
+    }
+    const double dir = rec.dir[rj];
+    const double dj = dir * lim.j_max[j];
+    const double vsnap = rec.v_drive[rj] * dir;                                       // cc:823
+    const bool modp = (double)rec.mod[rj] == 1.0;
+    // phase jerks (cc:735-744) and the nine possible correction terms (cc:771-807), as in build_run_tables step (2)
+    const double J0 = dj * (modp ? -1.0 : 1.0), J2 = dj * (modp ? 1.0 : -1.0), J4 = dj * -1.0, J6 = dj * 1.0;
+    const double Jp[7] = {J0, dj * 0.0, J2, dj * 0.0, J4, dj * 0.0, J6};
+    const double d20 = (fr[2] - fr[0]) / Ts;
+    const double corr[9] = {frts[0] * J0, (1 - frts[1]) * J2, frts[2] * J2, d20 * J2, (1 - frts[3]) * J4,
+                            frts[4] * J4, 0.0, (1 - frts[5]) * J6, frts[6] * J6};
+    // Candidate cut points: every index where the jerk array or a snap rule (cc:815-829) can change — the same set as kCutBase /
+    // kCutDelta of the cooperative build: per sampled switch index s_g a few CONSECUTIVE integers s_g + lo_g .. s_g + hi_g. The next
+    // cut after b inside group g is therefore max(s_g + lo_g, b + 1) if that is <= s_g + hi_g: three operations per group instead of
+    // four per candidate. MATLAB semantics: the corrections sit one sample earlier, the constant-velocity samples are s2 .. s3-2
+    // and the tail starts at s6 (LTPlanner.m:616, 620).
+    constexpr int cut_lo[7] = {0, 0, 0, -1, 0, 0, 0}, cut_hi[7] = {2, 1, 2, 1, 2, 1, 2};
+    constexpr int mcut_lo[7] = {0, -1, 0, -1, -1, -1, 0}, mcut_hi[7] = {1, 0, 1, 0, 1, 0, 1};
+    int glo[7], ghi[7];
+#pragma unroll
+    for (int g = 0; g < 7; ++g) {
+        glo[g] = sw[g] + (SEM == kSemMatlab ? mcut_lo[g] : cut_lo[g]);
+        ghi[g] = sw[g] + (SEM == kSemMatlab ? mcut_hi[g] : cut_hi[g]);
+    }
+    const bool phase4 = sw[3] - sw[2] > 2;                                            // cc:813
+    int b = 0;
+    for (int run = 0; run < kMaxSegments && b < len; ++run) {
+        int e = len;                                                                  // next cut point after b
+#pragma unroll
+        for (int g = 0; g < 7; ++g) {
+            const int c = glo[g] > b ? glo[g] : b + 1;
+            e = (c <= ghi[g] && c < e) ? c : e;
+        }
+        int mode = 0;
+        if constexpr (SEM == kSemMatlab) {
+            if (b >= sw[6]) mode |= last_joint ? kModeTail : (kModeTail | kModeKeepA);
+            if (phase4 && b >= sw[2] && b < sw[3] - 1) mode |= kModeVSnap;
+        } else {
+            if (b > sw[6]) mode |= kModeTail;
+            if (phase4 && b >= sw[2] + 1 && b < sw[3] - 1) mode |= kModeVSnap;
+        }
+        const double J = jerk_at<SEM>(sw, Jp, corr, b);
+        const RunCoef rc = run_coef<SEM>(mode, J, a, v, q, vsnap, Ts);
+        if (visit(b, e, rc)) return;
+        if constexpr (SEM == kSemMatlab) {
+            // LTPlanner.m:604-624: a, v, q are cumulative sums over the arrays as they stand — behind the constant-velocity
+            // samples (and in the tail) v continues from the UN-snapped sum, the acceleration sum never stops
+            const double md = (double)(e - b);
+            const double v2 = 0.5 * (Ts * (Ts * J));
+            const double v_cum = __builtin_fma(__builtin_fma(v2, md, Ts * a + v2), md, v);   // run_eval's v of an ordinary run
+            const double a_cum = __builtin_fma(Ts * J, md, a);
+            double vv, aa, jj;
+            run_eval(rc.c, e - b, q, vv, aa, jj);
+            v = v_cum;
+            a = a_cum;
+        } else {
+            double jj;
+            run_eval(rc.c, e - b, q, v, a, jj);
+        }
+        b = e;
+    }
+}
+
+}  // namespace ltp

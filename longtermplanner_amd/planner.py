@@ -436,6 +436,20 @@ class LongTermPlanner:
                                                  int(n_windows), out.data_ptr(), self._stream()))
         return out
 
+    def buildRunTables(self, batch: DeviceBatch, first, count, out=None):
+        """NEW (the consumer HOOK): the packed run tables of plans [first, first+count) in a caller buffer
+        (ltp_build_tables_batch; format and device functions: include/ltp_run_tables.hpp). Returns an int64 CUDA tensor of
+        ltp_run_tables_bytes / 8 words; lane (plan - first) * dof + joint."""
+        import torch
+        words = int(self._lib.ltp_run_tables_bytes(self._h, count)) // 8
+        if out is None:
+            out = torch.empty(max(words, 2), dtype=torch.int64, device=batch.offsets.device)
+        assert out.is_cuda and out.is_contiguous() and out.dtype == torch.int64      # (the size is checked by the library)
+        rec = batch.c_records()
+        self._check(self._lib.ltp_build_tables_batch(self._h, first, count, C.byref(batch.queries), C.byref(rec), out.data_ptr(),
+                                                     out.numel() * 8, self._stream()))
+        return out
+
     def replanStates(self, batch: DeviceBatch, first, count, tile, sample_index, layout="query_major"):
         """NEW: start states (q_0, v_0, a_0) of the next plans = sample k of the trajectories that
         sampleBatch(batch, first, count, tile) wrote. sample_index: int or int32 CUDA tensor [count]."""

@@ -78,6 +78,24 @@ def test_cpp_dropin_builds_with_plain_gxx_and_fails_loudly_without_gpu(abi):
         assert r.returncode == 2 and "no CPU fallback" in r.stdout
 
 
+def test_user_side_consumer_builds_against_the_public_device_header_only(abi):
+    """tests/cpp/example_consumer.hip — a user's own on-device consumer of the run tables — compiles with plain
+    hipcc against include/ltp_run_tables.hpp and nothing else of this repository, and the build records whether it saw the
+    reference (tests/cpp/build_stamp.txt, read by the GPU suite)."""
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "cpp"), "-s", "all"])
+    src = open(os.path.join(ROOT, "tests", "cpp", "example_consumer.hip")).read()
+    includes = re.findall(r'#include\s+[<"]([^>"]+)[>"]', src)
+    assert sorted(includes) == ["hip/hip_runtime.h", "ltp_run_tables.hpp"], includes
+    hdr = open(os.path.join(ROOT, "include", "ltp_run_tables.hpp")).read()
+    assert re.findall(r'#include\s+[<"]([^>"]+)[>"]', hdr) == ["hip/hip_runtime.h"], "the public device header must be self-contained"
+    lib = C.CDLL(os.path.join(ROOT, "tests", "cpp", "libexample_consumer.so"))
+    assert hasattr(lib, "example_peak_velocity") and hasattr(lib, "example_box_clearance")
+    stamp = open(os.path.join(ROOT, "tests", "cpp", "build_stamp.txt")).read()
+    assert ("reference_present=1" in stamp) == os.path.exists("/root/reference/tests/src/long_term_planner_tests.cc")
+    if "reference_present=1" in stamp:
+        assert os.path.exists(os.path.join(ROOT, "tests", "cpp", "reference_tests"))
+
+
 def _build_cmake_consumer(tmp_path):
     import shutil
     if shutil.which("cmake") is None:

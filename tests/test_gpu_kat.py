@@ -222,8 +222,13 @@ def test_reference_own_test_suite_against_the_dropin():
     All 10 tests — the KAT tables, the three end-point suites and both grid sweeps, 755 090 expectations, the same
     count SURVEY.md App. B reports for the compiled reference — must pass on the GPU."""
     exe = os.path.join(ROOT, "tests", "cpp", "reference_tests")
+    stamp = os.path.join(ROOT, "tests", "cpp", "build_stamp.txt")
+    built_with_reference = os.path.exists(stamp) and "reference_present=1" in open(stamp).read()
     if not os.path.exists(exe):
-        pytest.skip("tests/cpp/reference_tests was not built (needs /root/reference at build time)")
+        # the build that produced this tree saw the reference (tests/cpp/Makefile writes the stamp): then the binary has to be here
+        assert not built_with_reference, "tests/cpp/reference_tests is missing although the build saw /root/reference"
+        assert not os.path.exists("/root/reference"), "tests/cpp/reference_tests was not built although /root/reference exists: run __graft_entry__.build()"
+        pytest.skip("tests/cpp/reference_tests was not built: no /root/reference at build time (see tests/cpp/build_stamp.txt)")
     r = subprocess.run([exe], capture_output=True, text=True, timeout=1500)
     tail = r.stdout[-1500:]
     assert r.returncode == 0, tail

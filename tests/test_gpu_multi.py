@@ -205,6 +205,28 @@ def test_bench_spawns_its_ranks_and_shards_one_global_batch():
     assert p.returncode == 0, p.stderr[-2000:]
     line = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][0])
     assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["config"]["global_batch"] == 40000
+    assert line["config"]["backend"].startswith("gloo") and line["config"]["rank_devices"] == [0, 0]
+
+
+def test_two_rank_bench_line_is_complete():
+    """An N > 1 line carries everything the N = 1 line does: roofline (HIP events of rank 0), cpu_baseline (rank 0, after the timed
+    steps), the backend that carried the barrier and the device of every rank — so that the first 8-GPU run yields a complete record."""
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--device", "0", "--batch", "40000",
+                        "--steps", "2", "--warmup", "1", "--tile-gib", "16", "--no-secondary"], capture_output=True, text=True, timeout=900, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    out = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(out) == 1, p.stdout
+    line = json.loads(out[0])
+    assert line["n_gpus"] == 2 and line["config"]["backend"].startswith("gloo") and line["config"]["rank_devices"] == [0, 0]
+    r = line["roofline"]
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["unit"] == "GB/s" and 0.0 < r["frac"] < 1.0 and r["kernel"] == "k_sample"
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and "traffic" in r
+    c = line["cpu_baseline"]
+    assert c["kind"] == "port" and c["unit"] == "plans/s" and c["value"] > 0 and 1 <= c["cores"] <= 32 and "rank 0 of 2" in c["measured_on"]
+    assert c["cores"] <= c["host_cores_affinity"] and "sample" in c
 
 
 def test_two_batches_in_flight_give_the_same_records():
