@@ -9,6 +9,12 @@
 //   reference   Eigen::Matrix<std::complex<T>, Dynamic, Dynamic> roots(Eigen::Matrix<T, Dynamic, 1> poly_vals)
 //   here        std::vector<std::complex<T>>                      roots(const std::vector<T>& poly_vals)      T = float, double
 // Degrees 1..8. A HIP device is required (std::runtime_error otherwise: there is no CPU fallback).
+//
+// For users who DO have Eigen: when <Eigen/Dense> is on the include path (and LTP_ROOTS_NO_EIGEN is not defined) the reference's
+// exact signatures exist as well — roots<T>(Eigen::Matrix<T, Dynamic, 1>) returning an n x 1 complex Eigen matrix and
+// getSmallestPositiveNonComplexRoot<T>(Eigen::Matrix<std::complex<T>, Dynamic, Dynamic>) — delegating to the same device call, so
+// the reference's tests/src/roots_tests.cc:9-32 compiles against this header unchanged. NOTE: that block has never been
+// compiled in this repository's build image (Eigen is not installed there); it is provided as is.
 #ifndef roots_H
 #define roots_H
 
@@ -67,4 +73,35 @@ T getSmallestPositiveNonComplexRoot(const std::vector<std::complex<T>>& r) {
 }
 
 }  // namespace long_term_planner
+
+#if !defined(LTP_ROOTS_NO_EIGEN) && defined(__has_include)
+#if __has_include(<Eigen/Dense>)
+#include <Eigen/Dense>
+namespace long_term_planner {
+
+/** @brief reference roots.h:22-34 with its exact types: the eigenvalues as an n x 1 complex matrix, in Eigen's order. */
+template <class T>
+Eigen::Matrix<std::complex<T>, Eigen::Dynamic, Eigen::Dynamic> roots(Eigen::Matrix<T, Eigen::Dynamic, 1> poly_vals) {
+  std::vector<T> c(static_cast<size_t>(poly_vals.size()));
+  for (size_t i = 0; i < c.size(); ++i) c[i] = poly_vals[static_cast<Eigen::Index>(i)];
+  const std::vector<std::complex<T>> r = roots<T>(c);
+  Eigen::Matrix<std::complex<T>, Eigen::Dynamic, Eigen::Dynamic> out(static_cast<Eigen::Index>(r.size()), 1);
+  for (size_t i = 0; i < r.size(); ++i) out(static_cast<Eigen::Index>(i), 0) = r[i];
+  return out;
+}
+
+/** @brief reference roots.h:43-50 with its exact type (the first column holds the roots). */
+template <class T>
+T getSmallestPositiveNonComplexRoot(Eigen::Matrix<std::complex<T>, Eigen::Dynamic, Eigen::Dynamic> r) {
+  T smallest_val = INFINITY;
+  for (Eigen::Index i = 0; i < r.rows(); ++i) {
+    const std::complex<T> root = r(i, 0);
+    if (root.imag() == 0 && root.real() > 1e-7) smallest_val = std::min(smallest_val, root.real());
+  }
+  return smallest_val;
+}
+
+}  // namespace long_term_planner
+#endif
+#endif
 #endif  // roots_H

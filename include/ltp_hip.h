@@ -193,7 +193,8 @@ int ltp_end_limit_batch(ltp_planner* p, long long first, long long count, const 
  * plan p is written at out + (offsets[p] - offsets[first]); plans that would end beyond
  * `capacity` doubles get LTP_STATUS_OVERFLOW and are skipped.
  * flags: bit 0 = non-temporal stores (recommended); bit 1 = diagnostic dry run (stores without arithmetic);
- * bit 2 = force the table pass, bit 3 = force the fused table build (default: ltp_set_table_pass);
+ * bit 2 = force the table pass, bit 3 = force the fused table build (default: ltp_set_table_pass); bit 4 = table pass without the
+ * two-plans-per-item kernels (rows of <= 64 float64 / 128 float32 samples and dof <= 7 otherwise take them: same rows);
  * bits 8..23 = block interleave factor (0 = default 64, 1 = blocks in plan order). Large tiles (>= 64 GiB)
  * written with the default interleave reach the HBM fill ceiling; see DESIGN.md. */
 int ltp_sample_batch(ltp_planner* p, long long first, long long count, const ltp_queries* in, const ltp_records* rec,
@@ -231,7 +232,10 @@ int ltp_build_tables_batch(ltp_planner* p, long long first, long long count, con
  * trajectories sampled into `tile` by ltp_sample_batch(first, count, ...). sample_index: device int[count] or NULL
  * (then uniform_index for all); k is clamped to the stored samples; plans that were not sampled — traj_len 0,
  * LTP_STATUS_OVERFLOW, or rows that would end beyond `capacity` elements of `tile` (the capacity given to
- * ltp_sample_batch) — keep the start state they had in `in`; nothing outside the tile is read. Output element (local plan i, joint j) at ptr[i*query_stride + j*joint_stride]. */
+ * ltp_sample_batch) — keep the start state they had in `in`; nothing outside the tile is read. Output element (local plan i, joint j) at
+ * ptr[i*query_stride + j*joint_stride]. The float64 form does not read the tile at all: a stored float64 sample has the bits of the
+ * closed-form run evaluation, so the state is recomputed from the records (a quarter of the time of 8-byte gathers from the tile);
+ * the float32 form returns the ROUNDED values the tile holds. */
 int ltp_replan_states_batch(ltp_planner* p, long long first, long long count, const ltp_queries* in, const ltp_records* rec,
                             const unsigned long long* offsets, const double* tile, unsigned long long capacity,
                             const int* sample_index, int uniform_index,
@@ -349,6 +353,9 @@ int ltp_debug_last_matlab_flags(const ltp_planner* p);
 /* MATLAB's roots() as the MATLAB-semantics kernels compute it, n polynomials of degree 1..6: re, im [n][degree] in MATLAB's
  * output order, nroots [n] (degree minus stripped leading zeros), status [n] (0 ok, 1 no convergence, 2 NaN / Inf) */
 int ltp_debug_roots_matlab_host(ltp_planner* p, long long n, int degree, const double* coef, double* re, double* im, int* nroots, int* status);
+/* plans the two-plans-per-item short-row sampler (k_sample_tab2_*) left to its list pass in the latest (piece of the latest)
+ * ltp_sample_batch* call: plans with a joint of more than 8 runs inside the row cap. Synchronises the device. */
+int ltp_debug_tab_list_count(ltp_planner* p);
 /* device_buffer (3 x count u64, or NULL to switch off): k_sample block start / run tables ready / end on the
  * 100 MHz wall clock; ltp_envelope_batch writes 16 u64 per (plan, joint group) item instead: loop top, item drawn,
  * traj_len read, after each of the seven table-build barriers, reduction done */

@@ -183,6 +183,45 @@ k_state_at(long long first, long long count, int dof, double t_sample, Limits li
     a_0[dst] = a;
 }
 
+// ltp_replan_states_batch for float64 tiles: the restart state = STORED sample k of the rows ltp_sample_batch wrote. Those rows hold
+// run_eval(run_coef(..)) of the run walk below, bit for bit, so the state is recomputed from the records (k_state_at's walk, ~0.1 ms
+// per 1 M plans) instead of being gathered from the tile by 21 M scattered 8-byte reads (0.385 ms, at the rate of DRAM sectors):
+// the tile is not read at all. Same rules as k_replan_states for plans the sampler skipped (no trajectory, LTP_STATUS_OVERFLOW,
+// rows that would end beyond the tile): they keep their start state.
+template <int SEM>
+__global__ void __launch_bounds__(256)
+k_replan_walk(long long first, long long count, int dof, double t_sample, RowSpec rows, Limits lim, Queries in, Records rec,
+              const unsigned long long* __restrict__ offsets, unsigned long long capacity, const int* __restrict__ sample_index, int uniform_index,
+              double* __restrict__ q_0, double* __restrict__ v_0, double* __restrict__ a_0, long long sq, long long sj)
+{
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= count * dof) return;
+    const long long local = idx / dof;
+    const int j = (int)(idx - local * dof);
+    const long long p = first + local;
+    const long long dst = local * sq + (long long)j * sj;
+    const long long ix = p * in.sq + (long long)j * in.sj;
+    double q = in.q_0[ix], v = in.v_0[ix], a = in.a_0[ix];
+    const int len = rec.traj_len[p];
+    const int slen = stored_len(len, rows);
+    const unsigned long long stride = ((unsigned long long)slen + (kRowAlign - 1)) / kRowAlign * kRowAlign;
+    const unsigned long long rel = offsets[p] - offsets[first];
+    if (slen > 0 && !(rec.status[p] & kStatusOverflow) && rel + 4ull * dof * stride <= capacity) {
+        int k = sample_index ? sample_index[local] : uniform_index;
+        k = k < 0 ? 0 : (k >= slen ? slen - 1 : k);               // beyond the stored samples: the last stored state
+        const int kt = k * (rows.stride > 1 ? rows.stride : 1);   // stored sample k is trajectory sample k * stride (< len)
+        for_each_run<SEM>(lim, rec, p * dof + j, j, len, t_sample, q, v, a, [&](int b, int e, const RunCoef& rc) {
+            if (kt >= e) return false;
+            double jj;
+            run_eval(rc.c, kt + 1 - b, q, v, a, jj);
+            return true;
+        }, j == dof - 1);
+    }
+    q_0[dst] = q;
+    v_0[dst] = v;
+    a_0[dst] = a;
+}
+
 // planTrajectory's end-limit check (cc:59-61) without sampled rows: lane = (plan, joint) walks its runs to the last
 // trajectory sample — the bits k_sample would have stored at traj_len-1, which is also what build_run_tables step (5)
 // tests — and flags the plan if that position lies outside the joint range.
@@ -335,17 +374,20 @@ void launch_envelope(hipStream_t s, long long first, long long count, long long 
 void launch_replan_states(hipStream_t s, long long first, long long count, int dof, RowSpec rows, Queries in, Records rec,
                           const unsigned long long* offsets, const void* tile, bool f32, unsigned long long capacity,
                           const int* sample_index, int uniform_index,
-                          double* q_0, double* v_0, double* a_0, long long sq, long long sj)
+                          double* q_0, double* v_0, double* a_0, long long sq, long long sj, double t_sample, Limits lim, int semantics)
 {
     if (count <= 0 || dof <= 0) return;
     const long long total = count * dof;
     const dim3 grid((unsigned)((total + 255) / 256)), block(256);
-    if (f32)
+    if (f32)      // float rows hold ROUNDED values: the caller gets what the tile holds
         hipLaunchKernelGGL(k_replan_states<float>, grid, block, 0, s, first, count, dof, rows, in, rec, offsets,
                            (const float*)tile, capacity, sample_index, uniform_index, q_0, v_0, a_0, sq, sj);
+    else if (semantics == kSemMatlab)
+        hipLaunchKernelGGL(k_replan_walk<kSemMatlab>, grid, block, 0, s, first, count, dof, t_sample, rows, lim, in, rec, offsets, capacity, sample_index,
+                           uniform_index, q_0, v_0, a_0, sq, sj);
     else
-        hipLaunchKernelGGL(k_replan_states<double>, grid, block, 0, s, first, count, dof, rows, in, rec, offsets,
-                           (const double*)tile, capacity, sample_index, uniform_index, q_0, v_0, a_0, sq, sj);
+        hipLaunchKernelGGL(k_replan_walk<kSemCpp>, grid, block, 0, s, first, count, dof, t_sample, rows, lim, in, rec, offsets, capacity, sample_index,
+                           uniform_index, q_0, v_0, a_0, sq, sj);
 }
 
 void launch_end_limit(hipStream_t s, long long first, long long count, int dof, double t_sample, Limits lim, Queries in, Records rec)

@@ -112,7 +112,11 @@ void launch_sample_tab(hipStream_t s, long long first, long long count, long lon
                        const unsigned long long* offsets, void* out, bool f32, unsigned long long capacity, int flags, RowSpec rows,
                        unsigned long long* next_item /* zeroed on the same stream */, int resident_blocks, const unsigned long long* tables,
                        double t_sample /* the one the tables were built with */,
-                       unsigned long long* stamps = nullptr /* diagnostic: 8 per (plan, joint group) item */);
+                       unsigned long long* stamps = nullptr /* diagnostic: 8 per (plan, joint group) item */,
+                       unsigned* overflow_list = nullptr /* count + 1 words, [0] zeroed on the same stream: enables the two-plans-per-item
+                                                            kernels (rows of <= 32 slots, dof <= 7); their left-overs go through this list */,
+                       unsigned long long* next_item_list = nullptr /* zeroed work-queue head of the list pass */);
+bool sample_tab_dual_applies(int dof, RowSpec rows, bool f32);
 int sample_tab_resident_blocks(int device, bool f32);
 int sample_resident_blocks(int device, int which /* 0 k_sample f64, 1 k_sample f32, 2 k_envelope */);
 int envelope_resident_blocks(int device);
@@ -123,7 +127,8 @@ void launch_envelope(hipStream_t s, long long first, long long count, long long 
 void launch_replan_states(hipStream_t s, long long first, long long count, int dof, RowSpec rows, Queries in, Records rec,
                           const unsigned long long* offsets, const void* tile, bool f32, unsigned long long capacity,
                           const int* sample_index, int uniform_index,
-                          double* q_0, double* v_0, double* a_0, long long sq, long long sj);
+                          double* q_0, double* v_0, double* a_0, long long sq, long long sj,
+                          double t_sample, Limits lim, int semantics /* float64 tiles: the states are recomputed from the records, same bits */);
 void launch_end_limit(hipStream_t s, long long first, long long count, int dof, double t_sample, Limits lim, Queries in, Records rec);
 void launch_state_at(hipStream_t s, long long first, long long count, int dof, double t_sample, Limits lim, Queries in,
                      Records rec, const int* sample_index, int uniform_index, double* q_0, double* v_0, double* a_0,

@@ -879,3 +879,70 @@ def test_table_pass_matches_the_fused_sampler_on_a_large_range(amd, limits, n, c
         res[mode] = (t64, t32, sub, b.status.clone())
     for got, want in zip(res["tables"], res["fused"]):
         assert torch.equal(got, want)
+
+
+@pytest.mark.parametrize("limits,dof,n", [("panda", None, 3001), ("ref", 3, 2000), ("ref", 6, 1001), ("ref", 1, 700)])
+def test_two_plans_per_item_sampler_gives_the_bits_of_the_other_samplers(amd, limits, dof, n):
+    """Rows of at most 32 slots (64 float64 / 128 float32 stored samples) of up to 7 joints are written by k_sample_tab2_*: an item
+    is a PAIR of neighbouring plans, tables held in compact form (8 runs), and a plan with more than 8 runs inside the cap goes
+    through a list to the single-plan kernel. Whatever the cap, stride, range, odd counts, rejected plans inside pairs, short
+    trajectories (every run inside the cap: the list pass) or tiles too small for some plans: the rows, statuses and lengths are
+    those of the single-plan table sampler and of the fused sampler, bit for bit."""
+    import torch
+    D, lim = amd.limit_set(limits, dof)
+    ltp = amd.LongTermPlanner(D, 0.001, device=0, **lim)
+    qg, q0, v0, a0 = (x.clone() for x in ltp.generateQueries(n, seed=5))
+    q0[11, 0] = 99.0                                            # rejected plans: first of a pair, second of a pair, both
+    q0[14, 0] = 99.0
+    q0[20, 0] = 99.0; q0[21, 0] = 99.0
+    # short moves from rest: trajectories of a few dozen samples whose runs ALL lie inside the cap (more than 8 per joint)
+    short = torch.arange(100, min(n, 900), 7, device=qg.device)
+    qg[short] = q0[short] + 0.02 * torch.sign(qg[short] - q0[short] + 1e-9)    # (beyond the 4e-3 rad early exit of cc:104-109)
+    v0[short] = 0.0
+    a0[short] = 0.0
+    lo = torch.tensor(lim["q_min"], dtype=torch.float64, device=qg.device)
+    hi = torch.tensor(lim["q_max"], dtype=torch.float64, device=qg.device)
+    qg[short] = torch.minimum(torch.maximum(qg[short], lo), hi)
+    listed_total = 0
+    for cap, stride, f32 in ((64, 1, False), (63, 1, False), (1, 1, False), (2, 1, False), (17, 3, False), (33, 1, False), (128, 1, True), (5, 2, True), (100, 1, True)):
+        ltp.setMaxSamples(cap); ltp.setSampleStride(stride)
+        b = ltp.planSwitchTimesBatch(qg, q0, v0, a0)
+        total = int(b.offsets[-1].item())
+        dt = torch.float32 if f32 else torch.float64
+        res = {}
+        for mode in ("fused", "single", "dual", "dual_pieces"):
+            ltp.setTablePass(0, (1 << 32) if mode != "dual_pieces" else 37 * D * 912)
+            b = ltp.planSwitchTimesBatch(qg, q0, v0, a0)
+            full = torch.full((total,), 3.0, dtype=dt, device="cuda")
+            ltp.sampleBatch(b, 0, n, full, tables=(mode != "fused"), dual=mode.startswith("dual"))
+            kern = ltp.lastSamplerKernel()
+            assert ("tab2" in kern) == mode.startswith("dual"), (mode, kern)
+            if mode == "dual":
+                listed = ltp._lib.ltp_debug_tab_list_count(ltp._h)
+                assert listed >= 0
+                listed_total += listed
+            # an odd sub-range that starts inside a pair of the full range, into its own tile; and a tile too small for the last plans
+            sub = torch.full((int((b.offsets[n - 2] - b.offsets[41]).item()) + 8,), 3.0, dtype=dt, device="cuda")
+            ltp.sampleBatch(b, 41, n - 43, sub, tables=(mode != "fused"), dual=mode.startswith("dual"), spread=48)
+            b2 = ltp.planSwitchTimesBatch(qg, q0, v0, a0)
+            small = torch.full((int(b2.offsets[n // 2].item()) + 5,), 3.0, dtype=dt, device="cuda")
+            ltp.sampleBatch(b2, 0, n, small, tables=(mode != "fused"), dual=mode.startswith("dual"), streaming=False)
+            torch.cuda.synchronize()
+            res[mode] = (full, sub, small, b.status.clone(), b.traj_len.clone(), b2.status.clone())
+        for mode in ("single", "dual", "dual_pieces"):
+            for k, (got, want) in enumerate(zip(res[mode], res["fused"])):
+                if k == 5:
+                    # a plan that does not fit the tile: the table pass has walked it to its end (END_LIMIT set), the fused sampler
+                    # never built its tables; everything else about the statuses is equal, and the table samplers agree exactly
+                    skipped = (want & 32) != 0
+                    assert torch.equal(got & ~torch.where(skipped, 8, 0), want), (cap, stride, f32, mode, k)
+                    assert torch.equal(got, res["single"][5]), (cap, stride, f32, mode, "statuses of the table samplers")
+                    assert skipped.any()
+                    continue
+                assert torch.equal(got, want), (cap, stride, f32, mode, k)
+    if limits == "panda":
+        assert listed_total > 0, "no plan took the list pass: the short moves did not produce more than 8 runs inside the cap"
+    ltp.setMaxSamples(65)                                       # 33 slots: not for the pair kernels
+    b = ltp.planSwitchTimesBatch(qg, q0, v0, a0)
+    ltp.sampleBatch(b, 0, n, torch.empty(int(b.offsets[-1].item()), dtype=torch.float64, device="cuda"), tables=True)
+    assert "tab2" not in ltp.lastSamplerKernel()

@@ -212,3 +212,100 @@ def test_device_roots_all_eigenvalues_in_eigen_order(amd, oracle_mod, kat):
             assert np.allclose(g.real, ore, rtol=1e-9, atol=1e-11) and np.allclose(g.imag, oim, rtol=1e-9, atol=1e-11), (deg, p, g, ore, oim)
     # leading zero coefficient / non-finite companion matrix: NaN everywhere (defined here; the reference: uninitialised)
     assert np.all(np.isnan(ltp.roots([0.0, 1.0, 2.0, 3.0, 4.0])[0].real))
+
+
+def test_dense_trajectories_parity_budget(amd, oracle_mod, capsys):
+    """EVERY q/v/a/j sample of >= 200 k dense trajectories against the oracle's planTrajectory (cc:7-63 incl. getTrajectory
+    cc:706-841): panda, the reference's limits, 30-DoF and 24 fuzzed limit sets (dof 1-12, Ts 0.1-10 ms, j_max / Ts up to 1e9,
+    slow-jerk sets with 1e4-1e5 samples per trajectory). The bar and its one stated exception:
+      * verdicts, trajectory lengths and end-limit flags equal everywhere; q and v within 1e-9 everywhere;
+      * a and j within 1e-9 EXCEPT on jerk-correction samples (cc:768-807) of plans whose switching times differ from the oracle's
+        in the last bits (libm's pow, see tools/pow_experiment.py: the device is bit-identical to the oracle built with the device's
+        pow rule): such a sample is (t - Ts floor(t / Ts)) / Ts * j_max and carries |dt| * j_max / Ts. Every plan beyond 1e-9
+        must be explained that way — |dt| <= 1e-9, |dj| <= 2 |dt| j_max / Ts, |da| <= 2 |dt| j_max — and such plans must be rare:
+        at most 2e-5 of a named set (>= 3 allowed), 1e-3 of the fuzzed sets (whose j_max / Ts reaches 1e9).
+    Prints the parity report line SURVEY.md §8(d) asks for."""
+    import json
+    import os
+    import dense_compare as dc
+    bufs = dc.pinned_buffers()
+    report = {"tolerance": TOL, "sets": {}}
+    named = [("panda", 110_000), ("ref", 60_000), ("ref30", 8_000)]
+    for name, n in named:
+        D, lim = amd.limit_set(name)
+        report["sets"][name] = dc.soak(name, D, lim, 0.001, n, 777, bufs, quiet=True)
+    rng = np.random.default_rng(31337)
+    fuzz = {"dense_plans": 0, "sampled": 0, "values_compared": 0, "plans_beyond_tolerance": 0, "outliers_examined": 0, "outliers_explained_by_dt": 0,
+            "verdict_mismatches": 0, "length_mismatches": 0, "end_limit_flag_mismatches": 0, "max_abs_d": {k: 0.0 for k in "qvaj"}, "outliers": []}
+    for trial in range(24):
+        D, ts, lim = dc.fuzz_limits(rng, trial, wide=True)
+        r = dc.soak(f"fuzz{trial}", D, lim, ts, 1_100, 9000 + trial, bufs, quiet=True)
+        for k in ("dense_plans", "sampled", "values_compared", "plans_beyond_tolerance", "outliers_examined", "outliers_explained_by_dt",
+                  "verdict_mismatches", "length_mismatches", "end_limit_flag_mismatches"):
+            fuzz[k] += r[k]
+        for k in "qvaj":
+            fuzz["max_abs_d"][k] = max(fuzz["max_abs_d"][k], r["max_abs_d"][k])
+        fuzz["outliers"] += r["outliers"]
+    report["sets"]["fuzzed"] = fuzz
+    total = sum(s["dense_plans"] for s in report["sets"].values())
+    values = sum(s["values_compared"] for s in report["sets"].values())
+    beyond = sum(s["plans_beyond_tolerance"] for s in report["sets"].values())
+    line = {"dense_trajectories": total, "values_compared": values, "tolerance": TOL,
+            "max_abs_d": {k: max(s["max_abs_d"][k] for s in report["sets"].values()) for k in "qvaj"},
+            "fraction_of_plans_within_tolerance": 1.0 - beyond / total, "plans_beyond_tolerance": beyond,
+            "outliers": [{"set": name, **{k: o[k] for k in ("query", "max_abs_d", "max_abs_dt", "cause")}} for name, s in report["sets"].items() for o in s["outliers"]]}
+    with capsys.disabled():
+        print("\nparity report (dense): " + json.dumps(line))
+    try:
+        os.makedirs(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out"), exist_ok=True)
+        with open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "parity_report_dense_test.json"), "w") as f:
+            json.dump({"line": line, "sets": report["sets"]}, f, indent=1)
+    except OSError:
+        pass
+    assert total >= 200_000
+    for name, s in report["sets"].items():
+        assert s["verdict_mismatches"] == 0 and s["length_mismatches"] == 0 and s["end_limit_flag_mismatches"] == 0, (name, s)
+        assert s["max_abs_d"]["q"] <= TOL and s["max_abs_d"]["v"] <= TOL, (name, s["max_abs_d"])
+        assert s["outliers_examined"] == s["plans_beyond_tolerance"], (name, "more outliers than the examiner looks at")
+        assert s["outliers_explained_by_dt"] == s["plans_beyond_tolerance"], (name, s["outliers"])
+        budget = max(3, int(np.ceil((1e-3 if name == "fuzzed" else 2e-5) * s["dense_plans"])))
+        assert s["plans_beyond_tolerance"] <= budget, (name, s["plans_beyond_tolerance"], budget)
+    assert report["sets"]["fuzzed"]["sampled"] >= 15_000
+
+
+@pytest.mark.parametrize("name,n", [("panda", 300_000), ("ref", 300_000), ("ref30", 40_000)])
+def test_records_are_bit_identical_to_the_oracle_with_the_device_pow_rule(amd, oracle_mod, name, n):
+    """The cause of every last-bit difference between the device and the oracle is libm's pow: against the oracle's DIAGNOSTIC twin
+    (-DLTPO_EXACT_POW: pow(x, 3 | 4 | 6) as one rounding of the exact product, pow(x, 0.5) as sqrt — csrc/ltp_math.hpp restated in C)
+    every switching time, v_drive, t_required and every integer field of the device's records has the twin's BITS, and the default
+    (libm) oracle differs from the twin exactly where it differs from the device. (tools/pow_experiment.py: 28.8 M queries.)"""
+    from concurrent.futures import ThreadPoolExecutor
+    D, lim = amd.limit_set(name)
+    ltp = amd.LongTermPlanner(D, 0.001, device=0, **lim)
+    q = amd.generate_queries(n, lim, seed=424242)
+    dev = ltp.planBatchHost(*q, sample=False)
+    parts = 16
+    cuts = [n * i // parts for i in range(parts + 1)]
+
+    def run(orc):
+        with ThreadPoolExecutor(parts) as ex:
+            outs = list(ex.map(lambda i: orc.plan_batch(*[x[cuts[i]:cuts[i + 1]] for x in q], sample=False), range(parts)))
+        return {k: np.concatenate([o[k] for o in outs]) for k in outs[0] if k != "n_ok"}
+    libm = run(oracle_mod.Oracle(D, 0.001, **lim))
+    twin = run(oracle_mod.Oracle(D, 0.001, exact_pow=True, **lim))
+    ok = (dev["status"] & 0x57) == 0
+    assert np.array_equal(ok, twin["status"] != 0) and np.array_equal(ok, libm["status"] != 0)
+
+    def same(a, b):
+        return (a.view(np.uint64) == b.view(np.uint64)) | (np.isnan(a) & np.isnan(b))
+    differing = 0
+    for k in ("t_opt", "t_scaled", "v_drive", "t_required", "dir"):
+        d, t, l = (np.ascontiguousarray(x[k][ok]) for x in (dev, twin, libm))
+        assert same(d, t).all(), (k, int((~same(d, t)).sum()))
+        assert np.array_equal(same(d, l), same(t, l)), k
+        differing += int((~same(t, l)).sum())
+        diff = np.abs(d - l)
+        assert diff[np.isfinite(diff)].max() < TOL
+    for k in ("mod", "slowest", "traj_len"):
+        assert np.array_equal(dev[k][ok], twin[k][ok]) and np.array_equal(dev[k][ok], libm[k][ok]), k
+    assert differing > 0, "libm's pow and the exact products never differed on this batch: the test would prove nothing"

@@ -1,6 +1,6 @@
 #!/bin/bash
 # After `gpurun -- bash tools/refresh_profiles.sh TAG` has merged its output into gpurun_out/: condense it into profiles/.
-TAG=${1:-r03}
+TAG=${1:-r04}
 cd "$(dirname "$0")/.."
 python profiles/summarize.py $TAG gpurun_out/prof_stats gpurun_out/prof_write gpurun_out/prof_fetch || exit 1
 cp gpurun_out/bench_default.json profiles/${TAG}_bench.json

@@ -12,20 +12,17 @@ pow(x, 0.5) restated in C) instead of the libm oracle. If libm's pow is the only
 are then bit-identical in every plan and nothing lies beyond the tolerance (tools/pow_experiment.py has the records' side).
 --wide-fuzz: limit sets with j_max / Ts up to 1e9, Ts down to 0.1 ms and slow-jerk sets whose trajectories have 1e4-1e5 samples.
 """
-import ctypes as C
 import json
 import os
 import sys
-import time
-from concurrent.futures import ThreadPoolExecutor
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
-import torch
 import longtermplanner_amd as amd
-import oracle
+from dense_compare import THREADS, TOL, fuzz_limits, pinned_buffers, soak as _soak
 
-TOL = 1e-9
 EXACT = "--exact-pow" in sys.argv[1:]
 WIDE = "--wide-fuzz" in sys.argv[1:]
 argv = [a for a in sys.argv[1:] if not a.startswith("--")]
@@ -36,129 +33,16 @@ n_fuzz_sets = int(argv[3]) if len(argv) > 3 else 24
 n_fuzz = int(argv[4]) if len(argv) > 4 else 2_500
 out_path = argv[5] if len(argv) > 5 else "gpurun_out/dense_soak.json"
 seed_shift = int(argv[6]) if len(argv) > 6 else 0          # other query sets than the committed report's (seeds 4242 / 5000 + trial)
-THREADS = max(1, min(len(os.sched_getaffinity(0)), 32))
-CHUNK_BYTES = 3 << 30                       # per host buffer; two buffers in flight
-
-_dp = C.POINTER(C.c_double)
-_ip = C.POINTER(C.c_int)
-_up = C.POINTER(C.c_ulonglong)
-olib = oracle.lib(EXACT)
-
-
-def cause(ltp, orc, q):
-    """Why this query differs: compare the device's records with the oracle's (SURVEY.md §8(d) classes)."""
-    dev = ltp.planBatchHost(*q, sample=False)
-    o = orc.plan_batch(*q, sample=False)
-    if np.any(dev["mod"][0] != o["mod"][0]) or np.any(dev["dir"][0] != o["dir"][0]) or dev["slowest"][0] != o["slowest"][0]:
-        dv = np.abs(dev["v_drive"][0] - o["v_drive"][0])
-        return "root-classification" if np.any(np.isfinite(dv) & (dv > 1e-6)) else "window-test flip"
-    if dev["traj_len"][0] != o["traj_len"][0]:
-        return "sample-index flip (trajectory length)"
-    Ts = ltp.t_sample
-    a, b = dev["t_scaled"][0] / Ts, o["t_scaled"][0] / Ts
-    if np.any(np.floor(a) != np.floor(b)) or np.any(np.ceil(a) != np.ceil(b)):
-        return "sample-index flip"
-    dt = float(np.nanmax(np.abs(dev["t_scaled"][0] - o["t_scaled"][0])))
-    gain = float(np.max(orc.j_max)) / Ts
-    if dt > 0.0:
-        # cc:771-807: a fractional jerk sample is (t - Ts floor(t / Ts)) / Ts * j_max — a last-bit difference of a switching time
-        # (pow's last bit, which also differs between libm builds) reaches that ONE jerk sample multiplied by j_max / Ts
-        return (f"rounding: switching times differ by {dt:.2e} (last bits); the fractional jerk samples (cc:771-807) carry that "
-                f"times j_max / Ts = {gain:.1e}")
-    return "rounding"
 
 
 def soak(name, D, lim, Ts, n, seed, bufs):
-    ltp = amd.LongTermPlanner(D, Ts, device=0, **lim)
-    orc = oracle.Oracle(D, Ts, exact_pow=EXACT, **lim)
-    t0 = time.time()
-    dq = ltp.generateQueries(n, seed=seed)
-    b = ltp.planSwitchTimesBatch(*dq)
-    torch.cuda.synchronize()
-    host = [np.ascontiguousarray(x.cpu().numpy()) for x in dq]
-    off = b.offsets.cpu().numpy().view(np.uint64)
-    cap = CHUNK_BYTES // 8
-    tile = torch.empty(cap, dtype=torch.float64, device="cuda")
-    maxd = np.zeros((n, 4))
-    flag = np.zeros(n, dtype=np.int32)
-    compared = [0]
-    pending = [None, None]
-    bounds, first = [], 0
-    while first < n:
-        end = int(np.searchsorted(off, off[first] + np.uint64(cap), side="right")) - 1
-        assert end > first, "one trajectory does not fit the chunk buffer"
-        bounds.append((first, min(end, n)))
-        first = min(end, n)
-    with ThreadPoolExecutor(THREADS) as ex:
-        # the device's lengths / status words are complete only after a chunk's sampler ran (END_LIMIT bits): per chunk copies
-        for ci, (f, e) in enumerate(bounds):
-            slot = ci & 1
-            if pending[slot] is not None:
-                for fut in pending[slot]:
-                    compared[0] += fut.result()
-            used = int(off[e] - off[f])
-            tile[:used].zero_()
-            ltp.sampleBatch(b, f, e - f, tile)
-            hb = bufs[slot]
-            hb[:used].copy_(tile[:used], non_blocking=True)
-            torch.cuda.synchronize()
-            dev_len = np.ascontiguousarray(b.traj_len[f:e].cpu().numpy())
-            dev_st = np.ascontiguousarray(b.status[f:e].cpu().numpy())
-            hnp = hb.numpy()
-            step = -(-(e - f) // THREADS)
+    return _soak(name, D, lim, Ts, n, seed, bufs, exact=EXACT)
 
-            def work(t, f=f, e=e, hnp=hnp, dev_len=dev_len, dev_st=dev_st):
-                lo = f + t * step
-                cnt = min(step, e - lo)
-                if cnt <= 0:
-                    return 0
-                # the comparator indexes inputs / offsets / device records by absolute plan number: shift the chunk-local arrays
-                return int(olib.ltpo_compare_dense(orc._ref, C.c_long(lo), C.c_long(cnt), *[x.ctypes.data_as(_dp) for x in host],
-                                                   hnp.ctypes.data_as(_dp), off.ctypes.data_as(_up), C.c_ulonglong(int(off[f])),
-                                                   C.cast(dev_len.ctypes.data - 4 * f, _ip), C.cast(dev_st.ctypes.data - 4 * f, _ip),
-                                                   maxd[lo:].ctypes.data_as(_dp), flag[lo:].ctypes.data_as(_ip)))
-            pending[slot] = [ex.submit(work, t) for t in range(THREADS)]
-        for slot in (0, 1):
-            if pending[slot] is not None:
-                for fut in pending[slot]:
-                    compared[0] += fut.result()
-    worst = maxd.max(axis=0)
-    beyond = np.nonzero((maxd.max(axis=1) > TOL) | ((flag & 7) != 0))[0]
-    outliers = []
-    explained = 0
-    gain = float(np.max(orc.j_max)) / Ts
-    for p in beyond[:200]:
-        q = [x[p:p + 1] for x in host]
-        o = {"query": int(p), "max_abs_d": [float(x) for x in maxd[p]], "flags": int(flag[p]), "cause": cause(ltp, orc, q)}
-        # the budget of tests/test_gpu_parity.py: an a / j sample beyond 1e-9 is explained when q and v hold, the verdicts agree and the
-        # plan's switching times differ by |dt| <= 1e-9 with |d j| <= 2 |dt| j_max / Ts (a: the same integrated once: 2 |dt| j_max)
-        devr, orr = ltp.planBatchHost(*q, sample=False), orc.plan_batch(*q, sample=False)
-        dt = float(np.nanmax(np.abs(devr["t_scaled"][0] - orr["t_scaled"][0])))
-        o["max_abs_dt"] = dt
-        o["explained_by_dt_times_jmax_over_ts"] = bool((flag[p] & 7) == 0 and maxd[p][0] <= TOL and maxd[p][1] <= TOL and dt <= 1e-9 and
-                                                        maxd[p][3] <= 2.0 * dt * gain and maxd[p][2] <= max(TOL, 2.0 * dt * gain * Ts))
-        explained += o["explained_by_dt_times_jmax_over_ts"]
-        if len(outliers) < 40:
-            outliers.append(o)
-    st = b.status.cpu().numpy()
-    res = {"dof": D, "t_sample": Ts, "seed": seed, "dense_plans": int(n), "sampled": int(np.sum((st & 0x57) == 0)),
-           "values_compared": int(compared[0]), "bytes_compared": int(compared[0]) * 8,
-           "max_abs_d": {k: float(worst[i]) for i, k in enumerate("qvaj")},
-           "plans_beyond_tolerance": int(np.sum(maxd.max(axis=1) > TOL)),
-           "verdict_mismatches": int(np.sum((flag & 1) != 0)), "length_mismatches": int(np.sum((flag & 2) != 0)),
-           "end_limit_flag_mismatches": int(np.sum((flag & 4) != 0)), "end_limit_false": int(np.sum((st & 8) != 0)),
-           "plans_with_bit_identical_jerk_rows": int(np.sum(((flag & 8) == 0) & ((flag & 3) == 0) & ((st & 0x57) == 0))),
-           "fraction_within_tolerance": float(1.0 - beyond.size / n), "outliers_examined": int(min(beyond.size, 200)),
-           "outliers_explained_by_dt": int(explained), "outliers": outliers,
-           "seconds": round(time.time() - t0, 1)}
-    del tile
-    torch.cuda.empty_cache()
-    print(name, json.dumps(res), flush=True)
-    return res
+
 
 
 def main():
-    bufs = [torch.empty(CHUNK_BYTES // 8, dtype=torch.float64, pin_memory=True) for _ in range(2)]
+    bufs = pinned_buffers()
     report = {"tolerance": TOL, "host_threads": THREADS, "oracle": "exact-pow twin (diagnostic)" if EXACT else "libm (the parity reference)",
               "what": "every q/v/a/j sample of the device's dense rows vs the oracle's planTrajectory", "sets": {}}
     for name, n in (("panda", n_panda), ("ref", n_ref), ("ref30", n_ref30)):
@@ -169,17 +53,8 @@ def main():
     fuzz = {"sets": [], "dense_plans": 0, "sampled": 0, "outliers_examined": 0, "outliers_explained_by_dt": 0, "values_compared": 0, "plans_beyond_tolerance": 0, "max_abs_d": {k: 0.0 for k in "qvaj"},
             "verdict_mismatches": 0, "length_mismatches": 0, "end_limit_flag_mismatches": 0, "plans_with_bit_identical_jerk_rows": 0, "outliers": []}
     for trial in range(n_fuzz_sets):
-        D = int(rng.integers(1, 13))
-        ts = float(rng.choice([0.0001, 0.00025, 0.001, 0.002, 0.004, 0.01] if WIDE else [0.001, 0.002, 0.004, 0.01]))
-        v_max = rng.uniform(0.5, 3.0, D)
-        a_max = rng.uniform(1.0, 20.0, D)
-        j_max = a_max * rng.uniform(5.0, 600.0, D)
-        if WIDE and trial % 3 == 1:
-            j_max = np.minimum(a_max * rng.uniform(500.0, 5000.0, D), 1e9 * ts)       # j_max / Ts up to 1e9
-        elif WIDE and trial % 3 == 2:
-            j_max = a_max * rng.uniform(0.05, 2.0, D)                                  # slow jerk: 1e4-1e5 samples per trajectory
-        q_hi = rng.uniform(1.0, 3.5, D)
-        lim = dict(q_min=list(-q_hi), q_max=list(q_hi), v_max=list(v_max), a_max=list(a_max), j_max=list(j_max))
+        D, ts, lim = fuzz_limits(rng, trial, WIDE)
+        j_max = np.asarray(lim["j_max"])
         r = soak(f"fuzz{trial}", D, lim, ts, n_fuzz, 5000 + trial + 100 * seed_shift, bufs)
         fuzz["sets"].append({"dof": D, "t_sample": ts, "j_max_over_ts_max": float(np.max(j_max) / ts), "max_abs_d": r["max_abs_d"],
                              "plans_beyond_tolerance": r["plans_beyond_tolerance"], "sampled": r["sampled"]})

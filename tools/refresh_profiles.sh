@@ -2,7 +2,7 @@
 # Runs on the GPU box (gpurun -- bash tools/refresh_profiles.sh [tag]): headline bench, workload variants and the rocprofv3
 # passes whose summaries are kept under profiles/. Everything lands in gpurun_out/; profiles/summarize.py condenses it.
 set -o pipefail
-TAG=${1:-r03}
+TAG=${1:-r04}
 PART=${2:-all}      # all | bench (the bench lines) | prof (the rocprofv3 passes): two gpurun calls when one would run out of time
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$R/gpurun_out
@@ -16,7 +16,9 @@ echo "default done"; cut -c1-300 $O/bench_default.json
 for a in "--limits ref" "--limits ref30 --batch 200000" "--switch-only --batch 100000" "--switch-only --batch 100000 --end-limit" "--switch-only" \
          "--switch-only --end-limit" "--switch-only --limits ref" \
          "--switch-only --batch 100000 --in-flight 2 --steps 40 --warmup 4" "--switch-only --in-flight 2 --steps 20 --warmup 4" \
-         "--max-samples 256" "--max-samples 256 --table-pass off" "--max-samples 64" "--sample-stride 4" "--f32" "--f32 --limits ref" \
+         "--max-samples 256" "--max-samples 256 --table-pass off" "--max-samples 64" "--max-samples 64 --no-pair-items" "--max-samples 32" \
+         "--max-samples 32 --no-pair-items" "--max-samples 16" "--max-samples 16 --no-pair-items" "--f32 --max-samples 128" "--f32 --max-samples 128 --no-pair-items" \
+         "--receding 10:100 --max-samples 64" "--sample-stride 4" "--f32" "--f32 --limits ref" \
          "--f32 --max-samples 256" "--f32 --max-samples 256 --table-pass off" "--f32 --max-samples 1024" "--envelope 64:32" \
          "--envelope 64:32 --table-pass off" "--envelope 64:32 --limits ref" "--receding 10:100" "--receding 10:100 --end-limit" \
          "--receding 10:100 --max-samples 128" "--receding 10:100 --max-samples 128 --table-pass off" "--tile-gib 64" "--layout joint_major" \
@@ -36,8 +38,8 @@ for a in "" "--f32" "--max-samples 256 --table-pass off" "--limits ref"; do
   echo "dry $a done"
 done
 # N ranks rehearsed on this one GPU (gloo for the barrier; every rank on device 0): the launch path the 8-GPU node uses
-timeout -k 10 300 python bench.py --gpus 2 --backend gloo --device 0 --no-cpu-baseline --steps 3 > $O/bench_2ranks_gloo.json 2>> $O/bench_variants.err || exit 1
-timeout -k 10 300 python bench.py --gpus 4 --backend gloo --device 0 --no-cpu-baseline --no-secondary --global-batch 1000000 --steps 3 > $O/bench_4ranks_gloo_global.json 2>> $O/bench_variants.err || exit 1
+timeout -k 10 300 python bench.py --gpus 2 --backend gloo --device 0 --steps 3 > $O/bench_2ranks_gloo.json 2>> $O/bench_variants.err || exit 1
+timeout -k 10 300 python bench.py --gpus 4 --backend gloo --device 0 --no-secondary --global-batch 1000000 --steps 3 > $O/bench_4ranks_gloo_global.json 2>> $O/bench_variants.err || exit 1
 # BASELINE.json configs[3] at its real size, as far as one GPU goes: 10 M queries, four ranks (a box allows six GPU processes) sharing the device
 timeout -k 10 400 python bench.py --gpus 4 --backend gloo --device 0 --no-cpu-baseline --no-secondary --global-batch 10000000 --checksum --tile-gib 96 --steps 2 > $O/bench_config4_4ranks_gloo.json 2>> $O/bench_variants.err || exit 1
 echo "rank rehearsal done"
