@@ -237,13 +237,13 @@ void launch_single_opt_braking(hipStream_t s, int joint, double t_sample, Limits
 void launch_roots_matlab(hipStream_t s, long long n, int degree, const double* coef, double* re, double* im, int* nroots, int* status)
 {
     if (n <= 0) return;
-    hipLaunchKernelGGL(k_roots_matlab, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, n, degree, coef, re, im, nroots, status);
+    hipLaunchKernelGGL(k_roots_matlab, dim3((unsigned)((n + 63) / 64)), dim3(64), mr::matrix_lds_bytes(64), s, n, degree, coef, re, im, nroots, status);
 }
 void launch_single_opt_switch(hipStream_t s, int joint, double t_sample, Limits lim, double q_goal, double q_0, double v_0,
                               double a_0, double v_drive, double* io10, int semantics)
 {
     if (semantics == kSemMatlab)
-        hipLaunchKernelGGL(k_single_opt_switch<kSemMatlab>, dim3(1), dim3(1), 0, s, joint, t_sample, lim, q_goal, q_0, v_0, a_0, v_drive, io10);
+        hipLaunchKernelGGL(k_single_opt_switch<kSemMatlab>, dim3(1), dim3(1), mr::matrix_lds_bytes(1), s, joint, t_sample, lim, q_goal, q_0, v_0, a_0, v_drive, io10);
     else
         hipLaunchKernelGGL(k_single_opt_switch<kSemCpp>, dim3(1), dim3(1), 0, s, joint, t_sample, lim, q_goal, q_0, v_0, a_0, v_drive, io10);
 }
@@ -251,7 +251,7 @@ void launch_single_time_scaling(hipStream_t s, int joint, double t_sample, Limit
                                 double a_0, double dir, double t_required, double* out11, int semantics)
 {
     if (semantics == kSemMatlab)
-        hipLaunchKernelGGL(k_single_time_scaling<kSemMatlab>, dim3(1), dim3(1), 0, s, joint, t_sample, lim, q_goal, q_0, v_0, a_0, dir,
+        hipLaunchKernelGGL(k_single_time_scaling<kSemMatlab>, dim3(1), dim3(1), mr::matrix_lds_bytes(1), s, joint, t_sample, lim, q_goal, q_0, v_0, a_0, dir,
                            t_required, out11);
     else
         hipLaunchKernelGGL(k_single_time_scaling<kSemCpp>, dim3(1), dim3(1), 0, s, joint, t_sample, lim, q_goal, q_0, v_0, a_0, dir,

@@ -583,9 +583,9 @@ void launch_switch_times(hipStream_t s, long long n, int dof, double t_sample, i
     if (b_blocks > 1024) b_blocks = 1024;
     if (semantics == kSemMatlab) {
         hipLaunchKernelGGL(k_opt_fast<kSemMatlab>, grid, block, 0, s, n, dof, t_sample, goal_check, lim, in, out, lane_flags, qa);
-        hipLaunchKernelGGL(k_opt_slow<kSemMatlab>, dim3((unsigned)a_blocks), dim3(64), 0, s, dof, t_sample, lim, in, out, lane_flags, qa);
+        hipLaunchKernelGGL(k_opt_slow<kSemMatlab>, dim3((unsigned)a_blocks), dim3(64), mr::matrix_lds_bytes(64), s, dof, t_sample, lim, in, out, lane_flags, qa);
         hipLaunchKernelGGL(k_reduce_scale<kSemMatlab>, grid, block, 0, s, n, dof, t_sample, lim, in, out, lane_flags, qb);
-        hipLaunchKernelGGL(k_scaling_slow<kSemMatlab>, dim3((unsigned)b_blocks), dim3(kQueriesPerBlock, 8), 0, s, dof, t_sample, lim, in, out, qb);
+        hipLaunchKernelGGL(k_scaling_slow<kSemMatlab>, dim3((unsigned)b_blocks), dim3(kQueriesPerBlock, 8), mr::matrix_lds_bytes(kQueriesPerBlock * 8), s, dof, t_sample, lim, in, out, qb);
         return;
     }
     hipLaunchKernelGGL(k_opt_fast<kSemCpp>, grid, block, 0, s, n, dof, t_sample, goal_check, lim, in, out, lane_flags, qa);

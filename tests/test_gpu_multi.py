@@ -134,7 +134,8 @@ def test_config4_ten_million_queries_in_eight_shards(oracle_mod):
 
     one = line("--gpus", "1", "--switch-only", "--end-limit")
     eight = line("--gpus", "8", "--one-process", "--device", "0", "--switch-only", "--end-limit")
-    assert eight["n_gpus"] == 8 and eight["scaling"] == "strong" and eight["config"]["global_batch"] == G
+    # (n_gpus counts DISTINCT devices — all eight shards sit on device 0 here — and n_shards the shards)
+    assert eight["n_gpus"] == 1 and eight["n_shards"] == 8 and eight["scaling"] == "strong" and eight["config"]["global_batch"] == G
     assert one["n_gpus"] == 1 and one["config"]["global_batch"] == G
     for key in keys:
         assert eight["config"][key] == one["config"][key], key
