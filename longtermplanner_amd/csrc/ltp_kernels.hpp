@@ -117,6 +117,13 @@ void launch_sample_tab(hipStream_t s, long long first, long long count, long lon
                                                             kernels (rows of <= 32 slots, dof <= 7); their left-overs go through this list */,
                        unsigned long long* next_item_list = nullptr /* zeroed work-queue head of the list pass */);
 bool sample_tab_dual_applies(int dof, RowSpec rows, bool f32);
+// Capped rows (<= 256 stored samples, <= 28 joints, C++ semantics) without any table traffic: a builder wave per block walks the
+// runs into LDS, seven streaming waves write the rows (ltp_sampler_walk.hip).
+bool sample_walk_applies(int dof, RowSpec rows);
+int sample_walk_resident_blocks(int device, bool f32);
+void launch_sample_walk(hipStream_t s, long long first, long long count, int dof, double t_sample, Limits lim, Queries in, Records rec,
+                        const unsigned long long* offsets, void* out, bool f32, unsigned long long capacity, int flags, RowSpec rows,
+                        unsigned long long* next_item /* zeroed on the same stream */, int resident_blocks);
 int sample_tab_resident_blocks(int device, bool f32);
 int sample_resident_blocks(int device, int which /* 0 k_sample f64, 1 k_sample f32, 2 k_envelope */);
 int envelope_resident_blocks(int device);

@@ -65,23 +65,40 @@ LTP_DEV double matlab_mod(double x, double y)
     return x - y * dfloor(q);
 }
 
+// what the walk reads of a (plan, joint) record: loaded in one place so that a caller can issue the loads ahead of time
+struct JointRecord {
+    double t[7];            // t_scaled (cc:20, 43-55)
+    double dir, v_drive;
+    double mod;             // the jerk-profile flag as a double (cc:24)
+};
+LTP_DEV JointRecord load_joint_record(const Records& rec, long long rj)
+{
+    JointRecord R;
+#pragma unroll
+    for (int x = 0; x < 7; ++x) R.t[x] = rec.t_scaled[rj * 7 + x];
+    R.dir = rec.dir[rj];
+    R.v_drive = rec.v_drive[rj];
+    R.mod = (double)rec.mod[rj];
+    return R;
+}
+
 template <int SEM = kSemCpp, class Visit>
-LTP_DEV void for_each_run(const Limits& lim, const Records& rec, long long rj, int j, int len, double Ts, double& q, double& v,
-                          double& a, Visit&& visit, bool last_joint = true)
+LTP_DEV void for_each_run_loaded(const JointRecord& R, double j_max, int len, double Ts, double& q, double& v, double& a, Visit&& visit,
+                                 bool last_joint = true)
 {
     int sw[7];                                                                        // sampled switch indices (cc:751-757)
     double fr[7], frts[7];
 #pragma unroll
     for (int x = 0; x < 7; ++x) {
-        const double tk = rec.t_scaled[rj * 7 + x];
+        const double tk = R.t[x];
         fr[x] = SEM == kSemMatlab ? matlab_mod(tk, Ts) : tk - Ts * dfloor(tk / Ts);   // cc:747 / LTPlanner.m:531
         frts[x] = fr[x] / Ts;
         sw[x] = (x & 1) ? (int)dceil(tk / Ts) : (int)dfloor(tk / Ts);
     }
-    const double dir = rec.dir[rj];
-    const double dj = dir * lim.j_max[j];
-    const double vsnap = rec.v_drive[rj] * dir;                                       // cc:823
-    const bool modp = (double)rec.mod[rj] == 1.0;
+    const double dir = R.dir;
+    const double dj = dir * j_max;
+    const double vsnap = R.v_drive * dir;                                             // cc:823
+    const bool modp = R.mod == 1.0;
     // phase jerks (cc:735-744) and the nine possible correction terms (cc:771-807), as in build_run_tables step (2)
     const double J0 = dj * (modp ? -1.0 : 1.0), J2 = dj * (modp ? 1.0 : -1.0), J4 = dj * -1.0, J6 = dj * 1.0;
     const double Jp[7] = {J0, dj * 0.0, J2, dj * 0.0, J4, dj * 0.0, J6};
@@ -138,6 +155,13 @@ LTP_DEV void for_each_run(const Limits& lim, const Records& rec, long long rj, i
         }
         b = e;
     }
+}
+
+template <int SEM = kSemCpp, class Visit>
+LTP_DEV void for_each_run(const Limits& lim, const Records& rec, long long rj, int j, int len, double Ts, double& q, double& v,
+                          double& a, Visit&& visit, bool last_joint = true)
+{
+    for_each_run_loaded<SEM>(load_joint_record(rec, rj), lim.j_max[j], len, Ts, q, v, a, visit, last_joint);
 }
 
 }  // namespace ltp

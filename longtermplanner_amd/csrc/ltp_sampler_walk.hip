@@ -1,0 +1,395 @@
+// ltp_sampler_walk.hip — the sampler of CAPPED rows whose run tables never leave the compute unit (round 4), gfx950.
+//
+// The table pass (k_build_tables + k_sample_tab*) pays a round trip through HBM per plan — 3 KB of packed tables written, 3.4 KB of
+// lines read back — and the reads cost the write stream more than their bytes: that mixed pattern tops out at 5.3-5.6 TB/s of total
+// traffic against 7.07 TB/s for pure row writes (profiles/EXPERIMENTS.md E6.3). Here one persistent block of 8 waves keeps the
+// tables in LDS:
+//   * the BUILDER wave (wave 7) walks the runs of up to 63 (plan, joint) lanes at a time — a batch of consecutive plans — with
+//     for_each_run (ltp_runs.hpp: the register walk of k_build_tables / k_state_at), leaves per lane the state before each of the
+//     first kWalkRuns runs that start inside the row cap in one of two LDS batch buffers, applies the end-limit check (cc:59-61) and
+//     the capacity rule, and publishes the batch;
+//   * the seven STREAMING waves take the (plan, joint) slots of the published batch, expand a run's coefficients on the fly
+//     (run_coef: six LDS reads and ~15 operations per run instead of ten reads of an expanded table) and store the rows —
+//     they read LDS and issue stores only, as in k_sample_tab;
+//   * buffers change hands through LDS flags (s_ready / s_consumed), no block barrier in the loop; a final "done" batch lets every
+//     wave leave.
+// No table traffic, no table launch; the only global reads are the 13 record words per (plan, joint). A batch is normally COMPACT
+// (9 consecutive 7-DoF plans, the first kWalkRuns = 8 runs per lane); when one of its lanes has more runs inside the cap —
+// trajectories that end inside the cap: a few per million of random queries, most plans in the tail of a receding-horizon loop —
+// the builder rebuilds the same plans as WIDE batches (4 plans, all 20 runs per lane) in the same buffers. Rows are bit-identical
+// to every other sampler's: same run walk, same run_coef / run_eval (include/ltp_run_tables.hpp).
+// C++ semantics only (the MATLAB mode keeps the table pass).
+#include "ltp_sampler_lds.hpp"
+
+#include <type_traits>
+
+namespace ltp {
+
+constexpr int kWalkRuns = 8;                                  // runs per (plan, joint) of a COMPACT batch
+constexpr int kWalkLanes = 63;                                // (plan, joint) lanes of a compact batch: 9 plans of 7 joints
+constexpr int kWalkMaxPlans = 9;
+constexpr int kWideLanes = 28;                                // lanes of a WIDE batch (all kMaxSegments runs per lane): 4 plans of 7 joints
+constexpr int kWalkStreamWaves = 7;
+constexpr int kWalkThreads = (kWalkStreamWaves + 1) * 64;
+constexpr int kWalkBuffers = 2;
+template <int RUNS>
+struct WalkSlotT {
+    int nseg;                                                 // runs stored (<= RUNS)
+    int pad0;
+    int start[RUNS + 2];                                      // first sample of run r; start[nseg] = first sample NOT covered (>= the cap, or traj_len)
+    double vsnap;                                             // v_drive * dir (cc:823)
+    double pad1;
+    double run[RUNS][kPackedRunWords];                        // a, v, q before the run, its jerk, its mode bits (as in the packed tables)
+};
+typedef WalkSlotT<kWalkRuns> WalkSlot;                        // 48 words
+typedef WalkSlotT<kMaxSegments> WideSlot;                     // 114 words
+static_assert(sizeof(WalkSlot) == 384 && sizeof(WideSlot) == 912, "48 / 114 words");
+struct WalkBatch {
+    union {
+        WalkSlot slot[kWalkLanes];                            // compact batch: up to 9 consecutive plans, 8 runs per lane
+        WideSlot wslot[kWideLanes];                           // wide batch: up to 4 consecutive plans, every run of every lane
+    };
+    unsigned long long rel0;                                  // element offset in `out` of the first row of the batch's first sampled plan
+    unsigned long long span;                                  // elements from rel0 to the end of the batch's last sampled plan
+    int nplans;                                               // plans in the batch (slots = nplans * dof)
+    int done;                                                 // 1 = the queue is exhausted
+    int wide;                                                 // which member of the union holds the batch
+    int pad;
+    int slen[kWalkMaxPlans];                                  // stored samples per row of plan k of the batch; 0 = nothing to stream
+    unsigned rel[kWalkMaxPlans];                              // row offset of plan k relative to rel0, in units of kRowAlign elements
+};
+static_assert(kWalkBuffers * sizeof(WalkBatch) <= 53 * 1024, "three blocks per compute unit");
+
+// rows this kernel takes: capped at <= 256 stored samples, at most 28 joints (a wide batch holds at least one plan)
+bool sample_walk_applies(int dof, RowSpec rows)
+{
+    return dof >= 1 && dof <= kWideLanes && rows.max_samples > 0 && rows.max_samples <= 256;
+}
+
+template <bool STREAMING, typename T, class Slot>
+LTP_DEV void walk_stream(const WalkBatch& B, const Slot* __restrict__ slots, int dof, T* __restrict__ out, RowSpec rows, double Ts, int wave)
+{
+    typedef typename OutVec<T>::type V;
+    constexpr int N = OutVec<T>::N;
+    constexpr int RUNS = (int)(sizeof(Slot::run) / sizeof(double) / kPackedRunWords);
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const int sstride = rows.stride > 1 ? rows.stride : 1;
+    const int nplans = __builtin_amdgcn_readfirstlane(B.nplans);
+    const int total = nplans * dof;
+    // lanes per row: the cap bounds every row of the call (wave-uniform, the same in every batch)
+    const int max_slots = (rows.max_samples + N - 1) / N;
+    const int lg = max_slots > 32 ? 6 : (max_slots > 16 ? 5 : 4);
+    const int rows_per_pass = 64 >> lg;
+    // one buffer descriptor over the batch's rows (they are neighbours in the tile; at most 63 rows x 4 arrays of <= 256 samples)
+    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(out + B.rel0, 0, (int)(unsigned)(B.span * sizeof(T)), 0x00020000);
+    for (int s0 = wave * rows_per_pass; s0 < total; s0 += kWalkStreamWaves * rows_per_pass) {
+        const int s = s0 + (lane >> lg);                                          // this lane's (plan, joint) slot
+        const bool in = s < total;
+        const int pl = in ? s / dof : 0, j = in ? s - pl * dof : 0;
+        const int slen = in ? B.slen[pl] : 0;
+        if (__builtin_amdgcn_ballot_w64(slen > 0) == 0ull) continue;
+        const unsigned stride = ((unsigned)slen + (kRowAlign - 1)) / kRowAlign * kRowAlign;
+        const unsigned arr_bytes = (unsigned)dof * stride * (unsigned)sizeof(T);
+        const unsigned row_bytes = (B.rel[pl] * (unsigned)kRowAlign + (unsigned)j * stride) * (unsigned)sizeof(T);   // q row, bytes from the descriptor base
+        const int nslots = slen > 0 ? (slen + N - 1) / N : 0;
+        const Slot& W = slots[in ? s : 0];
+        const int nruns = W.nseg;
+        int kr = 0, cur = 0, nxt = nruns > 1 ? W.start[1] : 0x7fffffff;
+        for (int slot = lane & ((1 << lg) - 1); slot < nslots; slot += 1 << lg) {
+            const int i0 = N * slot;
+            const int t0 = i0 * sstride;
+            while (nxt <= t0) {
+                ++kr;
+                cur = nxt;
+                nxt = kr + 1 < nruns ? W.start[kr + 1] : 0x7fffffff;
+            }
+            V o[4];
+            // sample by sample when a run boundary or the end of the row lies inside the slot (the tail of the last slot is row
+            // padding: zero); otherwise one run, its coefficients expanded once
+            const bool single = !(t0 + (N - 1) * sstride >= nxt || i0 + N > slen);
+            int kh = kr, ch = cur, nh = nxt;
+            RunCoef rc = run_coef<kSemMatlab>((int)(unsigned)__builtin_bit_cast(unsigned long long, W.run[kr][4]), W.run[kr][3], W.run[kr][0], W.run[kr][1],
+                                              W.run[kr][2], W.vsnap, Ts);
+#pragma unroll
+            for (int h = 0; h < N; ++h) {
+                const int i = t0 + h * sstride;
+                if (!single) {
+                    bool moved = false;
+                    while (nh <= i) {
+                        ++kh;
+                        ch = nh;
+                        nh = kh + 1 < nruns ? W.start[kh + 1] : 0x7fffffff;
+                        moved = true;
+                    }
+                    if (moved) {
+                        const int kk = kh < RUNS ? kh : RUNS - 1;
+                        rc = run_coef<kSemMatlab>((int)(unsigned)__builtin_bit_cast(unsigned long long, W.run[kk][4]), W.run[kk][3], W.run[kk][0], W.run[kk][1],
+                                                  W.run[kk][2], W.vsnap, Ts);
+                    }
+                }
+                const bool pad = i0 + h >= slen;
+                double x4[4];
+                run_eval(rc.c, i - ch + 1, x4[0], x4[1], x4[2], x4[3]);
+#pragma unroll
+                for (int x = 0; x < 4; ++x) o[x][h] = pad ? (T)0 : (T)x4[x];
+            }
+            const unsigned voff = row_bytes + (unsigned)i0 * (unsigned)sizeof(T);
+#pragma unroll
+            for (int x = 0; x < 4; ++x)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o[x]), rsrc, voff + (unsigned)x * arr_bytes, 0, STREAMING ? /*nt | sc1*/ (2 | 16) : 0);
+        }
+    }
+}
+
+// what the builder holds of its (plan, joint) lane between "loads issued" and "walk"
+struct WalkLaneIn {
+    JointRecord R;
+    double q0, v0, a0, j_max, q_min, q_max;
+    unsigned long long rel;
+    int len;
+};
+
+// The walk of one lane into its slot of the batch under construction. Returns true if the lane has more runs inside the cap than
+// the slot holds (compact batches only: the batch is then rebuilt wide). q_end receives the last trajectory sample (cc:59-61).
+template <class Slot>
+LTP_DEV bool walk_lane(Slot& W, const WalkLaneIn& L, long long needed_end, double Ts, double& q_end)
+{
+    constexpr int RUNS = (int)(sizeof(Slot::run) / sizeof(double) / kPackedRunWords);
+    double q = L.q0, v = L.v0, a = L.a0;
+    int runs = 0, last_b = L.len;
+    bool too_many = false;
+    for_each_run_loaded<kSemCpp>(L.R, L.j_max, L.len, Ts, q, v, a, [&](int b, int, const RunCoef& rc) {
+        if ((long long)b < needed_end) {
+            if (runs < RUNS) {
+                // q, v, a still hold the state before this run: the walk advances them after the visit
+                W.start[runs] = b;
+                W.run[runs][0] = a; W.run[runs][1] = v; W.run[runs][2] = q; W.run[runs][3] = rc.c[9];
+                W.run[runs][4] = __builtin_bit_cast(double, (unsigned long long)(unsigned)rc.mode);
+                ++runs;
+            } else {
+                too_many = true;
+            }
+        } else if (last_b == L.len) {
+            last_b = b;                                                          // first run that is not needed: it ends the last stored one
+        }
+        return false;                                                            // the walk goes to the last sample: end-limit check
+    });
+    W.start[runs] = last_b;
+    W.nseg = runs;
+    W.vsnap = L.R.v_drive * L.R.dir;                                             // as the walk forms it (cc:823)
+    q_end = q;
+    return too_many;
+}
+
+template <bool STREAMING, typename T>
+LTP_DEV void sample_walk_body(long long first, long long count, int dof, double t_sample, Limits lim, Queries in, Records rec,
+                              const unsigned long long* __restrict__ offsets, T* __restrict__ out, unsigned long long capacity, int spread, RowSpec rows,
+                              unsigned long long* __restrict__ next_item)
+{
+    __shared__ WalkBatch buf[kWalkBuffers];
+    __shared__ int s_ready[kWalkBuffers];
+    __shared__ int s_consumed[kWalkStreamWaves];
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (threadIdx.x < kWalkBuffers) s_ready[threadIdx.x] = 0;
+    if (threadIdx.x < kWalkStreamWaves) s_consumed[threadIdx.x] = 0;
+    __syncthreads();
+    if (wave < kWalkStreamWaves) {
+        // ---- streaming waves: LDS reads and row stores only ----
+        for (int seq = 0;; ++seq) {
+            const int b = seq % kWalkBuffers;
+            while (__hip_atomic_load(&s_ready[b], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != seq + 1) __builtin_amdgcn_s_sleep(1);
+            if (__builtin_amdgcn_readfirstlane(buf[b].done)) break;
+            if (__builtin_amdgcn_readfirstlane(buf[b].wide)) walk_stream<STREAMING, T, WideSlot>(buf[b], buf[b].wslot, dof, out, rows, t_sample, wave);
+            else walk_stream<STREAMING, T, WalkSlot>(buf[b], buf[b].slot, dof, out, rows, t_sample, wave);
+            // (release orders the wave's LDS reads of buf[b]; its row stores carry their data in registers)
+            if ((threadIdx.x & 63) == 0) __hip_atomic_store(&s_consumed[wave], seq + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        return;
+    }
+    // ---- builder wave: ordinary loads and LDS stores. A queue item is a COMPACT batch of ppb consecutive plans; if one of its lanes
+    // has more than kWalkRuns runs inside the cap (trajectories that end inside it: the tail of a receding-horizon loop is full of
+    // them), the same plans are built again as WIDE batches of wpb plans each, every run kept. The walk is one long dependent chain
+    // on a SIMD it shares with streaming waves that wait for the memory system anyway: it runs at raised issue priority. ----
+    __builtin_amdgcn_s_setprio(3);
+    const int lane = (int)(threadIdx.x & 63);
+    const int ppb = (kWalkLanes / dof) < kWalkMaxPlans ? (kWalkLanes / dof) : kWalkMaxPlans;      // plans per compact batch
+    const int wpb = kWideLanes / dof;                                                             // plans per wide batch (>= 1)
+    const long long nbatches = (count + ppb - 1) / ppb;
+    const long long per = (nbatches + spread - 1) / spread;
+    const unsigned long long total = (unsigned long long)per * (unsigned long long)spread;
+    const unsigned long long off0 = offsets[first];
+    const int sstride = rows.stride > 1 ? rows.stride : 1;
+    const long long needed_end = (long long)rows.max_samples * sstride;                          // runs that start at or after this sample are not needed
+    int seq = 0;
+    auto wait_buffer_free = [&]() {
+        if (seq < kWalkBuffers) return;
+        const int need = seq - kWalkBuffers + 1;                                                  // every streaming wave past the batch that used this buffer
+        for (;;) {
+            const int c = __hip_atomic_load(&s_consumed[lane < kWalkStreamWaves ? lane : 0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (!__builtin_amdgcn_ballot_w64(c < need)) break;
+            __builtin_amdgcn_s_sleep(1);
+        }
+    };
+    auto draw = [&]() -> unsigned long long {
+        unsigned long long item = 0ull;
+        if (lane == 0) item = atomicAdd(next_item, 1ull);
+        return ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(item >> 32)) << 32) |
+               (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)item);
+    };
+    // first plan (local number) and plan count of a queue item; 0 plans: a hole of the interleave
+    auto item_plans = [&](unsigned long long item, long long& pb, int& np) {
+        const long long bi = (long long)(item % (unsigned long long)spread) * per + (long long)(item / (unsigned long long)spread);
+        pb = bi * ppb;
+        np = bi < nbatches ? (int)((count - pb) < ppb ? (count - pb) : ppb) : 0;
+    };
+    // issues the loads of lane (plan pb + lane / dof, joint lane % dof) of a batch of np plans; nothing here waits
+    auto load_lane = [&](long long pb, int np) -> WalkLaneIn {
+        WalkLaneIn L;
+        const int pl = lane / dof, j = lane - pl * dof;
+        L.len = 0;
+        if (pl < np) {
+            const long long p = first + pb + pl;
+            const long long ix = p * in.sq + (long long)j * in.sj;
+            L.len = rec.traj_len[p];
+            L.rel = offsets[p] - off0;
+            L.R = load_joint_record(rec, p * dof + j);
+            L.q0 = in.q_0[ix]; L.v0 = in.v_0[ix]; L.a0 = in.a_0[ix];
+            L.j_max = lim.j_max[j]; L.q_min = lim.q_min[j]; L.q_max = lim.q_max[j];
+        }
+        return L;
+    };
+    // builds and publishes one batch (np plans from local plan pb; lanes as in load_lane) into the free buffer. Returns false without
+    // publishing if a lane of a compact batch has too many runs.
+    auto build = [&](long long pb, int np, auto wide_tag) -> bool {
+        constexpr bool WIDE = decltype(wide_tag)::value;
+        const WalkLaneIn L = load_lane(pb, np);
+        WalkBatch& B = buf[seq % kWalkBuffers];
+        const int pl = lane / dof, j = lane - pl * dof;
+        const bool mine = pl < np;
+        const long long p = first + pb + (mine ? pl : 0);
+        int slen = mine ? stored_len(L.len, rows) : 0;
+        const unsigned long long stride = ((unsigned long long)slen + (kRowAlign - 1)) / kRowAlign * kRowAlign;
+        if (slen > 0 && L.rel + 4ull * dof * stride > capacity) {
+            if (j == 0) atomicOr(&rec.status[p], kStatusOverflow);
+            slen = 0;
+        }
+        bool too_many = false;
+        if (slen > 0) {
+            double q_end;
+            if constexpr (WIDE) too_many = walk_lane(B.wslot[lane], L, needed_end, t_sample, q_end);
+            else too_many = walk_lane(B.slot[lane], L, needed_end, t_sample, q_end);
+            if (q_end < L.q_min || q_end > L.q_max) atomicOr(&rec.status[p], kStatusEndLimit);   // cc:59-61: the last sample
+        }
+        if (__builtin_amdgcn_ballot_w64(too_many) != 0ull) return false;
+        // plan-level header: lane (plan pl, joint 0) holds the plan's stored length and row offset
+        if (lane < kWalkMaxPlans) { B.slen[lane] = 0; B.rel[lane] = 0u; }
+        wave_sync();
+        if (mine && j == 0) B.slen[pl] = slen;
+        wave_sync();
+        // the span of rows this batch writes: from the first sampled plan to the end of the last one (plans are neighbours in the tile)
+        const int sl = lane < np ? B.slen[lane] : 0;
+        const unsigned long long mask = __builtin_amdgcn_ballot_w64(sl > 0);
+        const int src = lane < np ? lane * dof : 0;                                               // lane k < np takes plan k's row offset from the plan's first joint
+        const unsigned long long my_rel = ((unsigned long long)(unsigned)__shfl((int)(unsigned)(L.rel >> 32), src) << 32) |
+                                          (unsigned long long)(unsigned)__shfl((int)(unsigned)L.rel, src);
+        unsigned long long r_lo = 0ull, span = 0ull;
+        if (mask != 0ull) {
+            const int firstp = __builtin_amdgcn_readfirstlane(__builtin_ctzll(mask)), lastp = __builtin_amdgcn_readfirstlane(63 - __builtin_clzll(mask));
+            r_lo = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(my_rel >> 32), firstp) << 32) |
+                   (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)my_rel, firstp);
+            const unsigned long long r_hi = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(my_rel >> 32), lastp) << 32) |
+                                            (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)my_rel, lastp);
+            const int s_hi = __builtin_amdgcn_readlane(sl, lastp);
+            const unsigned long long stride_hi = ((unsigned long long)s_hi + (kRowAlign - 1)) / kRowAlign * kRowAlign;
+            span = r_hi + 4ull * dof * stride_hi - r_lo;
+        }
+        if (lane < np && sl > 0) B.rel[lane] = (unsigned)((my_rel - r_lo) / kRowAlign);
+        if (lane == 0) {
+            B.rel0 = r_lo;
+            B.span = span;
+            B.nplans = np;
+            B.done = 0;
+            B.wide = WIDE ? 1 : 0;
+        }
+        // publish: everything above is LDS traffic of this one wave, in order
+        __hip_atomic_store(&s_ready[seq % kWalkBuffers], seq + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        ++seq;
+        return true;
+    };
+    typedef std::integral_constant<bool, false> CompactTag;
+    typedef std::integral_constant<bool, true> WideTag;
+
+    for (;;) {
+        wait_buffer_free();
+        const unsigned long long item = draw();
+        if (item >= total) {
+            if (lane == 0) buf[seq % kWalkBuffers].done = 1;
+            __hip_atomic_store(&s_ready[seq % kWalkBuffers], seq + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            break;
+        }
+        long long pb = 0;
+        int np = 0;
+        item_plans(item, pb, np);
+        // a plan whose whole trajectory lies inside the cap has (nearly always) more than kWalkRuns runs there: straight to wide
+        const int pl = lane / dof;
+        const int len_here = pl < np ? rec.traj_len[first + pb + pl] : 0;
+        bool wide = __builtin_amdgcn_ballot_w64(len_here > 0 && (long long)len_here <= needed_end) != 0ull;
+        if (!wide) wide = !build(pb, np, CompactTag{});
+        if (wide) {
+            for (int sub = 0; sub < np; sub += wpb) {
+                if (sub > 0) wait_buffer_free();
+                (void)build(pb + sub, np - sub < wpb ? np - sub : wpb, WideTag{});
+            }
+        }
+    }
+}
+
+#define LTP_WALK_KERNEL(NAME, ST, TY, WAVES)                                                                                          \
+    __global__ void __launch_bounds__(kWalkThreads) __attribute__((amdgpu_waves_per_eu(WAVES, 8)))                                    \
+    NAME(long long first, long long count, int dof, double t_sample, Limits lim, Queries in, Records rec,                             \
+         const unsigned long long* __restrict__ offsets, TY* __restrict__ out, unsigned long long capacity, int spread, RowSpec rows, \
+         unsigned long long* __restrict__ next_item)                                                                                  \
+    {                                                                                                                                 \
+        sample_walk_body<ST, TY>(first, count, dof, t_sample, lim, in, rec, offsets, out, capacity, spread, rows, next_item);         \
+    }
+LTP_WALK_KERNEL(k_sample_walk_f64, false, double, 6)
+LTP_WALK_KERNEL(k_sample_walk_f64_nt, true, double, 6)
+LTP_WALK_KERNEL(k_sample_walk_f32, false, float, 4)      // four samples per lane in flight: at 80 VGPRs the streaming loop spills
+LTP_WALK_KERNEL(k_sample_walk_f32_nt, true, float, 4)
+#undef LTP_WALK_KERNEL
+
+int sample_walk_resident_blocks(int device, bool f32)
+{
+    int cus = 0, per_cu = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus <= 0) cus = 256;
+    hipError_t e = f32 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_sample_walk_f32_nt, kWalkThreads, 0)
+                       : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_sample_walk_f64_nt, kWalkThreads, 0);
+    if (e != hipSuccess || per_cu <= 0) per_cu = 3;
+    return cus * per_cu;
+}
+
+void launch_sample_walk(hipStream_t s, long long first, long long count, int dof, double t_sample, Limits lim, Queries in, Records rec,
+                        const unsigned long long* offsets, void* out, bool f32, unsigned long long capacity, int flags, RowSpec rows,
+                        unsigned long long* next_item, int resident_blocks)
+{
+    if (count <= 0) return;
+    const int ppb = (kWalkLanes / dof) < kWalkMaxPlans ? (kWalkLanes / dof) : kWalkMaxPlans;
+    const long long nbatches = (count + ppb - 1) / ppb;
+    int spread = (flags >> 8) & 0xFFFF;
+    if (spread == 0) spread = kSampleSpread;
+    if ((long long)spread > nbatches) spread = (int)nbatches;
+    long long blocks = resident_blocks > 0 ? resident_blocks : 768;
+    if (blocks > nbatches) blocks = nbatches;
+    const dim3 grid((unsigned)blocks), block(kWalkThreads);
+#define LTP_WALK_CASE(K, TY) hipLaunchKernelGGL(K, grid, block, 0, s, first, count, dof, t_sample, lim, in, rec, offsets, (TY*)out, capacity, spread, rows, next_item)
+    switch ((flags & 1) | (f32 ? 2 : 0)) {
+    case 0: LTP_WALK_CASE(k_sample_walk_f64, double); break;
+    case 1: LTP_WALK_CASE(k_sample_walk_f64_nt, double); break;
+    case 2: LTP_WALK_CASE(k_sample_walk_f32, float); break;
+    default: LTP_WALK_CASE(k_sample_walk_f32_nt, float); break;
+    }
+#undef LTP_WALK_CASE
+}
+
+}  // namespace ltp

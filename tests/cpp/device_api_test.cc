@@ -216,7 +216,9 @@ int main()
         HIP(hipGraphDestroy(graph));
     }
 
-    // ---- 6. table-pass calls under capture (envelopes take the table pass by default, rows capped at <= 256 samples too) ----
+    // ---- 6. calls under capture that need (or do not need) the table workspace: envelopes take the table pass by default; rows
+    //         capped at <= 256 samples take k_sample_walk_* (tables kept in the compute unit: no workspace at all) unless flag bit 2
+    //         asks for the table-pass kernels ----
     {
         ltp_planner* h1 = h;
         ltp_planner* h = nullptr;                         // the LTP macro reports this handle's error text
@@ -225,11 +227,12 @@ int main()
         LTP(ltp_set_max_samples(h, cap_samples));
         LTP(ltp_reserve_batch(h, n));
         unsigned long long* offsets2;
-        double *tile3, *tile4, *env2, *env3;
+        double *tile3, *tile4, *tile5, *env2, *env3;
         const unsigned long long cap3 = (unsigned long long)n * 4 * dof * (unsigned long long)ltp_row_stride(cap_samples);
         HIP(hipMalloc((void**)&offsets2, (n + 1) * sizeof(unsigned long long)));
         HIP(hipMalloc((void**)&tile3, cap3 * sizeof(double)));
         HIP(hipMalloc((void**)&tile4, cap3 * sizeof(double)));
+        HIP(hipMalloc((void**)&tile5, cap3 * sizeof(double)));
         HIP(hipMalloc((void**)&env2, nd * K * 2 * sizeof(double)));
         HIP(hipMalloc((void**)&env3, nd * K * 2 * sizeof(double)));
         hipGraph_t graph;
@@ -237,10 +240,12 @@ int main()
         HIP(hipStreamBeginCapture(s, hipStreamCaptureModeGlobal));
         const int ra = ltp_plan_switch_times_batch(h, n, &q, &rec, offsets2, s);
         const int rb = ltp_envelope_batch(h, 0, n, &q, &rec, W, K, env2, s);
-        const int rc4 = ltp_sample_batch(h, 0, n, &q, &rec, offsets2, tile3, cap3, 1, s);
+        const int rc4 = ltp_sample_batch(h, 0, n, &q, &rec, offsets2, tile3, cap3, 1 | 4, s);      // the table-pass kernels: need the workspace
+        const int rc5 = ltp_sample_batch(h, 0, n, &q, &rec, offsets2, tile5, cap3, 1, s);          // default for these rows: no workspace needed
         HIP(hipStreamEndCapture(s, &graph));
         HIP(hipGraphDestroy(graph));
-        CHECK(ra == LTP_OK && rb == LTP_ERR_INVALID_ARGUMENT && rc4 == LTP_ERR_INVALID_ARGUMENT);
+        CHECK(ra == LTP_OK && rb == LTP_ERR_INVALID_ARGUMENT && rc4 == LTP_ERR_INVALID_ARGUMENT && rc5 == LTP_OK);
+        CHECK(std::strncmp(ltp_last_sampler_kernel(h), "k_sample_walk_f64", 17) == 0);
         // (b) a workspace bounded to 16 MiB, about a third of the batch: the captured calls run in pieces, nothing is allocated
         // or freed — neither inside the capture nor by the eager calls below (growing the workspace would free the buffer the
         // instantiated graph points to)
@@ -250,21 +255,24 @@ int main()
         HIP(hipStreamBeginCapture(s, hipStreamCaptureModeGlobal));
         const int r1 = ltp_plan_switch_times_batch(h, n, &q, &rec, offsets2, s);
         const int r2 = ltp_envelope_batch(h, 0, n, &q, &rec, W, K, env2, s);
-        const int r3 = ltp_sample_batch(h, 0, n, &q, &rec, offsets2, tile3, cap3, 1, s);
+        const int r3 = ltp_sample_batch(h, 0, n, &q, &rec, offsets2, tile3, cap3, 1 | 4, s);
+        CHECK(std::strncmp(ltp_last_sampler_kernel(h), "k_sample_tab", 12) == 0);
+        const int r4 = ltp_sample_batch(h, 0, n, &q, &rec, offsets2, tile5, cap3, 1, s);
         HIP(hipStreamEndCapture(s, &graph));
-        CHECK(r1 == LTP_OK && r2 == LTP_OK && r3 == LTP_OK);
-        CHECK(std::strncmp(ltp_last_sampler_kernel(h), "k_sample_tab_f64", 16) == 0);
+        CHECK(r1 == LTP_OK && r2 == LTP_OK && r3 == LTP_OK && r4 == LTP_OK);
+        CHECK(std::strncmp(ltp_last_sampler_kernel(h), "k_sample_walk_f64", 17) == 0);
         HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
         for (unsigned long long seed = 7; seed <= 8; ++seed) {
             LTP(ltp_generate_queries_batch(h, n, seed, 0, in[0], in[1], in[2], in[3], dof, 1, s));
             HIP(hipMemsetAsync(tile3, 0, cap3 * sizeof(double), s));
             HIP(hipMemsetAsync(tile4, 0, cap3 * sizeof(double), s));
+            HIP(hipMemsetAsync(tile5, 0, cap3 * sizeof(double), s));
             HIP(hipGraphLaunch(exec, s));
             HIP(hipStreamSynchronize(s));
             const std::vector<unsigned long long> off_g = download(offsets2, (size_t)n + 1);
             const std::vector<int> st_g = download(status, (size_t)n);
             CHECK(off_g[n] <= cap3 && off_g[n] > 0);
-            const std::vector<double> rows_g = download(tile3, (size_t)off_g[n]), env_g = download(env2, nd * K * 2);
+            const std::vector<double> rows_g = download(tile3, (size_t)off_g[n]), rows_w = download(tile5, (size_t)off_g[n]), env_g = download(env2, nd * K * 2);
             // the same eagerly, rows by the fused kernel for good measure
             LTP(ltp_plan_switch_times_batch(h, n, &q, &rec, offsets2, s));
             LTP(ltp_envelope_batch(h, 0, n, &q, &rec, W, K, env3, s));
@@ -275,6 +283,7 @@ int main()
             CHECK(download(status, (size_t)n) == st_g);
             const std::vector<double> rows_e = download(tile4, (size_t)off_g[n]), env_e = download(env3, nd * K * 2);
             CHECK(std::memcmp(rows_e.data(), rows_g.data(), rows_e.size() * sizeof(double)) == 0);
+            CHECK(std::memcmp(rows_e.data(), rows_w.data(), rows_e.size() * sizeof(double)) == 0);
             CHECK(std::memcmp(env_e.data(), env_g.data(), env_e.size() * sizeof(double)) == 0);
         }
         HIP(hipGraphExecDestroy(exec));

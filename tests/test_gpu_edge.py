@@ -905,33 +905,35 @@ def test_two_plans_per_item_sampler_gives_the_bits_of_the_other_samplers(amd, li
     qg[short] = torch.minimum(torch.maximum(qg[short], lo), hi)
     listed_total = 0
     for cap, stride, f32 in ((64, 1, False), (63, 1, False), (1, 1, False), (2, 1, False), (17, 3, False), (33, 1, False), (128, 1, True), (5, 2, True), (100, 1, True)):
+        walk_modes = ("walk",)
         ltp.setMaxSamples(cap); ltp.setSampleStride(stride)
         b = ltp.planSwitchTimesBatch(qg, q0, v0, a0)
         total = int(b.offsets[-1].item())
         dt = torch.float32 if f32 else torch.float64
         res = {}
-        for mode in ("fused", "single", "dual", "dual_pieces"):
+        for mode in ("fused", "single", "dual", "dual_pieces") + walk_modes:
             ltp.setTablePass(0, (1 << 32) if mode != "dual_pieces" else 37 * D * 912)
             b = ltp.planSwitchTimesBatch(qg, q0, v0, a0)
             full = torch.full((total,), 3.0, dtype=dt, device="cuda")
-            ltp.sampleBatch(b, 0, n, full, tables=(mode != "fused"), dual=mode.startswith("dual"))
+            kw = dict(walk=True) if mode == "walk" else dict(tables=(mode != "fused"), dual=mode.startswith("dual"), walk=False)
+            ltp.sampleBatch(b, 0, n, full, **kw)
             kern = ltp.lastSamplerKernel()
-            assert ("tab2" in kern) == mode.startswith("dual"), (mode, kern)
+            assert ("tab2" in kern) == mode.startswith("dual") and ("walk" in kern) == (mode == "walk"), (mode, kern)
             if mode == "dual":
                 listed = ltp._lib.ltp_debug_tab_list_count(ltp._h)
                 assert listed >= 0
                 listed_total += listed
             # an odd sub-range that starts inside a pair of the full range, into its own tile; and a tile too small for the last plans
             sub = torch.full((int((b.offsets[n - 2] - b.offsets[41]).item()) + 8,), 3.0, dtype=dt, device="cuda")
-            ltp.sampleBatch(b, 41, n - 43, sub, tables=(mode != "fused"), dual=mode.startswith("dual"), spread=48)
+            ltp.sampleBatch(b, 41, n - 43, sub, spread=48, **kw)
             b2 = ltp.planSwitchTimesBatch(qg, q0, v0, a0)
             small = torch.full((int(b2.offsets[n // 2].item()) + 5,), 3.0, dtype=dt, device="cuda")
-            ltp.sampleBatch(b2, 0, n, small, tables=(mode != "fused"), dual=mode.startswith("dual"), streaming=False)
+            ltp.sampleBatch(b2, 0, n, small, streaming=False, **kw)
             torch.cuda.synchronize()
             res[mode] = (full, sub, small, b.status.clone(), b.traj_len.clone(), b2.status.clone())
-        for mode in ("single", "dual", "dual_pieces"):
+        for mode in ("single", "dual", "dual_pieces") + walk_modes:
             for k, (got, want) in enumerate(zip(res[mode], res["fused"])):
-                if k == 5:
+                if k == 5 and mode != "walk":        # (k_sample_walk never walks a plan that does not fit: the fused sampler's statuses)
                     # a plan that does not fit the tile: the table pass has walked it to its end (END_LIMIT set), the fused sampler
                     # never built its tables; everything else about the statuses is equal, and the table samplers agree exactly
                     skipped = (want & 32) != 0
@@ -946,3 +948,50 @@ def test_two_plans_per_item_sampler_gives_the_bits_of_the_other_samplers(amd, li
     b = ltp.planSwitchTimesBatch(qg, q0, v0, a0)
     ltp.sampleBatch(b, 0, n, torch.empty(int(b.offsets[-1].item()), dtype=torch.float64, device="cuda"), tables=True)
     assert "tab2" not in ltp.lastSamplerKernel()
+
+
+@pytest.mark.parametrize("limits,dof,n", [("panda", None, 2503), ("ref", 28, 401), ("ref", 2, 1500), ("ref", 9, 900)])
+def test_walk_sampler_keeps_its_tables_in_the_compute_unit_and_gives_the_same_rows(amd, limits, dof, n):
+    """k_sample_walk_*: capped rows (<= 256 stored samples, <= 63 joints) with the run tables built by a builder wave inside the
+    sampler's block — no table pass, no table traffic. It is what the library takes automatically for such rows; rows, statuses and
+    lengths must be those of the fused sampler bit for bit: every cap / stride / element type, batches of 9 / 2 / 9 / 7 plans (wide: 4 / 1 / 14 / 3),
+    ranges that start anywhere, tiles too small for the last plans, rejected plans, and plans with more than 8 runs inside the cap
+    (the list pass through the fused kernel)."""
+    import torch
+    D, lim = amd.limit_set(limits, dof)
+    ltp = amd.LongTermPlanner(D, 0.001, device=0, **lim)
+    qg, q0, v0, a0 = (x.clone() for x in ltp.generateQueries(n, seed=9))
+    q0[7, 0] = 99.0; q0[8, 0] = 99.0; q0[30, D - 1] = 99.0
+    short = torch.arange(60, min(n, 800), 5, device=qg.device)
+    qg[short] = q0[short] + 0.02 * torch.sign(qg[short] - q0[short] + 1e-9)
+    v0[short] = 0.0
+    a0[short] = 0.0
+    qg[short] = torch.minimum(torch.maximum(qg[short], torch.tensor(lim["q_min"], dtype=torch.float64, device=qg.device)),
+                              torch.tensor(lim["q_max"], dtype=torch.float64, device=qg.device))
+    for cap, stride, f32 in ((256, 1, False), (255, 1, True), (129, 2, False), (64, 1, False), (200, 4, True), (1, 1, False), (31, 1, True)):
+        ltp.setMaxSamples(cap); ltp.setSampleStride(stride)
+        dt = torch.float32 if f32 else torch.float64
+        res = {}
+        for mode in ("fused", "walk", "auto"):
+            b = ltp.planSwitchTimesBatch(qg, q0, v0, a0)
+            total = int(b.offsets[-1].item())
+            kw = dict(tables=False, walk=False) if mode == "fused" else (dict(walk=True) if mode == "walk" else {})
+            full = torch.full((total,), 3.0, dtype=dt, device="cuda")
+            ltp.sampleBatch(b, 0, n, full, **kw)
+            kern = ltp.lastSamplerKernel()
+            assert ("walk" in kern) == (mode != "fused"), (mode, kern, cap)          # automatic choice: the walk kernel for these caps
+            sub = torch.full((int((b.offsets[n - 2] - b.offsets[13]).item()) + 8,), 3.0, dtype=dt, device="cuda")
+            ltp.sampleBatch(b, 13, n - 15, sub, spread=48, **kw)
+            b2 = ltp.planSwitchTimesBatch(qg, q0, v0, a0)
+            small = torch.full((int(b2.offsets[n // 2 + 3].item()) + 5,), 3.0, dtype=dt, device="cuda")
+            ltp.sampleBatch(b2, 0, n, small, streaming=False, spread=1, **kw)
+            torch.cuda.synchronize()
+            res[mode] = (full, sub, small, b.status.clone(), b.traj_len.clone(), b2.status.clone())
+        for mode in ("walk", "auto"):
+            for k, (got, want) in enumerate(zip(res[mode], res["fused"])):
+                assert torch.equal(got, want), (cap, stride, f32, mode, k)
+        assert (res["fused"][5] & 32).any(), "the small tile did not leave any plan out"
+    ltp.setMaxSamples(257)
+    b = ltp.planSwitchTimesBatch(qg, q0, v0, a0)
+    ltp.sampleBatch(b, 0, n, torch.empty(int(b.offsets[-1].item()), dtype=torch.float64, device="cuda"))
+    assert "walk" not in ltp.lastSamplerKernel()
