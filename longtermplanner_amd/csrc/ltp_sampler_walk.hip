@@ -60,10 +60,12 @@ struct WalkBatch {
 };
 static_assert(kWalkBuffers * sizeof(WalkBatch) <= 53 * 1024, "three blocks per compute unit");
 
-// rows this kernel takes: capped at <= 256 stored samples, at most 28 joints (a wide batch holds at least one plan)
+// rows this kernel takes: capped at <= 1024 stored samples (a batch's rows lie behind one buffer descriptor with 32-bit offsets; the
+// automatic choice sends it what the table pass used to get: <= 256 float64 / 1024 float32 samples), at most 28 joints (a wide
+// batch holds at least one plan)
 bool sample_walk_applies(int dof, RowSpec rows)
 {
-    return dof >= 1 && dof <= kWideLanes && rows.max_samples > 0 && rows.max_samples <= 256;
+    return dof >= 1 && dof <= kWideLanes && rows.max_samples > 0 && rows.max_samples <= 1024;
 }
 
 template <bool STREAMING, typename T, class Slot>
@@ -81,7 +83,7 @@ LTP_DEV void walk_stream(const WalkBatch& B, const Slot* __restrict__ slots, int
     const int max_slots = (rows.max_samples + N - 1) / N;
     const int lg = max_slots > 32 ? 6 : (max_slots > 16 ? 5 : 4);
     const int rows_per_pass = 64 >> lg;
-    // one buffer descriptor over the batch's rows (they are neighbours in the tile; at most 63 rows x 4 arrays of <= 256 samples)
+    // one buffer descriptor over the batch's rows (they are neighbours in the tile; at most 63 rows x 4 arrays of <= 1024 samples)
     __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(out + B.rel0, 0, (int)(unsigned)(B.span * sizeof(T)), 0x00020000);
     for (int s0 = wave * rows_per_pass; s0 < total; s0 += kWalkStreamWaves * rows_per_pass) {
         const int s = s0 + (lane >> lg);                                          // this lane's (plan, joint) slot

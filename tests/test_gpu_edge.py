@@ -991,7 +991,75 @@ def test_walk_sampler_keeps_its_tables_in_the_compute_unit_and_gives_the_same_ro
             for k, (got, want) in enumerate(zip(res[mode], res["fused"])):
                 assert torch.equal(got, want), (cap, stride, f32, mode, k)
         assert (res["fused"][5] & 32).any(), "the small tile did not leave any plan out"
-    ltp.setMaxSamples(257)
+    ltp.setMaxSamples(257)                                      # float64 rows beyond 8 KB: the fused sampler by default, the walk kernel on request
     b = ltp.planSwitchTimesBatch(qg, q0, v0, a0)
-    ltp.sampleBatch(b, 0, n, torch.empty(int(b.offsets[-1].item()), dtype=torch.float64, device="cuda"))
+    t0 = torch.full((int(b.offsets[-1].item()),), 3.0, dtype=torch.float64, device="cuda")
+    ltp.sampleBatch(b, 0, n, t0)
     assert "walk" not in ltp.lastSamplerKernel()
+    t1 = torch.full_like(t0, 3.0)
+    ltp.sampleBatch(b, 0, n, t1, walk=True)
+    assert "walk" in ltp.lastSamplerKernel() and torch.equal(t0, t1)
+    ltp.setMaxSamples(1024)                                     # float32 rows up to 16 KB: the walk kernel by default
+    b = ltp.planSwitchTimesBatch(qg, q0, v0, a0)
+    f0 = torch.full((int(b.offsets[-1].item()),), 3.0, dtype=torch.float32, device="cuda")
+    f1 = torch.full_like(f0, 3.0)
+    ltp.sampleBatch(b, 0, n, f0)
+    assert "walk" in ltp.lastSamplerKernel()
+    ltp.sampleBatch(b, 0, n, f1, tables=False, walk=False)
+    assert ltp.lastSamplerKernel() == "k_sample" and torch.equal(f0, f1)
+    ltp.setMaxSamples(1025)
+    b = ltp.planSwitchTimesBatch(qg, q0, v0, a0)
+    ltp.sampleBatch(b, 0, n, torch.empty(int(b.offsets[-1].item()), dtype=torch.float32, device="cuda"), walk=True)
+    assert "walk" not in ltp.lastSamplerKernel()
+
+
+def test_walk_sampler_random_configurations_against_the_fused_sampler(amd):
+    """A randomized differential test of k_sample_walk_* (the default writer of capped rows) against the fused sampler: 48 random
+    combinations of joints (1-28), sample time, cap (1-1024), stride (1-6), element type, batch size, sub-range, block interleave and
+    tile size, on random limit sets (fast and slow jerk, i.e. many and few runs inside the cap) with rejected plans and short moves
+    mixed in. Rows, statuses and lengths must agree bit for bit."""
+    import torch
+    rng = np.random.default_rng(20260401)
+    for trial in range(48):
+        D = int(rng.integers(1, 29))
+        ts = float(rng.choice([0.0005, 0.001, 0.002, 0.004]))
+        v_max = rng.uniform(0.5, 3.0, D)
+        a_max = rng.uniform(1.0, 20.0, D)
+        j_max = a_max * (rng.uniform(5.0, 600.0, D) if trial % 3 else rng.uniform(0.5, 5.0, D))
+        q_hi = rng.uniform(1.0, 3.5, D)
+        lim = dict(q_min=list(-q_hi), q_max=list(q_hi), v_max=list(v_max), a_max=list(a_max), j_max=list(j_max))
+        ltp = amd.LongTermPlanner(D, ts, device=0, **lim)
+        n = int(rng.integers(1, 900))
+        qg, q0, v0, a0 = (x.clone() for x in ltp.generateQueries(n, seed=1000 + trial))
+        for p in rng.integers(0, n, size=max(1, n // 50)):
+            q0[int(p), 0] = 99.0
+        short = torch.as_tensor(rng.integers(0, n, size=max(1, n // 6)), device=qg.device)
+        qg[short] = torch.clamp(q0[short] + float(rng.choice([0.01, 0.03, 0.1])) * torch.sign(qg[short] - q0[short] + 1e-9), -99.0, 99.0)
+        qg[short] = torch.minimum(torch.maximum(qg[short], torch.tensor(lim["q_min"], dtype=torch.float64, device=qg.device)),
+                                  torch.tensor(lim["q_max"], dtype=torch.float64, device=qg.device))
+        v0[short] = 0.0
+        a0[short] = 0.0
+        cap = int(rng.choice([1, 2, 7, 16, 31, 64, 100, 128, 255, 256, 500, 1024]))
+        stride = int(rng.integers(1, 7))
+        f32 = bool(rng.integers(0, 2))
+        spread = int(rng.choice([0, 1, 3, 48, 5000]))
+        first = int(rng.integers(0, n))
+        count = int(rng.integers(0, n - first + 1))
+        ltp.setMaxSamples(cap); ltp.setSampleStride(stride)
+        dt = torch.float32 if f32 else torch.float64
+        res = {}
+        for mode in ("fused", "walk"):
+            kw = dict(tables=False, walk=False) if mode == "fused" else dict(walk=True)
+            b = ltp.planSwitchTimesBatch(qg, q0, v0, a0)
+            need = int((b.offsets[first + count] - b.offsets[first]).item())
+            tile = torch.full((need + 8,), 3.0, dtype=dt, device="cuda")
+            ltp.sampleBatch(b, first, count, tile, spread=spread, **kw)
+            if count:
+                assert ("walk" in ltp.lastSamplerKernel()) == (mode == "walk"), (trial, ltp.lastSamplerKernel())
+            b2 = ltp.planSwitchTimesBatch(qg, q0, v0, a0)
+            small = torch.full((int(b2.offsets[n // 2].item()) + 3,), 3.0, dtype=dt, device="cuda")
+            ltp.sampleBatch(b2, 0, n, small, streaming=bool(trial & 1), **kw)
+            torch.cuda.synchronize()
+            res[mode] = (tile, small, b.status.clone(), b.traj_len.clone(), b2.status.clone())
+        for k, (got, want) in enumerate(zip(res["walk"], res["fused"])):
+            assert torch.equal(got, want), (trial, D, ts, cap, stride, f32, n, first, count, spread, k)

@@ -7,7 +7,7 @@ PART=${2:-all}      # all | bench (the bench lines) | prof (the rocprofv3 passes
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$R/gpurun_out
 mkdir -p $O
-if [ "$PART" != bench ]; then rm -rf $O/prof_stats $O/prof_write $O/prof_fetch $O/prof_tab_stats $O/prof_switch_100000 $O/prof_switch_1000000 $O/prof_sq_first256 $O/prof_sq_switch100k $O/prof_sq_f32 $O/prof_sq_envelope $O/prof_f32_stats; fi
+if [ "$PART" != bench ]; then rm -rf $O/prof_stats $O/prof_write $O/prof_fetch $O/prof_tab_stats $O/prof_switch_100000 $O/prof_switch_1000000 $O/prof_sq_first256 $O/prof_sq_first256_tab $O/prof_sq_first64 $O/prof_sq_first64_tab $O/prof_sq_switch100k $O/prof_sq_f32 $O/prof_sq_envelope $O/prof_f32_stats; fi
 cd $R
 if [ "$PART" != prof ]; then
 timeout -k 10 400 python bench.py > $O/bench_default.json 2> $O/bench_default.err || exit 1
@@ -16,12 +16,14 @@ echo "default done"; cut -c1-300 $O/bench_default.json
 for a in "--limits ref" "--limits ref30 --batch 200000" "--switch-only --batch 100000" "--switch-only --batch 100000 --end-limit" "--switch-only" \
          "--switch-only --end-limit" "--switch-only --limits ref" \
          "--switch-only --batch 100000 --in-flight 2 --steps 40 --warmup 4" "--switch-only --in-flight 2 --steps 20 --warmup 4" \
-         "--max-samples 256" "--max-samples 256 --table-pass off" "--max-samples 64" "--max-samples 64 --no-pair-items" "--max-samples 32" \
-         "--max-samples 32 --no-pair-items" "--max-samples 16" "--max-samples 16 --no-pair-items" "--f32 --max-samples 128" "--f32 --max-samples 128 --no-pair-items" \
-         "--receding 10:100 --max-samples 64" "--sample-stride 4" "--f32" "--f32 --limits ref" \
-         "--f32 --max-samples 256" "--f32 --max-samples 256 --table-pass off" "--f32 --max-samples 1024" "--envelope 64:32" \
+         "--max-samples 256" "--max-samples 256 --no-walk" "--max-samples 256 --table-pass off" "--max-samples 128" "--max-samples 128 --no-walk" \
+         "--max-samples 64" "--max-samples 64 --no-walk" "--max-samples 64 --no-walk --no-pair-items" "--max-samples 32" "--max-samples 32 --no-walk" \
+         "--max-samples 32 --no-walk --no-pair-items" "--max-samples 16" "--max-samples 16 --no-walk" "--max-samples 16 --no-walk --no-pair-items" \
+         "--f32 --max-samples 128" "--f32 --max-samples 128 --no-walk" "--f32 --max-samples 128 --no-walk --no-pair-items" \
+         "--receding 10:100 --max-samples 64" "--receding 10:100 --max-samples 64 --no-walk" "--sample-stride 4" "--f32" "--f32 --limits ref" \
+         "--f32 --max-samples 256" "--f32 --max-samples 256 --table-pass off" "--f32 --max-samples 1024" "--f32 --max-samples 1024 --no-walk" "--envelope 64:32" \
          "--envelope 64:32 --table-pass off" "--envelope 64:32 --limits ref" "--receding 10:100" "--receding 10:100 --end-limit" \
-         "--receding 10:100 --max-samples 128" "--receding 10:100 --max-samples 128 --table-pass off" "--tile-gib 64" "--layout joint_major" \
+         "--receding 10:100 --max-samples 128" "--receding 10:100 --max-samples 128 --no-walk" "--receding 10:100 --max-samples 128 --table-pass off" "--tile-gib 64" "--layout joint_major" \
          "--semantics matlab --steps 3" "--semantics matlab --limits ref --steps 2" "--semantics matlab --switch-only --batch 100000 --steps 30 --warmup 3" \
          "--semantics matlab --switch-only --batch 100000 --limits ref --steps 30 --warmup 3" "--semantics matlab --envelope 64:32" \
          "--gpus 8 --one-process --device 0 --global-batch 10000000 --switch-only --end-limit --checksum --steps 5" \
@@ -60,10 +62,13 @@ done
 echo "switching-times stats passes done"
 SQ="SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU"
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d $O/prof_sq_first256 -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary --max-samples 256 > $O/prof_sq_first256.log 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d $O/prof_sq_first256_tab -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary --max-samples 256 --no-walk > $O/prof_sq_first256_tab.log 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d $O/prof_sq_first64 -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary --max-samples 64 > $O/prof_sq_first64.log 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d $O/prof_sq_first64_tab -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary --max-samples 64 --no-walk > $O/prof_sq_first64_tab.log 2>&1 || exit 1
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d $O/prof_sq_switch100k -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary --switch-only --batch 100000 > $O/prof_sq_switch100k.log 2>&1 || exit 1
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d $O/prof_sq_f32 -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-secondary --f32 > $O/prof_sq_f32.log 2>&1 || exit 1
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d $O/prof_sq_envelope -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-secondary --envelope 64:32 > $O/prof_sq_envelope.log 2>&1 || exit 1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_f32_stats -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary --f32 > $O/prof_f32_stats.log 2>&1 || exit 1
 echo "SQ counter passes done"
 # keep only the small CSVs
-find $O/prof_stats $O/prof_write $O/prof_fetch $O/prof_tab_stats $O/prof_switch_100000 $O/prof_switch_1000000 $O/prof_sq_first256 $O/prof_sq_switch100k $O/prof_sq_f32 $O/prof_sq_envelope $O/prof_f32_stats -type f ! -name "*_kernel_stats.csv" ! -name "*_counter_collection.csv" -delete
+find $O/prof_stats $O/prof_write $O/prof_fetch $O/prof_tab_stats $O/prof_switch_100000 $O/prof_switch_1000000 $O/prof_sq_first256 $O/prof_sq_first256_tab $O/prof_sq_first64 $O/prof_sq_first64_tab $O/prof_sq_switch100k $O/prof_sq_f32 $O/prof_sq_envelope $O/prof_f32_stats -type f ! -name "*_kernel_stats.csv" ! -name "*_counter_collection.csv" -delete
