@@ -645,6 +645,10 @@ def main():
                  dict(switch_only=True, in_flight=2, steps=max(args.steps, 20), warmup=4)),
                 ("configs[4]: 1 M x 30-DoF (S-ref30), full sampling through the reused tile",
                  dict(limits="ref30", steps=few, warmup=1)),
+                ("first 256 samples of every row (SURVEY §8(f).2): k_sample_walk, run tables kept in the compute unit",
+                 dict(max_samples=256, steps=max(args.steps, 5), warmup=1)),
+                ("receding horizon (SURVEY §8(f).1): 10 cycles per step through 128-sample rows, replan from stored sample 100",
+                 dict(receding="10:100", max_samples=128, steps=few, warmup=1)),
             ]
         else:
             plans = [(f"configs[3]: 10 M x 7-DoF queries sharded over {world} GPUs, full sampling",

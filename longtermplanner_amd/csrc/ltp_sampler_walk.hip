@@ -15,7 +15,8 @@
 //     wave leave.
 // No table traffic, no table launch; the only global reads are the 13 record words per (plan, joint). A batch is normally COMPACT
 // (9 consecutive 7-DoF plans, the first kWalkRuns = 8 runs per lane); when one of its lanes has more runs inside the cap —
-// trajectories that end inside the cap: a few per million of random queries, most plans in the tail of a receding-horizon loop —
+// a few per million of random queries, up to 4 % of the plans (a third of the batches) in the later cycles of a receding-horizon
+// loop, tools/wide_batch_fraction.py —
 // the builder rebuilds the same plans as WIDE batches (4 plans, all 20 runs per lane) in the same buffers. Rows are bit-identical
 // to every other sampler's: same run walk, same run_coef / run_eval (include/ltp_run_tables.hpp).
 // C++ semantics only (the MATLAB mode keeps the table pass).
@@ -210,8 +211,8 @@ LTP_DEV void sample_walk_body(long long first, long long count, int dof, double 
         return;
     }
     // ---- builder wave: ordinary loads and LDS stores. A queue item is a COMPACT batch of ppb consecutive plans; if one of its lanes
-    // has more than kWalkRuns runs inside the cap (trajectories that end inside it: the tail of a receding-horizon loop is full of
-    // them), the same plans are built again as WIDE batches of wpb plans each, every run kept. The walk is one long dependent chain
+    // has more than kWalkRuns runs inside the cap (plans that restart mid-motion close to their goal, trajectories that end inside
+    // the cap), the same plans are built again as WIDE batches of wpb plans each, every run kept. The walk is one long dependent chain
     // on a SIMD it shares with streaming waves that wait for the memory system anyway: it runs at raised issue priority. ----
     __builtin_amdgcn_s_setprio(3);
     const int lane = (int)(threadIdx.x & 63);

@@ -138,16 +138,24 @@ def test_full_size_short_rows_table_pass_equals_fused_sampler(name, N, cap, f32)
     q[1][123456 % N, 0] = 99.0                                   # a rejected plan
     ltp.setMaxSamples(cap)
     got = {}
-    for mode in ("fused", "tables"):
+    for mode in ("fused", "tables", "default"):
         b = ltp.planSwitchTimesBatch(*q)
         total = int(b.offsets[-1].item())
         tile = torch.full((total,), 7.0, dtype=torch.float32 if f32 else torch.float64, device="cuda")
-        ltp.sampleBatch(b, 0, N, tile, tables=(mode == "tables"))
+        kw = {} if mode == "default" else dict(tables=(mode == "tables"), walk=False)
+        ltp.sampleBatch(b, 0, N, tile, **kw)
         torch.cuda.synchronize()
-        assert ltp.lastSamplerKernel().startswith("k_sample_tab") == (mode == "tables")
+        kern = ltp.lastSamplerKernel()
+        # what the library takes by itself for capped rows: the walk kernel (tables kept in the compute unit) up to 28 joints, the
+        # table pass beyond
+        if mode == "default":
+            assert kern.startswith("k_sample_walk" if D <= 28 else "k_sample_tab"), kern
+        else:
+            assert kern.startswith("k_sample_tab") == (mode == "tables"), (mode, kern)
         got[mode] = (tile, b.status.clone(), b.traj_len.clone())
-    for a, w in zip(got["tables"], got["fused"]):
-        assert torch.equal(a, w)
+    for mode in ("tables", "default"):
+        for a, w in zip(got[mode], got["fused"]):
+            assert torch.equal(a, w), mode
     assert int((got["fused"][1] == 0).sum().item()) > 0.99 * N
     del got
     ltp.setMaxSamples(0)
@@ -158,3 +166,36 @@ def test_full_size_short_rows_table_pass_equals_fused_sampler(name, N, cap, f32)
         env[mode] = ltp.envelopeBatch(b, 0, N, 64, 16).clone()
     torch.cuda.synchronize()
     assert torch.equal(env["tables"].nan_to_num(5.0), env["fused"].nan_to_num(5.0))
+
+
+def test_full_size_receding_horizon_through_rows_walk_kernel_equals_fused():
+    """Ten receding-horizon cycles of 1 M plans through 128-sample rows, as bench.py --receding 10:100 --max-samples 128 runs them:
+    every cycle's rows (k_sample_walk by default; plans that restart mid-motion and trajectories that end inside the cap bring wide batches)
+    must equal the fused sampler's rows of the same cycle bit for bit, and so must the restart states."""
+    import torch
+    import longtermplanner_amd as amd
+    D, lim = amd.limit_set("panda")
+    N = 1_000_000
+    ltp = amd.LongTermPlanner(D, 0.001, device=0, **lim)
+    qg, q0, v0, a0 = ltp.generateQueries(N, seed=4711)
+    ltp.setMaxSamples(128)
+    s0, s1, s2 = q0, v0, a0
+    wide_cycles = 0
+    for cycle in range(10):
+        b = ltp.planSwitchTimesBatch(qg, s0, s1, s2)
+        total = int(b.offsets[-1].item())
+        t_walk = torch.full((total,), 7.0, dtype=torch.float64, device="cuda")
+        t_fused = torch.full((total,), 7.0, dtype=torch.float64, device="cuda")
+        ltp.sampleBatch(b, 0, N, t_walk)
+        assert ltp.lastSamplerKernel().startswith("k_sample_walk")
+        st_walk = b.status.clone()
+        b2 = ltp.planSwitchTimesBatch(qg, s0, s1, s2)
+        ltp.sampleBatch(b2, 0, N, t_fused, tables=False, walk=False)
+        assert ltp.lastSamplerKernel() == "k_sample"
+        torch.cuda.synchronize()
+        assert torch.equal(t_walk, t_fused), cycle
+        assert torch.equal(st_walk, b2.status) and torch.equal(b.traj_len, b2.traj_len), cycle
+        wide_cycles += int(((b.traj_len > 0) & (b.traj_len <= 128)).sum().item())
+        s0, s1, s2 = ltp.replanStates(b, 0, N, t_walk, 100)
+        del t_walk, t_fused
+    assert wide_cycles >= 1000, "hardly any trajectory ended inside the cap: the wide batches were not exercised at scale"
