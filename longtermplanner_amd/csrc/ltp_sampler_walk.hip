@@ -17,7 +17,8 @@
 // (9 consecutive 7-DoF plans, the first kWalkRuns = 8 runs per lane); when one of its lanes has more runs inside the cap —
 // a few per million of random queries, up to 4 % of the plans (a third of the batches) in the later cycles of a receding-horizon
 // loop, tools/wide_batch_fraction.py —
-// the builder rebuilds the same plans as WIDE batches (4 plans, all 20 runs per lane) in the same buffers. Rows are bit-identical
+// the builder rebuilds the same plans as WIDE batches (4 plans, all 20 runs per lane; beyond 28 joints: 28 joints of one plan at a
+// time) in the same buffers. Rows are bit-identical
 // to every other sampler's: same run walk, same run_coef / run_eval (include/ltp_run_tables.hpp).
 // C++ semantics only (the MATLAB mode keeps the table pass).
 #include "ltp_sampler_lds.hpp"
@@ -52,9 +53,11 @@ struct WalkBatch {
     };
     unsigned long long rel0;                                  // element offset in `out` of the first row of the batch's first sampled plan
     unsigned long long span;                                  // elements from rel0 to the end of the batch's last sampled plan
-    int nplans;                                               // plans in the batch (slots = nplans * dof)
+    int nplans;                                               // plans in the batch
     int done;                                                 // 1 = the queue is exhausted
     int wide;                                                 // which member of the union holds the batch
+    int j0, nj;                                               // the batch holds joints [j0, j0 + nj) of each of its plans (slots = nplans * nj):
+                                                              // all of them, except in wide batches of more than kWideLanes joints
     int pad;
     int slen[kWalkMaxPlans];                                  // stored samples per row of plan k of the batch; 0 = nothing to stream
     unsigned rel[kWalkMaxPlans];                              // row offset of plan k relative to rel0, in units of kRowAlign elements
@@ -62,11 +65,11 @@ struct WalkBatch {
 static_assert(kWalkBuffers * sizeof(WalkBatch) <= 53 * 1024, "three blocks per compute unit");
 
 // rows this kernel takes: capped at <= 1024 stored samples (a batch's rows lie behind one buffer descriptor with 32-bit offsets; the
-// automatic choice sends it what the table pass used to get: <= 256 float64 / 1024 float32 samples), at most 28 joints (a wide
-// batch holds at least one plan)
+// automatic choice sends it what the table pass used to get: <= 256 float64 / 1024 float32 samples), at most 63 joints (a compact
+// batch holds at least one plan; a wide batch holds whole plans up to 28 joints, and 28 joints of one plan at a time beyond that)
 bool sample_walk_applies(int dof, RowSpec rows)
 {
-    return dof >= 1 && dof <= kWideLanes && rows.max_samples > 0 && rows.max_samples <= 1024;
+    return dof >= 1 && dof <= kWalkLanes && rows.max_samples > 0 && rows.max_samples <= 1024;
 }
 
 template <bool STREAMING, typename T, class Slot>
@@ -79,7 +82,8 @@ LTP_DEV void walk_stream(const WalkBatch& B, const Slot* __restrict__ slots, int
     const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
     const int sstride = rows.stride > 1 ? rows.stride : 1;
     const int nplans = __builtin_amdgcn_readfirstlane(B.nplans);
-    const int total = nplans * dof;
+    const int nj = __builtin_amdgcn_readfirstlane(B.nj), j0 = __builtin_amdgcn_readfirstlane(B.j0);
+    const int total = nplans * nj;
     // lanes per row: the cap bounds every row of the call (wave-uniform, the same in every batch)
     const int max_slots = (rows.max_samples + N - 1) / N;
     const int lg = max_slots > 32 ? 6 : (max_slots > 16 ? 5 : 4);
@@ -89,7 +93,7 @@ LTP_DEV void walk_stream(const WalkBatch& B, const Slot* __restrict__ slots, int
     for (int s0 = wave * rows_per_pass; s0 < total; s0 += kWalkStreamWaves * rows_per_pass) {
         const int s = s0 + (lane >> lg);                                          // this lane's (plan, joint) slot
         const bool in = s < total;
-        const int pl = in ? s / dof : 0, j = in ? s - pl * dof : 0;
+        const int pl = in ? s / nj : 0, j = in ? j0 + (s - pl * nj) : 0;
         const int slen = in ? B.slen[pl] : 0;
         if (__builtin_amdgcn_ballot_w64(slen > 0) == 0ull) continue;
         const unsigned stride = ((unsigned)slen + (kRowAlign - 1)) / kRowAlign * kRowAlign;
@@ -217,7 +221,8 @@ LTP_DEV void sample_walk_body(long long first, long long count, int dof, double 
     __builtin_amdgcn_s_setprio(3);
     const int lane = (int)(threadIdx.x & 63);
     const int ppb = (kWalkLanes / dof) < kWalkMaxPlans ? (kWalkLanes / dof) : kWalkMaxPlans;      // plans per compact batch
-    const int wpb = kWideLanes / dof;                                                             // plans per wide batch (>= 1)
+    const int wpb = kWideLanes / dof > 1 ? kWideLanes / dof : 1;                                  // plans per wide batch
+    const int wide_nj = dof < kWideLanes ? dof : kWideLanes;                                      // joints per plan of a wide batch
     const long long nbatches = (count + ppb - 1) / ppb;
     const long long per = (nbatches + spread - 1) / spread;
     const unsigned long long total = (unsigned long long)per * (unsigned long long)spread;
@@ -246,10 +251,10 @@ LTP_DEV void sample_walk_body(long long first, long long count, int dof, double 
         pb = bi * ppb;
         np = bi < nbatches ? (int)((count - pb) < ppb ? (count - pb) : ppb) : 0;
     };
-    // issues the loads of lane (plan pb + lane / dof, joint lane % dof) of a batch of np plans; nothing here waits
-    auto load_lane = [&](long long pb, int np) -> WalkLaneIn {
+    // issues the loads of lane (plan pb + lane / nj, joint j0 + lane % nj) of a batch of np plans; nothing here waits
+    auto load_lane = [&](long long pb, int np, int j0, int nj) -> WalkLaneIn {
         WalkLaneIn L;
-        const int pl = lane / dof, j = lane - pl * dof;
+        const int pl = lane / nj, j = j0 + (lane - pl * nj);
         L.len = 0;
         if (pl < np) {
             const long long p = first + pb + pl;
@@ -262,19 +267,19 @@ LTP_DEV void sample_walk_body(long long first, long long count, int dof, double 
         }
         return L;
     };
-    // builds and publishes one batch (np plans from local plan pb; lanes as in load_lane) into the free buffer. Returns false without
-    // publishing if a lane of a compact batch has too many runs.
-    auto build = [&](long long pb, int np, auto wide_tag) -> bool {
+    // builds and publishes one batch (joints [j0, j0 + nj) of np plans from local plan pb; lanes as in load_lane) into the free
+    // buffer. Returns false without publishing if a lane of a compact batch has too many runs.
+    auto build = [&](long long pb, int np, int j0, int nj, auto wide_tag) -> bool {
         constexpr bool WIDE = decltype(wide_tag)::value;
-        const WalkLaneIn L = load_lane(pb, np);
+        const WalkLaneIn L = load_lane(pb, np, j0, nj);
         WalkBatch& B = buf[seq % kWalkBuffers];
-        const int pl = lane / dof, j = lane - pl * dof;
+        const int pl = lane / nj, jl = lane - pl * nj;
         const bool mine = pl < np;
         const long long p = first + pb + (mine ? pl : 0);
         int slen = mine ? stored_len(L.len, rows) : 0;
         const unsigned long long stride = ((unsigned long long)slen + (kRowAlign - 1)) / kRowAlign * kRowAlign;
         if (slen > 0 && L.rel + 4ull * dof * stride > capacity) {
-            if (j == 0) atomicOr(&rec.status[p], kStatusOverflow);
+            if (jl == 0) atomicOr(&rec.status[p], kStatusOverflow);
             slen = 0;
         }
         bool too_many = false;
@@ -285,15 +290,15 @@ LTP_DEV void sample_walk_body(long long first, long long count, int dof, double 
             if (q_end < L.q_min || q_end > L.q_max) atomicOr(&rec.status[p], kStatusEndLimit);   // cc:59-61: the last sample
         }
         if (__builtin_amdgcn_ballot_w64(too_many) != 0ull) return false;
-        // plan-level header: lane (plan pl, joint 0) holds the plan's stored length and row offset
+        // plan-level header: lane (plan pl, first joint of the batch) holds the plan's stored length and row offset
         if (lane < kWalkMaxPlans) { B.slen[lane] = 0; B.rel[lane] = 0u; }
         wave_sync();
-        if (mine && j == 0) B.slen[pl] = slen;
+        if (mine && jl == 0) B.slen[pl] = slen;
         wave_sync();
         // the span of rows this batch writes: from the first sampled plan to the end of the last one (plans are neighbours in the tile)
         const int sl = lane < np ? B.slen[lane] : 0;
         const unsigned long long mask = __builtin_amdgcn_ballot_w64(sl > 0);
-        const int src = lane < np ? lane * dof : 0;                                               // lane k < np takes plan k's row offset from the plan's first joint
+        const int src = lane < np ? lane * nj : 0;                                                // lane k < np takes plan k's row offset from the plan's first lane
         const unsigned long long my_rel = ((unsigned long long)(unsigned)__shfl((int)(unsigned)(L.rel >> 32), src) << 32) |
                                           (unsigned long long)(unsigned)__shfl((int)(unsigned)L.rel, src);
         unsigned long long r_lo = 0ull, span = 0ull;
@@ -312,6 +317,8 @@ LTP_DEV void sample_walk_body(long long first, long long count, int dof, double 
             B.rel0 = r_lo;
             B.span = span;
             B.nplans = np;
+            B.j0 = j0;
+            B.nj = nj;
             B.done = 0;
             B.wide = WIDE ? 1 : 0;
         }
@@ -338,11 +345,15 @@ LTP_DEV void sample_walk_body(long long first, long long count, int dof, double 
         const int pl = lane / dof;
         const int len_here = pl < np ? rec.traj_len[first + pb + pl] : 0;
         bool wide = __builtin_amdgcn_ballot_w64(len_here > 0 && (long long)len_here <= needed_end) != 0ull;
-        if (!wide) wide = !build(pb, np, CompactTag{});
+        if (!wide) wide = !build(pb, np, 0, dof, CompactTag{});
         if (wide) {
+            bool first_sub = true;
             for (int sub = 0; sub < np; sub += wpb) {
-                if (sub > 0) wait_buffer_free();
-                (void)build(pb + sub, np - sub < wpb ? np - sub : wpb, WideTag{});
+                for (int j0 = 0; j0 < dof; j0 += wide_nj) {
+                    if (!first_sub) wait_buffer_free();
+                    first_sub = false;
+                    (void)build(pb + sub, np - sub < wpb ? np - sub : wpb, j0, dof - j0 < wide_nj ? dof - j0 : wide_nj, WideTag{});
+                }
             }
         }
     }

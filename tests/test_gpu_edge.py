@@ -950,11 +950,13 @@ def test_two_plans_per_item_sampler_gives_the_bits_of_the_other_samplers(amd, li
     assert "tab2" not in ltp.lastSamplerKernel()
 
 
-@pytest.mark.parametrize("limits,dof,n", [("panda", None, 2503), ("ref", 28, 401), ("ref", 2, 1500), ("ref", 9, 900)])
+@pytest.mark.parametrize("limits,dof,n", [("panda", None, 2503), ("ref", 28, 401), ("ref", 2, 1500), ("ref", 9, 900), ("ref", 30, 301),
+                                           ("ref", 63, 140)])
 def test_walk_sampler_keeps_its_tables_in_the_compute_unit_and_gives_the_same_rows(amd, limits, dof, n):
     """k_sample_walk_*: capped rows (<= 256 stored samples, <= 63 joints) with the run tables built by a builder wave inside the
     sampler's block — no table pass, no table traffic. It is what the library takes automatically for such rows; rows, statuses and
-    lengths must be those of the fused sampler bit for bit: every cap / stride / element type, batches of 9 / 2 / 9 / 7 plans (wide: 4 / 1 / 14 / 3),
+    lengths must be those of the fused sampler bit for bit: every cap / stride / element type, batches of 9 / 2 / 9 / 7 / 2 / 1 plans (wide: 4 / 1 / 14 / 3 plans, then 28 + 2 joints and
+    28 + 28 + 7 joints of one plan at a time),
     ranges that start anywhere, tiles too small for the last plans, rejected plans, and plans with more than 8 runs inside the cap
     (the list pass through the fused kernel)."""
     import torch
@@ -1015,13 +1017,13 @@ def test_walk_sampler_keeps_its_tables_in_the_compute_unit_and_gives_the_same_ro
 
 def test_walk_sampler_random_configurations_against_the_fused_sampler(amd):
     """A randomized differential test of k_sample_walk_* (the default writer of capped rows) against the fused sampler: 48 random
-    combinations of joints (1-28), sample time, cap (1-1024), stride (1-6), element type, batch size, sub-range, block interleave and
+    combinations of joints (1-63), sample time, cap (1-1024), stride (1-6), element type, batch size, sub-range, block interleave and
     tile size, on random limit sets (fast and slow jerk, i.e. many and few runs inside the cap) with rejected plans and short moves
     mixed in. Rows, statuses and lengths must agree bit for bit."""
     import torch
     rng = np.random.default_rng(20260401)
     for trial in range(48):
-        D = int(rng.integers(1, 29))
+        D = int(rng.integers(1, 29)) if trial % 4 else int(rng.integers(29, 64))
         ts = float(rng.choice([0.0005, 0.001, 0.002, 0.004]))
         v_max = rng.uniform(0.5, 3.0, D)
         a_max = rng.uniform(1.0, 20.0, D)
