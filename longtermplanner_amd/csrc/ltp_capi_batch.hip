@@ -79,11 +79,11 @@ static int sample_batch_any(ltp_planner* p, long long first, long long count, co
     // MATLAB semantics: the run tables always come from the table pass (k_build_tables<MATLAB>); the sampler kernels that read
     // tables do not depend on the semantics, the fused build of k_sample exists for the C++ semantics only
     const bool matlab = p->semantics == LTP_SEMANTICS_MATLAB;
-    const bool tables_wanted = matlab || (!(flags & 2) && (!p->dbg_stamps || (flags & 4)) && ((flags & 4) || (!(flags & 8) && want_table_pass(p, row_bytes, f32))));
-    // Capped rows of <= 256 samples (C++ semantics): k_sample_walk_* — the tables stay in the compute unit, no table pass at all.
-    // Taken wherever the table pass would be chosen automatically (flags bit 6 forces it, bit 5 forbids it, bit 2 = "the table-pass
-    // kernels" keeps its meaning).
-    if (!matlab && !p->dbg_stamps && !(flags & (2 | 32)) && ltp::sample_walk_applies(p->dof, rows) && ((flags & 64) || (tables_wanted && !(flags & 4)))) {
+    // C++ semantics, up to 63 joints: k_sample_walk_* — the tables stay in the compute unit, no table pass at all. Taken by itself
+    // for the rows want_walk() names (capped, float32, sparse); flags bit 6 forces it, bit 5 forbids it, bit 2 = "the table-pass
+    // kernels" and bits 2-3 = "table pass on / off" keep their meaning.
+    if (!matlab && !p->dbg_stamps && !(flags & (2 | 32)) && ltp::sample_walk_applies(p->dof, rows) &&
+        ((flags & 64) || (!(flags & (4 | 8)) && want_walk(p, rows.max_samples, rows.stride, f32)))) {
         if (p->walk_blocks[f32 ? 1 : 0] == 0) p->walk_blocks[f32 ? 1 : 0] = ltp::sample_walk_resident_blocks(p->device, f32);
         unsigned long long* head = p->d_sample_next + (p->sample_next_slot++ & 63u);
         LTP_HIP_TRY(p, hipMemsetAsync(head, 0, sizeof(unsigned long long), s));

@@ -173,6 +173,18 @@ bool want_table_pass(const ltp_planner* p, unsigned long long row_bytes, bool f3
     return row_bytes > 0 && row_bytes <= (f32 ? 16384ull : 8192ull);
 }
 
+// k_sample_walk_* (tables built inside the sampler's block) or the fused build of k_sample? Measured, 1 M panda plans
+// unless noted (profiles/r04_whole_rows_walk_ab.txt, walk vs fused in TB/s): what decides is how many bytes a plan's rows have —
+// below ~150 KB the fused sampler's per-plan build shows. First-512 float64 7.16 vs 6.16, every 3rd sample 6.71 vs 5.85, every 4th
+// 6.29 vs 4.75, float32 every 4th sample 4.64 vs 2.40, whole float32 rows 6.83 vs 6.59 (S-ref: 6.80 vs 6.88); level or just behind
+// from ~190 KB per plan: first-1024 float64 7.02 vs 7.09, every 2nd sample 6.85 vs 6.91, whole float64 rows 7.03 vs 7.08, S-ref every
+// 4th sample 6.93 vs 6.97. The lengths are not known on the host, so the rule goes by what is: the cap, the stride, the element type.
+bool want_walk(const ltp_planner* p, int max_samples, int stride, bool f32)
+{
+    if (p->table_pass != 0) return p->table_pass > 0;
+    return f32 || stride >= 3 || (max_samples > 0 && max_samples <= 768);
+}
+
 // plans per piece so that the tables of a piece fit the workspace; grows the workspace (up to tables_cap) if needed.
 // While a stream is being captured into a hipGraph nothing may be allocated or freed (and a graph that was already
 // instantiated keeps the old pointer): then the range is cut into pieces that fit the workspace as it is

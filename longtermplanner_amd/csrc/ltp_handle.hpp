@@ -97,6 +97,7 @@ int workspace_release(ltp_planner* p, hipStream_t s, bool capturing);
 void capture_geometry(ltp_planner* p);
 int check_geometry(ltp_planner* p);
 bool want_table_pass(const ltp_planner* p, unsigned long long row_bytes, bool f32);
+bool want_walk(const ltp_planner* p, int max_samples, int stride, bool f32);
 int ensure_tables(ltp_planner* p, long long count, bool capturing, long long* plans_per_piece);
 
 // device-side record arrays owned for the duration of a *_host call

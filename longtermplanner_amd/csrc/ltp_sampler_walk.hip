@@ -1,4 +1,6 @@
-// ltp_sampler_walk.hip — the sampler of CAPPED rows whose run tables never leave the compute unit (round 4), gfx950.
+// ltp_sampler_walk.hip — the sampler whose run tables never leave the compute unit (round 4), gfx950: capped rows (first-N samples,
+// receding-horizon rows), float32 rows, sparse rows — every format in which a plan's rows have too few bytes to hide the fused
+// sampler's per-plan table build (ltp_sampler.hip), and on request any format.
 //
 // The table pass (k_build_tables + k_sample_tab*) pays a round trip through HBM per plan — 3 KB of packed tables written, 3.4 KB of
 // lines read back — and the reads cost the write stream more than their bytes: that mixed pattern tops out at 5.3-5.6 TB/s of total
@@ -18,7 +20,8 @@
 // a few per million of random queries, up to 4 % of the plans (a third of the batches) in the later cycles of a receding-horizon
 // loop, tools/wide_batch_fraction.py —
 // the builder rebuilds the same plans as WIDE batches (4 plans, all 20 runs per lane; beyond 28 joints: 28 joints of one plan at a
-// time) in the same buffers. Rows are bit-identical
+// time) in the same buffers. LONG rows (no cap, or a cap beyond 1024 samples) are wide batches from the start and are streamed one
+// row per wave pass (walk_stream_rows). Rows are bit-identical
 // to every other sampler's: same run walk, same run_coef / run_eval (include/ltp_run_tables.hpp).
 // C++ semantics only (the MATLAB mode keeps the table pass).
 #include "ltp_sampler_lds.hpp"
@@ -69,16 +72,87 @@ static_assert(kWalkBuffers * sizeof(WalkBatch) <= 53 * 1024, "three blocks per c
 // batch holds at least one plan; a wide batch holds whole plans up to 28 joints, and 28 joints of one plan at a time beyond that)
 bool sample_walk_applies(int dof, RowSpec rows)
 {
-    return dof >= 1 && dof <= kWalkLanes && rows.max_samples > 0 && rows.max_samples <= 1024;
+    return dof >= 1 && dof <= kWalkLanes && rows.max_samples >= 0;
 }
 
+// LONG rows — no cap, or a cap beyond kWalkBatchCap samples: wide batches only, one row per wave pass (walk_stream_rows). Short rows: compact
+// batches, several rows per pass, one descriptor with 32-bit offsets over the batch (walk_stream).
+constexpr int kWalkBatchCap = 1024;
+__host__ __device__ inline bool walk_long_rows(RowSpec rows) { return rows.max_samples <= 0 || rows.max_samples > kWalkBatchCap; }
+
+// plans per queue item: a compact batch; for long rows two wide batches
+__host__ __device__ inline int walk_plans_per_item(int dof, RowSpec rows)
+{
+    const int compact = (kWalkLanes / dof) < kWalkMaxPlans ? (kWalkLanes / dof) : kWalkMaxPlans;
+    if (!walk_long_rows(rows)) return compact;
+    const int two_wide = 2 * (kWideLanes / dof) > 1 ? 2 * (kWideLanes / dof) : 1;
+    return two_wide < compact ? two_wide : compact;
+}
+
+// a streaming lane's place in its row's runs
+struct WalkCursor {
+    int kr, cur, nxt;                                         // run in use, its first sample, the first sample of the next run
+};
+
+// The pair of samples of one slot (stored samples i0, i0 + 1 of a row of slen; trajectory samples i * sstride) from the runs of W.
+// A slot is a PAIR for float32 rows too (8-byte stores, a wave instruction still writes 512 contiguous bytes): four samples per lane
+// in flight need 123 VGPRs, i.e. 2 blocks per CU, and lost to this form at every cap (profiles/EXPERIMENTS.md E6.7).
+template <typename T, class Slot>
+LTP_DEV void walk_eval_slot(const Slot& W, int nruns, WalkCursor& c, int i0, int sstride, int slen, double Ts, T __attribute__((ext_vector_type(2))) (&o)[4])
+{
+    constexpr int RUNS = (int)(sizeof(Slot::run) / sizeof(double) / kPackedRunWords);
+    const int t0 = i0 * sstride;
+    while (c.nxt <= t0) {
+        ++c.kr;
+        c.cur = c.nxt;
+        c.nxt = c.kr + 1 < nruns ? W.start[c.kr + 1] : 0x7fffffff;
+    }
+    // sample by sample when a run boundary or the end of the row lies inside the pair (the tail of the last slot is row padding:
+    // zero); otherwise one run, its coefficients expanded once
+    const bool single = !(t0 + sstride >= c.nxt || i0 + 2 > slen);
+    int kh = c.kr, ch = c.cur, nh = c.nxt;
+    RunCoef rc = run_coef<kSemMatlab>((int)(unsigned)__builtin_bit_cast(unsigned long long, W.run[kh][4]), W.run[kh][3], W.run[kh][0], W.run[kh][1],
+                                      W.run[kh][2], W.vsnap, Ts);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int i = t0 + h * sstride;
+        if (!single) {
+            bool moved = false;
+            while (nh <= i) {
+                ++kh;
+                ch = nh;
+                nh = kh + 1 < nruns ? W.start[kh + 1] : 0x7fffffff;
+                moved = true;
+            }
+            if (moved) {
+                const int kk = kh < RUNS ? kh : RUNS - 1;
+                rc = run_coef<kSemMatlab>((int)(unsigned)__builtin_bit_cast(unsigned long long, W.run[kk][4]), W.run[kk][3], W.run[kk][0], W.run[kk][1],
+                                          W.run[kk][2], W.vsnap, Ts);
+            }
+        }
+        const bool pad = i0 + h >= slen;
+        double x4[4];
+        run_eval(rc.c, i - ch + 1, x4[0], x4[1], x4[2], x4[3]);
+#pragma unroll
+        for (int x = 0; x < 4; ++x) o[x][h] = pad ? (T)0 : (T)x4[x];
+    }
+}
+
+template <bool STREAMING, typename V>
+LTP_DEV void walk_store(V o, __amdgpu_buffer_rsrc_t rsrc, unsigned voff)
+{
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+    if constexpr (sizeof(V) == 16) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rsrc, voff, 0, STREAMING ? /*nt | sc1*/ (2 | 16) : 0);
+    else __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), rsrc, voff, 0, STREAMING ? /*nt | sc1*/ (2 | 16) : 0);
+}
+
+// CAPPED rows: several rows per wave pass when they are short, every row of the batch behind one descriptor
 template <bool STREAMING, typename T, class Slot>
 LTP_DEV void walk_stream(const WalkBatch& B, const Slot* __restrict__ slots, int dof, T* __restrict__ out, RowSpec rows, double Ts, int wave)
 {
-    typedef typename OutVec<T>::type V;
-    constexpr int N = OutVec<T>::N;
-    constexpr int RUNS = (int)(sizeof(Slot::run) / sizeof(double) / kPackedRunWords);
-    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    constexpr int N = 2;
+    typedef T V __attribute__((ext_vector_type(N)));                                  // what a lane stores per array and slot: 16 or 8 bytes
     const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
     const int sstride = rows.stride > 1 ? rows.stride : 1;
     const int nplans = __builtin_amdgcn_readfirstlane(B.nplans);
@@ -99,52 +173,60 @@ LTP_DEV void walk_stream(const WalkBatch& B, const Slot* __restrict__ slots, int
         const unsigned stride = ((unsigned)slen + (kRowAlign - 1)) / kRowAlign * kRowAlign;
         const unsigned arr_bytes = (unsigned)dof * stride * (unsigned)sizeof(T);
         const unsigned row_bytes = (B.rel[pl] * (unsigned)kRowAlign + (unsigned)j * stride) * (unsigned)sizeof(T);   // q row, bytes from the descriptor base
-        const int nslots = slen > 0 ? (slen + N - 1) / N : 0;
+        constexpr int NF = OutVec<T>::N;                                          // the other samplers' slot: rows are zero-padded to its end
+        const int nslots = slen > 0 ? (slen + NF - 1) / NF * (NF / N) : 0;
         const Slot& W = slots[in ? s : 0];
         const int nruns = W.nseg;
-        int kr = 0, cur = 0, nxt = nruns > 1 ? W.start[1] : 0x7fffffff;
+        WalkCursor c = {0, 0, nruns > 1 ? W.start[1] : 0x7fffffff};
         for (int slot = lane & ((1 << lg) - 1); slot < nslots; slot += 1 << lg) {
-            const int i0 = N * slot;
-            const int t0 = i0 * sstride;
-            while (nxt <= t0) {
-                ++kr;
-                cur = nxt;
-                nxt = kr + 1 < nruns ? W.start[kr + 1] : 0x7fffffff;
-            }
             V o[4];
-            // sample by sample when a run boundary or the end of the row lies inside the slot (the tail of the last slot is row
-            // padding: zero); otherwise one run, its coefficients expanded once
-            const bool single = !(t0 + (N - 1) * sstride >= nxt || i0 + N > slen);
-            int kh = kr, ch = cur, nh = nxt;
-            RunCoef rc = run_coef<kSemMatlab>((int)(unsigned)__builtin_bit_cast(unsigned long long, W.run[kr][4]), W.run[kr][3], W.run[kr][0], W.run[kr][1],
-                                              W.run[kr][2], W.vsnap, Ts);
+            walk_eval_slot<T, Slot>(W, nruns, c, N * slot, sstride, slen, Ts, o);
+            const unsigned voff = row_bytes + (unsigned)(N * slot) * (unsigned)sizeof(T);
 #pragma unroll
-            for (int h = 0; h < N; ++h) {
-                const int i = t0 + h * sstride;
-                if (!single) {
-                    bool moved = false;
-                    while (nh <= i) {
-                        ++kh;
-                        ch = nh;
-                        nh = kh + 1 < nruns ? W.start[kh + 1] : 0x7fffffff;
-                        moved = true;
-                    }
-                    if (moved) {
-                        const int kk = kh < RUNS ? kh : RUNS - 1;
-                        rc = run_coef<kSemMatlab>((int)(unsigned)__builtin_bit_cast(unsigned long long, W.run[kk][4]), W.run[kk][3], W.run[kk][0], W.run[kk][1],
-                                                  W.run[kk][2], W.vsnap, Ts);
-                    }
-                }
-                const bool pad = i0 + h >= slen;
-                double x4[4];
-                run_eval(rc.c, i - ch + 1, x4[0], x4[1], x4[2], x4[3]);
-#pragma unroll
-                for (int x = 0; x < 4; ++x) o[x][h] = pad ? (T)0 : (T)x4[x];
-            }
-            const unsigned voff = row_bytes + (unsigned)i0 * (unsigned)sizeof(T);
+            for (int x = 0; x < 4; ++x) walk_store<STREAMING>(o[x], rsrc, voff + (unsigned)x * arr_bytes);
+        }
+    }
+}
+
+// LONG rows (no cap, or a cap beyond kWalkBatchCap): wide batches only, one (plan, joint) row per wave pass, per row and array a
+// descriptor over a window of the row (as stream_rows of the fused sampler: rows may be longer than 32-bit offsets reach)
+constexpr int kWalkWindowSlots = 1 << 24;
+template <bool STREAMING, typename T>
+LTP_DEV void walk_stream_rows(const WalkBatch& B, int dof, T* __restrict__ out, RowSpec rows, double Ts, int wave)
+{
+    constexpr int N = 2;
+    typedef T V __attribute__((ext_vector_type(N)));
+    const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const int sstride = rows.stride > 1 ? rows.stride : 1;
+    const int nplans = __builtin_amdgcn_readfirstlane(B.nplans);
+    const int nj = __builtin_amdgcn_readfirstlane(B.nj), j0 = __builtin_amdgcn_readfirstlane(B.j0);
+    const int total = nplans * nj;
+    const unsigned long long rel0 = B.rel0;
+    for (int s = wave; s < total; s += kWalkStreamWaves) {                        // (wave-uniform: scalar arithmetic below)
+        const int pl = s / nj, j = j0 + (s - pl * nj);
+        const int slen = __builtin_amdgcn_readfirstlane(B.slen[pl]);
+        if (slen <= 0) continue;
+        const unsigned long long stride = ((unsigned long long)slen + (kRowAlign - 1)) / kRowAlign * kRowAlign;
+        const unsigned long long arr = (unsigned long long)dof * stride;
+        T* row = out + rel0 + (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)B.rel[pl]) * kRowAlign + (unsigned long long)j * stride;
+        constexpr int NF = OutVec<T>::N;
+        const int nslots = (slen + NF - 1) / NF * (NF / N);
+        const WideSlot& W = B.wslot[s];
+        const int nruns = __builtin_amdgcn_readfirstlane(W.nseg);
+        WalkCursor c = {0, 0, nruns > 1 ? W.start[1] : 0x7fffffff};
+        for (int wbase = 0; wbase < nslots; wbase += kWalkWindowSlots) {
+            const int wend = nslots - wbase < kWalkWindowSlots ? nslots : wbase + kWalkWindowSlots;
+            __amdgpu_buffer_rsrc_t rsrc[4];
 #pragma unroll
             for (int x = 0; x < 4; ++x)
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o[x]), rsrc, voff + (unsigned)x * arr_bytes, 0, STREAMING ? /*nt | sc1*/ (2 | 16) : 0);
+                rsrc[x] = __builtin_amdgcn_make_buffer_rsrc(row + x * arr + (unsigned long long)wbase * N, 0, (wend - wbase) * (int)sizeof(V), 0x00020000);
+            for (int slot = wbase + lane; slot < wend; slot += 64) {
+                V o[4];
+                walk_eval_slot<T, WideSlot>(W, nruns, c, N * slot, sstride, slen, Ts, o);
+                const unsigned voff = (unsigned)(slot - wbase) * (unsigned)sizeof(V);
+#pragma unroll
+                for (int x = 0; x < 4; ++x) walk_store<STREAMING>(o[x], rsrc[x], voff);
+            }
         }
     }
 }
@@ -207,7 +289,8 @@ LTP_DEV void sample_walk_body(long long first, long long count, int dof, double 
             const int b = seq % kWalkBuffers;
             while (__hip_atomic_load(&s_ready[b], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != seq + 1) __builtin_amdgcn_s_sleep(1);
             if (__builtin_amdgcn_readfirstlane(buf[b].done)) break;
-            if (__builtin_amdgcn_readfirstlane(buf[b].wide)) walk_stream<STREAMING, T, WideSlot>(buf[b], buf[b].wslot, dof, out, rows, t_sample, wave);
+            if (walk_long_rows(rows)) walk_stream_rows<STREAMING, T>(buf[b], dof, out, rows, t_sample, wave);
+            else if (__builtin_amdgcn_readfirstlane(buf[b].wide)) walk_stream<STREAMING, T, WideSlot>(buf[b], buf[b].wslot, dof, out, rows, t_sample, wave);
             else walk_stream<STREAMING, T, WalkSlot>(buf[b], buf[b].slot, dof, out, rows, t_sample, wave);
             // (release orders the wave's LDS reads of buf[b]; its row stores carry their data in registers)
             if ((threadIdx.x & 63) == 0) __hip_atomic_store(&s_consumed[wave], seq + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -220,7 +303,7 @@ LTP_DEV void sample_walk_body(long long first, long long count, int dof, double 
     // on a SIMD it shares with streaming waves that wait for the memory system anyway: it runs at raised issue priority. ----
     __builtin_amdgcn_s_setprio(3);
     const int lane = (int)(threadIdx.x & 63);
-    const int ppb = (kWalkLanes / dof) < kWalkMaxPlans ? (kWalkLanes / dof) : kWalkMaxPlans;      // plans per compact batch
+    const int ppb = walk_plans_per_item(dof, rows);                                               // plans per queue item = per compact batch
     const int wpb = kWideLanes / dof > 1 ? kWideLanes / dof : 1;                                  // plans per wide batch
     const int wide_nj = dof < kWideLanes ? dof : kWideLanes;                                      // joints per plan of a wide batch
     const long long nbatches = (count + ppb - 1) / ppb;
@@ -228,7 +311,8 @@ LTP_DEV void sample_walk_body(long long first, long long count, int dof, double 
     const unsigned long long total = (unsigned long long)per * (unsigned long long)spread;
     const unsigned long long off0 = offsets[first];
     const int sstride = rows.stride > 1 ? rows.stride : 1;
-    const long long needed_end = (long long)rows.max_samples * sstride;                          // runs that start at or after this sample are not needed
+    const bool long_rows = walk_long_rows(rows);
+    const long long needed_end = rows.max_samples > 0 ? (long long)rows.max_samples * sstride : 0x7fffffffffffffffll;   // runs that start at or after this sample are not needed
     int seq = 0;
     auto wait_buffer_free = [&]() {
         if (seq < kWalkBuffers) return;
@@ -344,7 +428,7 @@ LTP_DEV void sample_walk_body(long long first, long long count, int dof, double 
         // a plan whose whole trajectory lies inside the cap has (nearly always) more than kWalkRuns runs there: straight to wide
         const int pl = lane / dof;
         const int len_here = pl < np ? rec.traj_len[first + pb + pl] : 0;
-        bool wide = __builtin_amdgcn_ballot_w64(len_here > 0 && (long long)len_here <= needed_end) != 0ull;
+        bool wide = long_rows || __builtin_amdgcn_ballot_w64(len_here > 0 && (long long)len_here <= needed_end) != 0ull;
         if (!wide) wide = !build(pb, np, 0, dof, CompactTag{});
         if (wide) {
             bool first_sub = true;
@@ -359,18 +443,18 @@ LTP_DEV void sample_walk_body(long long first, long long count, int dof, double 
     }
 }
 
-#define LTP_WALK_KERNEL(NAME, ST, TY, WAVES)                                                                                          \
-    __global__ void __launch_bounds__(kWalkThreads) __attribute__((amdgpu_waves_per_eu(WAVES, 8)))                                    \
+#define LTP_WALK_KERNEL(NAME, ST, TY)                                                                                          \
+    __global__ void __launch_bounds__(kWalkThreads) __attribute__((amdgpu_waves_per_eu(6, 8)))                                    \
     NAME(long long first, long long count, int dof, double t_sample, Limits lim, Queries in, Records rec,                             \
          const unsigned long long* __restrict__ offsets, TY* __restrict__ out, unsigned long long capacity, int spread, RowSpec rows, \
          unsigned long long* __restrict__ next_item)                                                                                  \
     {                                                                                                                                 \
         sample_walk_body<ST, TY>(first, count, dof, t_sample, lim, in, rec, offsets, out, capacity, spread, rows, next_item);         \
     }
-LTP_WALK_KERNEL(k_sample_walk_f64, false, double, 6)
-LTP_WALK_KERNEL(k_sample_walk_f64_nt, true, double, 6)
-LTP_WALK_KERNEL(k_sample_walk_f32, false, float, 4)      // four samples per lane in flight: at 80 VGPRs the streaming loop spills
-LTP_WALK_KERNEL(k_sample_walk_f32_nt, true, float, 4)
+LTP_WALK_KERNEL(k_sample_walk_f64, false, double)
+LTP_WALK_KERNEL(k_sample_walk_f64_nt, true, double)
+LTP_WALK_KERNEL(k_sample_walk_f32, false, float)
+LTP_WALK_KERNEL(k_sample_walk_f32_nt, true, float)
 #undef LTP_WALK_KERNEL
 
 int sample_walk_resident_blocks(int device, bool f32)
@@ -388,7 +472,7 @@ void launch_sample_walk(hipStream_t s, long long first, long long count, int dof
                         unsigned long long* next_item, int resident_blocks)
 {
     if (count <= 0) return;
-    const int ppb = (kWalkLanes / dof) < kWalkMaxPlans ? (kWalkLanes / dof) : kWalkMaxPlans;
+    const int ppb = walk_plans_per_item(dof, rows);
     const long long nbatches = (count + ppb - 1) / ppb;
     int spread = (flags >> 8) & 0xFFFF;
     if (spread == 0) spread = kSampleSpread;

@@ -953,7 +953,7 @@ def test_two_plans_per_item_sampler_gives_the_bits_of_the_other_samplers(amd, li
 @pytest.mark.parametrize("limits,dof,n", [("panda", None, 2503), ("ref", 28, 401), ("ref", 2, 1500), ("ref", 9, 900), ("ref", 30, 301),
                                            ("ref", 63, 140)])
 def test_walk_sampler_keeps_its_tables_in_the_compute_unit_and_gives_the_same_rows(amd, limits, dof, n):
-    """k_sample_walk_*: capped rows (<= 256 stored samples, <= 63 joints) with the run tables built by a builder wave inside the
+    """k_sample_walk_*: capped rows (<= 63 joints) with the run tables built by a builder wave inside the
     sampler's block — no table pass, no table traffic. It is what the library takes automatically for such rows; rows, statuses and
     lengths must be those of the fused sampler bit for bit: every cap / stride / element type, batches of 9 / 2 / 9 / 7 / 2 / 1 plans (wide: 4 / 1 / 14 / 3 plans, then 28 + 2 joints and
     28 + 28 + 7 joints of one plan at a time),
@@ -993,31 +993,26 @@ def test_walk_sampler_keeps_its_tables_in_the_compute_unit_and_gives_the_same_ro
             for k, (got, want) in enumerate(zip(res[mode], res["fused"])):
                 assert torch.equal(got, want), (cap, stride, f32, mode, k)
         assert (res["fused"][5] & 32).any(), "the small tile did not leave any plan out"
-    ltp.setMaxSamples(257)                                      # float64 rows beyond 8 KB: the fused sampler by default, the walk kernel on request
-    b = ltp.planSwitchTimesBatch(qg, q0, v0, a0)
-    t0 = torch.full((int(b.offsets[-1].item()),), 3.0, dtype=torch.float64, device="cuda")
-    ltp.sampleBatch(b, 0, n, t0)
-    assert "walk" not in ltp.lastSamplerKernel()
-    t1 = torch.full_like(t0, 3.0)
-    ltp.sampleBatch(b, 0, n, t1, walk=True)
-    assert "walk" in ltp.lastSamplerKernel() and torch.equal(t0, t1)
-    ltp.setMaxSamples(1024)                                     # float32 rows up to 16 KB: the walk kernel by default
-    b = ltp.planSwitchTimesBatch(qg, q0, v0, a0)
-    f0 = torch.full((int(b.offsets[-1].item()),), 3.0, dtype=torch.float32, device="cuda")
-    f1 = torch.full_like(f0, 3.0)
-    ltp.sampleBatch(b, 0, n, f0)
-    assert "walk" in ltp.lastSamplerKernel()
-    ltp.sampleBatch(b, 0, n, f1, tables=False, walk=False)
-    assert ltp.lastSamplerKernel() == "k_sample" and torch.equal(f0, f1)
-    ltp.setMaxSamples(1025)
-    b = ltp.planSwitchTimesBatch(qg, q0, v0, a0)
-    ltp.sampleBatch(b, 0, n, torch.empty(int(b.offsets[-1].item()), dtype=torch.float32, device="cuda"), walk=True)
-    assert "walk" not in ltp.lastSamplerKernel()
+    # what the library takes by itself (want_walk): caps up to 768 samples, float32 rows, every 3rd sample or sparser -> the walk
+    # kernel; whole or long float64 rows at stride 1-2 -> the fused sampler. Either can be forced; the rows are the same.
+    for cap, stride, f32, walk_by_default in ((257, 1, False, True), (768, 2, False, True), (769, 1, False, False), (1025, 1, False, False), (1025, 1, True, True),
+                                              (0, 1, False, False), (0, 2, False, False), (0, 3, False, True), (0, 1, True, True), (3000, 5, False, True)):
+        ltp.setMaxSamples(cap); ltp.setSampleStride(stride)
+        b = ltp.planSwitchTimesBatch(qg, q0, v0, a0)
+        dt = torch.float32 if f32 else torch.float64
+        t0 = torch.full((int(b.offsets[-1].item()),), 3.0, dtype=dt, device="cuda")
+        ltp.sampleBatch(b, 0, n, t0)
+        assert ("walk" in ltp.lastSamplerKernel()) == walk_by_default, (cap, stride, f32, ltp.lastSamplerKernel())
+        t1 = torch.full_like(t0, 3.0)
+        ltp.sampleBatch(b, 0, n, t1, **(dict(tables=False, walk=False) if walk_by_default else dict(walk=True)))
+        assert ("walk" in ltp.lastSamplerKernel()) == (not walk_by_default), (cap, stride, f32, ltp.lastSamplerKernel())
+        assert torch.equal(t0, t1), (cap, stride, f32)
+        del t0, t1
 
 
 def test_walk_sampler_random_configurations_against_the_fused_sampler(amd):
     """A randomized differential test of k_sample_walk_* (the default writer of capped rows) against the fused sampler: 48 random
-    combinations of joints (1-63), sample time, cap (1-1024), stride (1-6), element type, batch size, sub-range, block interleave and
+    combinations of joints (1-63), sample time, cap (1-2500), stride (1-6), element type, batch size, sub-range, block interleave and
     tile size, on random limit sets (fast and slow jerk, i.e. many and few runs inside the cap) with rejected plans and short moves
     mixed in. Rows, statuses and lengths must agree bit for bit."""
     import torch
@@ -1041,7 +1036,7 @@ def test_walk_sampler_random_configurations_against_the_fused_sampler(amd):
                                   torch.tensor(lim["q_max"], dtype=torch.float64, device=qg.device))
         v0[short] = 0.0
         a0[short] = 0.0
-        cap = int(rng.choice([1, 2, 7, 16, 31, 64, 100, 128, 255, 256, 500, 1024]))
+        cap = int(rng.choice([1, 2, 7, 16, 31, 64, 100, 128, 255, 256, 500, 1024, 1025, 2500]))
         stride = int(rng.integers(1, 7))
         f32 = bool(rng.integers(0, 2))
         spread = int(rng.choice([0, 1, 3, 48, 5000]))
@@ -1065,3 +1060,37 @@ def test_walk_sampler_random_configurations_against_the_fused_sampler(amd):
             res[mode] = (tile, small, b.status.clone(), b.traj_len.clone(), b2.status.clone())
         for k, (got, want) in enumerate(zip(res["walk"], res["fused"])):
             assert torch.equal(got, want), (trial, D, ts, cap, stride, f32, n, first, count, spread, k)
+
+
+@pytest.mark.parametrize("limits,dof,n", [("panda", None, 1201), ("ref", None, 400), ("ref", 30, 60), ("ref", 3, 500)])
+def test_walk_sampler_whole_rows_equal_the_fused_sampler(amd, limits, dof, n):
+    """k_sample_walk_* on request (flag bit 6) for rows WITHOUT a cap: wide batches only, one row per wave pass, windowed row
+    descriptors. Every stride / element type, a range that starts anywhere, a tile too small for the last plans, rejected plans:
+    rows, statuses and lengths are those of the fused sampler bit for bit."""
+    import torch
+    D, lim = amd.limit_set(limits, dof)
+    ltp = amd.LongTermPlanner(D, 0.001, device=0, **lim)
+    qg, q0, v0, a0 = (x.clone() for x in ltp.generateQueries(n, seed=19))
+    q0[5, 0] = 99.0; q0[6, D - 1] = 99.0; q0[n - 1, 0] = 99.0
+    ltp.setMaxSamples(0)
+    for stride, f32 in ((1, False), (2, False), (4, False), (1, True), (3, True), (7, False)):
+        ltp.setSampleStride(stride)
+        dt = torch.float32 if f32 else torch.float64
+        res = {}
+        for mode in ("fused", "walk"):
+            kw = dict(tables=False, walk=False) if mode == "fused" else dict(walk=True)
+            b = ltp.planSwitchTimesBatch(qg, q0, v0, a0)
+            full = torch.full((int(b.offsets[-1].item()),), 3.0, dtype=dt, device="cuda")
+            ltp.sampleBatch(b, 0, n, full, **kw)
+            assert ("walk" in ltp.lastSamplerKernel()) == (mode == "walk"), (mode, ltp.lastSamplerKernel())
+            sub = torch.full((int((b.offsets[n - 3] - b.offsets[11]).item()) + 8,), 3.0, dtype=dt, device="cuda")
+            ltp.sampleBatch(b, 11, n - 14, sub, spread=7, **kw)
+            b2 = ltp.planSwitchTimesBatch(qg, q0, v0, a0)
+            small = torch.full((int(b2.offsets[n // 2 + 1].item()) + 5,), 3.0, dtype=dt, device="cuda")
+            ltp.sampleBatch(b2, 0, n, small, streaming=False, spread=1, **kw)
+            torch.cuda.synchronize()
+            res[mode] = (full, sub, small, b.status.clone(), b.traj_len.clone(), b2.status.clone())
+        for k, (got, want) in enumerate(zip(res["walk"], res["fused"])):
+            assert torch.equal(got, want), (stride, f32, k)
+        assert (res["fused"][5] & 32).any(), "the small tile did not leave any plan out"
+        del res

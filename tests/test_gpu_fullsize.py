@@ -146,10 +146,10 @@ def test_full_size_short_rows_table_pass_equals_fused_sampler(name, N, cap, f32)
         ltp.sampleBatch(b, 0, N, tile, **kw)
         torch.cuda.synchronize()
         kern = ltp.lastSamplerKernel()
-        # what the library takes by itself for capped rows: the walk kernel (tables kept in the compute unit) up to 28 joints, the
+        # what the library takes by itself for capped rows: the walk kernel (tables kept in the compute unit) up to 63 joints, the
         # table pass beyond
         if mode == "default":
-            assert kern.startswith("k_sample_walk" if D <= 28 else "k_sample_tab"), kern
+            assert kern.startswith("k_sample_walk" if D <= 63 else "k_sample_tab"), kern
         else:
             assert kern.startswith("k_sample_tab") == (mode == "tables"), (mode, kern)
         got[mode] = (tile, b.status.clone(), b.traj_len.clone())
