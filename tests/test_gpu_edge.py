@@ -1,4 +1,6 @@
 """Edge cases of the batched path: empty / ragged batches, invalid and degenerate queries, tile overflow, layouts."""
+import os
+
 import numpy as np
 import pytest
 
@@ -1016,8 +1018,9 @@ def test_walk_sampler_random_configurations_against_the_fused_sampler(amd):
     tile size, on random limit sets (fast and slow jerk, i.e. many and few runs inside the cap) with rejected plans and short moves
     mixed in. Rows, statuses and lengths must agree bit for bit."""
     import torch
-    rng = np.random.default_rng(20260401)
-    for trial in range(48):
+    # (a soak: LTP_WALK_TRIALS=3000 LTP_WALK_SEED=1 python -m pytest tests/test_gpu_edge.py -k random_configurations)
+    rng = np.random.default_rng(20260401 + int(os.environ.get("LTP_WALK_SEED", "0")))
+    for trial in range(int(os.environ.get("LTP_WALK_TRIALS", "48"))):
         D = int(rng.integers(1, 29)) if trial % 4 else int(rng.integers(29, 64))
         ts = float(rng.choice([0.0005, 0.001, 0.002, 0.004]))
         v_max = rng.uniform(0.5, 3.0, D)
@@ -1094,3 +1097,37 @@ def test_walk_sampler_whole_rows_equal_the_fused_sampler(amd, limits, dof, n):
             assert torch.equal(got, want), (stride, f32, k)
         assert (res["fused"][5] & 32).any(), "the small tile did not leave any plan out"
         del res
+
+
+def test_rows_longer_than_a_descriptor_window(amd):
+    """A row of 160 M samples (Ts = 40 ns): longer than the 2^27 samples one buffer descriptor of the fused sampler spans and than the
+    2^25 of the walk kernel's long-row form — both advance a window along the row. The two samplers must agree bit for bit, and the
+    samples either side of every window boundary and the last one must be the states k_state_at computes from the records alone."""
+    import torch
+    D, lim = amd.limit_set("ref", 2)
+    ltp = amd.LongTermPlanner(D, 4e-8, device=0, **lim)
+    qg = torch.tensor([[3.0, -2.5], [0.3, 0.1]], dtype=torch.float64, device="cuda")
+    q0 = torch.tensor([[-3.0, 2.5], [0.2, 0.0]], dtype=torch.float64, device="cuda")
+    v0 = torch.zeros_like(q0)
+    a0 = torch.zeros_like(q0)
+    b = ltp.planSwitchTimesBatch(qg, q0, v0, a0)
+    L = int(b.traj_len[0].item())
+    assert L > (1 << 27) + 1000, L
+    total = int(b.offsets[-1].item())
+    tiles = {}
+    for mode in ("fused", "walk"):
+        bb = ltp.planSwitchTimesBatch(qg, q0, v0, a0)
+        t = torch.full((total,), 3.0, dtype=torch.float64, device="cuda")
+        ltp.sampleBatch(bb, 0, 2, t, **(dict(walk=True) if mode == "walk" else dict(tables=False, walk=False)))
+        assert ("walk" in ltp.lastSamplerKernel()) == (mode == "walk")
+        torch.cuda.synchronize()
+        assert int(bb.status[0].item()) & ~8 == 0
+        tiles[mode] = t
+    assert torch.equal(tiles["fused"], tiles["walk"])
+    stride = (L + 31) // 32 * 32
+    rows = tiles["walk"][: 4 * D * stride].view(4, D, stride)
+    for k in ((1 << 25) - 1, 1 << 25, (1 << 25) + 1, (1 << 26) - 1, 1 << 26, (1 << 27) - 1, 1 << 27, (1 << 27) + 1, L - 2, L - 1):
+        q, v, a = ltp.stateAt(b, 0, 1, k)
+        for x, got in enumerate((q, v, a)):
+            assert torch.equal(got[0], rows[x, :, k]), (k, x)
+    del tiles
