@@ -195,9 +195,9 @@ int ltp_end_limit_batch(ltp_planner* p, long long first, long long count, const 
  * flags: bit 0 = non-temporal stores (recommended); bit 1 = diagnostic dry run (stores without arithmetic);
  * bit 2 = force the table pass, bit 3 = force the fused table build (default: ltp_set_table_pass); bit 4 = table pass without the
  * two-plans-per-item kernels (rows of <= 64 float64 / 128 float32 samples and dof <= 7 otherwise take them: same rows);
- * bit 5 = never k_sample_walk_* (C++ semantics, <= 63 joints: rows under a cap of <= 768 samples, float32 rows and rows of every
- * 3rd sample or sparser take it by themselves: the run tables then stay in the compute unit, no table pass at all; same rows),
- * bit 6 = force it where it applies (C++ semantics, <= 63 joints, any row format);
+ * bit 5 = never k_sample_walk_* (<= 63 joints: rows under a cap of <= 768 samples, float32 rows, rows of every 3rd sample or
+ * sparser, and every row format in MATLAB semantics take it by themselves: the run tables then stay in the compute unit, no table
+ * pass at all; same rows), bit 6 = force it where it applies (<= 63 joints, any row format);
  * bits 8..23 = block interleave factor (0 = default 64, 1 = blocks in plan order). Large tiles (>= 64 GiB)
  * written with the default interleave reach the HBM fill ceiling; see DESIGN.md. */
 int ltp_sample_batch(ltp_planner* p, long long first, long long count, const ltp_queries* in, const ltp_records* rec,

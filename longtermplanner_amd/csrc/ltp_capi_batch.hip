@@ -79,18 +79,20 @@ static int sample_batch_any(ltp_planner* p, long long first, long long count, co
     // MATLAB semantics: the run tables always come from the table pass (k_build_tables<MATLAB>); the sampler kernels that read
     // tables do not depend on the semantics, the fused build of k_sample exists for the C++ semantics only
     const bool matlab = p->semantics == LTP_SEMANTICS_MATLAB;
-    // C++ semantics, up to 63 joints: k_sample_walk_* — the tables stay in the compute unit, no table pass at all. Taken by itself
-    // for the rows want_walk() names (capped, float32, sparse); flags bit 6 forces it, bit 5 forbids it, bit 2 = "the table-pass
-    // kernels" and bits 2-3 = "table pass on / off" keep their meaning.
-    if (!matlab && !p->dbg_stamps && !(flags & (2 | 32)) && ltp::sample_walk_applies(p->dof, rows) &&
-        ((flags & 64) || (!(flags & (4 | 8)) && want_walk(p, rows.max_samples, rows.stride, f32)))) {
+    // Up to 63 joints: k_sample_walk_* — the tables stay in the compute unit, no table pass at all. Taken by itself for the rows
+    // want_walk() names (capped, float32, sparse) and for every row format in MATLAB semantics (whose only other sampler is the table
+    // pass); flags bit 6 forces it, bit 5 forbids it, bit 2 = "the table-pass kernels" and bits 2-3 = "table pass on / off" keep
+    // their meaning.
+    if (!p->dbg_stamps && !(flags & (2 | 32)) && ltp::sample_walk_applies(p->dof, rows) &&
+        ((flags & 64) || (!(flags & (4 | 8)) && (matlab || want_walk(p, rows.max_samples, rows.stride, f32))))) {
         if (p->walk_blocks[f32 ? 1 : 0] == 0) p->walk_blocks[f32 ? 1 : 0] = ltp::sample_walk_resident_blocks(p->device, f32);
         unsigned long long* head = p->d_sample_next + (p->sample_next_slot++ & 63u);
         LTP_HIP_TRY(p, hipMemsetAsync(head, 0, sizeof(unsigned long long), s));
         ltp::launch_sample_walk(s, first, count, p->dof, p->t_sample, dev_limits(p), to_dev(in), to_dev(rec), offsets, out, f32, capacity, flags, rows, head,
-                                p->sample_blocks_override > 0 ? p->sample_blocks_override : p->walk_blocks[f32 ? 1 : 0]);
+                                p->sample_blocks_override > 0 ? p->sample_blocks_override : p->walk_blocks[f32 ? 1 : 0], matlab ? ltp::kSemMatlab : ltp::kSemCpp);
         LTP_HIP_TRY(p, hipGetLastError());
-        p->last_kernel = f32 ? ((flags & 1) ? "k_sample_walk_f32_nt" : "k_sample_walk_f32") : ((flags & 1) ? "k_sample_walk_f64_nt" : "k_sample_walk_f64");
+        p->last_kernel = matlab ? (f32 ? ((flags & 1) ? "k_sample_walk_matlab_f32_nt" : "k_sample_walk_matlab_f32") : ((flags & 1) ? "k_sample_walk_matlab_f64_nt" : "k_sample_walk_matlab_f64"))
+                                : (f32 ? ((flags & 1) ? "k_sample_walk_f32_nt" : "k_sample_walk_f32") : ((flags & 1) ? "k_sample_walk_f64_nt" : "k_sample_walk_f64"));
         return LTP_OK;
     }
     if (matlab || (!(flags & 2) && (!p->dbg_stamps || (flags & 4)) && ((flags & 4) || (!(flags & 8) && want_table_pass(p, row_bytes, f32))))) {

@@ -123,7 +123,7 @@ bool sample_walk_applies(int dof, RowSpec rows);
 int sample_walk_resident_blocks(int device, bool f32);
 void launch_sample_walk(hipStream_t s, long long first, long long count, int dof, double t_sample, Limits lim, Queries in, Records rec,
                         const unsigned long long* offsets, void* out, bool f32, unsigned long long capacity, int flags, RowSpec rows,
-                        unsigned long long* next_item /* zeroed on the same stream */, int resident_blocks);
+                        unsigned long long* next_item /* zeroed on the same stream */, int resident_blocks, int semantics = kSemCpp);
 int sample_tab_resident_blocks(int device, bool f32);
 int sample_resident_blocks(int device, int which /* 0 k_sample f64, 1 k_sample f32, 2 k_envelope */);
 int envelope_resident_blocks(int device);

@@ -23,7 +23,7 @@
 // time) in the same buffers. LONG rows (no cap, or a cap beyond 1024 samples) are wide batches from the start and are streamed one
 // row per wave pass (walk_stream_rows). Rows are bit-identical
 // to every other sampler's: same run walk, same run_coef / run_eval (include/ltp_run_tables.hpp).
-// C++ semantics only (the MATLAB mode keeps the table pass).
+// Both semantics: the builder's walk is for_each_run<SEM> (ltp_runs.hpp), the streaming side does not depend on it.
 #include "ltp_sampler_lds.hpp"
 
 #include <type_traits>
@@ -241,14 +241,14 @@ struct WalkLaneIn {
 
 // The walk of one lane into its slot of the batch under construction. Returns true if the lane has more runs inside the cap than
 // the slot holds (compact batches only: the batch is then rebuilt wide). q_end receives the last trajectory sample (cc:59-61).
-template <class Slot>
-LTP_DEV bool walk_lane(Slot& W, const WalkLaneIn& L, long long needed_end, double Ts, double& q_end)
+template <int SEM, class Slot>
+LTP_DEV bool walk_lane(Slot& W, const WalkLaneIn& L, long long needed_end, double Ts, double& q_end, bool last_joint)
 {
     constexpr int RUNS = (int)(sizeof(Slot::run) / sizeof(double) / kPackedRunWords);
     double q = L.q0, v = L.v0, a = L.a0;
     int runs = 0, last_b = L.len;
     bool too_many = false;
-    for_each_run_loaded<kSemCpp>(L.R, L.j_max, L.len, Ts, q, v, a, [&](int b, int, const RunCoef& rc) {
+    for_each_run_loaded<SEM>(L.R, L.j_max, L.len, Ts, q, v, a, [&](int b, int, const RunCoef& rc) {
         if ((long long)b < needed_end) {
             if (runs < RUNS) {
                 // q, v, a still hold the state before this run: the walk advances them after the visit
@@ -263,7 +263,7 @@ LTP_DEV bool walk_lane(Slot& W, const WalkLaneIn& L, long long needed_end, doubl
             last_b = b;                                                          // first run that is not needed: it ends the last stored one
         }
         return false;                                                            // the walk goes to the last sample: end-limit check
-    });
+    }, last_joint);
     W.start[runs] = last_b;
     W.nseg = runs;
     W.vsnap = L.R.v_drive * L.R.dir;                                             // as the walk forms it (cc:823)
@@ -271,7 +271,7 @@ LTP_DEV bool walk_lane(Slot& W, const WalkLaneIn& L, long long needed_end, doubl
     return too_many;
 }
 
-template <bool STREAMING, typename T>
+template <bool STREAMING, typename T, int SEM>
 LTP_DEV void sample_walk_body(long long first, long long count, int dof, double t_sample, Limits lim, Queries in, Records rec,
                               const unsigned long long* __restrict__ offsets, T* __restrict__ out, unsigned long long capacity, int spread, RowSpec rows,
                               unsigned long long* __restrict__ next_item)
@@ -369,9 +369,11 @@ LTP_DEV void sample_walk_body(long long first, long long count, int dof, double 
         bool too_many = false;
         if (slen > 0) {
             double q_end;
-            if constexpr (WIDE) too_many = walk_lane(B.wslot[lane], L, needed_end, t_sample, q_end);
-            else too_many = walk_lane(B.slot[lane], L, needed_end, t_sample, q_end);
-            if (q_end < L.q_min || q_end > L.q_max) atomicOr(&rec.status[p], kStatusEndLimit);   // cc:59-61: the last sample
+            if constexpr (WIDE) too_many = walk_lane<SEM>(B.wslot[lane], L, needed_end, t_sample, q_end, j0 + jl == dof - 1);
+            else too_many = walk_lane<SEM>(B.slot[lane], L, needed_end, t_sample, q_end, j0 + jl == dof - 1);
+            if constexpr (SEM == kSemCpp) {                                                      // (LTPlanner.m has no position limits)
+                if (q_end < L.q_min || q_end > L.q_max) atomicOr(&rec.status[p], kStatusEndLimit);   // cc:59-61: the last sample
+            }
         }
         if (__builtin_amdgcn_ballot_w64(too_many) != 0ull) return false;
         // plan-level header: lane (plan pl, first joint of the batch) holds the plan's stored length and row offset
@@ -443,18 +445,22 @@ LTP_DEV void sample_walk_body(long long first, long long count, int dof, double 
     }
 }
 
-#define LTP_WALK_KERNEL(NAME, ST, TY)                                                                                          \
+#define LTP_WALK_KERNEL(NAME, ST, TY, SEM)                                                                                          \
     __global__ void __launch_bounds__(kWalkThreads) __attribute__((amdgpu_waves_per_eu(6, 8)))                                    \
     NAME(long long first, long long count, int dof, double t_sample, Limits lim, Queries in, Records rec,                             \
          const unsigned long long* __restrict__ offsets, TY* __restrict__ out, unsigned long long capacity, int spread, RowSpec rows, \
          unsigned long long* __restrict__ next_item)                                                                                  \
     {                                                                                                                                 \
-        sample_walk_body<ST, TY>(first, count, dof, t_sample, lim, in, rec, offsets, out, capacity, spread, rows, next_item);         \
+        sample_walk_body<ST, TY, SEM>(first, count, dof, t_sample, lim, in, rec, offsets, out, capacity, spread, rows, next_item);         \
     }
-LTP_WALK_KERNEL(k_sample_walk_f64, false, double)
-LTP_WALK_KERNEL(k_sample_walk_f64_nt, true, double)
-LTP_WALK_KERNEL(k_sample_walk_f32, false, float)
-LTP_WALK_KERNEL(k_sample_walk_f32_nt, true, float)
+LTP_WALK_KERNEL(k_sample_walk_f64, false, double, kSemCpp)
+LTP_WALK_KERNEL(k_sample_walk_f64_nt, true, double, kSemCpp)
+LTP_WALK_KERNEL(k_sample_walk_f32, false, float, kSemCpp)
+LTP_WALK_KERNEL(k_sample_walk_f32_nt, true, float, kSemCpp)
+LTP_WALK_KERNEL(k_sample_walk_matlab_f64, false, double, kSemMatlab)      // LTPlanner.m's sampler (ltp_runs.hpp): same batches, same streaming
+LTP_WALK_KERNEL(k_sample_walk_matlab_f64_nt, true, double, kSemMatlab)
+LTP_WALK_KERNEL(k_sample_walk_matlab_f32, false, float, kSemMatlab)
+LTP_WALK_KERNEL(k_sample_walk_matlab_f32_nt, true, float, kSemMatlab)
 #undef LTP_WALK_KERNEL
 
 int sample_walk_resident_blocks(int device, bool f32)
@@ -469,7 +475,7 @@ int sample_walk_resident_blocks(int device, bool f32)
 
 void launch_sample_walk(hipStream_t s, long long first, long long count, int dof, double t_sample, Limits lim, Queries in, Records rec,
                         const unsigned long long* offsets, void* out, bool f32, unsigned long long capacity, int flags, RowSpec rows,
-                        unsigned long long* next_item, int resident_blocks)
+                        unsigned long long* next_item, int resident_blocks, int semantics)
 {
     if (count <= 0) return;
     const int ppb = walk_plans_per_item(dof, rows);
@@ -481,11 +487,15 @@ void launch_sample_walk(hipStream_t s, long long first, long long count, int dof
     if (blocks > nbatches) blocks = nbatches;
     const dim3 grid((unsigned)blocks), block(kWalkThreads);
 #define LTP_WALK_CASE(K, TY) hipLaunchKernelGGL(K, grid, block, 0, s, first, count, dof, t_sample, lim, in, rec, offsets, (TY*)out, capacity, spread, rows, next_item)
-    switch ((flags & 1) | (f32 ? 2 : 0)) {
+    switch ((flags & 1) | (f32 ? 2 : 0) | (semantics == kSemMatlab ? 4 : 0)) {
     case 0: LTP_WALK_CASE(k_sample_walk_f64, double); break;
     case 1: LTP_WALK_CASE(k_sample_walk_f64_nt, double); break;
     case 2: LTP_WALK_CASE(k_sample_walk_f32, float); break;
-    default: LTP_WALK_CASE(k_sample_walk_f32_nt, float); break;
+    case 3: LTP_WALK_CASE(k_sample_walk_f32_nt, float); break;
+    case 4: LTP_WALK_CASE(k_sample_walk_matlab_f64, double); break;
+    case 5: LTP_WALK_CASE(k_sample_walk_matlab_f64_nt, double); break;
+    case 6: LTP_WALK_CASE(k_sample_walk_matlab_f32, float); break;
+    default: LTP_WALK_CASE(k_sample_walk_matlab_f32_nt, float); break;
     }
 #undef LTP_WALK_CASE
 }

@@ -199,5 +199,42 @@ def test_matlab_mode_single_call_and_misuse(amd, oracle_mod):
         ltp.sampleBatch(b, 0, 4, tile)
     ltp.setSemantics("matlab")
     ltp.sampleBatch(b, 0, 4, tile)
-    assert ltp.lastSamplerKernel().startswith("k_sample_tab")
+    assert ltp.lastSamplerKernel().startswith("k_sample_walk_matlab")      # MATLAB semantics: the walk kernel for every row format ...
+    tile2 = torch.zeros_like(tile)
+    ltp.sampleBatch(b, 0, 4, tile2, walk=False)
+    assert ltp.lastSamplerKernel().startswith("k_sample_tab")              # ... or the table pass (dof > 63, on request): same rows
     torch.cuda.synchronize()
+    assert torch.equal(tile, tile2)
+
+
+@pytest.mark.parametrize("limits,dof,n", [("panda", None, 900), ("ref", 9, 300), ("ref", 30, 80)])
+def test_matlab_walk_sampler_equals_the_table_pass(amd, limits, dof, n):
+    """MATLAB semantics through k_sample_walk_matlab_* (run tables built inside the sampler's block by for_each_run<MATLAB>) against
+    the table pass (k_build_tables<MATLAB> + k_sample_tab*): every row format, bit for bit — rows, statuses, lengths."""
+    import torch
+    D, lim = amd.limit_set(limits, dof)
+    ltp = amd.LongTermPlanner(D, 0.001, device=0, **lim)
+    ltp.setSemantics("matlab")
+    qg, q0, v0, a0 = (x.clone() for x in ltp.generateQueries(n, seed=23))
+    v0[3, 0] = 99.0                                              # (MATLAB's checkInputs has no position limits: a velocity it rejects)
+    short = torch.arange(20, n, 7, device=qg.device)
+    qg[short] = q0[short] + 0.03
+    v0[short] = 0.0
+    a0[short] = 0.0
+    for cap, stride, f32 in ((0, 1, False), (0, 1, True), (0, 4, False), (256, 1, False), (64, 1, False), (100, 3, True), (16, 1, False), (2000, 2, False)):
+        ltp.setMaxSamples(cap); ltp.setSampleStride(stride)
+        dt = torch.float32 if f32 else torch.float64
+        res = {}
+        for mode in ("walk", "tables"):
+            b = ltp.planSwitchTimesBatch(qg, q0, v0, a0)
+            full = torch.full((int(b.offsets[-1].item()),), 3.0, dtype=dt, device="cuda")
+            ltp.sampleBatch(b, 0, n, full, **({} if mode == "walk" else dict(walk=False)))
+            kern = ltp.lastSamplerKernel()
+            assert kern.startswith("k_sample_walk_matlab" if mode == "walk" else "k_sample_tab"), (mode, kern)
+            sub = torch.full((int((b.offsets[n - 2] - b.offsets[9]).item()) + 8,), 3.0, dtype=dt, device="cuda")
+            ltp.sampleBatch(b, 9, n - 11, sub, spread=5, **({} if mode == "walk" else dict(walk=False)))
+            torch.cuda.synchronize()
+            res[mode] = (full, sub, b.status.clone(), b.traj_len.clone())
+        for k, (got, want) in enumerate(zip(res["walk"], res["tables"])):
+            assert torch.equal(got, want), (cap, stride, f32, k)
+        assert int((res["walk"][3] > 0).sum().item()) > 0.9 * n
