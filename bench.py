@@ -141,7 +141,6 @@ def parse_args(argv=None):
                     help="where the sampler's run tables are built: by the table pass (a kernel of its own) or inside the sampler kernel (ltp_set_table_pass)")
     ap.add_argument("--no-walk", action="store_true", help="A/B: capped rows of <= 256 samples through the table pass instead of k_sample_walk_* (tables kept in the compute unit)")
     ap.add_argument("--walk", action="store_true", help="A/B: force k_sample_walk_* (also for rows it is not chosen for automatically: whole rows, float64 caps beyond 256)")
-    ap.add_argument("--no-pair-items", action="store_true", help="A/B: rows of <= 32 slots through the single-plan table sampler instead of the two-plans-per-item kernels")
     ap.add_argument("--in-flight", type=int, default=1, help="switching times only: steps alternate between this many planner handles, each on its own stream "
                     "(two batches in flight: the latency-bound queue-B kernel of one step runs under the next step's stages); 1 = one batch at a time")
     ap.add_argument("--table-gib", type=float, default=0.0, help="upper bound of the table-pass workspace (default: library default, 1/16 of device memory)")
@@ -204,7 +203,6 @@ class Workload:
         self.plain_stores, self.dry, self.spread, self.window_gib = args.plain_stores, args.dry_sampler, args.spread, args.window_gib
         self.sample_blocks, self.gather, self.checksum, self.seed = args.sample_blocks, args.gather, args.checksum, args.seed
         self.table_pass, self.table_gib = args.table_pass, args.table_gib
-        self.pair_items = not args.no_pair_items
         self.walk = False if args.no_walk else (True if args.walk else None)
         self.end_limit = args.end_limit
         self.in_flight = args.in_flight
@@ -293,7 +291,7 @@ def run_workload(wl, ctx):
                 if timed:
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record()
-                ltp.sampleBatch(batch, 0, n, tile, streaming=not wl.plain_stores, spread=wl.spread, dual=wl.pair_items, walk=wl.walk)
+                ltp.sampleBatch(batch, 0, n, tile, streaming=not wl.plain_stores, spread=wl.spread, walk=wl.walk)
                 if timed:
                     e1.record()
                     ev_pairs.append((e0, e1))
@@ -327,7 +325,7 @@ def run_workload(wl, ctx):
             if timed:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-            ltp.sampleBatch(batch, first, end - first, view, streaming=not wl.plain_stores, dry=wl.dry, spread=wl.spread, dual=wl.pair_items, walk=wl.walk)
+            ltp.sampleBatch(batch, first, end - first, view, streaming=not wl.plain_stores, dry=wl.dry, spread=wl.spread, walk=wl.walk)
             if timed:
                 e1.record()
                 ev_pairs.append((e0, e1))
@@ -623,7 +621,7 @@ def main():
     primary = Workload(args)
     out = run_workload(primary, ctx)
 
-    variant = (args.no_walk or args.walk or args.no_pair_items or args.switch_only or args.end_limit or args.f32 or args.max_samples or args.sample_stride > 1 or args.envelope or args.receding or args.dry_sampler
+    variant = (args.no_walk or args.walk or args.switch_only or args.end_limit or args.f32 or args.max_samples or args.sample_stride > 1 or args.envelope or args.receding or args.dry_sampler
                or args.in_flight > 1 or args.semantics != "cpp" or args.table_pass != "auto" or args.limits != "panda" or args.batch != 1_000_000 or args.global_batch or args.window_gib or args.layout != "query_major")
     secondary = []
     if not args.no_secondary and not variant:

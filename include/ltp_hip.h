@@ -193,11 +193,11 @@ int ltp_end_limit_batch(ltp_planner* p, long long first, long long count, const 
  * plan p is written at out + (offsets[p] - offsets[first]); plans that would end beyond
  * `capacity` doubles get LTP_STATUS_OVERFLOW and are skipped.
  * flags: bit 0 = non-temporal stores (recommended); bit 1 = diagnostic dry run (stores without arithmetic);
- * bit 2 = force the table pass, bit 3 = force the fused table build (default: ltp_set_table_pass); bit 4 = table pass without the
- * two-plans-per-item kernels (rows of <= 64 float64 / 128 float32 samples and dof <= 7 otherwise take them: same rows);
- * bit 5 = never k_sample_walk_* (<= 63 joints: rows under a cap of <= 768 samples, float32 rows, rows of every 3rd sample or
- * sparser, and every row format in MATLAB semantics take it by themselves: the run tables then stay in the compute unit, no table
- * pass at all; same rows), bit 6 = force it where it applies (<= 63 joints, any row format);
+ * bit 2 = force the table pass (k_build_tables + k_sample_tab_*: kept as the sampler that reads the packed run tables of
+ * include/ltp_run_tables.hpp; nothing takes it by itself any more), bit 3 = force the fused table build; bit 4 = reserved;
+ * bit 5 = never k_sample_walk_* (rows under a cap of <= 768 samples, float32 rows, rows of every 3rd sample or sparser, and every
+ * row format in MATLAB semantics take it by themselves: the run tables then stay in the compute unit, no table pass at all; same
+ * rows), bit 6 = force it (any row format);
  * bits 8..23 = block interleave factor (0 = default 64, 1 = blocks in plan order). Large tiles (>= 64 GiB)
  * written with the default interleave reach the HBM fill ceiling; see DESIGN.md. */
 int ltp_sample_batch(ltp_planner* p, long long first, long long count, const ltp_queries* in, const ltp_records* rec,
@@ -356,9 +356,6 @@ int ltp_debug_last_matlab_flags(const ltp_planner* p);
 /* MATLAB's roots() as the MATLAB-semantics kernels compute it, n polynomials of degree 1..6: re, im [n][degree] in MATLAB's
  * output order, nroots [n] (degree minus stripped leading zeros), status [n] (0 ok, 1 no convergence, 2 NaN / Inf) */
 int ltp_debug_roots_matlab_host(ltp_planner* p, long long n, int degree, const double* coef, double* re, double* im, int* nroots, int* status);
-/* plans the two-plans-per-item short-row sampler (k_sample_tab2_*) left to its list pass in the latest (piece of the latest)
- * ltp_sample_batch* call: plans with a joint of more than 8 runs inside the row cap. Synchronises the device. */
-int ltp_debug_tab_list_count(ltp_planner* p);
 /* device_buffer (3 x count u64, or NULL to switch off): k_sample block start / run tables ready / end on the
  * 100 MHz wall clock; ltp_envelope_batch writes 16 u64 per (plan, joint group) item instead: loop top, item drawn,
  * traj_len read, after each of the seven table-build barriers, reduction done */

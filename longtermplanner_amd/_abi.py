@@ -137,7 +137,6 @@ _SIGNATURES = {
                                         C.c_double, _dp, _dp, C.c_char_p, _ip, _ip]),
     "ltp_roots_f64_host": (C.c_int, [C.c_void_p, C.c_longlong, C.c_int, _dp, _dp, _dp]),
     "ltp_roots_f32_host": (C.c_int, [C.c_void_p, C.c_longlong, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
-    "ltp_debug_tab_list_count": (C.c_int, [C.c_void_p]),
     "ltp_debug_set_sample_stamps": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ltp_debug_math_probe_host": (C.c_int, [C.c_void_p, C.c_longlong, _dp, _dp, _dp]),
     "ltp_debug_roots_probe_host": (C.c_int, [C.c_void_p, C.c_longlong, C.c_int, _dp, _dp]),

@@ -101,28 +101,16 @@ static int sample_batch_any(ltp_planner* p, long long first, long long count, co
         if ((rc = workspace_acquire(p, s, capturing)) != LTP_OK) return rc;
         long long piece = 0;
         if ((rc = ensure_tables(p, count, capturing, &piece)) != LTP_OK) return rc;
-        bool used_dual = false;
         for (long long f = first; f < first + count; f += piece) {
             const long long c = first + count - f < piece ? first + count - f : piece;
             unsigned long long* head = p->d_sample_next + (p->sample_next_slot++ & 63u);
             LTP_HIP_TRY(p, hipMemsetAsync(head, 0, sizeof(unsigned long long), s));
             ltp::launch_build_tables(s, f, c, p->dof, p->t_sample, dev_limits(p), to_dev(in), to_dev(rec), rows, false, offsets, first, p->d_tables, p->semantics);
-            // rows of at most 32 slots: two plans per item (k_sample_tab2_*), then the list pass for what did not fit (flags bit 4: off)
-            unsigned long long* head2 = nullptr;
-            const bool dual = p->d_tab_list && !p->dbg_stamps && !(flags & 16) && ltp::sample_tab_dual_applies(p->dof, rows, f32);
-            if (dual) {
-                head2 = p->d_sample_next + (p->sample_next_slot++ & 63u);
-                LTP_HIP_TRY(p, hipMemsetAsync(head2, 0, sizeof(unsigned long long), s));
-                LTP_HIP_TRY(p, hipMemsetAsync(p->d_tab_list, 0, sizeof(unsigned), s));
-            }
-            used_dual = used_dual || dual;
             ltp::launch_sample_tab(s, f, c, first, p->dof, to_dev(rec), offsets, out, f32, capacity, flags & ~2, rows, head,
-                                   p->sample_blocks_override > 0 ? p->sample_blocks_override : p->sample_blocks[f32 ? 4 : 3], p->d_tables, p->t_sample, p->dbg_stamps,
-                                   dual ? p->d_tab_list : nullptr, head2);
+                                   p->sample_blocks_override > 0 ? p->sample_blocks_override : p->sample_blocks[f32 ? 4 : 3], p->d_tables, p->t_sample, p->dbg_stamps);
         }
         LTP_HIP_TRY(p, hipGetLastError());
-        p->last_kernel = used_dual ? (f32 ? ((flags & 1) ? "k_sample_tab2_f32_nt" : "k_sample_tab2_f32") : ((flags & 1) ? "k_sample_tab2_f64_nt" : "k_sample_tab2_f64"))
-                                   : (f32 ? ((flags & 1) ? "k_sample_tab_f32_nt" : "k_sample_tab_f32") : ((flags & 1) ? "k_sample_tab_f64_nt" : "k_sample_tab_f64"));
+        p->last_kernel = f32 ? ((flags & 1) ? "k_sample_tab_f32_nt" : "k_sample_tab_f32") : ((flags & 1) ? "k_sample_tab_f64_nt" : "k_sample_tab_f64");
         return workspace_release(p, s, capturing);
     }
     // each launch gets its own work-queue head from a ring of 64, zeroed in stream order just before the kernel
@@ -283,16 +271,6 @@ int ltp_generate_queries_batch(ltp_planner* p, long long n, unsigned long long s
 }
 
 
-int ltp_debug_tab_list_count(ltp_planner* p)
-{
-    if (!p) return -1;
-    std::lock_guard<std::mutex> g(p->mu);
-    if (!p->d_tab_list) return 0;
-    unsigned n = 0;
-    if (hipSetDevice(p->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess ||
-        hipMemcpy(&n, p->d_tab_list, sizeof(n), hipMemcpyDeviceToHost) != hipSuccess) return -1;
-    return (int)n;
-}
 
 int ltp_debug_set_sample_stamps(ltp_planner* p, unsigned long long* device_buffer)
 {

@@ -205,9 +205,7 @@ int ensure_tables(ltp_planner* p, long long count, bool capturing, long long* pl
     }
     if (want > p->tables_bytes) {
         if (p->d_tables) LTP_HIP_TRY(p, hipFree(p->d_tables));
-        if (p->d_tab_list) LTP_HIP_TRY(p, hipFree(p->d_tab_list));
         p->d_tables = nullptr;
-        p->d_tab_list = nullptr;
         p->tables_bytes = 0;
         // the workspace is a convenience: when the device cannot spare `want` bytes, take what it can (more pieces)
         for (;;) {
@@ -219,8 +217,6 @@ int ensure_tables(ltp_planner* p, long long count, bool capturing, long long* pl
             want = want / 2 / per_tile * per_tile;
         }
         p->tables_bytes = want;
-        // (optional: without it short rows take the single-plan kernels)
-        if (hipMalloc((void**)&p->d_tab_list, sizeof(unsigned) * (size_t)(want / per_tile * 64 + 2)) != hipSuccess) { p->d_tab_list = nullptr; (void)hipGetLastError(); }
     }
     long long plans = (long long)(p->tables_bytes / per_tile) * 64 / dof;
     if (plans < 1) return fail(p, LTP_ERR_OUT_OF_MEMORY, "table workspace too small for one plan");
@@ -272,7 +268,6 @@ void ltp_destroy(ltp_planner* p)
     if (p->d_offsets_scratch) (void)hipFree(p->d_offsets_scratch);
     if (p->d_small) (void)hipFree(p->d_small);
     if (p->d_tables) (void)hipFree(p->d_tables);
-    if (p->d_tab_list) (void)hipFree(p->d_tab_list);
     if (p->d_sample_next) (void)hipFree(p->d_sample_next);
     if (p->d_arena) (void)hipFree(p->d_arena);
     if (p->h_arena) (void)hipHostFree(p->h_arena);

@@ -43,8 +43,6 @@ struct ltp_planner {
     int table_pass = 0;                    // 0 = automatic, 1 = always, -1 = never (ltp_set_table_pass)
     unsigned long long* d_tables = nullptr;   // run tables of the table pass (k_build_tables); part of the workspace
     unsigned long long tables_bytes = 0;      // allocated
-    unsigned* d_tab_list = nullptr;           // [0] counter + entries: the plans a short-row sampler (k_sample_tab2_*, k_sample_walk_*) leaves to its list pass
-    unsigned long long tab_list_cap = 0;      // entries allocated
     int walk_blocks[2] = {0, 0};              // resident blocks of k_sample_walk f64 / f32
     unsigned long long tables_cap = 4ull << 30;   // upper bound for d_tables (ltp_create: 1/16 of the device's memory if that
                                                   // is more — 18 GiB of 288); longer ranges are processed in pieces

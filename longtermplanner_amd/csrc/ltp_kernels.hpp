@@ -112,11 +112,7 @@ void launch_sample_tab(hipStream_t s, long long first, long long count, long lon
                        const unsigned long long* offsets, void* out, bool f32, unsigned long long capacity, int flags, RowSpec rows,
                        unsigned long long* next_item /* zeroed on the same stream */, int resident_blocks, const unsigned long long* tables,
                        double t_sample /* the one the tables were built with */,
-                       unsigned long long* stamps = nullptr /* diagnostic: 8 per (plan, joint group) item */,
-                       unsigned* overflow_list = nullptr /* count + 1 words, [0] zeroed on the same stream: enables the two-plans-per-item
-                                                            kernels (rows of <= 32 slots, dof <= 7); their left-overs go through this list */,
-                       unsigned long long* next_item_list = nullptr /* zeroed work-queue head of the list pass */);
-bool sample_tab_dual_applies(int dof, RowSpec rows, bool f32);
+                       unsigned long long* stamps = nullptr /* diagnostic: 8 per (plan, joint group) item */);
 // Capped rows (<= 256 stored samples, <= 28 joints, C++ semantics) without any table traffic: a builder wave per block walks the
 // runs into LDS, seven streaming waves write the rows (ltp_sampler_walk.hip).
 bool sample_walk_applies(int dof, RowSpec rows);

@@ -234,8 +234,7 @@ LTP_DEV void sample_tab_body(long long first, long long count, long long base_fi
                              const unsigned long long* __restrict__ offsets, T* __restrict__ out, unsigned long long capacity, int spread,
                              RowSpec rows, unsigned long long* __restrict__ next_item, const unsigned long long* __restrict__ tables,
                              int draw_chunk, unsigned long long* __restrict__ stamps /* diagnostic: 8 per item, nullptr in product calls */,
-                             double t_sample, const unsigned* __restrict__ plan_list = nullptr /* LIST MODE: plan_list[0] = how many, then that many
-                             local plan numbers (what k_sample_tab_dual could not place: a joint with more than 8 runs inside the cap) */)
+                             double t_sample)
 {
     // stamps[8 * item + k] (wall clock, tools/tab_probe.py): loader — 0 its iteration starts (a buffer is free), 6 the next
     // item's loads are issued, 1 this item's loads are in, 3 it is published, 7 the previous publication, 2 = 1 if the tables
@@ -297,8 +296,7 @@ LTP_DEV void sample_tab_body(long long first, long long count, long long base_fi
     static_assert(kTabAhead + 2 <= kTabBuffers, "buffers: one being streamed, one being published, kTabAhead in flight");
     const int ngroups = (dof + kTabJointGroup - 1) / kTabJointGroup;
     const long long per = (count + spread - 1) / spread;
-    const unsigned long long total = plan_list ? (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)plan_list[0]) * ngroups
-                                               : (unsigned long long)per * spread * ngroups;
+    const unsigned long long total = (unsigned long long)per * spread * ngroups;
     constexpr unsigned kTileBytes = (unsigned)kPackedWords * 64u * 8u;
     // capped rows mostly touch the first runs only (a switch of the jerk profile cuts up to three runs: 8 runs is what
     // 256 samples of a 7-DoF plan need in 99.95 % of the items): kCappedPairs word pairs (54 words, 8 packed runs) per joint — an
@@ -349,8 +347,7 @@ LTP_DEV void sample_tab_body(long long first, long long count, long long base_fi
             else { group = (int)(item % (unsigned long long)ngroups); slot = item / (unsigned long long)ngroups; }
         }
         long long l;
-        if (plan_list) l = (long long)plan_list[1 + slot];                                  // rare path: a load the loader waits for
-        else if (spread_log2 >= 0) l = (long long)(slot & (unsigned long long)(spread - 1)) * per + (long long)(slot >> spread_log2);
+        if (spread_log2 >= 0) l = (long long)(slot & (unsigned long long)(spread - 1)) * per + (long long)(slot >> spread_log2);
         else if (total <= 0xffffffffull) l = (long long)((unsigned)slot % (unsigned)spread) * per + (long long)((unsigned)slot / (unsigned)spread);
         else l = (long long)(slot % (unsigned long long)spread) * per + (long long)(slot / (unsigned long long)spread);
         j0 = group * kTabJointGroup;
@@ -503,403 +500,15 @@ LTP_DEV void sample_tab_body(long long first, long long count, long long base_fi
     __global__ void __launch_bounds__(kTabThreads) __attribute__((amdgpu_waves_per_eu(WAVES, 8)))                                    \
     NAME(long long first, long long count, long long base_first, int dof, Records rec, const unsigned long long* __restrict__ offsets, \
          TY* __restrict__ out, unsigned long long capacity, int spread, RowSpec rows, unsigned long long* __restrict__ next_item,     \
-         const unsigned long long* __restrict__ tables, int draw_chunk, unsigned long long* __restrict__ stamps, double t_sample,     \
-         const unsigned* __restrict__ plan_list)                                                                                      \
+         const unsigned long long* __restrict__ tables, int draw_chunk, unsigned long long* __restrict__ stamps, double t_sample)     \
     {                                                                                                                                 \
-        sample_tab_body<ST, TY>(first, count, base_first, dof, rec, offsets, out, capacity, spread, rows, next_item, tables, draw_chunk, stamps, t_sample, plan_list); \
+        sample_tab_body<ST, TY>(first, count, base_first, dof, rec, offsets, out, capacity, spread, rows, next_item, tables, draw_chunk, stamps, t_sample); \
     }
 LTP_TAB_KERNEL(k_sample_tab_f64, false, double, 6)
 LTP_TAB_KERNEL(k_sample_tab_f64_nt, true, double, 6)
 LTP_TAB_KERNEL(k_sample_tab_f32, false, float, 4)
 LTP_TAB_KERNEL(k_sample_tab_f32_nt, true, float, 4)
 #undef LTP_TAB_KERNEL
-
-// ---------------------------------------------------------------------------------------
-// TWO plans per item, for rows of at most 32 slots (64 float64 / 128 float32 stored samples) and dof <= 7 (round 4).
-// Rows this short leave k_sample_tab's streaming waves half empty (two joints share a wave, so a 7-joint item keeps 4 of the 7
-// waves busy) and make the loader the bottleneck: per item it waits for a buffer, draws, requests, waits and publishes in ~2.4 us
-// whatever the rows hold (tools/tab_probe.py at 64 samples: loader 2.44 us, streaming wave 2.57 us per item). Here an item is the
-// PAIR of plans (2 L, 2 L + 1): 14 joint slots, two per streaming wave — every wave busy — and the loader's fixed costs (buffer
-// hand-over, queue position, address arithmetic, LDS round trips of the publication) are paid once per two plans.
-// The tables of a pair fit the LDS of one single-plan buffer because a capped row needs few runs: a CompactTable holds 8 runs
-// (92 words instead of 212); the packed form of 8 runs (54 words) lands at its end and is expanded in place like the full tables.
-// A plan one of whose joints has MORE than 8 runs inside the cap (a few per million with panda limits; trajectories that end
-// inside the cap) is not streamed here: the loader appends it to a list, and k_sample_tab runs over that list afterwards (list
-// mode, full tables). Same per-sample arithmetic as tab_stream, same bits.
-// ---------------------------------------------------------------------------------------
-constexpr int kDualRuns = 8;
-struct CompactTable {
-    int nseg;
-    int len;
-    int start[kMaxSegments + 2];
-    double c[kDualRuns][kRunCoefs];
-};
-constexpr int kCompactWords = 1 + (kMaxSegments + 2) / 2 + kDualRuns * kRunCoefs;                       // 92
-constexpr int kCompactPacked = kPackedHeaderWords + kDualRuns * kPackedRunWords;                       // 54
-constexpr int kCompactAt = kCompactWords - kCompactPacked;                                             // 38
-static_assert(sizeof(CompactTable) == kCompactWords * 8 && sizeof(CompactTable) % 16 == 0 && kCompactAt % 2 == 0 && kCompactPacked % 2 == 0, "16-byte units");
-static_assert(12 + kRunCoefs * kDualRuns <= kCompactWords, "eight expanded runs fit");
-constexpr int kDualSlots = 2 * kTabJointGroup;                                                         // 14 joint slots: plan A's, then plan B's
-struct DualItem {
-    unsigned long long rel[2];            // element offset of plan A / B inside `out`
-    int slen[2];                          // stored samples per row; 0 = nothing to stream for that plan
-    int nj;
-    int done;
-    unsigned long long item;
-};
-struct alignas(16) DualBuffer {
-    CompactTable ct[kDualSlots];
-    DualItem hdr;
-};
-static_assert(sizeof(DualItem) == 40 && offsetof(DualBuffer, hdr) % 16 == 0, "header read as 16-byte pieces");
-
-template <bool STREAMING, typename T>
-LTP_DEV void tab_stream_dual(const DualBuffer& B, unsigned long long rel_a, unsigned long long rel_b, int slen_a, int slen_b, int nj, int dof,
-                             T* __restrict__ out, int sstride, int wave)
-{
-    typedef typename OutVec<T>::type V;
-    constexpr int N = OutVec<T>::N;
-    const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-    // joint slot of this half wave: 2 * wave + lane / 32; slots 0..6 are plan A's joints, 7..13 plan B's
-    const int slot_ix = 2 * wave + (lane >> 5);
-    const bool is_b = slot_ix >= kTabJointGroup;
-    const int joint = is_b ? slot_ix - kTabJointGroup : slot_ix;
-    const int slen = is_b ? slen_b : slen_a;
-    const bool mine = joint < nj && slen > 0;
-    if (__builtin_amdgcn_ballot_w64(mine) == 0ull) return;
-    const unsigned long long stride = ((unsigned long long)(mine ? slen : 0) + (kRowAlign - 1)) / kRowAlign * kRowAlign;
-    const unsigned long long arr_stride = (unsigned long long)dof * stride;
-    const int nslots = mine ? (slen + N - 1) / N : 0;
-    // one buffer descriptor over the rows of both plans: they are neighbours in the packed tile (offsets are a scan), plan A first
-    const unsigned long long base_rel = slen_a > 0 ? rel_a : rel_b;
-    const unsigned long long stride_b = ((unsigned long long)slen_b + (kRowAlign - 1)) / kRowAlign * kRowAlign;
-    const unsigned long long stride_a = ((unsigned long long)slen_a + (kRowAlign - 1)) / kRowAlign * kRowAlign;
-    const unsigned long long end_rel = slen_b > 0 ? rel_b + 4ull * dof * stride_b : rel_a + 4ull * dof * stride_a;
-    const unsigned long long span_bytes = (end_rel - base_rel) * sizeof(T);
-    const bool buffer_stores = STREAMING && sizeof(T) == 8 && span_bytes <= 0xffffff00ull;
-    T* const base = out + base_rel;
-    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(base, 0, buffer_stores ? (int)(unsigned)span_bytes : 0, 0x00020000);
-    const unsigned long long plan_at = (is_b ? rel_b : rel_a) - base_rel;                       // element offset of this lane's plan inside the span
-    const unsigned long long row_at = plan_at + (unsigned long long)(mine ? joint : 0) * stride;   // ... of the joint's q row
-    const CompactTable& jt = B.ct[mine ? slot_ix : 0];
-    const int* st = jt.start;
-    const int nruns = jt.nseg;
-    const int slot = lane & 31;
-    if (slot < nslots) {
-        const int i0 = N * slot;
-        V o[4];
-        const int t0 = i0 * sstride;
-        int kr = 0, cur = 0, nxt = nruns > 1 ? st[1] : 0x7fffffff;
-        while (nxt <= t0) {
-            ++kr;
-            cur = nxt;
-            nxt = kr + 1 < nruns ? st[kr + 1] : 0x7fffffff;
-        }
-        const bool straddles = t0 + (N - 1) * sstride >= nxt;
-        if (straddles || i0 + N > slen) {
-            // a run boundary or the end of the row inside the slot: sample by sample (tab_stream's rule: the tail of the last slot is
-            // row padding and stays zero)
-            int kh = kr, ch = cur, nh = nxt;
-#pragma unroll
-            for (int h = 0; h < N; ++h) {
-                const int i = t0 + h * sstride;
-                while (nh <= i) {
-                    ++kh;
-                    ch = nh;
-                    nh = kh + 1 < nruns ? st[kh + 1] : 0x7fffffff;
-                }
-                const bool pad = i0 + h >= slen;
-                double x4[4];
-                run_eval(jt.c[kh < kDualRuns ? kh : kDualRuns - 1], i - ch + 1, x4[0], x4[1], x4[2], x4[3]);
-#pragma unroll
-                for (int x = 0; x < 4; ++x) o[x][h] = pad ? (T)0 : (T)x4[x];
-            }
-        } else {
-            double c[kRunCoefs];
-#pragma unroll
-            for (int x = 0; x < kRunCoefs; ++x) c[x] = jt.c[kr][x];
-#pragma unroll
-            for (int h = 0; h < N; ++h) {
-                double x4[4];
-                run_eval(c, t0 + h * sstride - cur + 1, x4[0], x4[1], x4[2], x4[3]);
-#pragma unroll
-                for (int x = 0; x < 4; ++x) o[x][h] = (T)x4[x];
-            }
-        }
-        if (buffer_stores) {
-            if constexpr (STREAMING && sizeof(T) == 8) {
-                const unsigned voff = (unsigned)((row_at + (unsigned long long)i0) * sizeof(T));
-                const unsigned arr_bytes = (unsigned)(arr_stride * sizeof(T));
-#pragma unroll
-                for (int x = 0; x < 4; ++x)
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o[x]), rsrc, voff + (unsigned)x * arr_bytes, 0, /*nt | sc1*/ 2 | 16);
-            }
-        } else if constexpr (STREAMING) {
-#pragma unroll
-            for (int x = 0; x < 4; ++x) __builtin_nontemporal_store(o[x], reinterpret_cast<V*>(base + row_at + x * arr_stride + i0));
-        } else {
-#pragma unroll
-            for (int x = 0; x < 4; ++x) *reinterpret_cast<V*>(base + row_at + x * arr_stride + i0) = o[x];
-        }
-    }
-}
-
-template <bool STREAMING, typename T>
-LTP_DEV void sample_tab_dual_body(long long first, long long count, int dof, Records rec, T* __restrict__ out, unsigned long long capacity, int spread,
-                                  RowSpec rows, unsigned long long* __restrict__ next_item, const unsigned long long* __restrict__ tables, int draw_chunk,
-                                  double t_sample, unsigned* __restrict__ overflow_list /* [0] counter (zeroed by the host), then local plan numbers */)
-{
-    __shared__ DualBuffer buf[kTabBuffers];
-    __shared__ int s_ready[kTabBuffers];
-    __shared__ int s_consumed[kTabStreamWaves];
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int sstride = rows.stride > 1 ? rows.stride : 1;
-    if (threadIdx.x < kTabBuffers) s_ready[threadIdx.x] = 0;
-    if (threadIdx.x < kTabStreamWaves) s_consumed[threadIdx.x] = 0;
-    __syncthreads();
-    if (wave < kTabStreamWaves) {
-        // ---- streaming waves: LDS reads and row stores only ----
-        for (int seq = 0;; ++seq) {
-            const int b = seq % kTabBuffers;
-            while (__hip_atomic_load(&s_ready[b], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != seq + 1) __builtin_amdgcn_s_sleep(1);
-            typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-            static_assert(offsetof(DualItem, slen) == 16 && offsetof(DualItem, nj) == 24 && offsetof(DualItem, done) == 28, "read as two u32x4");
-            const u32x4 h0 = reinterpret_cast<const u32x4*>(&buf[b].hdr)[0], h1 = reinterpret_cast<const u32x4*>(&buf[b].hdr)[1];
-            if (__builtin_amdgcn_readfirstlane((int)h1[3])) break;                       // done
-            const unsigned long long rel_a = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)h0[1]) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)h0[0]);
-            const unsigned long long rel_b = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)h0[3]) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)h0[2]);
-            const int slen_a = __builtin_amdgcn_readfirstlane((int)h1[0]), slen_b = __builtin_amdgcn_readfirstlane((int)h1[1]);
-            const int nj = __builtin_amdgcn_readfirstlane((int)h1[2]);
-            if (slen_a > 0 || slen_b > 0) tab_stream_dual<STREAMING, T>(buf[b], rel_a, rel_b, slen_a, slen_b, nj, dof, out, sstride, wave);
-            if ((threadIdx.x & 63) == 0) __hip_atomic_store(&s_consumed[wave], seq + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
-        return;
-    }
-    // ---- loader wave (see sample_tab_body: LDS-direct loads two items ahead, one counted wait, untracked LDS accesses) ----
-    __builtin_amdgcn_s_setprio(3);
-    constexpr int kTabAhead = 2;
-    constexpr int kPairsPerTable = kCompactPacked / 2;                                       // 27 word pairs: header + 8 packed runs
-    constexpr unsigned kPackedByte = (unsigned)kCompactAt * 8u;
-    static_assert(kTabAhead + 2 <= kTabBuffers && kTabAhead * kDualSlots < 64, "buffers; the counted wait fits vmcnt");
-    const long long npairs = (count + 1) / 2;
-    const long long per = (npairs + spread - 1) / spread;
-    const unsigned long long total = (unsigned long long)per * spread;
-    constexpr unsigned kTileBytes = (unsigned)kPackedWords * 64u * 8u;
-    typedef __attribute__((address_space(3))) void* lds_ptr;
-    auto uniform64 = [](unsigned long long x) -> unsigned long long {
-        return ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(x >> 32)) << 32) |
-               (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)x);
-    };
-    unsigned long long chunk_cur = 0ull, chunk_pending = 0ull;
-    int chunk_i = 0;
-    bool chunk_wanted = false;
-    if (fresh_lane() == 0) chunk_pending = atomicAdd(next_item, (unsigned long long)draw_chunk);
-    chunk_cur = uniform64(chunk_pending);
-    auto next_item_id = [&]() __attribute__((always_inline)) -> unsigned long long {
-        const unsigned long long id = chunk_cur + (unsigned long long)chunk_i;
-        if (++chunk_i == draw_chunk) {
-            if (fresh_lane() == 0) chunk_pending = atomicAdd(next_item, (unsigned long long)draw_chunk);
-            chunk_wanted = true;
-        }
-        return id;
-    };
-    auto finish_draw = [&]() __attribute__((always_inline)) {
-        __builtin_amdgcn_sched_barrier(0);
-        if (chunk_wanted) {
-            chunk_cur = uniform64(chunk_pending);
-            chunk_i = 0;
-            chunk_wanted = false;
-        }
-    };
-    const int spread_log2 = (spread & (spread - 1)) == 0 ? 31 - __builtin_clz((unsigned)spread) : -1;
-    // item -> first plan of the pair (local, even) or -1
-    auto decode = [&](unsigned long long item) __attribute__((always_inline)) -> long long {
-        if (item >= total) return -1;
-        long long l;
-        if (spread_log2 >= 0) l = (long long)(item & (unsigned long long)(spread - 1)) * per + (long long)(item >> spread_log2);
-        else if (total <= 0xffffffffull) l = (long long)((unsigned)item % (unsigned)spread) * per + (long long)((unsigned)item / (unsigned)spread);
-        else l = (long long)(item % (unsigned long long)spread) * per + (long long)(item / (unsigned long long)spread);
-        return l < npairs ? 2 * l : -1;
-    };
-    // the 14 loads of a pair (nothing here waits): joint slot x < 7 = plan A's joint x, slot 7 + x = plan B's; slots without a joint
-    // (dof < 7, no plan B, holes) re-read the pair's first lane into a table nobody streams, so that every pair issues exactly 14
-    auto request = [&](DualBuffer& B, unsigned long long item) __attribute__((always_inline)) {
-        const long long pa = decode(item);
-        const bool real = pa >= 0;
-        const bool has_b = real && pa + 1 < count;
-        const int lane = fresh_lane();
-        const unsigned long long l0 = (unsigned long long)(real ? pa : 0) * dof;                  // table lane of plan A's joint 0 (wave-uniform)
-        const __amdgpu_buffer_rsrc_t r_tab = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<unsigned long long*>(tables) + (l0 >> 6) * (unsigned long long)(kPackedWords * 64), 0, (int)(2u * kTileBytes), 0x00020000);
-        // lane x < 14 computes where slot x starts inside the descriptor
-        const int xs = lane < kDualSlots ? lane : 0;
-        const int xj = xs < kTabJointGroup ? xs : xs - kTabJointGroup;
-        const bool slot_real = real && xj < dof && (xs < kTabJointGroup || has_b);
-        const unsigned in_tile = (unsigned)(l0 & 63ull) + (slot_real ? (unsigned)(xs < kTabJointGroup ? xj : dof + xj) : 0u);
-        const unsigned slot_base = (in_tile >> 6) * kTileBytes + (in_tile & 63u) * 16u;
-        const unsigned lane_off = (unsigned)lane * 1024u;
-        const bool wanted = lane < kPairsPerTable;
-#pragma unroll
-        for (int x = 0; x < kDualSlots; ++x) {
-            const unsigned base = (unsigned)__builtin_amdgcn_readlane((int)slot_base, x);
-            if (wanted)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(r_tab, (lds_ptr)(reinterpret_cast<char*>(&B.ct[x]) + kPackedByte), 16, base + lane_off, 0, 0, 0);
-        }
-    };
-    auto publish_header = [&](DualBuffer& B, unsigned long long item) __attribute__((always_inline)) {
-        const int lane = fresh_lane();
-        if (item >= total) {
-            if (lane == 0) lds_poke32(lds_offset(&B.hdr.done), 1);
-            return;
-        }
-        const long long pa = decode(item);
-        const int nj = dof < kTabJointGroup ? dof : kTabJointGroup;
-        int slen_a = 0, slen_b = 0;
-        unsigned long long rel_a = 0ull, rel_b = 0ull;
-        if (pa >= 0) {
-            const bool has_b = pa + 1 < count;
-            // one LDS round trip: lanes 0..13 the run counts of the 14 joint slots, 14 / 15 the lengths of plan A / B, 16 / 17 their row
-            // offsets (packed word 0 = nseg | len; the row offset is the upper half of packed word 11)
-            const unsigned pk_a = lds_offset(&B.ct[0]) + kPackedByte, pk_b = lds_offset(&B.ct[kTabJointGroup]) + kPackedByte;
-            constexpr unsigned kRelAt = (unsigned)(1 + (kMaxSegments + 1) / 2) * 8u + 4u * ((kMaxSegments + 1) & 1);
-            const unsigned peek_at = lane < kDualSlots ? lds_offset(&B.ct[lane]) + kPackedByte
-                                     : (lane == 14 ? pk_a + 4u : (lane == 15 ? pk_b + 4u : (lane == 16 ? pk_a + kRelAt : pk_b + kRelAt)));
-            const int peeked = lds_peek32(peek_at);
-            const int len_a = __builtin_amdgcn_readlane(peeked, 14), len_b = has_b ? __builtin_amdgcn_readlane(peeked, 15) : 0;
-            slen_a = stored_len(len_a, rows);
-            slen_b = stored_len(len_b, rows);
-            rel_a = (unsigned long long)(unsigned)__builtin_amdgcn_readlane(peeked, 16) * (unsigned long long)kRowAlign;
-            rel_b = (unsigned long long)(unsigned)__builtin_amdgcn_readlane(peeked, 17) * (unsigned long long)kRowAlign;
-            const unsigned long long stride_a = ((unsigned long long)slen_a + (kRowAlign - 1)) / kRowAlign * kRowAlign;
-            const unsigned long long stride_b = ((unsigned long long)slen_b + (kRowAlign - 1)) / kRowAlign * kRowAlign;
-            if (slen_a > 0 && rel_a + 4ull * dof * stride_a > capacity) {
-                if (lane == 0) atomicOr(&rec.status[first + pa], kStatusOverflow);
-                slen_a = 0;
-            }
-            if (slen_b > 0 && rel_b + 4ull * dof * stride_b > capacity) {
-                if (lane == 0) atomicOr(&rec.status[first + pa + 1], kStatusOverflow);
-                slen_b = 0;
-            }
-            // run counts: a plan with a joint of more than kDualRuns runs inside the cap goes to the list (k_sample_tab in list mode)
-            int max_a = 0, max_b = 0;
-#pragma unroll
-            for (int x = 0; x < kTabJointGroup; ++x) {
-                const int na = x < nj ? __builtin_amdgcn_readlane(peeked, x) : 0, nb = x < nj ? __builtin_amdgcn_readlane(peeked, kTabJointGroup + x) : 0;
-                max_a = na > max_a ? na : max_a;
-                max_b = nb > max_b ? nb : max_b;
-            }
-            const bool over_a = slen_a > 0 && max_a > kDualRuns, over_b = slen_b > 0 && max_b > kDualRuns;
-            if (over_a || over_b) {
-                if (lane == 0) {
-                    // A returning atomic the compiler does not see: it would otherwise guard the result register with "wait for ALL
-                    // vector-memory operations" at every join of the loop, i.e. drain the prefetches of every pair. This rare path
-                    // waits for everything itself.
-                    unsigned at = (over_a ? 1u : 0u) + (over_b ? 1u : 0u);
-                    asm volatile("global_atomic_add %0, %1, %0, off sc0\n\ts_waitcnt vmcnt(0)" : "+v"(at) : "v"(overflow_list) : "memory");
-                    unsigned k = at;
-                    if (over_a) __builtin_nontemporal_store((unsigned)pa, &overflow_list[1 + k++]);
-                    if (over_b) __builtin_nontemporal_store((unsigned)(pa + 1), &overflow_list[1 + k]);
-                }
-                if (over_a) slen_a = 0;
-                if (over_b) slen_b = 0;
-            }
-            if (slen_a > 0 || slen_b > 0) {
-                // expansion in place: lane -> (joint slot 8 * pass + lane / 8, run lane % 8); every lane reads its header words and
-                // its run before any lane writes (one wave, one instruction stream; the LDS serves it in order and the reads wait
-                // for their data); the coefficients overwrite packed words of the SAME table only
-#pragma unroll
-                for (int pass = 0; pass < 2; ++pass) {
-                    const int x = 8 * pass + (lane >> 3), i = lane & 7;
-                    const bool slot_live = x < kDualSlots && (x < kTabJointGroup ? (x < nj && slen_a > 0) : (x - kTabJointGroup < nj && slen_b > 0));
-                    const unsigned jt = lds_offset(&B.ct[slot_live ? x : 0]);
-                    const unsigned pk = jt + kPackedByte;
-                    unsigned long long hd[4];
-                    lds_peek64x4(pk + 8u * (unsigned)i, pk + 8u * (unsigned)(8 + (i < 4 ? i : 0)), pk, pk + 12u * 8u, hd);
-                    const int nseg = (int)(unsigned)hd[2];
-                    const double vsnap = __builtin_bit_cast(double, hd[3]);
-                    const bool live = slot_live && i < nseg;
-                    const unsigned src = pk + (unsigned)(kPackedHeaderWords + kPackedRunWords * (live ? i : 0)) * 8u;
-                    unsigned long long st5[5];
-                    lds_peek64x5(src, st5);
-                    const RunCoef rc = run_coef<kSemMatlab>((int)(unsigned)st5[4], __builtin_bit_cast(double, st5[3]), __builtin_bit_cast(double, st5[0]),
-                                                            __builtin_bit_cast(double, st5[1]), __builtin_bit_cast(double, st5[2]), vsnap, t_sample);
-                    if (slot_live) {
-                        lds_poke64(jt + 8u * (unsigned)i, hd[0]);
-                        if (i < 4) lds_poke64(jt + 8u * (unsigned)(8 + i), hd[1]);
-                    }
-                    if (live) {
-                        const unsigned dst = jt + (unsigned)(12 + kRunCoefs * i) * 8u;
-#pragma unroll
-                        for (int c = 0; c < kRunCoefs; ++c) lds_poke64(dst + 8u * (unsigned)c, __builtin_bit_cast(unsigned long long, rc.c[c]));
-                    }
-                }
-            }
-        }
-        if (lane == 0) {
-            lds_poke64(lds_offset(&B.hdr.rel[0]), rel_a);
-            lds_poke64(lds_offset(&B.hdr.rel[1]), rel_b);
-            lds_poke32(lds_offset(&B.hdr.slen[0]), slen_a);
-            lds_poke32(lds_offset(&B.hdr.slen[1]), slen_b);
-            lds_poke32(lds_offset(&B.hdr.nj), nj);
-            lds_poke32(lds_offset(&B.hdr.done), 0);
-        }
-    };
-    auto wait_buffer_free = [&](int seq) __attribute__((always_inline)) {
-        if (seq < kTabBuffers) return;
-        const int need = seq - kTabBuffers + 1;
-        const int lane = fresh_lane();
-        const unsigned watch = lds_offset(&s_consumed[lane < kTabStreamWaves ? lane : 0]);
-        for (;;) {
-            const int c = lds_peek32(watch);
-            if (!__builtin_amdgcn_ballot_w64(c < need)) break;
-            __builtin_amdgcn_s_sleep(1);
-        }
-    };
-    unsigned long long ids[kTabAhead + 1];
-#pragma unroll
-    for (int d = 0; d < kTabAhead; ++d) {
-        ids[d] = next_item_id();
-        request(buf[d], ids[d]);
-        finish_draw();
-    }
-    for (int seq = 0;; ++seq) {
-        wait_buffer_free(seq + kTabAhead);
-        ids[kTabAhead] = next_item_id();
-        request(buf[(seq + kTabAhead) % kTabBuffers], ids[kTabAhead]);
-        LTP_WAIT_VMCNT(kTabAhead * kDualSlots);          // pair seq is in when at most the loads of the kTabAhead younger pairs are outstanding
-        DualBuffer& B = buf[seq % kTabBuffers];
-        const unsigned long long item = ids[0];
-        publish_header(B, item);
-        if (fresh_lane() == 0) lds_poke32(lds_offset(&s_ready[seq % kTabBuffers]), seq + 1);
-        finish_draw();
-        if (item >= total) break;
-#pragma unroll
-        for (int d = 0; d < kTabAhead; ++d) ids[d] = ids[d + 1];
-    }
-    LTP_WAIT_VMCNT(0);
-}
-
-#define LTP_TAB_DUAL_KERNEL(NAME, ST, TY, WAVES)                                                                                     \
-    __global__ void __launch_bounds__(kTabThreads) __attribute__((amdgpu_waves_per_eu(WAVES, 8)))                                    \
-    NAME(long long first, long long count, int dof, Records rec, TY* __restrict__ out, unsigned long long capacity, int spread,       \
-         RowSpec rows, unsigned long long* __restrict__ next_item, const unsigned long long* __restrict__ tables, int draw_chunk,     \
-         double t_sample, unsigned* __restrict__ overflow_list)                                                                       \
-    {                                                                                                                                 \
-        sample_tab_dual_body<ST, TY>(first, count, dof, rec, out, capacity, spread, rows, next_item, tables, draw_chunk, t_sample, overflow_list); \
-    }
-LTP_TAB_DUAL_KERNEL(k_sample_tab2_f64, false, double, 6)
-LTP_TAB_DUAL_KERNEL(k_sample_tab2_f64_nt, true, double, 6)
-LTP_TAB_DUAL_KERNEL(k_sample_tab2_f32, false, float, 4)
-LTP_TAB_DUAL_KERNEL(k_sample_tab2_f32_nt, true, float, 4)
-#undef LTP_TAB_DUAL_KERNEL
-
-// rows the two-plans-per-item sampler takes: at most 32 slots per row (64 float64 / 128 float32 stored samples), one joint group
-bool sample_tab_dual_applies(int dof, RowSpec rows, bool f32)
-{
-    const int n = f32 ? 4 : 2;
-    return dof >= 1 && dof <= kTabJointGroup && rows.max_samples > 0 && (rows.max_samples + n - 1) / n <= 32;
-}
 
 int sample_tab_resident_blocks(int device, bool f32)
 {
@@ -914,7 +523,7 @@ int sample_tab_resident_blocks(int device, bool f32)
 void launch_sample_tab(hipStream_t s, long long first, long long count, long long base_first, int dof, Records rec,
                        const unsigned long long* offsets, void* out, bool f32, unsigned long long capacity, int flags, RowSpec rows,
                        unsigned long long* next_item, int resident_blocks, const unsigned long long* tables, double t_sample,
-                       unsigned long long* stamps, unsigned* overflow_list, unsigned long long* next_item_list)
+                       unsigned long long* stamps)
 {
     if (count <= 0) return;
     int spread = (flags >> 8) & 0xFFFF;
@@ -924,32 +533,10 @@ void launch_sample_tab(hipStream_t s, long long first, long long count, long lon
     const dim3 block(kTabThreads);
     // (the loader pays one exposed atomic round trip per draw: larger chunks than k_sample's)
     const int draw_chunk = 2 * queue_draw_chunk(rows, f32, dof < kTabJointGroup ? dof : kTabJointGroup);
-    // flags bit 4: never the two-plans-per-item kernels (A/B runs, tests of both paths)
-    const bool dual = overflow_list && next_item_list && !stamps && !(flags & 16) && sample_tab_dual_applies(dof, rows, f32);
-    if (dual) {
-        // pairs of neighbouring plans per item; what does not fit a pair's compact tables lands in overflow_list and is sampled by
-        // the single-plan kernel right behind (list mode, a small grid: a few plans per million)
-        const long long npairs = (count + 1) / 2;
-        int sp = spread;
-        if ((long long)sp > npairs) sp = (int)npairs;
-        long long b2 = blocks > npairs ? npairs : blocks;
-        const dim3 grid((unsigned)b2);
-#define LTP_TAB2_CASE(K, TY) hipLaunchKernelGGL(K, grid, block, 0, s, first, count, dof, rec, (TY*)out, capacity, sp, rows, next_item, tables, draw_chunk, t_sample, overflow_list)
-        switch ((flags & 1) | (f32 ? 2 : 0)) {
-        case 0: LTP_TAB2_CASE(k_sample_tab2_f64, double); break;
-        case 1: LTP_TAB2_CASE(k_sample_tab2_f64_nt, double); break;
-        case 2: LTP_TAB2_CASE(k_sample_tab2_f32, float); break;
-        default: LTP_TAB2_CASE(k_sample_tab2_f32_nt, float); break;
-        }
-#undef LTP_TAB2_CASE
-    }
     if ((long long)spread > count) spread = (int)count;
     if (blocks > count * ngroups) blocks = count * ngroups;
-    if (dual && blocks > 64) blocks = 64;
     const dim3 grid((unsigned)blocks);
-    const unsigned* list = dual ? overflow_list : nullptr;
-    unsigned long long* head = dual ? next_item_list : next_item;
-#define LTP_TAB_CASE(K, TY) hipLaunchKernelGGL(K, grid, block, 0, s, first, count, base_first, dof, rec, offsets, (TY*)out, capacity, spread, rows, head, tables, dual ? 1 : draw_chunk, stamps, t_sample, list)
+#define LTP_TAB_CASE(K, TY) hipLaunchKernelGGL(K, grid, block, 0, s, first, count, base_first, dof, rec, offsets, (TY*)out, capacity, spread, rows, next_item, tables, draw_chunk, stamps, t_sample)
     switch ((flags & 1) | (f32 ? 2 : 0)) {
     case 0: LTP_TAB_CASE(k_sample_tab_f64, double); break;
     case 1: LTP_TAB_CASE(k_sample_tab_f64_nt, double); break;

@@ -67,12 +67,11 @@ struct WalkBatch {
 };
 static_assert(kWalkBuffers * sizeof(WalkBatch) <= 53 * 1024, "three blocks per compute unit");
 
-// rows this kernel takes: capped at <= 1024 stored samples (a batch's rows lie behind one buffer descriptor with 32-bit offsets; the
-// automatic choice sends it what the table pass used to get: <= 256 float64 / 1024 float32 samples), at most 63 joints (a compact
-// batch holds at least one plan; a wide batch holds whole plans up to 28 joints, and 28 joints of one plan at a time beyond that)
+// rows this kernel takes: every format, any number of joints (a compact batch holds whole plans up to 63 joints and 63 joints of
+// one plan at a time beyond that; a wide batch whole plans up to 28 joints, 28 joints of one plan at a time beyond)
 bool sample_walk_applies(int dof, RowSpec rows)
 {
-    return dof >= 1 && dof <= kWalkLanes && rows.max_samples >= 0;
+    return dof >= 1 && rows.max_samples >= 0;
 }
 
 // LONG rows — no cap, or a cap beyond kWalkBatchCap samples: wide batches only, one row per wave pass (walk_stream_rows). Short rows: compact
@@ -83,6 +82,7 @@ __host__ __device__ inline bool walk_long_rows(RowSpec rows) { return rows.max_s
 // plans per queue item: a compact batch; for long rows two wide batches
 __host__ __device__ inline int walk_plans_per_item(int dof, RowSpec rows)
 {
+    if (dof > kWalkLanes) return 1;                                                // one plan, kWalkLanes joints at a time
     const int compact = (kWalkLanes / dof) < kWalkMaxPlans ? (kWalkLanes / dof) : kWalkMaxPlans;
     if (!walk_long_rows(rows)) return compact;
     const int two_wide = 2 * (kWideLanes / dof) > 1 ? 2 * (kWideLanes / dof) : 1;
@@ -355,6 +355,7 @@ LTP_DEV void sample_walk_body(long long first, long long count, int dof, double 
     // buffer. Returns false without publishing if a lane of a compact batch has too many runs.
     auto build = [&](long long pb, int np, int j0, int nj, auto wide_tag) -> bool {
         constexpr bool WIDE = decltype(wide_tag)::value;
+        wait_buffer_free();                                                                       // (returns at once if the buffer is free already)
         const WalkLaneIn L = load_lane(pb, np, j0, nj);
         WalkBatch& B = buf[seq % kWalkBuffers];
         const int pl = lane / nj, jl = lane - pl * nj;
@@ -430,17 +431,14 @@ LTP_DEV void sample_walk_body(long long first, long long count, int dof, double 
         // a plan whose whole trajectory lies inside the cap has (nearly always) more than kWalkRuns runs there: straight to wide
         const int pl = lane / dof;
         const int len_here = pl < np ? rec.traj_len[first + pb + pl] : 0;
-        bool wide = long_rows || __builtin_amdgcn_ballot_w64(len_here > 0 && (long long)len_here <= needed_end) != 0ull;
-        if (!wide) wide = !build(pb, np, 0, dof, CompactTag{});
-        if (wide) {
-            bool first_sub = true;
-            for (int sub = 0; sub < np; sub += wpb) {
-                for (int j0 = 0; j0 < dof; j0 += wide_nj) {
-                    if (!first_sub) wait_buffer_free();
-                    first_sub = false;
-                    (void)build(pb + sub, np - sub < wpb ? np - sub : wpb, j0, dof - j0 < wide_nj ? dof - j0 : wide_nj, WideTag{});
-                }
-            }
+        const bool wide_at_once = long_rows || __builtin_amdgcn_ballot_w64(len_here > 0 && (long long)len_here <= needed_end) != 0ull;
+        // (beyond kWalkLanes joints an item is one plan, taken kWalkLanes joints at a time)
+        for (int jc = 0; jc < dof; jc += kWalkLanes) {
+            const int jc_end = dof - jc < kWalkLanes ? dof : jc + kWalkLanes;
+            if (!wide_at_once && build(pb, np, jc, jc_end - jc, CompactTag{})) continue;
+            for (int sub = 0; sub < np; sub += wpb)
+                for (int j0 = jc; j0 < jc_end; j0 += wide_nj)
+                    (void)build(pb + sub, np - sub < wpb ? np - sub : wpb, j0, jc_end - j0 < wide_nj ? jc_end - j0 : wide_nj, WideTag{});
         }
     }
 }

@@ -884,17 +884,17 @@ def test_table_pass_matches_the_fused_sampler_on_a_large_range(amd, limits, n, c
 
 
 @pytest.mark.parametrize("limits,dof,n", [("panda", None, 3001), ("ref", 3, 2000), ("ref", 6, 1001), ("ref", 1, 700)])
-def test_two_plans_per_item_sampler_gives_the_bits_of_the_other_samplers(amd, limits, dof, n):
-    """Rows of at most 32 slots (64 float64 / 128 float32 stored samples) of up to 7 joints are written by k_sample_tab2_*: an item
-    is a PAIR of neighbouring plans, tables held in compact form (8 runs), and a plan with more than 8 runs inside the cap goes
-    through a list to the single-plan kernel. Whatever the cap, stride, range, odd counts, rejected plans inside pairs, short
-    trajectories (every run inside the cap: the list pass) or tiles too small for some plans: the rows, statuses and lengths are
-    those of the single-plan table sampler and of the fused sampler, bit for bit."""
+def test_short_rows_table_pass_and_walk_kernel_give_the_bits_of_the_fused_sampler(amd, limits, dof, n):
+    """Rows of a few dozen samples through all three samplers: the fused one, the table pass (k_build_tables + k_sample_tab_*, whole
+    and in pieces of a small workspace) and the walk kernel (compact batches; plans with more than 8 runs inside the cap — short
+    moves from rest — rebuilt as wide batches). Whatever the cap, stride, range, odd counts, rejected neighbours or tiles too small
+    for some plans: rows, statuses and lengths agree bit for bit. (Round 4 also had a two-plans-per-item form of the table sampler,
+    profiles/EXPERIMENTS.md E6.3; the walk kernel superseded it and it was removed.)"""
     import torch
     D, lim = amd.limit_set(limits, dof)
     ltp = amd.LongTermPlanner(D, 0.001, device=0, **lim)
     qg, q0, v0, a0 = (x.clone() for x in ltp.generateQueries(n, seed=5))
-    q0[11, 0] = 99.0                                            # rejected plans: first of a pair, second of a pair, both
+    q0[11, 0] = 99.0                                            # rejected plans, alone and as neighbours
     q0[14, 0] = 99.0
     q0[20, 0] = 99.0; q0[21, 0] = 99.0
     # short moves from rest: trajectories of a few dozen samples whose runs ALL lie inside the cap (more than 8 per joint)
@@ -905,27 +905,21 @@ def test_two_plans_per_item_sampler_gives_the_bits_of_the_other_samplers(amd, li
     lo = torch.tensor(lim["q_min"], dtype=torch.float64, device=qg.device)
     hi = torch.tensor(lim["q_max"], dtype=torch.float64, device=qg.device)
     qg[short] = torch.minimum(torch.maximum(qg[short], lo), hi)
-    listed_total = 0
     for cap, stride, f32 in ((64, 1, False), (63, 1, False), (1, 1, False), (2, 1, False), (17, 3, False), (33, 1, False), (128, 1, True), (5, 2, True), (100, 1, True)):
-        walk_modes = ("walk",)
         ltp.setMaxSamples(cap); ltp.setSampleStride(stride)
         b = ltp.planSwitchTimesBatch(qg, q0, v0, a0)
         total = int(b.offsets[-1].item())
         dt = torch.float32 if f32 else torch.float64
         res = {}
-        for mode in ("fused", "single", "dual", "dual_pieces") + walk_modes:
-            ltp.setTablePass(0, (1 << 32) if mode != "dual_pieces" else 37 * D * 912)
+        for mode in ("fused", "tables", "tables_pieces", "walk"):
+            ltp.setTablePass(0, (1 << 32) if mode != "tables_pieces" else 37 * D * 912)
             b = ltp.planSwitchTimesBatch(qg, q0, v0, a0)
             full = torch.full((total,), 3.0, dtype=dt, device="cuda")
-            kw = dict(walk=True) if mode == "walk" else dict(tables=(mode != "fused"), dual=mode.startswith("dual"), walk=False)
+            kw = dict(walk=True) if mode == "walk" else dict(tables=(mode != "fused"), walk=False)
             ltp.sampleBatch(b, 0, n, full, **kw)
             kern = ltp.lastSamplerKernel()
-            assert ("tab2" in kern) == mode.startswith("dual") and ("walk" in kern) == (mode == "walk"), (mode, kern)
-            if mode == "dual":
-                listed = ltp._lib.ltp_debug_tab_list_count(ltp._h)
-                assert listed >= 0
-                listed_total += listed
-            # an odd sub-range that starts inside a pair of the full range, into its own tile; and a tile too small for the last plans
+            assert ("tab" in kern) == mode.startswith("tables") and ("walk" in kern) == (mode == "walk"), (mode, kern)
+            # an odd sub-range into its own tile; and a tile too small for the last plans
             sub = torch.full((int((b.offsets[n - 2] - b.offsets[41]).item()) + 8,), 3.0, dtype=dt, device="cuda")
             ltp.sampleBatch(b, 41, n - 43, sub, spread=48, **kw)
             b2 = ltp.planSwitchTimesBatch(qg, q0, v0, a0)
@@ -933,23 +927,18 @@ def test_two_plans_per_item_sampler_gives_the_bits_of_the_other_samplers(amd, li
             ltp.sampleBatch(b2, 0, n, small, streaming=False, **kw)
             torch.cuda.synchronize()
             res[mode] = (full, sub, small, b.status.clone(), b.traj_len.clone(), b2.status.clone())
-        for mode in ("single", "dual", "dual_pieces") + walk_modes:
+        for mode in ("tables", "tables_pieces", "walk"):
             for k, (got, want) in enumerate(zip(res[mode], res["fused"])):
                 if k == 5 and mode != "walk":        # (k_sample_walk never walks a plan that does not fit: the fused sampler's statuses)
                     # a plan that does not fit the tile: the table pass has walked it to its end (END_LIMIT set), the fused sampler
                     # never built its tables; everything else about the statuses is equal, and the table samplers agree exactly
                     skipped = (want & 32) != 0
                     assert torch.equal(got & ~torch.where(skipped, 8, 0), want), (cap, stride, f32, mode, k)
-                    assert torch.equal(got, res["single"][5]), (cap, stride, f32, mode, "statuses of the table samplers")
+                    assert torch.equal(got, res["tables"][5]), (cap, stride, f32, mode, "statuses of the table samplers")
                     assert skipped.any()
                     continue
                 assert torch.equal(got, want), (cap, stride, f32, mode, k)
-    if limits == "panda":
-        assert listed_total > 0, "no plan took the list pass: the short moves did not produce more than 8 runs inside the cap"
-    ltp.setMaxSamples(65)                                       # 33 slots: not for the pair kernels
-    b = ltp.planSwitchTimesBatch(qg, q0, v0, a0)
-    ltp.sampleBatch(b, 0, n, torch.empty(int(b.offsets[-1].item()), dtype=torch.float64, device="cuda"), tables=True)
-    assert "tab2" not in ltp.lastSamplerKernel()
+    ltp.setTablePass(0, 1 << 32)
 
 
 @pytest.mark.parametrize("limits,dof,n", [("panda", None, 2503), ("ref", 28, 401), ("ref", 2, 1500), ("ref", 9, 900), ("ref", 30, 301),
@@ -1131,3 +1120,40 @@ def test_rows_longer_than_a_descriptor_window(amd):
         for x, got in enumerate((q, v, a)):
             assert torch.equal(got[0], rows[x, :, k]), (k, x)
     del tiles
+
+
+@pytest.mark.parametrize("dof", [64, 100])
+def test_walk_sampler_beyond_63_joints(amd, dof):
+    """More joints than a compact batch has lanes: an item is one plan, taken 63 joints at a time (wide: 28). Capped, sparse, float32
+    and whole rows against the fused sampler, bit for bit."""
+    import torch
+    half = dof // 2
+    D, lim = amd.limit_set("ref", dof)
+    ltp = amd.LongTermPlanner(D, 0.001, device=0, **lim)
+    Dh, limh = amd.limit_set("ref", half)
+    gen = amd.LongTermPlanner(Dh, 0.001, device=0, **limh)
+    n = 70
+    parts = [gen.generateQueries(n, seed=s) for s in (3, 4)]
+    qg, q0, v0, a0 = (torch.cat([parts[0][k], parts[1][k]], dim=1).contiguous() for k in range(4))
+    q0[4, dof - 1] = 99.0
+    short = torch.arange(10, n, 6, device=qg.device)
+    qg[short] = torch.clamp(q0[short] + 0.02, -3.0, 3.0)
+    v0[short] = 0.0
+    a0[short] = 0.0
+    for cap, stride, f32 in ((128, 1, False), (16, 1, True), (0, 4, False), (0, 1, True), (600, 2, False), (0, 1, False)):
+        ltp.setMaxSamples(cap); ltp.setSampleStride(stride)
+        dt = torch.float32 if f32 else torch.float64
+        res = {}
+        for mode in ("fused", "walk"):
+            kw = dict(tables=False, walk=False) if mode == "fused" else dict(walk=True)
+            b = ltp.planSwitchTimesBatch(qg, q0, v0, a0)
+            full = torch.full((int(b.offsets[-1].item()),), 3.0, dtype=dt, device="cuda")
+            ltp.sampleBatch(b, 0, n, full, **kw)
+            assert ("walk" in ltp.lastSamplerKernel()) == (mode == "walk"), (mode, ltp.lastSamplerKernel())
+            sub = torch.full((int((b.offsets[n - 2] - b.offsets[5]).item()) + 8,), 3.0, dtype=dt, device="cuda")
+            ltp.sampleBatch(b, 5, n - 9, sub, spread=3, **kw)
+            torch.cuda.synchronize()
+            res[mode] = (full, sub, b.status.clone(), b.traj_len.clone())
+        for k, (got, want) in enumerate(zip(res["walk"], res["fused"])):
+            assert torch.equal(got, want), (cap, stride, f32, k)
+        assert int((res["walk"][3] > 0).sum().item()) >= n - 1

@@ -19,7 +19,7 @@ out = {"command": "rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ
        "note": "per-launch means over all launches of the run (warm-up included); SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles (MI355X_MICROARCH.md)", "workloads": {}}
 for d, name in (("prof_sq_first256", "--max-samples 256 (1 M plans, first 256 samples, k_sample_walk: tables kept in the compute unit)"),
                 ("prof_sq_first256_tab", "--max-samples 256 --no-walk (the same through the table pass: k_build_tables + k_sample_tab)"),
-                ("prof_sq_first64", "--max-samples 64 (k_sample_walk)"), ("prof_sq_first64_tab", "--max-samples 64 --no-walk (table pass, pair items)"), ("prof_sq_switch100k", "--switch-only --batch 100000 (config 2)"),
+                ("prof_sq_first64", "--max-samples 64 (k_sample_walk)"), ("prof_sq_first64_tab", "--max-samples 64 --no-walk (table pass)"), ("prof_sq_switch100k", "--switch-only --batch 100000 (config 2)"),
                 ("prof_sq_f32", "--f32 (1 M plans, float32 rows)"), ("prof_sq_envelope", "--envelope 64:32 (1 M plans, envelope consumer)")):
     f = max(glob.glob(f"gpurun_out/{d}/**/*_counter_collection.csv", recursive=True), key=lambda x: __import__("os").path.getmtime(x))
     agg = collections.defaultdict(lambda: collections.defaultdict(list))

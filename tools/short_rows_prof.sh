@@ -4,7 +4,7 @@ cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/short_rows_prof
 mkdir -p $O
-if [ $# -eq 0 ]; then set -- "--max-samples 64" "--max-samples 64 --no-pair-items" "--max-samples 256" "--receding 10:100 --max-samples 128"; fi
+if [ $# -eq 0 ]; then set -- "--max-samples 64" "--max-samples 64 --no-walk" "--max-samples 256" "--receding 10:100 --max-samples 128"; fi
 i=0
 for v in "$@"; do
   i=$((i+1))
