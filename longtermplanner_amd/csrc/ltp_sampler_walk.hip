@@ -323,9 +323,14 @@ LTP_DEV void sample_walk_body(long long first, long long count, int dof, double 
             __builtin_amdgcn_s_sleep(1);
         }
     };
-    auto draw = [&]() -> unsigned long long {
+    // the queue is drawn ONE ITEM AHEAD: the atomic's round trip (1-2 us behind the block's own row stores) runs beside the walk
+    // of the current item; its result is first looked at when the next item starts
+    auto draw_issue = [&]() -> unsigned long long {
         unsigned long long item = 0ull;
         if (lane == 0) item = atomicAdd(next_item, 1ull);
+        return item;
+    };
+    auto draw_result = [&](unsigned long long item) -> unsigned long long {
         return ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(item >> 32)) << 32) |
                (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)item);
     };
@@ -351,12 +356,17 @@ LTP_DEV void sample_walk_body(long long first, long long count, int dof, double 
         }
         return L;
     };
-    // builds and publishes one batch (joints [j0, j0 + nj) of np plans from local plan pb; lanes as in load_lane) into the free
-    // buffer. Returns false without publishing if a lane of a compact batch has too many runs.
+    // builds and publishes one batch (joints [j0, j0 + nj) of np plans from local plan pb; L = load_lane() of the same arguments)
+    // into the buffer the caller has waited for. Returns false without publishing if a lane of a compact batch has too many runs.
     auto build = [&](long long pb, int np, int j0, int nj, auto wide_tag) -> bool {
         constexpr bool WIDE = decltype(wide_tag)::value;
-        wait_buffer_free();                                                                       // (returns at once if the buffer is free already)
+        wait_buffer_free();
         const WalkLaneIn L = load_lane(pb, np, j0, nj);
+        if constexpr (!WIDE) {
+            // a plan whose whole trajectory lies inside the cap has (nearly always) more than kWalkRuns runs there: straight to wide
+            // batches (the lengths arrive with the rest of the records: no round trip of their own)
+            if (__builtin_amdgcn_ballot_w64(L.len > 0 && (long long)L.len <= needed_end) != 0ull) return false;
+        }
         WalkBatch& B = buf[seq % kWalkBuffers];
         const int pl = lane / nj, jl = lane - pl * nj;
         const bool mine = pl < np;
@@ -417,28 +427,28 @@ LTP_DEV void sample_walk_body(long long first, long long count, int dof, double 
     typedef std::integral_constant<bool, false> CompactTag;
     typedef std::integral_constant<bool, true> WideTag;
 
+    unsigned long long drawn = draw_issue();
     for (;;) {
-        wait_buffer_free();
-        const unsigned long long item = draw();
+        const unsigned long long item = draw_result(drawn);
         if (item >= total) {
+            wait_buffer_free();
             if (lane == 0) buf[seq % kWalkBuffers].done = 1;
             __hip_atomic_store(&s_ready[seq % kWalkBuffers], seq + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
             break;
         }
+        drawn = draw_issue();
         long long pb = 0;
         int np = 0;
         item_plans(item, pb, np);
-        // a plan whose whole trajectory lies inside the cap has (nearly always) more than kWalkRuns runs there: straight to wide
-        const int pl = lane / dof;
-        const int len_here = pl < np ? rec.traj_len[first + pb + pl] : 0;
-        const bool wide_at_once = long_rows || __builtin_amdgcn_ballot_w64(len_here > 0 && (long long)len_here <= needed_end) != 0ull;
         // (beyond kWalkLanes joints an item is one plan, taken kWalkLanes joints at a time)
         for (int jc = 0; jc < dof; jc += kWalkLanes) {
             const int jc_end = dof - jc < kWalkLanes ? dof : jc + kWalkLanes;
-            if (!wide_at_once && build(pb, np, jc, jc_end - jc, CompactTag{})) continue;
+            if (!long_rows && build(pb, np, jc, jc_end - jc, CompactTag{})) continue;
             for (int sub = 0; sub < np; sub += wpb)
-                for (int j0 = jc; j0 < jc_end; j0 += wide_nj)
-                    (void)build(pb + sub, np - sub < wpb ? np - sub : wpb, j0, jc_end - j0 < wide_nj ? jc_end - j0 : wide_nj, WideTag{});
+                for (int j0 = jc; j0 < jc_end; j0 += wide_nj) {
+                    const int npw = np - sub < wpb ? np - sub : wpb, njw = jc_end - j0 < wide_nj ? jc_end - j0 : wide_nj;
+                    (void)build(pb + sub, npw, j0, njw, WideTag{});
+                }
         }
     }
 }
