@@ -648,6 +648,10 @@ def main():
                  dict(max_samples=256, steps=max(args.steps, 5), warmup=1)),
                 ("receding horizon (SURVEY §8(f).1): 10 cycles per step through 128-sample rows, replan from stored sample 100",
                  dict(receding="10:100", max_samples=128, steps=few, warmup=1)),
+                ("every 4th sample of every row (SURVEY §8(f).2, strided rows): k_sample_walk, long-row form",
+                 dict(sample_stride=4, steps=max(args.steps, 5), warmup=1)),
+                ("float32 rows (SURVEY §8(f).2): the same binary64 results rounded once, k_sample_walk in sample pairs",
+                 dict(f32=True, steps=few, warmup=1)),
             ]
         else:
             plans = [(f"configs[3]: 10 M x 7-DoF queries sharded over {world} GPUs, full sampling",

@@ -113,8 +113,9 @@ void launch_sample_tab(hipStream_t s, long long first, long long count, long lon
                        unsigned long long* next_item /* zeroed on the same stream */, int resident_blocks, const unsigned long long* tables,
                        double t_sample /* the one the tables were built with */,
                        unsigned long long* stamps = nullptr /* diagnostic: 8 per (plan, joint group) item */);
-// Capped rows (<= 256 stored samples, <= 28 joints, C++ semantics) without any table traffic: a builder wave per block walks the
-// runs into LDS, seven streaming waves write the rows (ltp_sampler_walk.hip).
+// Rows without any table traffic (every row format, both semantics, any number of joints; taken by itself for capped, float32 and
+// sparse rows and in MATLAB semantics): a builder wave per block walks the runs into LDS, seven streaming waves write the rows
+// (ltp_sampler_walk.hip).
 bool sample_walk_applies(int dof, RowSpec rows);
 int sample_walk_resident_blocks(int device, bool f32);
 void launch_sample_walk(hipStream_t s, long long first, long long count, int dof, double t_sample, Limits lim, Queries in, Records rec,

@@ -1,6 +1,9 @@
 // ltp_sampler_tab.hip — the sampler for rows that are short compared with an item's fixed costs (first-N-samples rows,
 // receding-horizon rows), gfx950: run tables from the table pass (k_build_tables, ltp_consumers.hip), a loader wave with LDS-direct
 // loads, seven streaming waves that never wait. Rows are bit-identical to k_sample's (ltp_sampler.hip).
+// Since round 4 nothing takes this sampler by itself (ltp_sampler_walk.hip keeps the tables in the compute unit and is ahead at every
+// cap); it stays ON REQUEST (ltp_sample_batch flag bit 2) as the library's own reader of the packed table format that
+// include/ltp_run_tables.hpp publishes, and as the A/B partner of bench.py --no-walk.
 #include "ltp_sampler_lds.hpp"
 
 namespace ltp {
