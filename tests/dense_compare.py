@@ -68,14 +68,17 @@ def cause(ltp, orc, q):
     return "rounding"
 
 
-def soak(name, D, lim, Ts, n, seed, bufs, exact=False, quiet=False):
-    """exact: compare against the oracle's DIAGNOSTIC exact-pow twin instead of the libm oracle (the parity reference)."""
+def soak(name, D, lim, Ts, n, seed, bufs, exact=False, quiet=False, matlab=False):
+    """exact: compare against the oracle's DIAGNOSTIC exact-pow twin instead of the libm oracle (the parity reference).
+    matlab: both sides in MATLAB semantics (LTPlanner.m; the device's rows then come from k_sample_walk_matlab_*)."""
     import torch
     import longtermplanner_amd as amd
     import oracle
     olib = oracle.lib(exact)
     ltp = amd.LongTermPlanner(D, Ts, device=0, **lim)
-    orc = oracle.Oracle(D, Ts, exact_pow=exact, **lim)
+    orc = oracle.Oracle(D, Ts, exact_pow=exact, semantics="matlab" if matlab else "cpp", **lim)
+    if matlab:
+        ltp.setSemantics("matlab")
     t0 = time.time()
     dq = ltp.generateQueries(n, seed=seed)
     b = ltp.planSwitchTimesBatch(*dq)
