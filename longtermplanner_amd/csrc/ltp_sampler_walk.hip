@@ -60,7 +60,7 @@ struct WalkBatch {
     int done;                                                 // 1 = the queue is exhausted
     int wide;                                                 // which member of the union holds the batch
     int j0, nj;                                               // the batch holds joints [j0, j0 + nj) of each of its plans (slots = nplans * nj):
-                                                              // all of them, except in wide batches of more than kWideLanes joints
+                                                              // all of them up to 63 (compact) / 28 (wide) joints, a part of ONE plan beyond
     int pad;
     int slen[kWalkMaxPlans];                                  // stored samples per row of plan k of the batch; 0 = nothing to stream
     unsigned rel[kWalkMaxPlans];                              // row offset of plan k relative to rel0, in units of kRowAlign elements
