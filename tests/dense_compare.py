@@ -139,12 +139,15 @@ def soak(name, D, lim, Ts, n, seed, bufs, exact=False, quiet=False, matlab=False
         q = [x[p:p + 1] for x in host]
         o = {"query": int(p), "max_abs_d": [float(x) for x in maxd[p]], "flags": int(flag[p]), "cause": cause(ltp, orc, q)}
         # the budget of tests/test_gpu_parity.py: an a / j sample beyond 1e-9 is explained when q and v hold, the verdicts agree and the
-        # plan's switching times differ by |dt| <= 1e-9 with |d j| <= 2 |dt| j_max / Ts (a: the same integrated once: 2 |dt| j_max)
+        # plan's switching times differ by |dt| <= 1e-9 with |d j| <= 4 |dt| j_max / Ts (a: the same integrated once: 4 |dt| j_max).
+        # The factor: a jerk sample that collects corrections is a sum of terms +-(f_k / Ts) j_max, f_k = t_k - Ts floor(t_k / Ts)
+        # (cc:747); the worst index (cc:798) collects f_4 J_4 + f_0 J_0 + (f_2 - f_0) J_2 = (-f_4 +- 2 f_0 -+ f_2) dir j_max / Ts —
+        # four |dt|; cc:781 collects (2 f_0 - f_2): three. (Seen: exactly 2 |dt| j_max / Ts, twice in 5.3 M fuzzed plans.)
         devr, orr = ltp.planBatchHost(*q, sample=False), orc.plan_batch(*q, sample=False)
         dt = float(np.nanmax(np.abs(devr["t_scaled"][0] - orr["t_scaled"][0])))
         o["max_abs_dt"] = dt
         o["explained_by_dt_times_jmax_over_ts"] = bool((flag[p] & 7) == 0 and maxd[p][0] <= TOL and maxd[p][1] <= TOL and dt <= 1e-9 and
-                                                        maxd[p][3] <= 2.0 * dt * gain and maxd[p][2] <= max(TOL, 2.0 * dt * gain * Ts))
+                                                        maxd[p][3] <= 4.0 * dt * gain and maxd[p][2] <= max(TOL, 4.0 * dt * gain * Ts))
         explained += o["explained_by_dt_times_jmax_over_ts"]
         if len(outliers) < 40:
             outliers.append(o)

@@ -222,7 +222,8 @@ def test_dense_trajectories_parity_budget(amd, oracle_mod, capsys):
       * a and j within 1e-9 EXCEPT on jerk-correction samples (cc:768-807) of plans whose switching times differ from the oracle's
         in the last bits (libm's pow, see tools/pow_experiment.py: the device is bit-identical to the oracle built with the device's
         pow rule): such a sample is (t - Ts floor(t / Ts)) / Ts * j_max and carries |dt| * j_max / Ts. Every plan beyond 1e-9
-        must be explained that way — |dt| <= 1e-9, |dj| <= 2 |dt| j_max / Ts, |da| <= 2 |dt| j_max — and such plans must be rare:
+        must be explained that way — |dt| <= 1e-9, |dj| <= 4 |dt| j_max / Ts, |da| <= 4 |dt| j_max (the worst correction sample,
+        cc:798, collects four fractional parts: tests/dense_compare.py) — and such plans must be rare:
         at most 2e-5 of a named set (>= 3 allowed), 1e-3 of the fuzzed sets (whose j_max / Ts reaches 1e9).
     Prints the parity report line SURVEY.md §8(d) asks for."""
     import json
