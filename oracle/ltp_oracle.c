@@ -1121,6 +1121,7 @@ long ltpo_plan_batch(const ltpo_planner *P, long first, long count, const double
  * side only counts as +inf) and flag bits: 1 = one side planned the query and the other rejected it,
  * 2 = trajectory lengths differ (nothing compared), 4 = end-limit verdicts (cc:59-61) differ, 8 = compared and the JERK
  * rows are not bit-identical (informational; q, v, a come from a different but equivalent summation order on the device).
+ * 16 = visited (set for every plan of the call: the caller verifies that each plan was visited, i.e. no range was skipped).
  * dev_status: the device's LTP_STATUS_* word (bits 1|2|4|16|64 = rejected before sampling, 8 = end limit).
  * Returns the number of values compared.
  */
@@ -1143,7 +1144,7 @@ long long ltpo_compare_dense(const ltpo_planner *P, long first, long count, cons
         int *fl = flag + (p - first);
         const int dev_rejected = (dev_status[p] & (1 | 2 | 4 | 16 | 64)) != 0;
         md[0] = md[1] = md[2] = md[3] = 0.0;
-        *fl = 0;
+        *fl = 16;                                            /* visited: the caller checks that every plan was, exactly once per call */
         st = plan_trajectory_impl(P, q_goal + (size_t)p * D, q_0 + (size_t)p * D, v_0 + (size_t)p * D, a_0 + (size_t)p * D,
                                   t_opt, t_sc, dirv, mod, vd, &treq, &slow, &len, NULL, NULL, reuse, &reuse_cap);
         if ((st == 0) != dev_rejected) { *fl |= 1; continue; }

@@ -115,7 +115,10 @@ def soak(name, D, lim, Ts, n, seed, bufs, exact=False, quiet=False, matlab=False
             hnp = hb.numpy()
             step = -(-(e - f) // THREADS)
 
-            def work(t, f=f, e=e, hnp=hnp, dev_len=dev_len, dev_st=dev_st):
+            # (everything a task reads is bound here: tasks of this chunk may still be queued when the loop variables move on — an
+            # unbound `step` let late-starting tasks of small multi-chunk sets cover the wrong plan ranges, found in round 4 through
+            # values_compared differing between two runs of one set; the visited check below now proves full coverage)
+            def work(t, f=f, e=e, hnp=hnp, dev_len=dev_len, dev_st=dev_st, step=step):
                 lo = f + t * step
                 cnt = min(step, e - lo)
                 if cnt <= 0:
@@ -130,6 +133,10 @@ def soak(name, D, lim, Ts, n, seed, bufs, exact=False, quiet=False, matlab=False
             if pending[slot] is not None:
                 for fut in pending[slot]:
                     compared[0] += fut.result()
+    assert np.all((flag & 16) != 0), f"{int(np.sum((flag & 16) == 0))} plans were never visited by the comparator"
+    lens_host = b.traj_len.cpu().numpy().astype(np.int64)
+    expect = int(4 * D * np.sum(lens_host[((flag & 3) == 0) & ((b.status.cpu().numpy() & 0x57) == 0)]))
+    assert compared[0] == expect, (compared[0], expect, "every sample of every accepted plan exactly once")
     worst = maxd.max(axis=0)
     beyond = np.nonzero((maxd.max(axis=1) > TOL) | ((flag & 7) != 0))[0]
     outliers = []
@@ -137,7 +144,7 @@ def soak(name, D, lim, Ts, n, seed, bufs, exact=False, quiet=False, matlab=False
     gain = float(np.max(orc.j_max)) / Ts
     for p in beyond[:200]:
         q = [x[p:p + 1] for x in host]
-        o = {"query": int(p), "max_abs_d": [float(x) for x in maxd[p]], "flags": int(flag[p]), "cause": cause(ltp, orc, q)}
+        o = {"query": int(p), "max_abs_d": [float(x) for x in maxd[p]], "flags": int(flag[p]) & 15, "cause": cause(ltp, orc, q)}
         # the budget of tests/test_gpu_parity.py: an a / j sample beyond 1e-9 is explained when q and v hold, the verdicts agree and the
         # plan's switching times differ by |dt| <= 1e-9 with |d j| <= 4 |dt| j_max / Ts (a: the same integrated once: 4 |dt| j_max).
         # The factor: a jerk sample that collects corrections is a sum of terms +-(f_k / Ts) j_max, f_k = t_k - Ts floor(t_k / Ts)

@@ -157,7 +157,8 @@ def test_dense_comparator_of_the_soak_tool(oracle_mod):
         cnt = lib.ltpo_compare_dense(orc._ref, C.c_long(0), C.c_long(n), *[x.ctypes.data_as(dp) for x in qs], packed.ctypes.data_as(dp),
                                      off.ctypes.data_as(C.POINTER(C.c_ulonglong)), C.c_ulonglong(0), lens.ctypes.data_as(ip),
                                      status.ctypes.data_as(ip), maxd.ctypes.data_as(dp), flag.ctypes.data_as(ip))
-        return cnt, maxd, flag
+        assert np.all(flag & 16)                            # every plan visited
+        return cnt, maxd, flag & ~16
     cnt, maxd, flag = run()
     assert cnt == 4 * D * int(lens.sum()) and not maxd.any() and not flag.any()
     packed[int(off[5]) + 7] += 1e-6                          # q of joint 0, sample 7 of plan 5
