@@ -2,7 +2,8 @@
   tools/pow_experiment.py          -> records: device vs the exact-pow twin (bit for bit), vs the libm oracle, libm vs twin by branch
   tools/dense_soak.py [--wide-fuzz] -> dense: every q/v/a/j sample vs the libm oracle (the parity reference)
   tools/dense_soak.py --exact-pow   -> dense: the same vs the twin (diagnostic)
-usage: python tools/collect_parity_report.py r04 gpurun_out/r04_pow_experiment.json gpurun_out/r04_dense_libm.json gpurun_out/r04_dense_exact.json"""
+usage: python tools/collect_parity_report.py r04 gpurun_out/r04_pow_experiment.json gpurun_out/r04_dense_libm.json gpurun_out/r04_dense_exact.json
+(aggregates profiles/rNN_dense_soak_*_{more_seeds,wide_fuzz,matlab}*.json from tools/aggregate_dense_soaks.py are added as totals when present)"""
 import json
 import sys
 
@@ -58,6 +59,18 @@ report = {"round": tag,
                           "rows are bit-identical to the twin's in every plan, and against the libm oracle every a / j sample beyond 1e-9 is a "
                           "jerk-correction sample (cc:768-807) that carries |dt| x j_max / Ts of a plan whose |dt| <= 1e-9"},
           "records": records, "dense_vs_libm_oracle": dense_summary(dl), "dense_vs_exact_pow_oracle": dense_summary(de)}
+# further dense soaks of the round, condensed by tools/aggregate_dense_soaks.py (other seeds, wide fuzz, MATLAB semantics): totals only
+import os
+more = {}
+for key, stem in (("more_seeds", "dense_soak_{}_more_seeds"), ("wide_fuzz", "dense_soak_wide_fuzz_{}"), ("matlab_semantics", "dense_soak_matlab_{}")):
+    for oracle_key, oracle_name in (("vs_libm_oracle", "libm"), ("vs_exact_pow_oracle", "exact_pow")):
+        path = f"profiles/{tag}_" + stem.format(oracle_name) + ".json"
+        if os.path.exists(path):
+            a = json.load(open(path))
+            more.setdefault(key, {})[oracle_key] = {"file": path, "runs": len(a["runs"]), "total": a["total"], "max_abs_d": a["max_abs_d"],
+                                                    "fraction_of_plans_within_tolerance": a["fraction_of_plans_within_tolerance"]}
+if more:
+    report["dense_further_soaks"] = more
 out = f"profiles/{tag}_parity_report.json"
 with open(out, "w") as f:
     json.dump(report, f, indent=1)
