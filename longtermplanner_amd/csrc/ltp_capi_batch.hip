@@ -76,13 +76,13 @@ static int sample_batch_any(ltp_planner* p, long long first, long long count, co
     const int blocks = p->sample_blocks_override > 0 ? p->sample_blocks_override : p->sample_blocks[f32 ? 1 : 0];
     // bytes of one joint's four rows when the cap applies (a cap is the only way rows are known to be short up front)
     const unsigned long long row_bytes = p->max_samples > 0 ? 4ull * (f32 ? 4 : 8) * (unsigned long long)p->max_samples : 0ull;
-    // MATLAB semantics: the run tables always come from the table pass (k_build_tables<MATLAB>); the sampler kernels that read
-    // tables do not depend on the semantics, the fused build of k_sample exists for the C++ semantics only
+    // MATLAB semantics: the fused build of k_sample exists for the C++ semantics only; the walk kernel and the table pass (whose
+    // builders are for_each_run<SEM>) serve both, and the kernels that read tables do not depend on the semantics
     const bool matlab = p->semantics == LTP_SEMANTICS_MATLAB;
-    // Up to 63 joints: k_sample_walk_* — the tables stay in the compute unit, no table pass at all. Taken by itself for the rows
-    // want_walk() names (capped, float32, sparse) and for every row format in MATLAB semantics (whose only other sampler is the table
-    // pass); flags bit 6 forces it, bit 5 forbids it, bit 2 = "the table-pass kernels" and bits 2-3 = "table pass on / off" keep
-    // their meaning.
+    // k_sample_walk_* — the tables stay in the compute unit, no table pass at all. Taken by itself for the rows want_walk() names
+    // (capped, float32, sparse) and for every row format in MATLAB semantics; flags bit 6 forces it, bit 5 forbids it, bit 2 = "the
+    // table-pass kernels" and bit 3 = "the fused build" keep their meaning. (Diagnostic runs — dry stores, stamps — stay with the
+    // kernels that implement them.)
     if (!p->dbg_stamps && !(flags & (2 | 32)) && ltp::sample_walk_applies(p->dof, rows) &&
         ((flags & 64) || (!(flags & (4 | 8)) && (matlab || want_walk(p, rows.max_samples, rows.stride, f32))))) {
         if (p->walk_blocks[f32 ? 1 : 0] == 0) p->walk_blocks[f32 ? 1 : 0] = ltp::sample_walk_resident_blocks(p->device, f32);
