@@ -89,6 +89,12 @@ __host__ __device__ inline int walk_plans_per_item(int dof, RowSpec rows)
     return two_wide < compact ? two_wide : compact;
 }
 
+LTP_DEV unsigned long long walk_uniform(unsigned long long x)     // a value every lane holds alike -> scalar registers
+{
+    return ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(x >> 32)) << 32) |
+           (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)x);
+}
+
 // a streaming lane's place in its row's runs
 struct WalkCursor {
     int kr, cur, nxt;                                         // run in use, its first sample, the first sample of the next run
@@ -163,7 +169,9 @@ LTP_DEV void walk_stream(const WalkBatch& B, const Slot* __restrict__ slots, int
     const int lg = max_slots > 32 ? 6 : (max_slots > 16 ? 5 : 4);
     const int rows_per_pass = 64 >> lg;
     // one buffer descriptor over the batch's rows (they are neighbours in the tile; at most 63 rows x 4 arrays of <= 1024 samples)
-    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(out + B.rel0, 0, (int)(unsigned)(B.span * sizeof(T)), 0x00020000);
+    // (rel0 and span are the same for the whole wave: made scalar, or every store gets a loop that checks its descriptor for uniformity)
+    const unsigned long long rel0 = walk_uniform(B.rel0), span = walk_uniform(B.span);
+    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(out + rel0, 0, (int)(unsigned)(span * sizeof(T)), 0x00020000);
     for (int s0 = wave * rows_per_pass; s0 < total; s0 += kWalkStreamWaves * rows_per_pass) {
         const int s = s0 + (lane >> lg);                                          // this lane's (plan, joint) slot
         const bool in = s < total;
@@ -201,7 +209,7 @@ LTP_DEV void walk_stream_rows(const WalkBatch& B, int dof, T* __restrict__ out, 
     const int nplans = __builtin_amdgcn_readfirstlane(B.nplans);
     const int nj = __builtin_amdgcn_readfirstlane(B.nj), j0 = __builtin_amdgcn_readfirstlane(B.j0);
     const int total = nplans * nj;
-    const unsigned long long rel0 = B.rel0;
+    const unsigned long long rel0 = walk_uniform(B.rel0);
     for (int s = wave; s < total; s += kWalkStreamWaves) {                        // (wave-uniform: scalar arithmetic below)
         const int pl = s / nj, j = j0 + (s - pl * nj);
         const int slen = __builtin_amdgcn_readfirstlane(B.slen[pl]);
