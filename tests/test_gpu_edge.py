@@ -1005,7 +1005,7 @@ def test_walk_sampler_random_configurations_against_the_fused_sampler(amd):
     """A randomized differential test of k_sample_walk_* (the default writer of capped rows) against the fused sampler: 48 random
     combinations of joints (1-63), sample time, cap (1-2500), stride (1-6), element type, batch size, sub-range, block interleave and
     tile size, on random limit sets (fast and slow jerk, i.e. many and few runs inside the cap) with rejected plans and short moves
-    mixed in. Rows, statuses and lengths must agree bit for bit."""
+    mixed in; every 7th configuration in MATLAB semantics (against the table pass). Rows, statuses and lengths must agree bit for bit."""
     import torch
     # (a soak: LTP_WALK_TRIALS=3000 LTP_WALK_SEED=1 python -m pytest tests/test_gpu_edge.py -k random_configurations)
     rng = np.random.default_rng(20260401 + int(os.environ.get("LTP_WALK_SEED", "0")))
@@ -1018,6 +1018,9 @@ def test_walk_sampler_random_configurations_against_the_fused_sampler(amd):
         q_hi = rng.uniform(1.0, 3.5, D)
         lim = dict(q_min=list(-q_hi), q_max=list(q_hi), v_max=list(v_max), a_max=list(a_max), j_max=list(j_max))
         ltp = amd.LongTermPlanner(D, ts, device=0, **lim)
+        matlab = trial % 7 == 3                                  # MATLAB semantics: no fused sampler there, the partner is the table pass
+        if matlab:
+            ltp.setSemantics("matlab")
         n = int(rng.integers(1, 900))
         qg, q0, v0, a0 = (x.clone() for x in ltp.generateQueries(n, seed=1000 + trial))
         for p in rng.integers(0, n, size=max(1, n // 50)):
@@ -1038,7 +1041,7 @@ def test_walk_sampler_random_configurations_against_the_fused_sampler(amd):
         dt = torch.float32 if f32 else torch.float64
         res = {}
         for mode in ("fused", "walk"):
-            kw = dict(tables=False, walk=False) if mode == "fused" else dict(walk=True)
+            kw = (dict(walk=False) if matlab else dict(tables=False, walk=False)) if mode == "fused" else dict(walk=True)
             b = ltp.planSwitchTimesBatch(qg, q0, v0, a0)
             need = int((b.offsets[first + count] - b.offsets[first]).item())
             tile = torch.full((need + 8,), 3.0, dtype=dt, device="cuda")
@@ -1051,7 +1054,7 @@ def test_walk_sampler_random_configurations_against_the_fused_sampler(amd):
             torch.cuda.synchronize()
             res[mode] = (tile, small, b.status.clone(), b.traj_len.clone(), b2.status.clone())
         for k, (got, want) in enumerate(zip(res["walk"], res["fused"])):
-            assert torch.equal(got, want), (trial, D, ts, cap, stride, f32, n, first, count, spread, k)
+            assert torch.equal(got, want), (trial, D, ts, cap, stride, f32, n, first, count, spread, matlab, k)
 
 
 @pytest.mark.parametrize("limits,dof,n", [("panda", None, 1201), ("ref", None, 400), ("ref", 30, 60), ("ref", 3, 500)])
