@@ -138,18 +138,24 @@ int ltp_get_sample_stride(const ltp_planner* p);
 int ltp_set_goal_check(ltp_planner* p, int enabled);
 int ltp_get_goal_check(const ltp_planner* p);
 /* LTP_SEMANTICS_CPP (default) or LTP_SEMANTICS_MATLAB, see above. Captured with the batch geometry: the
- * calls that consume a planned batch refuse a handle whose semantics changed in between. With MATLAB semantics rows and
- * envelopes always take the table pass, single calls the staged path; ltp_end_limit_batch does nothing. */
+ * calls that consume a planned batch refuse a handle whose semantics changed in between. With MATLAB semantics rows are
+ * written by k_sample_walk_matlab_* (or, on request, the table pass), envelopes take the table pass, single calls the staged
+ * path; ltp_end_limit_batch does nothing. */
 int ltp_set_semantics(ltp_planner* p, int semantics);
 int ltp_get_semantics(const ltp_planner* p);
 
-/* Table pass. A sampler / envelope item (one plan x <= 8 joints) needs the joint's run tables (<= 20 runs of constant jerk
- * with 10 closed-form coefficients each). They are either built inside the sampler kernel by the item's block (no extra
- * memory traffic, ~8 us of latency per item: right for long rows, which hide it) or by a kernel of their own before the
- * sampler (lane = (plan, joint); 912 bytes per joint written and read back through the handle's workspace; an item then
- * costs one prefetched read: right for short rows — first-N-samples rows, receding-horizon rows, envelopes). Both give
- * bit-identical rows. mode 0 = automatic (the pass for ltp_envelope_batch and when max_samples is at most 256 for float64 /
- * 1024 for float32 rows), 1 = always, -1 = never. ltp_sample_batch's flags bits 2 / 3 force the pass / the fused build per call. */
+/* Where the run tables come from. A sampler / envelope item needs the joint's run tables (<= 20 runs of constant jerk with 10
+ * closed-form coefficients each). Three ways, all with bit-identical results:
+ *   - built inside the sampler kernel by the item's whole block (k_sample, the envelope's fused form): no extra memory traffic,
+ *     ~8 us of latency per item — right for whole float64 rows, which hide it;
+ *   - built by one wave of the sampler's block beside its streaming waves (k_sample_walk_*, round 4): no extra memory traffic
+ *     either and nothing to hide — right for every row format whose plans have few bytes (capped, float32, sparse rows);
+ *   - the table pass: a kernel of their own before the consumer (lane = (plan, joint); 912 bytes per joint through the handle's
+ *     workspace) — what ltp_envelope_batch and ltp_build_tables_batch use, and ltp_sample_batch on request (flags bit 2).
+ * mode 0 = automatic (rows: k_sample_walk_* for a cap of <= 768 samples, float32 rows, every 3rd sample or sparser, MATLAB
+ * semantics, else k_sample; envelopes: the table pass), 1 = never the block-wide fused build (rows: always k_sample_walk_*;
+ * envelopes: the table pass), -1 = always the fused build (rows: k_sample; envelopes: built in the kernel). ltp_sample_batch's
+ * flags bits 2 / 3 / 5 / 6 choose per call. */
 int ltp_set_table_pass(ltp_planner* p, int mode);
 int ltp_get_table_pass(const ltp_planner* p);
 /* Upper bound (bytes) of the table workspace; default: the larger of 4 GiB and 1/16 of the device's memory (18 GiB on MI355X).

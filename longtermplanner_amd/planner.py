@@ -138,8 +138,9 @@ class LongTermPlanner:
         return re + 1j * im, nr, st
 
     def setTablePass(self, mode, workspace_bytes=None):
-        """NEW: where the sampler's run tables are built — 0 automatic, 1 always by the table pass (a kernel of its own,
-        912 B per joint through the workspace), -1 always inside the sampler kernel. Rows are bit-identical either way."""
+        """NEW: where the run tables are built (include/ltp_hip.h, ltp_set_table_pass) — 0 automatic; 1 never the block-wide fused
+        build (rows: k_sample_walk_*, envelopes: the table pass); -1 always the fused build (rows: k_sample, envelopes: in the
+        kernel). Results are bit-identical either way."""
         self._check(self._lib.ltp_set_table_pass(self._h, int(mode)))
         if workspace_bytes is not None:
             self._check(self._lib.ltp_set_table_workspace(self._h, int(workspace_bytes)))
