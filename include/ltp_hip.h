@@ -116,7 +116,8 @@ int ltp_get_dof(const ltp_planner* p);
 double ltp_get_sample_time(const ltp_planner* p);
 const char* ltp_last_error(const ltp_planner* p);
 /* name of the kernel that wrote the rows / envelopes of the latest ltp_sample_batch* / ltp_envelope_batch call of this
- * handle ("k_sample", "k_sample_tab_f64_nt", ...: the fused sampler or the table-pass sampler, see ltp_set_table_pass) */
+ * handle ("k_sample", "k_sample_walk_f64_nt", "k_sample_tab_f64_nt", ...: the fused sampler, the walk sampler or the table-pass
+ * sampler, see ltp_set_table_pass) */
 const char* ltp_last_sampler_kernel(const ltp_planner* p);
 /* rows of the packed trajectory layout are padded to this many elements (a multiple of 32) */
 int ltp_row_stride(int stored_samples);
@@ -173,7 +174,7 @@ int ltp_set_table_workspace(ltp_planner* p, unsigned long long bytes);
 int ltp_reserve_batch(ltp_planner* p, long long n);
 /* Allocates the table-pass workspace for ranges of up to n plans (at most ltp_set_table_workspace bytes; longer ranges
  * are processed in pieces). Needed before capturing a call that takes the table pass — ltp_envelope_batch by default,
- * ltp_sample_batch* when max_samples is at most 256 (float64) / 1024 (float32) or flag bit 2 is set: while a stream is
+ * ltp_build_tables_batch's callers with the library's workspace, ltp_sample_batch* only when flag bit 2 is set: while a stream is
  * being captured the library neither allocates nor frees; it cuts the range into pieces that fit the workspace it has
  * and returns LTP_ERR_INVALID_ARGUMENT if it has none. */
 int ltp_reserve_tables(ltp_planner* p, long long n);
