@@ -152,6 +152,13 @@ def parse_args(argv=None):
                     help="--gpus N from ONE process: one planner handle, stream and host thread per device, device-resident shards "
                          "(ltp_plan_switch_times_multi / ltp_envelope_multi / ltp_state_at_multi), no torch.distributed. Workloads without dense "
                          "rows: --switch-only, --envelope, --receding R:K. With --device D all shards sit on device D (rehearsal)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="--gpus 1 launched plainly: still create the torch.distributed process group (world size 1) and run every collective "
+                         "of the N > 1 path — barrier, all_reduce(MAX / SUM), all_gather — through it (with --backend nccl: RCCL, device tensors). "
+                         "Under torch.distributed.run (WORLD_SIZE in the environment) this happens by itself, also at world size 1")
+    ap.add_argument("--no-rccl-check", action="store_true",
+                    help="default --gpus 1 run: skip the RCCL self-check (a child process that runs a small batch through the nccl branch at "
+                         "world size 1 before this process touches the GPU; its verdict is quoted in the line as 'rccl_world1')")
     ap.add_argument("--checksum", action="store_true",
                     help="add an order-independent checksum of all records of the batch (summed over ranks) to the line: equal for any sharding of one global batch")
     return ap.parse_args(argv)
@@ -190,6 +197,29 @@ def spawn_ranks(args):
     return rc
 
 
+def rccl_self_check(args):
+    """The default single-GPU run has no process group; the N > 1 path's use of torch.distributed over RCCL (init with device_id,
+    barrier, all_reduce MAX / SUM of device tensors, all_gather of device tensors, --gather) is the only code of this file such a
+    run never executes. This runs it once, at world size 1, in a CHILD process (this process has not touched the GPU yet), on a
+    small batch, and returns the child's verdict for the line. It never fails the headline."""
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--force-dist", "--backend", "nccl", "--batch", "40000", "--steps", "2",
+           "--warmup", "1", "--tile-gib", "16", "--no-secondary", "--no-cpu-baseline", "--gather", "--checksum", "--seed", str(args.seed)]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    t0 = time.perf_counter()
+    try:
+        p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    except Exception as e:
+        return {"ok": False, "error": f"{type(e).__name__}: {e}"}
+    wall = round(time.perf_counter() - t0, 1)
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    if p.returncode != 0 or len(lines) != 1:
+        return {"ok": False, "returncode": p.returncode, "wall_s": wall, "stderr_tail": p.stderr[-600:]}
+    o = json.loads(lines[0])
+    return {"ok": True, "wall_s": wall, "command": " ".join(cmd[1:]).replace(ROOT + os.sep, ""), "backend": o["config"]["backend"],
+            "rank_devices": o["config"]["rank_devices"], "sharding": o["config"]["sharding"], "value": o["value"], "unit": o["unit"],
+            "records_checksum": o["config"].get("records_checksum"), "roofline_frac": (o.get("roofline") or {}).get("frac")}
+
+
 class Workload:
     """One measured configuration: limits, per-rank shard of the batch and the variant switches."""
 
@@ -220,6 +250,7 @@ def run_workload(wl, ctx):
     from longtermplanner_amd import LongTermPlanner, limit_set
 
     world, rank, dev, cdev, local_rank = ctx["world"], ctx["rank"], ctx["dev"], ctx["cdev"], ctx["local_rank"]
+    grouped = ctx["dist"]       # a process group exists (always for world > 1; at world size 1 under torch.distributed.run / --force-dist)
     dof, lim = limit_set(wl.limits)
     ltp = LongTermPlanner(dof, wl.t_sample, device=local_rank, **lim)
     if wl.semantics != "cpp":
@@ -267,7 +298,7 @@ def run_workload(wl, ctx):
             if wl.semantics != "cpp":
                 lane["ltp"].setSemantics(wl.semantics)
     step_no = 0
-    gather_buf = [torch.empty(n, dtype=torch.float64, device=cdev) for _ in range(world)] if (wl.gather and world > 1 and not wl.global_batch) else None
+    gather_buf = [torch.empty(n, dtype=torch.float64, device=cdev) for _ in range(world)] if (wl.gather and grouped and not wl.global_batch) else None
     ev_pairs = []
     n_chunks = 0
 
@@ -335,7 +366,7 @@ def run_workload(wl, ctx):
 
     def sync_all():
         torch.cuda.synchronize()
-        if world > 1:
+        if grouped:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -346,7 +377,7 @@ def run_workload(wl, ctx):
     sync_all()
     elapsed = time.perf_counter() - t0
     t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
-    if world > 1:
+    if grouped:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
@@ -369,12 +400,12 @@ def run_workload(wl, ctx):
         for x in (batch.mod, batch.slowest, batch.traj_len, batch.status):
             acc += int(x.to(torch.int64).sum().item()) % M
         c = torch.tensor([acc % M], dtype=torch.int64, device=cdev)
-        if world > 1:
+        if grouped:
             dist.all_reduce(c, op=dist.ReduceOp.SUM)
         checksum = int(c.item()) % M
     # (LTP_STATUS_MATLAB_COMPLEX = 256 is informational: the plan is delivered, planTrajectory returns true)
     counts = torch.tensor([float(((status & ~256) == 0).sum()), float(traj_len.sum()), float(alg_bytes_per_step)], dtype=torch.float64, device=cdev)
-    if world > 1:
+    if grouped:
         dist.all_reduce(counts, op=dist.ReduceOp.SUM)
     ok_total, len_total, bytes_total = (float(x) for x in counts.tolist())
     roofline = None
@@ -431,7 +462,7 @@ def run_workload(wl, ctx):
                             + f" into a reused {tile_gib} GiB tile ({n_chunks} chunks per step)")),
             "batch_per_gpu": n if not wl.global_batch else None, "global_batch": total_queries, "dof": dof, "t_sample": wl.t_sample,
             "limits": wl.limits, "input_layout": wl.layout, "table_pass": wl.table_pass, "batches_in_flight": wl.in_flight, "semantics": wl.semantics,
-            "sharding": "contiguous query ranges per rank, no data-path collective" + (", RCCL all_gather of t_required" if gather_buf else ""),
+            "sharding": "contiguous query ranges per rank, no data-path collective" + (", all_gather of t_required through the process group every step" if gather_buf else ""),
             "backend": ctx["backend"], "rank_devices": ctx["rank_devices"],
             "plans_ok_frac": round(ok_total / total_queries, 5),
             "plans_ok_is": ("planTrajectory's bool" if (wl.end_limit or not (wl.switch_only or rec_direct)) else
@@ -561,6 +592,14 @@ def main():
     env_world = os.environ.get("WORLD_SIZE")
     if env_world is None and args.gpus > 1:
         return spawn_ranks(args)            # no torch, no GPU in this process
+    grouped = env_world is not None or args.force_dist     # a launcher's rank (also a lone one) always makes its process group
+    if env_world is None and args.force_dist:
+        import socket
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        os.environ.update(RANK="0", LOCAL_RANK=str(args.device or 0), WORLD_SIZE="1", LOCAL_WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     world = int(env_world or "1")
     rank = int(os.environ.get("RANK", "0"))
     if world != args.gpus:
@@ -568,6 +607,12 @@ def main():
         if rank == 0:
             print(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE {world} rank(s)", file=sys.stderr)
         return 2
+
+    variant = (args.no_walk or args.walk or args.switch_only or args.end_limit or args.f32 or args.max_samples or args.sample_stride > 1 or args.envelope or args.receding or args.dry_sampler
+               or args.in_flight > 1 or args.semantics != "cpp" or args.table_pass != "auto" or args.limits != "panda" or args.batch != 1_000_000 or args.global_batch or args.window_gib or args.layout != "query_major")
+    rccl_world1 = None
+    if not grouped and not variant and not args.no_secondary and not args.no_rccl_check and args.backend == "nccl":
+        rccl_world1 = rccl_self_check(args)     # a child process, BEFORE this one imports torch or touches the GPU
 
     import torch
     import torch.distributed as dist
@@ -578,7 +623,7 @@ def main():
     if local_rank >= torch.cuda.device_count():
         print(f"bench.py: rank {rank} wants HIP device {local_rank}, but only {torch.cuda.device_count()} device(s) are visible", file=sys.stderr)
         return 3
-    if world > 1:
+    if grouped:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.backend == "nccl":      # "nccl" is RCCL on ROCm
             dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
@@ -611,18 +656,18 @@ def main():
 
     # which HIP device every rank drives, and what carried the barrier / reductions: stated in every line
     rank_devices = [local_rank]
-    if world > 1:
+    if grouped:
         gathered = [torch.zeros(1, dtype=torch.int64, device=cdev) for _ in range(world)]
         dist.all_gather(gathered, torch.tensor([local_rank], dtype=torch.int64, device=cdev))
         rank_devices = [int(x.item()) for x in gathered]
-    backend = "none (single rank)" if world == 1 else ("nccl (RCCL over xGMI)" if args.backend == "nccl" else "gloo (CPU tensors: rehearsal)")
-    ctx = {"world": world, "rank": rank, "dev": dev, "cdev": cdev, "local_rank": local_rank, "tile": get_tile, "backend": backend,
+    backend = "none (single rank)" if not grouped else ("nccl (RCCL over xGMI)" if args.backend == "nccl" else "gloo (CPU tensors: rehearsal)")
+    if grouped and world == 1:
+        backend += "; world size 1: every collective of the N > 1 path ran through the process group"
+    ctx = {"dist": grouped, "world": world, "rank": rank, "dev": dev, "cdev": cdev, "local_rank": local_rank, "tile": get_tile, "backend": backend,
            "rank_devices": rank_devices}
     primary = Workload(args)
     out = run_workload(primary, ctx)
 
-    variant = (args.no_walk or args.walk or args.switch_only or args.end_limit or args.f32 or args.max_samples or args.sample_stride > 1 or args.envelope or args.receding or args.dry_sampler
-               or args.in_flight > 1 or args.semantics != "cpp" or args.table_pass != "auto" or args.limits != "panda" or args.batch != 1_000_000 or args.global_batch or args.window_gib or args.layout != "query_major")
     secondary = []
     if not args.no_secondary and not variant:
         few = max(1, min(args.steps, 2))
@@ -661,7 +706,7 @@ def main():
                 o = run_workload(Workload(args, name=name, **over), ctx)
             except Exception as e:      # a secondary workload must not take the headline down
                 o = {"error": f"{type(e).__name__}: {e}"} if rank == 0 else None
-                if world > 1:
+                if grouped:
                     raise
             if o is not None:
                 keep = {k: o[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "scaling", "roofline") if k in o}
@@ -675,6 +720,8 @@ def main():
     if rank == 0:
         if secondary:
             out["secondary"] = secondary
+        if rccl_world1 is not None:
+            out["rccl_world1"] = rccl_world1
         if not args.no_cpu_baseline:
             # rank 0 only, outside every timed region; with N > 1 the other ranks wait in the final barrier meanwhile
             from longtermplanner_amd import limit_set
@@ -683,7 +730,7 @@ def main():
             if world > 1:
                 out["cpu_baseline"]["measured_on"] = f"rank 0 of {world}, after the timed steps, while the other ranks wait in the final barrier"
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if grouped:
         dist.barrier()
         dist.destroy_process_group()
     return 0

@@ -230,6 +230,62 @@ def test_two_rank_bench_line_is_complete():
     assert c["cores"] <= c["host_cores_affinity"] and "sample" in c
 
 
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _check_nccl_line(line):
+    c = line["config"]
+    assert line["n_gpus"] == 1 and c["backend"].startswith("nccl") and "world size 1" in c["backend"] and c["rank_devices"] == [0]
+    assert "all_gather of t_required" in c["sharding"]
+    r = line["roofline"]
+    assert r["bound"] == "hbm" and r["kernel"] == "k_sample" and 0.0 < r["frac"] < 1.0 and r["launches_timed"] >= 2
+    assert line["value"] > 0 and line["steps"] == 2 and c["plans_ok_frac"] > 0.99
+
+
+def test_nccl_branch_runs_at_world_size_one():
+    """everything bench.py does with torch.distributed when N > 1 — init_process_group("nccl", device_id=...),
+    the all_gather of the rank devices, barrier, all_reduce(MAX) of the elapsed time, all_reduce(SUM) of the counters and of the
+    checksum, the optional --gather of t_required, all on DEVICE tensors — runs over RCCL at world size 1, and the line it prints
+    has the numbers of the run without a process group."""
+    args = ("--batch", "40000", "--steps", "2", "--tile-gib", "16", "--checksum")
+    p = _bench("--gpus", "1", "--force-dist", "--backend", "nccl", "--gather", *args)
+    assert p.returncode == 0, p.stderr[-3000:]
+    out = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(out) == 1, p.stdout
+    line = json.loads(out[0])
+    _check_nccl_line(line)
+    q = _bench("--gpus", "1", *args)
+    assert q.returncode == 0, q.stderr[-3000:]
+    plain = json.loads([ln for ln in q.stdout.splitlines() if ln.startswith("{")][0])
+    assert plain["config"]["backend"].startswith("none")
+    for key in ("records_checksum", "plans_ok_frac", "mean_traj_len", "bytes_per_plan", "global_batch"):
+        assert line["config"][key] == plain["config"][key], key
+
+
+def test_nccl_branch_under_torch_distributed_run():
+    """The driver's own launch line for N > 1, with one rank: `python -m torch.distributed.run --nnodes=1 --nproc-per-node 1
+    --master-addr 127.0.0.1 --master-port P bench.py --gpus 1 ...`. WORLD_SIZE is in the environment, so the rank creates its
+    RCCL process group; the line must be complete, cpu_baseline included (rank 0 runs it while the group is alive)."""
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                        "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--batch", "40000", "--steps", "2",
+                        "--warmup", "1", "--tile-gib", "16", "--no-secondary", "--gather", "--checksum"],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    out = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(out) == 1, p.stdout
+    line = json.loads(out[0])
+    _check_nccl_line(line)
+    c = line["cpu_baseline"]
+    assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1
+
+
 def test_two_batches_in_flight_give_the_same_records():
     """`bench.py --switch-only --in-flight 2` alternates its steps between two handles on two streams (the queue-B kernel of
     one step runs under the next step's stages): the records are those of one batch at a time."""
