@@ -148,6 +148,9 @@ def parse_args(argv=None):
     ap.add_argument("--gather", action="store_true", help="also all_gather t_required over RCCL each step (optional path)")
     ap.add_argument("--semantics", default="cpp", choices=["cpp", "matlab"],
                     help="VARIANT (SURVEY §8(f).4): 'matlab' follows LTPlanner.m where the C++ translation diverges (ltp_set_semantics); rows then take the table pass")
+    ap.add_argument("--pow-rule", default="exact", choices=["exact", "libm"],
+                    help="VARIANT: how the reference's pow(x, 3 | 4 | 6 | 1/2) calls are formed (ltp_set_pow_rule): 'exact' = one rounding of the exact "
+                         "product (default), 'libm' = glibc's pow restated operation for operation (the bits of a gcc + glibc build of the reference)")
     ap.add_argument("--one-process", action="store_true",
                     help="--gpus N from ONE process: one planner handle, stream and host thread per device, device-resident shards "
                          "(ltp_plan_switch_times_multi / ltp_envelope_multi / ltp_state_at_multi), no torch.distributed. Workloads without dense "
@@ -237,6 +240,7 @@ class Workload:
         self.end_limit = args.end_limit
         self.in_flight = args.in_flight
         self.semantics = args.semantics
+        self.pow_rule = args.pow_rule
         self.name = "primary"
         for k, v in over.items():
             setattr(self, k, v)
@@ -255,6 +259,7 @@ def run_workload(wl, ctx):
     ltp = LongTermPlanner(dof, wl.t_sample, device=local_rank, **lim)
     if wl.semantics != "cpp":
         ltp.setSemantics(wl.semantics)
+    ltp.setPowRule(wl.pow_rule)
     if wl.global_batch:
         first_query, n = shard_range(wl.global_batch, rank, world)
         total_queries = wl.global_batch
@@ -297,6 +302,7 @@ def run_workload(wl, ctx):
         for lane in lanes[1:]:
             if wl.semantics != "cpp":
                 lane["ltp"].setSemantics(wl.semantics)
+            lane["ltp"].setPowRule(wl.pow_rule)
     step_no = 0
     gather_buf = [torch.empty(n, dtype=torch.float64, device=cdev) for _ in range(world)] if (wl.gather and grouped and not wl.global_batch) else None
     ev_pairs = []
@@ -461,7 +467,7 @@ def run_workload(wl, ctx):
                              f"q/v/a/j rows: every {wl.sample_stride}-th sample" + (f", first {wl.max_samples} stored" if wl.max_samples else ""))
                             + f" into a reused {tile_gib} GiB tile ({n_chunks} chunks per step)")),
             "batch_per_gpu": n if not wl.global_batch else None, "global_batch": total_queries, "dof": dof, "t_sample": wl.t_sample,
-            "limits": wl.limits, "input_layout": wl.layout, "table_pass": wl.table_pass, "batches_in_flight": wl.in_flight, "semantics": wl.semantics,
+            "limits": wl.limits, "input_layout": wl.layout, "table_pass": wl.table_pass, "batches_in_flight": wl.in_flight, "semantics": wl.semantics, "pow_rule": wl.pow_rule,
             "sharding": "contiguous query ranges per rank, no data-path collective" + (", all_gather of t_required through the process group every step" if gather_buf else ""),
             "backend": ctx["backend"], "rank_devices": ctx["rank_devices"],
             "plans_ok_frac": round(ok_total / total_queries, 5),
@@ -609,7 +615,7 @@ def main():
         return 2
 
     variant = (args.no_walk or args.walk or args.switch_only or args.end_limit or args.f32 or args.max_samples or args.sample_stride > 1 or args.envelope or args.receding or args.dry_sampler
-               or args.in_flight > 1 or args.semantics != "cpp" or args.table_pass != "auto" or args.limits != "panda" or args.batch != 1_000_000 or args.global_batch or args.window_gib or args.layout != "query_major")
+               or args.in_flight > 1 or args.semantics != "cpp" or args.pow_rule != "exact" or args.table_pass != "auto" or args.limits != "panda" or args.batch != 1_000_000 or args.global_batch or args.window_gib or args.layout != "query_major")
     rccl_world1 = None
     if not grouped and not variant and not args.no_secondary and not args.no_rccl_check and args.backend == "nccl":
         rccl_world1 = rccl_self_check(args)     # a child process, BEFORE this one imports torch or touches the GPU

@@ -115,6 +115,7 @@ class LongTermPlanner {
   int sample_stride_ = 1;
   bool goal_check_ = false;
   int semantics_ = LTP_SEMANTICS_CPP;
+  int pow_rule_ = LTP_POW_EXACT;
 
   static void raise(const ltp_planner* h, int rc, const char* what) {
     throw std::runtime_error(std::string("long_term_planner (MI355X): ") + what + " failed with code " + std::to_string(rc) +
@@ -145,6 +146,7 @@ class LongTermPlanner {
       if ((rc = ltp_set_sample_stride(t.h, sample_stride_)) != LTP_OK) raise(t.h, rc, "ltp_set_sample_stride");
       if ((rc = ltp_set_goal_check(t.h, goal_check_ ? 1 : 0)) != LTP_OK) raise(t.h, rc, "ltp_set_goal_check");
       if ((rc = ltp_set_semantics(t.h, semantics_)) != LTP_OK) raise(t.h, rc, "ltp_set_semantics");
+      if ((rc = ltp_set_pow_rule(t.h, pow_rule_)) != LTP_OK) raise(t.h, rc, "ltp_set_pow_rule");
       t.dirty = false;
     }
     return t.h;
@@ -205,12 +207,12 @@ class LongTermPlanner {
   LongTermPlanner(const LongTermPlanner& o)
       : dof_(o.dof_), t_sample_(o.t_sample_), q_min_(o.q_min_), q_max_(o.q_max_), v_max_(o.v_max_), a_max_(o.a_max_),
         j_max_(o.j_max_), device_(o.device_), max_samples_(o.max_samples_), sample_stride_(o.sample_stride_),
-        goal_check_(o.goal_check_), semantics_(o.semantics_) {}
+        goal_check_(o.goal_check_), semantics_(o.semantics_), pow_rule_(o.pow_rule_) {}
   LongTermPlanner& operator=(const LongTermPlanner& o) {
     if (this != &o) {
       dof_ = o.dof_; t_sample_ = o.t_sample_; q_min_ = o.q_min_; q_max_ = o.q_max_; v_max_ = o.v_max_; a_max_ = o.a_max_;
       j_max_ = o.j_max_; device_ = o.device_; max_samples_ = o.max_samples_; sample_stride_ = o.sample_stride_;
-      goal_check_ = o.goal_check_; semantics_ = o.semantics_; markDirty();
+      goal_check_ = o.goal_check_; semantics_ = o.semantics_; pow_rule_ = o.pow_rule_; markDirty();
     }
     return *this;
   }
@@ -372,6 +374,11 @@ class LongTermPlanner {
    * from it (positional root picks, zeros instead of failures, no position limits, 1-based sampler; ltp_hip.h
    * LTP_SEMANTICS_MATLAB). BatchTrajectory::status may then carry LTP_STATUS_MATLAB_ERROR / LTP_STATUS_MATLAB_COMPLEX. */
   inline void setMatlabSemantics(bool enabled) { semantics_ = enabled ? LTP_SEMANTICS_MATLAB : LTP_SEMANTICS_CPP; markDirty(); }
+
+  /** @brief NEW, default false: form the reference's pow(x, 3 | 4 | 6) and pow(x, 1.0 / 2) calls (cc:125-331, 378-621) as glibc's pow
+   * does, operation for operation, instead of as the correctly rounded power: with it every switching time and every sample has
+   * the bits of the reference built with gcc + glibc (>= 2.28) on a host with FMA (ltp_hip.h LTP_POW_LIBM). */
+  inline void setLibmPow(bool enabled) { pow_rule_ = enabled ? LTP_POW_LIBM : LTP_POW_EXACT; markDirty(); }
 
 
   /** @brief NEW: HIP device ordinal used by this planner (default 0). */

@@ -73,6 +73,19 @@ typedef enum {
 #define LTP_SEMANTICS_CPP 0
 #define LTP_SEMANTICS_MATLAB 1
 
+/* How the reference's pow(x, 3 | 4 | 6) and pow(x, 1.0 / 2) calls (src/long_term_planner.cc:125-331, 378-621) are formed
+ * (pow(x, 2) is x * x in every build: gcc folds it). Both rules are IEEE binary64; they differ in the last bit of about one
+ * power in a thousand, which timeScaling's cancelling v_drive formulas (cc:378-446) turn into up to ~5e-11 s of a switching
+ * time and the sampler's jerk corrections (cc:768-807) into |dt| * j_max / Ts of single jerk samples.
+ * LTP_POW_EXACT  one rounding of the exact product, sqrt for the power 1/2: what a correctly rounded pow returns; within
+ *                1 ulp of ANY libm; the faster rule and the default.
+ * LTP_POW_LIBM   glibc's pow (>= 2.28; the build glibc selects on x86-64 hosts with FMA) restated operation for operation
+ *                (csrc/ltp_libm_pow.hpp, bit-identical to the installed libm on 1.7e10 inputs): with it every record and
+ *                every sample has the bits a reference built with gcc + glibc computes on such a host — no 1e-9 exceptions
+ *                (tests/test_gpu_parity.py). Costs ~30 fp64 operations and 5 table reads per power in the stage kernels. */
+#define LTP_POW_EXACT 0
+#define LTP_POW_LIBM 1
+
 /* Queries: element (query p, joint j) of each array is ptr[p*query_stride + j*joint_stride].
  * Row-major [n][dof] (the reference's vector-per-query view): query_stride = dof, joint_stride = 1.
  * Joint-major SoA [dof][n]: query_stride = 1, joint_stride = n. */
@@ -144,6 +157,10 @@ int ltp_get_goal_check(const ltp_planner* p);
  * path; ltp_end_limit_batch does nothing. */
 int ltp_set_semantics(ltp_planner* p, int semantics);
 int ltp_get_semantics(const ltp_planner* p);
+/* LTP_POW_EXACT (default) or LTP_POW_LIBM, see above. Applies to the calls that plan (switching times, single-joint entry
+ * points, the one-launch single call); samplers and consumers form no powers and do not depend on it. */
+int ltp_set_pow_rule(ltp_planner* p, int rule);
+int ltp_get_pow_rule(const ltp_planner* p);
 
 /* Where the run tables come from. A sampler / envelope item needs the joint's run tables (<= 20 runs of constant jerk with 10
  * closed-form coefficients each). Three ways, all with bit-identical results:
@@ -373,6 +390,8 @@ int ltp_debug_set_sample_blocks(ltp_planner* p, int blocks);
 int ltp_debug_get_sample_blocks(ltp_planner* p, int which);
 /* out[i*8 + {0..7}] = x/y, sqrt|x|, x^3, x^4, x^6, floor(x/y), ceil(x/y), x*y+x computed on the device */
 int ltp_debug_math_probe_host(ltp_planner* p, long long n, const double* x, const double* y, double* out);
+/* out[i] = pow(x[i], y[i]) by the restated glibc pow of LTP_POW_LIBM (csrc/ltp_libm_pow.hpp), any finite or non-finite x, y */
+int ltp_debug_libm_pow_host(ltp_planner* p, long long n, const double* x, const double* y, double* out);
 /* root[i] = smallest positive exactly-real root of the degree-`degree` polynomial coef[i*7 .. i*7+degree]
  * (roots.h:22-50 semantics) */
 int ltp_debug_roots_probe_host(ltp_planner* p, long long n, int degree, const double* coef, double* root);

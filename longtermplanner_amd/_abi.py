@@ -24,6 +24,8 @@ STATUS_MATLAB_ERROR = 128
 STATUS_MATLAB_COMPLEX = 256
 SEMANTICS_CPP = 0
 SEMANTICS_MATLAB = 1
+POW_EXACT = 0
+POW_LIBM = 1
 
 ERROR_NAMES = {1: "LTP_ERR_INVALID_ARGUMENT", 2: "LTP_ERR_NO_DEVICE", 3: "LTP_ERR_OUT_OF_MEMORY", 4: "LTP_ERR_HIP"}
 
@@ -55,13 +57,27 @@ class Shard(C.Structure):
     _fields_ = [("in_", Queries), ("out", Records), ("offsets", C.c_void_p), ("stream", C.c_void_p)]
 
 
+def build_inputs():
+    """Every file libltp_hip.so is made from, as the Makefile itself lists them (`make print-deps`: the kernels, the C ABI sources
+    and ALL their headers, the public device header include/ltp_run_tables.hpp among them) — one list, kept in one place."""
+    out = subprocess.check_output(["make", "-C", CSRC, "-s", "--no-print-directory", "print-deps"], text=True)
+    return [os.path.normpath(os.path.join(CSRC, f)) for f in out.split()]
+
+
+def stale():
+    """True if libltp_hip.so is missing or older than one of its inputs. (Object files do not travel to the GPU box, so `make -q`
+    cannot be asked there: it would call an intact library out of date.)"""
+    if not os.path.exists(LIB_PATH):
+        return True
+    built = os.path.getmtime(LIB_PATH)
+    return any(os.path.getmtime(f) > built for f in build_inputs())
+
+
 def build(force=False):
     """Compile libltp_hip.so for gfx950 (hipcc cross-compiles without a GPU)."""
-    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".hpp", "Makefile"))]
-    srcs.append(os.path.join(os.path.dirname(_PKG), "include", "ltp_hip.h"))
-    newest = max(os.path.getmtime(s) for s in srcs)
-    if force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < newest:
+    if force or stale():
         subprocess.check_call(["make", "-C", CSRC, "-s", "-j4", "all"])
+        os.utime(LIB_PATH)          # make may have found the objects current (an input was only touched): the library is current too
     return LIB_PATH
 
 
@@ -102,6 +118,9 @@ _SIGNATURES = {
                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_longlong, C.c_void_p]),
     "ltp_set_semantics": (C.c_int, [C.c_void_p, C.c_int]),
     "ltp_get_semantics": (C.c_int, [C.c_void_p]),
+    "ltp_set_pow_rule": (C.c_int, [C.c_void_p, C.c_int]),
+    "ltp_get_pow_rule": (C.c_int, [C.c_void_p]),
+    "ltp_debug_libm_pow_host": (C.c_int, [C.c_void_p, C.c_longlong, _dp, _dp, _dp]),
     "ltp_debug_last_matlab_flags": (C.c_int, [C.c_void_p]),
     "ltp_debug_roots_matlab_host": (C.c_int, [C.c_void_p, C.c_longlong, C.c_int, _dp, _dp, _dp, _ip, _ip]),
     "ltp_set_goal_check": (C.c_int, [C.c_void_p, C.c_int]),

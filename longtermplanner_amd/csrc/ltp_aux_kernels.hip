@@ -143,12 +143,20 @@ __global__ void k_math_probe(long long n, const double* x, const double* y, doub
     double* o = out + i * 8;
     o[0] = a / b;
     o[1] = dsqrt(dabs(a));
-    o[2] = pw3(a);
-    o[3] = pw4(a);
-    o[4] = pw6(a);
+    o[2] = pw3_exact(a);
+    o[3] = pw4_exact(a);
+    o[4] = pw6_exact(a);
     o[5] = dfloor(a / b);
     o[6] = dceil(a / b);
     o[7] = a * b + a;
+}
+
+// the restated glibc pow (ltp_libm_pow.hpp, pow rule LTP_POW_LIBM) on arbitrary (x, y): tests compare it with the host's libm bit for bit
+__global__ void k_libm_pow_probe(long long n, const double* x, const double* y, double* out)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    out[i] = libm::pow(x[i], y[i]);
 }
 
 template <int N>
@@ -224,15 +232,17 @@ void launch_generate(hipStream_t s, long long n, int dof, Limits lim, unsigned l
                        q_goal, q_0, v_0, a_0, sq, sj);
 }
 
-void launch_check_inputs(hipStream_t s, int dof, Limits lim, const double* q_0, const double* v_0, const double* a_0, int* ok, int semantics)
+void launch_check_inputs(hipStream_t s, int dof, Limits lim, const double* q_0, const double* v_0, const double* a_0, int* ok, int variant)
 {
-    if (semantics == kSemMatlab) hipLaunchKernelGGL(k_check_inputs<kSemMatlab>, dim3(1), dim3(1), 0, s, dof, lim, q_0, v_0, a_0, ok);
-    else hipLaunchKernelGGL(k_check_inputs<kSemCpp>, dim3(1), dim3(1), 0, s, dof, lim, q_0, v_0, a_0, ok);
+    dispatch_variant(variant & 1, [&](auto v) {
+        hipLaunchKernelGGL(k_check_inputs<decltype(v)::value>, dim3(1), dim3(1), 0, s, dof, lim, q_0, v_0, a_0, ok);
+    });
 }
-void launch_single_opt_braking(hipStream_t s, int joint, double t_sample, Limits lim, double v_0, double a_0, double* out10, int semantics)
+void launch_single_opt_braking(hipStream_t s, int joint, double t_sample, Limits lim, double v_0, double a_0, double* out10, int variant)
 {
-    if (semantics == kSemMatlab) hipLaunchKernelGGL(k_single_opt_braking<kSemMatlab>, dim3(1), dim3(1), 0, s, joint, t_sample, lim, v_0, a_0, out10);
-    else hipLaunchKernelGGL(k_single_opt_braking<kSemCpp>, dim3(1), dim3(1), 0, s, joint, t_sample, lim, v_0, a_0, out10);
+    dispatch_variant(variant, [&](auto v) {
+        hipLaunchKernelGGL(k_single_opt_braking<decltype(v)::value>, dim3(1), dim3(1), 0, s, joint, t_sample, lim, v_0, a_0, out10);
+    });
 }
 void launch_roots_matlab(hipStream_t s, long long n, int degree, const double* coef, double* re, double* im, int* nroots, int* status)
 {
@@ -240,22 +250,27 @@ void launch_roots_matlab(hipStream_t s, long long n, int degree, const double* c
     hipLaunchKernelGGL(k_roots_matlab, dim3((unsigned)((n + 63) / 64)), dim3(64), mr::matrix_lds_bytes(64), s, n, degree, coef, re, im, nroots, status);
 }
 void launch_single_opt_switch(hipStream_t s, int joint, double t_sample, Limits lim, double q_goal, double q_0, double v_0,
-                              double a_0, double v_drive, double* io10, int semantics)
+                              double a_0, double v_drive, double* io10, int variant)
 {
-    if (semantics == kSemMatlab)
-        hipLaunchKernelGGL(k_single_opt_switch<kSemMatlab>, dim3(1), dim3(1), mr::matrix_lds_bytes(1), s, joint, t_sample, lim, q_goal, q_0, v_0, a_0, v_drive, io10);
-    else
-        hipLaunchKernelGGL(k_single_opt_switch<kSemCpp>, dim3(1), dim3(1), 0, s, joint, t_sample, lim, q_goal, q_0, v_0, a_0, v_drive, io10);
+    dispatch_variant(variant, [&](auto v) {
+        constexpr int SEM = decltype(v)::value;
+        hipLaunchKernelGGL(k_single_opt_switch<SEM>, dim3(1), dim3(1), sem_matlab(SEM) ? mr::matrix_lds_bytes(1) : 0, s, joint, t_sample, lim, q_goal, q_0,
+                           v_0, a_0, v_drive, io10);
+    });
 }
 void launch_single_time_scaling(hipStream_t s, int joint, double t_sample, Limits lim, double q_goal, double q_0, double v_0,
-                                double a_0, double dir, double t_required, double* out11, int semantics)
+                                double a_0, double dir, double t_required, double* out11, int variant)
 {
-    if (semantics == kSemMatlab)
-        hipLaunchKernelGGL(k_single_time_scaling<kSemMatlab>, dim3(1), dim3(1), mr::matrix_lds_bytes(1), s, joint, t_sample, lim, q_goal, q_0, v_0, a_0, dir,
-                           t_required, out11);
-    else
-        hipLaunchKernelGGL(k_single_time_scaling<kSemCpp>, dim3(1), dim3(1), 0, s, joint, t_sample, lim, q_goal, q_0, v_0, a_0, dir,
-                           t_required, out11);
+    dispatch_variant(variant, [&](auto v) {
+        constexpr int SEM = decltype(v)::value;
+        hipLaunchKernelGGL(k_single_time_scaling<SEM>, dim3(1), dim3(1), sem_matlab(SEM) ? mr::matrix_lds_bytes(1) : 0, s, joint, t_sample, lim, q_goal, q_0,
+                           v_0, a_0, dir, t_required, out11);
+    });
+}
+void launch_libm_pow_probe(hipStream_t s, long long n, const double* x, const double* y, double* out)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_libm_pow_probe, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, x, y, out);
 }
 void launch_math_probe(hipStream_t s, long long n, const double* x, const double* y, double* out)
 {

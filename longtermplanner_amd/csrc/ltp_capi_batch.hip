@@ -38,7 +38,7 @@ int ltp_plan_switch_times_batch(ltp_planner* p, long long n, const ltp_queries* 
     const ltp::Queries q = to_dev(in);
     const ltp::Records r = to_dev(out);
     LTP_HIP_TRY(p, hipMemsetAsync(p->d_queue_count, 0, 16 * sizeof(unsigned long long), s));
-    ltp::launch_switch_times(s, n, p->dof, p->t_sample, p->goal_check, L, q, r, p->d_lane_flags, p->d_queue, p->d_queue_count, p->semantics);
+    ltp::launch_switch_times(s, n, p->dof, p->t_sample, p->goal_check, L, q, r, p->d_lane_flags, p->d_queue, p->d_queue_count, stage_variant(p));
     ltp::launch_offsets(s, n, p->dof, p->t_sample, r, p->d_block_sums, offsets ? offsets : p->d_offsets_scratch, true, ltp::RowSpec{p->max_samples, p->sample_stride});
     LTP_HIP_TRY(p, hipGetLastError());
     return workspace_release(p, s, capturing);

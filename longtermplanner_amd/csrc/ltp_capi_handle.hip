@@ -341,6 +341,14 @@ int ltp_set_semantics(ltp_planner* p, int semantics)
     return LTP_OK;
 }
 int ltp_get_semantics(const ltp_planner* p) { return p ? p->semantics : -1; }
+int ltp_set_pow_rule(ltp_planner* p, int rule)
+{
+    if (!p || (rule != LTP_POW_EXACT && rule != LTP_POW_LIBM)) return fail(p, LTP_ERR_INVALID_ARGUMENT, "pow rule must be LTP_POW_EXACT or LTP_POW_LIBM");
+    std::lock_guard<std::mutex> g(p->mu);
+    p->pow_rule = rule;
+    return LTP_OK;
+}
+int ltp_get_pow_rule(const ltp_planner* p) { return p ? p->pow_rule : -1; }
 int ltp_set_table_pass(ltp_planner* p, int mode)
 {
     if (!p || mode < -1 || mode > 1) return fail(p, LTP_ERR_INVALID_ARGUMENT, "table pass mode must be -1, 0 or 1");

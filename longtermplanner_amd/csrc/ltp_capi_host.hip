@@ -252,7 +252,7 @@ int plan_batch_host_fused(ltp_planner* p, long long n, const double* const (&h_i
         capture_geometry(p);
         ltp::launch_plan_small(nullptr, (int)n, dof, p->t_sample, p->goal_check, ltp::RowSpec{p->max_samples, p->sample_stride}, dev_limits(p), in,
                                to_dev(&hr), (unsigned long long*)(p->h_arena + L.offsets), rows, kFusedRowsBytes / sizeof(double),
-                               (int*)(p->h_arena + ends_at), (unsigned int*)p->d_small, done, given != nullptr);
+                               (int*)(p->h_arena + ends_at), (unsigned int*)p->d_small, done, given != nullptr, p->pow_rule == LTP_POW_LIBM);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) { if (rows) g_pinned.release(rows); return hip_fail(p, e, "k_plan_small"); }   // nothing was launched
     }
@@ -348,7 +348,7 @@ int run_one_lane(ltp_planner* p, int joint, double (&buf)[16], Launch launch)
         std::lock_guard<std::mutex> g(p->mu);
         if (joint < 0 || joint >= p->lim_cap) return fail(p, LTP_ERR_INVALID_ARGUMENT, "joint out of range");
         t_sample = p->t_sample;
-        semantics = p->semantics;
+        semantics = stage_variant(p);                  // semantics | pow rule << 1
         lim = dev_limits(p);                           // stays valid: ltp_set_limits needs host_mu, which this call holds
     }
     LTP_HIP_TRY(p, hipSetDevice(p->device));
@@ -558,7 +558,7 @@ int ltp_check_inputs_host(ltp_planner* p, const double* q_0, const double* v_0, 
     memcpy(p->h_arena + row, v_0, sizeof(double) * dof);
     memcpy(p->h_arena + 2 * row, a_0, sizeof(double) * dof);
     ltp::launch_check_inputs(nullptr, dof, dev_limits(p), (const double*)p->h_arena, (const double*)(p->h_arena + row),
-                             (const double*)(p->h_arena + 2 * row), (int*)(p->h_arena + 3 * row), p->semantics);   // pinned: no copies
+                             (const double*)(p->h_arena + 2 * row), (int*)(p->h_arena + 3 * row), p->semantics);   // pinned: no copies (checkInputs forms no powers)
     LTP_HIP_TRY(p, hipGetLastError());
     LTP_HIP_TRY(p, hipStreamSynchronize(nullptr));
     *ok = *(const int*)(p->h_arena + 3 * row);
@@ -691,6 +691,23 @@ int ltp_debug_math_probe_host(ltp_planner* p, long long n, const double* x, cons
     ltp::launch_math_probe(nullptr, n, dx, dy, dout);
     LTP_HIP_TRY(p, hipGetLastError());
     LTP_HIP_TRY(p, hipMemcpy(out, dout, sizeof(double) * (size_t)n * 8, hipMemcpyDeviceToHost));
+    return LTP_OK;
+}
+
+int ltp_debug_libm_pow_host(ltp_planner* p, long long n, const double* x, const double* y, double* out)
+{
+    if (!p || n < 0 || !x || !y || !out) return fail(p, LTP_ERR_INVALID_ARGUMENT, "null argument");
+    LTP_HIP_TRY(p, hipSetDevice(p->device));
+    double *dx = nullptr, *dy = nullptr, *dout = nullptr;
+    DevRecords holder;
+    LTP_HIP_TRY(p, holder.alloc(&dx, (size_t)n));
+    LTP_HIP_TRY(p, holder.alloc(&dy, (size_t)n));
+    LTP_HIP_TRY(p, holder.alloc(&dout, (size_t)n));
+    LTP_HIP_TRY(p, hipMemcpy(dx, x, sizeof(double) * (size_t)n, hipMemcpyHostToDevice));
+    LTP_HIP_TRY(p, hipMemcpy(dy, y, sizeof(double) * (size_t)n, hipMemcpyHostToDevice));
+    ltp::launch_libm_pow_probe(nullptr, n, dx, dy, dout);
+    LTP_HIP_TRY(p, hipGetLastError());
+    LTP_HIP_TRY(p, hipMemcpy(out, dout, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost));
     return LTP_OK;
 }
 

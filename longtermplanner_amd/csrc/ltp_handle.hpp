@@ -50,6 +50,7 @@ struct ltp_planner {
     bool small_dirty = false;              // a fused small-batch call failed: k_plan_small's arrival word may be non-zero
     const char* last_kernel = "";          // row / envelope kernel of the latest ltp_sample_batch* / ltp_envelope_batch
     int semantics = 0;                     // LTP_SEMANTICS_CPP (the reference's C++, default) or LTP_SEMANTICS_MATLAB
+    int pow_rule = 0;                      // LTP_POW_EXACT (default) or LTP_POW_LIBM: how pow(x, 3 | 4 | 6 | 1/2) is formed (ltp_math.hpp)
     int last_matlab_flags = 0;             // MATLAB semantics: flags of the latest one-lane call (1 = complex intermediate, 2 = error)
     unsigned long long* dbg_stamps = nullptr; // diagnostic: per-block start/end stamps of k_sample (caller-owned)
     // persistent buffers of the small synchronous host-pointer calls (no hipMalloc per call)
@@ -85,6 +86,8 @@ int hip_fail(ltp_planner* p, hipError_t e, const char* what);
 
 int upload_limits(ltp_planner* p);
 ltp::Limits dev_limits(const ltp_planner* p);
+// the template variant of the stage kernels: semantics (bit 0) | pow rule (bit 1), see ltp::dispatch_variant
+inline int stage_variant(const ltp_planner* p) { return p->semantics | (p->pow_rule == LTP_POW_LIBM ? 2 : 0); }
 int check_config(ltp_planner* p);                        // the reference indexes its limit vectors unchecked (UB when short); here it is an error
 int reserve(ltp_planner* p, long long n);
 ltp::Queries to_dev(const ltp_queries* in);

@@ -14,6 +14,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 #include "../../include/ltp_run_tables.hpp"   // kMaxSegments, the packed run-table format (public)
 
 namespace ltp {
@@ -89,10 +90,23 @@ inline int queue_draw_chunk(RowSpec rows, bool f32, int joints_per_item)
     return k;
 }
 
+// variant = semantics (bit 0: 0 = the C++ reference, 1 = LTPlanner.m) | kPowLibm (bit 1: the pow rule LTP_POW_LIBM); the template
+// parameter SEM of ltp_profile.hpp and of the stage kernels. f is called with std::integral_constant<int, variant>.
+template <class F>
+inline void dispatch_variant(int variant, F&& f)
+{
+    switch (variant & 3) {
+    case 0: f(std::integral_constant<int, 0>{}); break;
+    case 1: f(std::integral_constant<int, 1>{}); break;
+    case 2: f(std::integral_constant<int, 2>{}); break;
+    default: f(std::integral_constant<int, 3>{}); break;
+    }
+}
+
 long long queue_segment(long long n, int dof);   // entries per queue shard; a batch needs 2 * 8 * this many u64
 void launch_switch_times(hipStream_t s, long long n, int dof, double t_sample, int goal_check, Limits lim, Queries in,
                          Records out, signed char* lane_flags, unsigned long long* queue_items, unsigned long long* counts,
-                         int semantics = 0 /* 0 = the C++ reference, 1 = LTPlanner.m (ltp_profile.hpp) */);
+                         int variant = 0 /* semantics | pow rule << 1 (dispatch_variant) */);
 void launch_offsets(hipStream_t s, long long n, int dof, double t_sample, Records rec,
                     unsigned long long* block_sums, unsigned long long* offsets, bool lens_ready, RowSpec rows);
 // Run tables: built inside the sampler / envelope kernel by the item's block, or by the table pass —
@@ -147,21 +161,23 @@ int small_batch_blocks(int dof, bool with_rows);
 void launch_plan_small(hipStream_t s, int n, int dof, double t_sample, int goal_check, RowSpec rows, Limits lim, const double* const in[4],
                        Records rec, unsigned long long* offsets, double* out_rows, unsigned long long capacity, int* end_flags,
                        unsigned int* arrivals, volatile int* done,
-                       bool records_given = false /* getTrajectory: t_scaled, dir, mod, v_drive of `rec` are inputs */);
+                       bool records_given = false /* getTrajectory: t_scaled, dir, mod, v_drive of `rec` are inputs */,
+                       bool libm_pow = false /* the pow rule LTP_POW_LIBM */);
 void launch_generate(hipStream_t s, long long n, int dof, Limits lim, unsigned long long seed, long long first_query,
                      double* q_goal, double* q_0, double* v_0, double* a_0, long long sq, long long sj);
 
-void launch_check_inputs(hipStream_t s, int dof, Limits lim, const double* q_0, const double* v_0, const double* a_0, int* ok, int semantics = 0);
+void launch_check_inputs(hipStream_t s, int dof, Limits lim, const double* q_0, const double* v_0, const double* a_0, int* ok, int variant = 0);
 // single-joint mirrors of the protected methods (one lane); io[11] receives the lane's MATLAB flags (kMatlabComplex | kMatlabError)
-void launch_single_opt_braking(hipStream_t s, int joint, double t_sample, Limits lim, double v_0, double a_0, double* out10, int semantics = 0);
+void launch_single_opt_braking(hipStream_t s, int joint, double t_sample, Limits lim, double v_0, double a_0, double* out10, int variant = 0);
 void launch_single_opt_switch(hipStream_t s, int joint, double t_sample, Limits lim, double q_goal, double q_0, double v_0,
-                              double a_0, double v_drive, double* io10, int semantics = 0);
+                              double a_0, double v_drive, double* io10, int variant = 0);
 void launch_single_time_scaling(hipStream_t s, int joint, double t_sample, Limits lim, double q_goal, double q_0, double v_0,
-                                double a_0, double dir, double t_required, double* out11, int semantics = 0);
+                                double a_0, double dir, double t_required, double* out11, int variant = 0);
 // MATLAB's roots() on the device (ltp_roots_matlab.hpp): n polynomials of `degree` <= 6, [n][degree+1] coefficients; re, im
 // [n][degree] in MATLAB's output order, nroots [n], status [n] (0 ok, 1 no convergence, 2 NaN / Inf)
 void launch_roots_matlab(hipStream_t s, long long n, int degree, const double* coef, double* re, double* im, int* nroots, int* status);
 void launch_math_probe(hipStream_t s, long long n, const double* x, const double* y, double* out);
+void launch_libm_pow_probe(hipStream_t s, long long n, const double* x, const double* y, double* out);   // out[i] = the restated glibc pow(x[i], y[i])
 void launch_roots_probe(hipStream_t s, long long n, int degree, const double* coef, double* root);
 void launch_roots_all(hipStream_t s, long long n, int degree, bool f32, const void* coef, void* re, void* im);
 

@@ -7,17 +7,28 @@
 //   * this translation unit is built with -ffp-contract=off and without fast-math,
 //     so a*b+c is two roundings exactly as on the host; '/' and sqrt() lower to the
 //     correctly rounded f64 sequences on gfx950;
-//   * pow(x, n) for the integer exponents the reference uses (2, 3, 4, 6) is
-//     evaluated through an error-free product (explicit fma) and rounded once,
-//     which is what a (nearly) correctly rounded libm pow returns.
+//   * pow(x, n) for the integer exponents the reference uses (3, 4, 6; gcc folds pow(x, 2) to x * x) and its one
+//     pow(x, 1.0 / 2) follow one of two POW RULES (ltp_set_pow_rule):
+//       LTP_POW_EXACT (default)  one rounding of the exact product (error-free products through fma), sqrt for 1/2:
+//                                what a correctly rounded pow returns; within 1 ulp of any libm;
+//       LTP_POW_LIBM             glibc's pow restated operation for operation (ltp_libm_pow.hpp): the bits a reference built
+//                                with gcc + glibc (>= 2.28, FMA host) computes.
+//     The rule rides in the template parameter SEM of ltp_profile.hpp next to the semantics: SEM = semantics | kPowLibm.
 #pragma once
 #include <hip/hip_runtime.h>
 #include "../../include/ltp_run_tables.hpp"   // LTP_DEV / LTP_HD, kSemCpp / kSemMatlab
+#include "ltp_libm_pow.hpp"
 
 namespace ltp {
 
 
 constexpr double kInf = __builtin_huge_val();
+
+// SEM = kSemCpp | kSemMatlab (bit 0: whose translation, include/ltp_run_tables.hpp), optionally | kPowLibm (bit 1: the pow rule).
+// Everything below the stage kernels (runs, samplers, consumers) has no powers and only ever sees bit 0.
+constexpr int kPowLibm = 2;
+constexpr bool sem_matlab(int sem) { return (sem & 1) != 0; }
+constexpr bool sem_libm(int sem) { return (sem & kPowLibm) != 0; }
 
 LTP_DEV double dabs(double x) { return __builtin_fabs(x); }
 LTP_DEV bool dfinite(double x) { return dabs(x) < kInf; }   // false for inf and NaN
@@ -37,7 +48,7 @@ LTP_DEV void two_prod(double a, double b, double& hi, double& lo)
 }
 
 // pow(x,3) rounded once
-LTP_DEV double pw3(double x)
+LTP_DEV double pw3_exact(double x)
 {
     double h, l, p, e;
     two_prod(x, x, h, l);
@@ -47,7 +58,7 @@ LTP_DEV double pw3(double x)
 }
 
 // pow(x,4) rounded once
-LTP_DEV double pw4(double x)
+LTP_DEV double pw4_exact(double x)
 {
     double h, l, p, e;
     two_prod(x, x, h, l);
@@ -57,7 +68,7 @@ LTP_DEV double pw4(double x)
 }
 
 // pow(x,6) rounded once
-LTP_DEV double pw6(double x)
+LTP_DEV double pw6_exact(double x)
 {
     double h, l, p3, e3, p, e;
     two_prod(x, x, h, l);
@@ -69,6 +80,12 @@ LTP_DEV double pw6(double x)
 }
 
 LTP_DEV double dsqrt(double x) { return __builtin_sqrt(x); }
+
+// the reference's pow(x, 3 | 4 | 6) and pow(x, 1.0 / 2) under the pow rule of SEM
+template <int SEM> LTP_DEV double pw3(double x) { if constexpr (sem_libm(SEM)) return libm::pow_fixed<6>(x); else return pw3_exact(x); }
+template <int SEM> LTP_DEV double pw4(double x) { if constexpr (sem_libm(SEM)) return libm::pow_fixed<8>(x); else return pw4_exact(x); }
+template <int SEM> LTP_DEV double pw6(double x) { if constexpr (sem_libm(SEM)) return libm::pow_fixed<12>(x); else return pw6_exact(x); }
+template <int SEM> LTP_DEV double pw_half(double x) { if constexpr (sem_libm(SEM)) return libm::pow_fixed<1>(x); else return dsqrt(x); }
 LTP_DEV double dfloor(double x) { return __builtin_floor(x); }
 LTP_DEV double dceil(double x) { return __builtin_ceil(x); }
 LTP_DEV double dmax(double a, double b) { return a < b ? b : a; }   // std::max semantics

@@ -47,7 +47,8 @@ struct SmallShared {             // LDS of one small-batch block
 // from io.rec, start states from io.in[1..3]); stages 1-3 are skipped, lengths are those of k_finalize.
 // Every thread of every block of the grid calls this (it contains block barriers); on return the block's part is done and,
 // in the last block to finish, *io.done has been set.
-template <bool GIVEN>
+// SEM: kSemCpp, or kSemCpp | kPowLibm (the pow rule; the kernel exists for the C++ semantics only).
+template <bool GIVEN, int SEM>
 LTP_DEV void plan_small_body(int n, int dof, double t_sample, int goal_check, RowSpec rows, const Limits& lim, const SmallHost& io,
                              SmallShared& sh)
 {
@@ -98,13 +99,13 @@ LTP_DEV void plan_small_body(int n, int dof, double t_sample, int goal_check, Ro
     if (pair) {
         L = load_limits(lim, j);
         qg = io.in[0][pid]; q0 = io.in[1][pid]; v0 = io.in[2][pid]; a0 = io.in[3][pid];
-        int flags = check_inputs_joint(L, q0, v0, a0) ? 0 : kStatusInvalidInput;
+        int flags = check_inputs_joint<SEM>(L, q0, v0, a0) ? 0 : kStatusInvalidInput;
         if (goal_check && !(qg >= L.q_min && qg <= L.q_max)) flags |= kStatusGoalOutside;
         double tt[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
         double dir = 0.0;
         int mod = 0;
         MatlabCtx mc;
-        if (opt_switch_times<true>(L.a_max, L.j_max, L.v_max, t_sample, qg, q0, v0, a0, L.v_max, tt, dir, mod, mc) == kOptFalse) flags |= kStatusOptFailed;
+        if (opt_switch_times<true, SEM>(L.a_max, L.j_max, L.v_max, t_sample, qg, q0, v0, a0, L.v_max, tt, dir, mod, mc) == kOptFalse) flags |= kStatusOptFailed;
 #pragma unroll
         for (int k = 0; k < 7; ++k) s_t_opt[pid][k] = tt[k];
         s_dir[pid] = dir;
@@ -140,7 +141,7 @@ LTP_DEV void plan_small_body(int n, int dof, double t_sample, int goal_check, Ro
             if (j != s_slowest[q]) {
                 int which = 0;
                 MatlabCtx mc;
-                time_scaling_full(L, t_sample, qg, q0, v0, a0, s_dir[pid], s_treq[q], vd, ts, mod, which, mc);
+                time_scaling_full<SEM>(L, t_sample, qg, q0, v0, a0, s_dir[pid], s_treq[q], vd, ts, mod, which, mc);
             }
             double mx = ts[0];
 #pragma unroll
@@ -255,12 +256,12 @@ LTP_DEV void plan_small_body(int n, int dof, double t_sample, int goal_check, Ro
     }
 }
 
-template <bool GIVEN>
+template <bool GIVEN, int SEM>
 __global__ void __launch_bounds__(kSampleThreads)
 k_plan_small(int n, int dof, double t_sample, int goal_check, RowSpec rows, Limits lim, SmallHost io)
 {
     __shared__ SmallShared sh;
-    plan_small_body<GIVEN>(n, dof, t_sample, goal_check, rows, lim, io, sh);
+    plan_small_body<GIVEN, SEM>(n, dof, t_sample, goal_check, rows, lim, io, sh);
 }
 
 int small_batch_pairs() { return kSmallPairs; }
@@ -268,15 +269,17 @@ int small_batch_blocks(int dof, bool with_rows) { return !with_rows ? 1 : (dof <
 
 void launch_plan_small(hipStream_t s, int n, int dof, double t_sample, int goal_check, RowSpec rows, Limits lim, const double* const in[4],
                        Records rec, unsigned long long* offsets, double* out_rows, unsigned long long capacity, int* end_flags,
-                       unsigned int* arrivals, volatile int* done, bool records_given)
+                       unsigned int* arrivals, volatile int* done, bool records_given, bool libm_pow)
 {
     SmallHost io;
     for (int k = 0; k < 4; ++k) io.in[k] = in[k];
     io.rec = rec; io.offsets = offsets; io.rows = out_rows; io.capacity = capacity; io.end_flags = end_flags; io.arrivals = arrivals;
     io.done = done;
     const dim3 grid((unsigned)small_batch_blocks(dof, out_rows != nullptr));
-    if (records_given) hipLaunchKernelGGL(k_plan_small<true>, grid, dim3(kSampleThreads), 0, s, n, dof, t_sample, goal_check, rows, lim, io);
-    else hipLaunchKernelGGL(k_plan_small<false>, grid, dim3(kSampleThreads), 0, s, n, dof, t_sample, goal_check, rows, lim, io);
+    // (with the records given there are no powers left to form: one instantiation)
+    if (records_given) hipLaunchKernelGGL((k_plan_small<true, kSemCpp>), grid, dim3(kSampleThreads), 0, s, n, dof, t_sample, goal_check, rows, lim, io);
+    else if (libm_pow) hipLaunchKernelGGL((k_plan_small<false, kSemCpp | kPowLibm>), grid, dim3(kSampleThreads), 0, s, n, dof, t_sample, goal_check, rows, lim, io);
+    else hipLaunchKernelGGL((k_plan_small<false, kSemCpp>), grid, dim3(kSampleThreads), 0, s, n, dof, t_sample, goal_check, rows, lim, io);
 }
 
 }  // namespace ltp

@@ -41,7 +41,7 @@ struct MatlabCtx {
 template <int SEM>
 LTP_DEV double sem_sqrt(double x, MatlabCtx& mc)
 {
-    if constexpr (SEM == kSemMatlab) {
+    if constexpr (sem_matlab(SEM)) {
         if (x < 0.0) {
             const double im = dsqrt(-x);
             mc.flags |= kMatlabComplex;
@@ -60,7 +60,7 @@ struct JointLimits {
 template <int SEM = kSemCpp>
 LTP_DEV bool check_inputs_joint(const JointLimits& L, double q_0, double v_0, double a_0)
 {
-    if constexpr (SEM == kSemCpp) {
+    if constexpr (!sem_matlab(SEM)) {
         if (q_0 < L.q_min || q_0 > L.q_max) return false;
     }
     if (dabs(v_0) > L.v_max || dabs(a_0) > L.a_max) return false;
@@ -93,8 +93,8 @@ LTP_DEV void opt_braking(double am, double jm, double t_sample, double v_0, doub
     }
     q = v_0 * (r[0] + r[1] + r[2]) +
         a_0 * (1.0 / 2.0 * pw2(r[0]) + r[0] * (r[1] + r[2]) + 1.0 / 2.0 * pw2(r[2])) +
-        jm * (1.0 / 6.0 * pw3(r[0]) + 1.0 / 2.0 * pw2(r[0]) * (r[1] + r[2]) -
-              1.0 / 6.0 * pw3(r[2]) + 1.0 / 2.0 * r[0] * pw2(r[2])) +
+        jm * (1.0 / 6.0 * pw3<SEM>(r[0]) + 1.0 / 2.0 * pw2(r[0]) * (r[1] + r[2]) -
+              1.0 / 6.0 * pw3<SEM>(r[2]) + 1.0 / 2.0 * r[0] * pw2(r[2])) +
         am * (1.0 / 2.0 * pw2(r[1]) + r[1] * r[2]);
     q = dir * q;
 }
@@ -136,7 +136,7 @@ __device__ inline double matlab_filtered_root(const double (&c)[N + 1], bool mus
 template <int N, int SEM>
 __device__ inline double root_squared(const double (&c)[N + 1], int k, MatlabCtx& mc)
 {
-    if constexpr (SEM == kSemMatlab) {
+    if constexpr (sem_matlab(SEM)) {
         double re[mr::kMaxN], im[mr::kMaxN];
         int nr = 0;
         const double nan = __builtin_nan("");
@@ -176,7 +176,7 @@ __device__ inline int opt_switch_times(double am, double jm, double vm, double t
 {
     double r[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
     mod = 0;
-    if constexpr (SEM == kSemMatlab) {
+    if constexpr (sem_matlab(SEM)) {
         // LTPlanner.m:131 -> :92-103: checkInputs inside optSwitchTimes, error() on violation (vm = the joint's v_max)
         mc.imag = 0.0;
         if (dabs(v_0) > vm || dabs(a_0) > am || dabs(v_0 + 1.0 / 2.0 * a_0 * dabs(a_0) / jm) > vm) {
@@ -241,15 +241,15 @@ __device__ inline int opt_switch_times(double am, double jm, double vm, double t
                   a_0 * (1.0 / 2.0 * pw2(r[0]) +
                          r[0] * (r[1] + r[2]) +
                          1.0 / 2.0 * pw2(r[2])) +
-                  jm * (1.0 / 6.0 * pw3(r[0]) +
+                  jm * (1.0 / 6.0 * pw3<SEM>(r[0]) +
                         1.0 / 2.0 * pw2(r[0]) * (r[1] + r[2]) -
-                        1.0 / 6.0 * pw3(r[2]) +
+                        1.0 / 6.0 * pw3<SEM>(r[2]) +
                         1.0 / 2.0 * r[0] * pw2(r[2])) +
                   am * (1.0 / 2.0 * pw2(r[1]) + r[1] * r[2]);
     }
-    const double q_part2 = jm * (1.0 / 6.0 * pw3(r[6]) +
+    const double q_part2 = jm * (1.0 / 6.0 * pw3<SEM>(r[6]) +
                                  1.0 / 2.0 * pw2(r[6]) * (r[5] + r[4]) -
-                                 1.0 / 6.0 * pw3(r[4]) +
+                                 1.0 / 6.0 * pw3<SEM>(r[4]) +
                                  1.0 / 2.0 * r[6] * pw2(r[4])) +
                            am * (1.0 / 2.0 * pw2(r[5]) +
                                  r[5] * r[4]);
@@ -258,16 +258,16 @@ __device__ inline int opt_switch_times(double am, double jm, double vm, double t
     if (r[3] < -kEps) {
         if (mod == 1) {
             zero7(t);
-            return SEM == kSemMatlab ? kOptTrue : kOptFalse;   // LTPlanner.m:222-227 returns the zeros like any other result; cc:195-200: false
+            return sem_matlab(SEM) ? kOptTrue : kOptFalse;   // LTPlanner.m:222-227 returns the zeros like any other result; cc:195-200: false
         }
         const double a2 = pw2(a_0), am2 = pw2(am);
-        const double r0_2 = pw2(r[0]), r0_3 = pw3(r[0]), r2_2 = pw2(r[2]), r2_3 = pw3(r[2]);
-        const double r4_2 = pw2(r[4]), r4_3 = pw3(r[4]), r6_3 = pw3(r[6]);
-        double root = (jm2 * pw4(r[0])) / 2 -
-                      (jm2 * pw4(r[2])) / 4 +
+        const double r0_2 = pw2(r[0]), r0_3 = pw3<SEM>(r[0]), r2_2 = pw2(r[2]), r2_3 = pw3<SEM>(r[2]);
+        const double r4_2 = pw2(r[4]), r4_3 = pw3<SEM>(r[4]), r6_3 = pw3<SEM>(r[6]);
+        double root = (jm2 * pw4<SEM>(r[0])) / 2 -
+                      (jm2 * pw4<SEM>(r[2])) / 4 +
                       (jm2 * r2_2 * r4_2) / 2 -
-                      (jm2 * pw4(r[4])) / 4 +
-                      (jm2 * pw4(r[6])) / 2 +
+                      (jm2 * pw4<SEM>(r[4])) / 4 +
+                      (jm2 * pw4<SEM>(r[6])) / 2 +
                       2.0 * jm * a_0 * r0_3 -
                       (2.0 * jm * am * r0_3) / 3 -
                       2.0 * jm * am * r[0] * r2_2 +
@@ -287,7 +287,7 @@ __device__ inline int opt_switch_times(double am, double jm, double vm, double t
                       2.0 * pw2(v_0);
         if (root > 0.0) {
             r[5] = -(4 * am * r[4] -
-                     2.0 * dsqrt(root) +
+                     2.0 * pw_half<SEM>(root) +
                      jm * r2_2 -
                      jm * r4_2 +
                      2.0 * jm * pw2(r[6])) / (4 * am);
@@ -313,9 +313,9 @@ __device__ inline int opt_switch_times(double am, double jm, double vm, double t
                     -24 * a2 + 48 * jm * v_0,
                     48 * dir * jm2 * q_0 -
                         48 * dir * jm2 * q_goal +
-                        16 * pw3(a_0) - 48 * a_0 * jm * v_0,
-                    -3 * pw4(a_0) + 12.0 * a2 * jm * v_0 - 12.0 * jm2 * pw2(v_0)};
-                if constexpr (SEM == kSemMatlab) {
+                        16 * pw3<SEM>(a_0) - 48 * a_0 * jm * v_0,
+                    -3 * pw4<SEM>(a_0) + 12.0 * a2 * jm * v_0 - 12.0 * jm2 * pw2(v_0)};
+                if constexpr (sem_matlab(SEM)) {
                     root = matlab_filtered_root<4>(c, false, mc);   // LTPlanner.m:247-250: the first root that passes the filter
                     if (mc.flags & kMatlabError) { zero7(t); return kOptFalse; }
                 } else {
@@ -336,7 +336,7 @@ __device__ inline int opt_switch_times(double am, double jm, double vm, double t
                 const double n0_2 = pw2(r[0]);
                 r[6] = 1.0 / jm * (am / 2 + sem_sqrt<SEM>(
                            9 * am2 + 6 * sem_sqrt<SEM>(
-                               -12.0 * am * pw3(jm) * pw3(r[0]) +
+                               -12.0 * am * pw3<SEM>(jm) * pw3<SEM>(r[0]) +
                                9 * a2 * jm2 * n0_2 -
                                18 * a_0 * am * jm2 * n0_2 +
                                9 * am2 * jm2 * n0_2 +
@@ -344,7 +344,7 @@ __device__ inline int opt_switch_times(double am, double jm, double vm, double t
                                72.0 * am * dir * jm2 * q_0 +
                                72.0 * am * dir * jm2 * q_goal -
                                36 * am * jm2 * r[0] * v_0 +
-                               3 * pw4(am) +
+                               3 * pw4<SEM>(am) +
                                36 * jm2 * pw2(v_0), mc), mc) / 6.0 - am);
                 r[4] = r[6] + am / jm;
                 r[1] = -(-jm * pw2(r[4]) -
@@ -368,13 +368,13 @@ __device__ inline int opt_switch_times(double am, double jm, double vm, double t
                         0.0,
                         24 * dir * jm2 * q_0 * am -
                             24 * dir * jm2 * q_goal * am +
-                            3 * pw4(a_0) + 8 * pw3(a_0) * am +
+                            3 * pw4<SEM>(a_0) + 8 * pw3<SEM>(a_0) * am +
                             6 * a2 * am2 -
                             12.0 * a2 * jm * v_0 -
                             24 * a_0 * jm * v_0 * am -
                             12.0 * am2 * jm * v_0 +
                             12.0 * jm2 * pw2(v_0)};
-                    if constexpr (SEM == kSemMatlab) {
+                    if constexpr (sem_matlab(SEM)) {
                         root = matlab_filtered_root<4>(c, true, mc);   // LTPlanner.m:272-275: the filter must leave exactly one root
                         if (mc.flags & kMatlabError) { zero7(t); return kOptFalse; }
                     } else {
@@ -396,7 +396,7 @@ __device__ inline int opt_switch_times(double am, double jm, double vm, double t
             r[3] = 0.0;
         }
     }
-    if constexpr (SEM == kSemMatlab) {
+    if constexpr (sem_matlab(SEM)) {
         // LTPlanner.m:288-303: any(t_rel < -eps) or any(|imag(t_rel)| > eps) zeroes t_rel (no failure); then
         // t_rel = max(0, real(t_rel)), which also turns NaN into 0 (MATLAB's max ignores NaN)
         bool zero_all = mc.imag > kEps;
@@ -435,27 +435,27 @@ __device__ inline double v_drive_candidate(double am, double jm, double q_goal, 
                 dsqrt(36 * am2 * jm2 * pw2(tr) -
                       36 * a2 * am * jm * tr +
                       72.0 * a_0 * am2 * jm * tr -
-                      72.0 * pw3(am) * jm * tr +
+                      72.0 * pw3<SEM>(am) * jm * tr +
                       144 * am * dir * jm2 * q_0 -
                       144 * am * dir * jm2 * q_goal +
                       72.0 * am * jm2 * v_0 * tr
-                      - 9 * pw4(a_0)
-                      + 12.0 * pw3(a_0) * am
+                      - 9 * pw4<SEM>(a_0)
+                      + 12.0 * pw3<SEM>(a_0) * am
                       + 36 * a2 * am2 +
                       36 * a2 * jm * v_0 -
-                      72.0 * a_0 * pw3(am) -
+                      72.0 * a_0 * pw3<SEM>(am) -
                       72.0 * a_0 * am * jm * v_0 +
-                      36 * pw4(am) -
+                      36 * pw4<SEM>(am) -
                       36 * jm2 * pw2(v_0)) / 12) / jm;
     } else if constexpr (C == 2) {
-        const double jm3 = pw3(jm);
+        const double jm3 = pw3<SEM>(jm);
         const double s = a_0 + am;                                       // a_0 + a_max
         const double w = (v_0 + (a_0 * (a_0 - am)) / (2.0 * jm)) / am;   // recurring quotient
         const double h = am / (2.0 * jm);
         const double g = (a_0 - am) / (2.0 * jm);
         return -(dir * (q_0 - q_goal) - jm * (
-                     pw3(s) / (6 * jm3) -
-                     pw3(am) / (6 * jm3) +
+                     pw3<SEM>(s) / (6 * jm3) -
+                     pw3<SEM>(am) / (6 * jm3) +
                      (am2 * s) / (2.0 * jm3) +
                      (pw2(s) *
                       (w +
@@ -491,8 +491,8 @@ __device__ inline double v_drive_candidate(double am, double jm, double q_goal, 
                 96 * dir * jm2 * am * q_0 +
                 96 * dir * jm2 * am * q_goal -
                 96 * am * jm2 * v_0 * tr +
-                12.0 * pw4(a_0) +
-                16 * pw3(a_0) * am -
+                12.0 * pw4<SEM>(a_0) +
+                16 * pw3<SEM>(a_0) * am -
                 24 * a2 * am2 -
                 48 * a2 * jm * v_0 +
                 48 * am2 * jm * v_0 +
@@ -507,14 +507,14 @@ __device__ inline double v_drive_candidate(double am, double jm, double q_goal, 
             0.0,
             -24 * dir * jm2 * am * q_0 +
                 24 * dir * jm2 * am * q_goal +
-                9 * pw4(a_0) -
-                12.0 * pw3(a_0) * am -
+                9 * pw4<SEM>(a_0) -
+                12.0 * pw3<SEM>(a_0) * am -
                 24 * a2 * jm * v_0 +
                 48 * a_0 * am * jm * v_0 +
-                4 * pw4(am) -
+                4 * pw4<SEM>(am) -
                 24 * am2 * jm * v_0 +
                 12.0 * jm2 * pw2(v_0) +
-                6 * pw3(a_0) +
+                6 * pw3<SEM>(a_0) +
                 6 * a2 * am -
                 12.0 * a_0 * am2 -
                 12.0 * a_0 * jm * v_0 +
@@ -524,14 +524,14 @@ __device__ inline double v_drive_candidate(double am, double jm, double q_goal, 
         const double root2 = root_squared<4, SEM>(c, 3, mc);      // LTPlanner.m:360 root(3)
         return root2 / jm;
     } else if constexpr (C == 5) {
-        const double a3 = pw3(a_0), jm3 = pw3(jm), jm4 = pw4(jm), d2 = pw2(dir);
+        const double a3 = pw3<SEM>(a_0), jm3 = pw3<SEM>(jm), jm4 = pw4<SEM>(jm), d2 = pw2(dir);
         const double c[6] = {
             (144 * jm * tr + 144 * a_0),
             (-72.0 * jm2 * pw2(tr) - 144 * a_0 * jm * tr + 36 * a2 - 216 * jm * v_0),
             (144 * dir * jm2 * q_0 - 144 * dir * jm2 * q_goal + 48 * a3 - 144 * a_0 * jm * v_0),
-            (-144 * dir * jm3 * q_0 * tr + 144 * dir * jm3 * q_goal * tr - 48 * a3 * jm * tr - 144 * a_0 * dir * jm2 * q_0 + 144 * a_0 * dir * jm2 * q_goal + 144 * a_0 * jm2 * v_0 * tr + 6 * pw4(a_0) - 72.0 * a2 * jm * v_0 + 216 * jm2 * pw2(v_0)),
+            (-144 * dir * jm3 * q_0 * tr + 144 * dir * jm3 * q_goal * tr - 48 * a3 * jm * tr - 144 * a_0 * dir * jm2 * q_0 + 144 * a_0 * dir * jm2 * q_goal + 144 * a_0 * jm2 * v_0 * tr + 6 * pw4<SEM>(a_0) - 72.0 * a2 * jm * v_0 + 216 * jm2 * pw2(v_0)),
             0.0,
-            -72.0 * d2 * jm4 * pw2(q_0) + 144 * d2 * jm4 * q_0 * q_goal - 72.0 * d2 * jm4 * pw2(q_goal) - 48 * a3 * dir * jm2 * q_0 + 48 * a3 * dir * jm2 * q_goal + 144 * a_0 * dir * jm3 * q_0 * v_0 - 144 * a_0 * dir * jm3 * q_goal * v_0 + pw6(a_0) - 6 * pw4(a_0) * jm * v_0 + 36 * a2 * jm2 * pw2(v_0) - 72.0 * jm3 * pw3(v_0)};
+            -72.0 * d2 * jm4 * pw2(q_0) + 144 * d2 * jm4 * q_0 * q_goal - 72.0 * d2 * jm4 * pw2(q_goal) - 48 * a3 * dir * jm2 * q_0 + 48 * a3 * dir * jm2 * q_goal + 144 * a_0 * dir * jm3 * q_0 * v_0 - 144 * a_0 * dir * jm3 * q_goal * v_0 + pw6<SEM>(a_0) - 6 * pw4<SEM>(a_0) * jm * v_0 + 36 * a2 * jm2 * pw2(v_0) - 72.0 * jm3 * pw3<SEM>(v_0)};
         const double root2 = root_squared<5, SEM>(c, 2, mc);      // LTPlanner.m:374 root(2)
         return root2 / jm;
     } else if constexpr (C == 6) {
@@ -540,7 +540,7 @@ __device__ inline double v_drive_candidate(double am, double jm, double q_goal, 
             -6 * dsqrt(2.0) * am,
             (12.0 * am * jm * tr - 6 * a2 - 12.0 * a_0 * am - 6 * am2 - 12.0 * jm * v_0),
             0.0,
-            -12.0 * a2 * am * jm * tr - 24 * dir * jm2 * am * q_0 + 24 * dir * jm2 * am * q_goal - 24 * am * jm2 * v_0 * tr + 3 * pw4(a_0) + 4 * pw3(a_0) * am + 6 * a2 * am2 + 12.0 * a2 * jm * v_0 + 12.0 * am2 * jm * v_0 + 12.0 * jm2 * pw2(v_0)};
+            -12.0 * a2 * am * jm * tr - 24 * dir * jm2 * am * q_0 + 24 * dir * jm2 * am * q_goal - 24 * am * jm2 * v_0 * tr + 3 * pw4<SEM>(a_0) + 4 * pw3<SEM>(a_0) * am + 6 * a2 * am2 + 12.0 * a2 * jm * v_0 + 12.0 * am2 * jm * v_0 + 12.0 * jm2 * pw2(v_0)};
         const double root2 = root_squared<4, SEM>(c, 3, mc);      // LTPlanner.m:388 root(3)
         return -(root2 - a2 - 2.0 * jm * v_0) / (2.0 * jm);
     } else if constexpr (C == 7) {
@@ -549,18 +549,18 @@ __device__ inline double v_drive_candidate(double am, double jm, double q_goal, 
             -24 * am,
             (24 * am * jm * tr - 12.0 * a2 - 24 * a_0 * am - 12.0 * am2 - 24 * jm * v_0),
             0.0,
-            24 * dir * jm2 * am * q_0 - 24 * dir * jm2 * am * q_goal + 3 * pw4(a_0) + 8 * pw3(a_0) * am + 6 * a2 * am2 + 12.0 * a2 * jm * v_0 + 24 * a_0 * am * jm * v_0 + 12.0 * am2 * jm * v_0 + 12.0 * jm2 * pw2(v_0)};
+            24 * dir * jm2 * am * q_0 - 24 * dir * jm2 * am * q_goal + 3 * pw4<SEM>(a_0) + 8 * pw3<SEM>(a_0) * am + 6 * a2 * am2 + 12.0 * a2 * jm * v_0 + 24 * a_0 * am * jm * v_0 + 12.0 * am2 * jm * v_0 + 12.0 * jm2 * pw2(v_0)};
         const double root2 = root_squared<4, SEM>(c, 3, mc);      // LTPlanner.m:402 root(3)
         return root2 / jm;
     } else {
         static_assert(C == 8, "case out of range");
-        const double a3 = pw3(a_0), jm3 = pw3(jm), jm4 = pw4(jm), d2 = pw2(dir);
+        const double a3 = pw3<SEM>(a_0), jm3 = pw3<SEM>(jm), jm4 = pw4<SEM>(jm), d2 = pw2(dir);
         const double c[7] = {
             144.0,
             (-144 * jm * tr + 144 * a_0),
             (72.0 * jm2 * pw2(tr) - 144 * a_0 * jm * tr - 36 * a2 - 216 * jm * v_0),
             (-144 * dir * jm2 * q_0 + 144 * dir * jm2 * q_goal - 48 * a3 - 144 * a_0 * jm * v_0),
-            (144 * dir * jm3 * q_0 * tr - 144 * dir * jm3 * q_goal * tr + 48 * a3 * jm * tr - 144 * a_0 * dir * jm2 * q_0 + 144 * a_0 * dir * jm2 * q_goal + 144 * a_0 * jm2 * v_0 * tr + 6 * pw4(a_0) + 72.0 * a2 * jm * v_0 + 216 * jm2 * pw2(v_0)),
+            (144 * dir * jm3 * q_0 * tr - 144 * dir * jm3 * q_goal * tr + 48 * a3 * jm * tr - 144 * a_0 * dir * jm2 * q_0 + 144 * a_0 * dir * jm2 * q_goal + 144 * a_0 * jm2 * v_0 * tr + 6 * pw4<SEM>(a_0) + 72.0 * a2 * jm * v_0 + 216 * jm2 * pw2(v_0)),
             0.0,
             72.0 * d2 * jm4 * pw2(q_0) -
                 144 * d2 * jm4 * q_0 * q_goal +
@@ -568,10 +568,10 @@ __device__ inline double v_drive_candidate(double am, double jm, double q_goal, 
                 48 * a3 * dir * jm2 * q_0 -
                 48 * a3 * dir * jm2 * q_goal +
                 144 * a_0 * dir * jm3 * q_0 * v_0 -
-                144 * a_0 * dir * jm3 * q_goal * v_0 - pw6(a_0) -
-                6 * pw4(a_0) * jm * v_0 -
+                144 * a_0 * dir * jm3 * q_goal * v_0 - pw6<SEM>(a_0) -
+                6 * pw4<SEM>(a_0) * jm * v_0 -
                 36 * a2 * jm2 * pw2(v_0) -
-                72.0 * jm3 * pw3(v_0)};
+                72.0 * jm3 * pw3<SEM>(v_0)};
         const double root2 = root_squared<6, SEM>(c, 4, mc);      // LTPlanner.m:416 root(4); the C++ notes "WAS root(4) --> Debug this" (cc:628)
         return root2 / jm;
     }

@@ -92,7 +92,7 @@ LTP_DEV unsigned long long queue_total(const Queue& Q, unsigned long long (&cnt)
 template <int SEM>
 LTP_DEV bool needs_fallback(const double (&ts)[7])
 {
-    if constexpr (SEM == kSemMatlab) {
+    if constexpr (sem_matlab(SEM)) {
         bool any = false;
 #pragma unroll
         for (int k = 0; k < 7; ++k) any = any || ts[k] != 0.0;
@@ -145,7 +145,7 @@ k_opt_fast(long long n, int dof, double t_sample, int goal_check, Limits lim, Qu
                 flags |= kLaneDeferred;
             } else {
                 if (rc == kOptFalse) flags |= kStatusOptFailed;
-                if constexpr (SEM == kSemMatlab) {
+                if constexpr (sem_matlab(SEM)) {
                     flags |= matlab_lane_bits(mc);
                     mod = 0;   // LTPlanner.m:64 discards optSwitchTimes' third output: mod_jerk_profile stays false after stage 1
                 }
@@ -176,11 +176,11 @@ k_opt_slow(int dof, double t_sample, Limits lim, Queries in, Records out, signed
         MatlabCtx mc;
         const int rc = opt_switch_times<true, SEM>(L.a_max, L.j_max, L.v_max, t_sample, in.q_goal[ix], in.q_0[ix], in.v_0[ix], in.a_0[ix],
                                                    L.v_max, t, dir, mod, mc);
-        if constexpr (SEM == kSemMatlab) mod = 0;   // LTPlanner.m:64
+        if constexpr (sem_matlab(SEM)) mod = 0;   // LTPlanner.m:64
         store_opt_record(out, rj, t, dir, mod);
         int flags = lane_flags[rj] & ~kLaneDeferred;
         if (rc == kOptFalse) flags |= kStatusOptFailed;
-        if constexpr (SEM == kSemMatlab) flags |= matlab_lane_bits(mc);
+        if constexpr (sem_matlab(SEM)) flags |= matlab_lane_bits(mc);
         lane_flags[rj] = (signed char)flags;
     }
 }
@@ -233,7 +233,7 @@ k_reduce_scale(long long n, int dof, double t_sample, Limits lim, Queries in, Re
     }
     if (slowest < 0) flags |= kStatusNoSlowest;
     if (flags & kLaneGoalOutside) flags = (flags & ~kLaneGoalOutside) | kStatusGoalOutside;
-    if constexpr (SEM == kSemMatlab) {
+    if constexpr (sem_matlab(SEM)) {
         // lane bits -> status bits, after the goal-outside bit has moved (its lane number is kStatusMatlabError's; the two MATLAB
         // lane bits share numbers with NONFINITE / OVERFLOW, which nothing has set yet)
         const int mb = ((flags & kLaneMatlabComplex) ? kStatusMatlabComplex : 0) | ((flags & kLaneMatlabError) ? kStatusMatlabError : 0);
@@ -300,7 +300,7 @@ k_reduce_scale(long long n, int dof, double t_sample, Limits lim, Queries in, Re
                     acc = try_v_drive<false, SEM>(L.a_max, L.j_max, L.v_max, t_sample, qg, q0, v0, a0, dir, t_required, vd, ts, mod, mc);
                 }
             }
-            if constexpr (SEM == kSemMatlab) {
+            if constexpr (sem_matlab(SEM)) {
                 if (mc.flags && acc != kOptDefer) atomicOr(&out.status[q], matlab_status_bits(mc));
             }
             if (acc == kOptTrue) finish(rj, x, planned, ts, vd, mod);
@@ -326,7 +326,7 @@ k_reduce_scale(long long n, int dof, double t_sample, Limits lim, Queries in, Re
             MatlabCtx mc;
             const double vd = v_drive_candidate<2, SEM>(L2.a_max, L2.j_max, qg, q0, v0, a0, dir, tr, mc);
             const int acc = try_v_drive<false, SEM>(L2.a_max, L2.j_max, L2.v_max, t_sample, qg, q0, v0, a0, dir, tr, vd, ts, mod, mc);
-            if constexpr (SEM == kSemMatlab) {
+            if constexpr (sem_matlab(SEM)) {
                 if (mc.flags && acc != kOptDefer) atomicOr(&out.status[q2], matlab_status_bits(mc));
             }
             if (acc == kOptTrue) finish(rj2, x2, true, ts, vd, mod);
@@ -409,7 +409,7 @@ k_scaling_slow(int dof, double t_sample, Limits lim, Queries in, Records out, Qu
                 zero7(ts);
                 vd = L.v_max;
             }
-            if constexpr (SEM == kSemMatlab) {
+            if constexpr (sem_matlab(SEM)) {
                 // LTPlanner.m tries the candidates one after the other: what a candidate BEHIND the accepted one would have
                 // raised or flagged never happens there
                 if (mc.flags && (first < 0 || c <= first)) atomicOr(&out.status[q], matlab_status_bits(mc));
@@ -567,7 +567,7 @@ long long queue_segment(long long n, int dof)
 
 void launch_switch_times(hipStream_t s, long long n, int dof, double t_sample, int goal_check, Limits lim, Queries in,
                          Records out, signed char* lane_flags, unsigned long long* queue_items /* 2 * 8 * queue_segment(n, dof) */,
-                         unsigned long long* counts /* [16], zeroed by the caller on the same stream */, int semantics)
+                         unsigned long long* counts /* [16], zeroed by the caller on the same stream */, int variant)
 {
     if (n <= 0) return;
     const int jb = dof < kMaxJointSlots ? dof : kMaxJointSlots;
@@ -581,17 +581,15 @@ void launch_switch_times(hipStream_t s, long long n, int dof, double t_sample, i
     if (a_blocks > 4096) a_blocks = 4096;
     long long b_blocks = (n * dof + kQueriesPerBlock - 1) / kQueriesPerBlock;
     if (b_blocks > 1024) b_blocks = 1024;
-    if (semantics == kSemMatlab) {
-        hipLaunchKernelGGL(k_opt_fast<kSemMatlab>, grid, block, 0, s, n, dof, t_sample, goal_check, lim, in, out, lane_flags, qa);
-        hipLaunchKernelGGL(k_opt_slow<kSemMatlab>, dim3((unsigned)a_blocks), dim3(64), mr::matrix_lds_bytes(64), s, dof, t_sample, lim, in, out, lane_flags, qa);
-        hipLaunchKernelGGL(k_reduce_scale<kSemMatlab>, grid, block, 0, s, n, dof, t_sample, lim, in, out, lane_flags, qb);
-        hipLaunchKernelGGL(k_scaling_slow<kSemMatlab>, dim3((unsigned)b_blocks), dim3(kQueriesPerBlock, 8), mr::matrix_lds_bytes(kQueriesPerBlock * 8), s, dof, t_sample, lim, in, out, qb);
-        return;
-    }
-    hipLaunchKernelGGL(k_opt_fast<kSemCpp>, grid, block, 0, s, n, dof, t_sample, goal_check, lim, in, out, lane_flags, qa);
-    hipLaunchKernelGGL(k_opt_slow<kSemCpp>, dim3((unsigned)a_blocks), dim3(64), 0, s, dof, t_sample, lim, in, out, lane_flags, qa);
-    hipLaunchKernelGGL(k_reduce_scale<kSemCpp>, grid, block, 0, s, n, dof, t_sample, lim, in, out, lane_flags, qb);
-    hipLaunchKernelGGL(k_scaling_slow<kSemCpp>, dim3((unsigned)b_blocks), dim3(kQueriesPerBlock, 8), 0, s, dof, t_sample, lim, in, out, qb);
+    dispatch_variant(variant, [&](auto v) {
+        constexpr int SEM = decltype(v)::value;
+        // MATLAB's roots() keeps its matrix in dynamic LDS (ltp_roots_matlab.hpp)
+        const unsigned lds_a = sem_matlab(SEM) ? mr::matrix_lds_bytes(64) : 0, lds_b = sem_matlab(SEM) ? mr::matrix_lds_bytes(kQueriesPerBlock * 8) : 0;
+        hipLaunchKernelGGL(k_opt_fast<SEM>, grid, block, 0, s, n, dof, t_sample, goal_check, lim, in, out, lane_flags, qa);
+        hipLaunchKernelGGL(k_opt_slow<SEM>, dim3((unsigned)a_blocks), dim3(64), lds_a, s, dof, t_sample, lim, in, out, lane_flags, qa);
+        hipLaunchKernelGGL(k_reduce_scale<SEM>, grid, block, 0, s, n, dof, t_sample, lim, in, out, lane_flags, qb);
+        hipLaunchKernelGGL(k_scaling_slow<SEM>, dim3((unsigned)b_blocks), dim3(kQueriesPerBlock, 8), lds_b, s, dof, t_sample, lim, in, out, qb);
+    });
 }
 
 void launch_offsets(hipStream_t s, long long n, int dof, double t_sample, Records rec,

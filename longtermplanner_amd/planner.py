@@ -124,6 +124,13 @@ class LongTermPlanner:
         code = {"cpp": _abi.SEMANTICS_CPP, "matlab": _abi.SEMANTICS_MATLAB}.get(semantics, semantics)
         self._check(self._lib.ltp_set_semantics(self._h, int(code)))
 
+    def setPowRule(self, rule):
+        """NEW: how the reference's pow(x, 3 | 4 | 6) and pow(x, 1.0 / 2) are formed — "exact" (default: one rounding of the exact
+        product, sqrt) or "libm" (glibc's pow restated operation for operation: the bits of a reference built with gcc + glibc on
+        an FMA host; include/ltp_hip.h LTP_POW_LIBM)."""
+        code = {"exact": _abi.POW_EXACT, "libm": _abi.POW_LIBM}.get(rule, rule)
+        self._check(self._lib.ltp_set_pow_rule(self._h, int(code)))
+
     def lastMatlabFlags(self):
         """MATLAB semantics: flags of the latest one-lane call (optBraking / optSwitchTimes / timeScaling): 1 = complex intermediate, 2 = error."""
         return self._lib.ltp_debug_last_matlab_flags(self._h)
@@ -503,6 +510,13 @@ class LongTermPlanner:
         x, y = _vec(x), _vec(y)
         out = np.zeros((x.size, 8))
         self._check(self._lib.ltp_debug_math_probe_host(self._h, x.size, _ptr(x), _ptr(y), _ptr(out)))
+        return out
+
+    def debugLibmPow(self, x, y):
+        """pow(x, y) elementwise by the device's restated glibc pow (the arithmetic of setPowRule("libm"))."""
+        x, y = _vec(x), _vec(y)
+        out = np.zeros(x.size)
+        self._check(self._lib.ltp_debug_libm_pow_host(self._h, x.size, _ptr(x), _ptr(y), _ptr(out)))
         return out
 
     def debugRootsProbe(self, degree, coef):

@@ -88,6 +88,16 @@ def _arr(x, n=None):
     return a
 
 
+def libm_pow(x, y):
+    """The host libm's pow, elementwise (numpy's own power may take a SIMD path with other last bits)."""
+    x = _arr(x); y = _arr(y, x.size)
+    out = np.empty(x.size)
+    f = lib().ltpo_libm_pow
+    f.restype = None
+    f(C.c_long(x.size), _d(x), _d(y), _d(out))
+    return out
+
+
 def roots_f64(poly):
     p = _arr(poly)
     n = p.size - 1

@@ -175,6 +175,15 @@ int ltpo_exact_pow(void) { return 1; }
 int ltpo_exact_pow(void) { return 0; }
 #endif
 
+/* exported for tests/: the HOST libm's pow, elementwise — what the product's pow rule LTP_POW_LIBM (csrc/ltp_libm_pow.hpp, a
+ * restatement of glibc's pow) is compared with bit for bit. Called through a volatile pointer so that no call is folded. */
+void ltpo_libm_pow(long n, const double *x, const double *y, double *out)
+{
+    double (*volatile f)(double, double) = (pow);
+    long i;
+    for (i = 0; i < n; i++) out[i] = f(x[i], y[i]);
+}
+
 /* optional polynomial log (tests dump the polynomials a run produced) */
 static double *g_poly_log = NULL;   /* rows of [degree, p0..p6, root] = 9 doubles */
 static long g_poly_cap = 0, g_poly_n = 0;

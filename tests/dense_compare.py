@@ -68,9 +68,10 @@ def cause(ltp, orc, q):
     return "rounding"
 
 
-def soak(name, D, lim, Ts, n, seed, bufs, exact=False, quiet=False, matlab=False):
+def soak(name, D, lim, Ts, n, seed, bufs, exact=False, quiet=False, matlab=False, pow_rule="exact"):
     """exact: compare against the oracle's DIAGNOSTIC exact-pow twin instead of the libm oracle (the parity reference).
-    matlab: both sides in MATLAB semantics (LTPlanner.m; the device's rows then come from k_sample_walk_matlab_*)."""
+    matlab: both sides in MATLAB semantics (LTPlanner.m; the device's rows then come from k_sample_walk_matlab_*).
+    pow_rule: the device's pow rule (ltp_set_pow_rule): "libm" forms the powers as the libm oracle's pow does."""
     import torch
     import longtermplanner_amd as amd
     import oracle
@@ -79,6 +80,7 @@ def soak(name, D, lim, Ts, n, seed, bufs, exact=False, quiet=False, matlab=False
     orc = oracle.Oracle(D, Ts, exact_pow=exact, semantics="matlab" if matlab else "cpp", **lim)
     if matlab:
         ltp.setSemantics("matlab")
+    ltp.setPowRule(pow_rule)
     t0 = time.time()
     dq = ltp.generateQueries(n, seed=seed)
     b = ltp.planSwitchTimesBatch(*dq)
@@ -159,7 +161,7 @@ def soak(name, D, lim, Ts, n, seed, bufs, exact=False, quiet=False, matlab=False
         if len(outliers) < 40:
             outliers.append(o)
     st = b.status.cpu().numpy()
-    res = {"dof": D, "t_sample": Ts, "seed": seed, "dense_plans": int(n), "sampled": int(np.sum((st & 0x57) == 0)),
+    res = {"dof": D, "t_sample": Ts, "seed": seed, "device_pow_rule": pow_rule, "dense_plans": int(n), "sampled": int(np.sum((st & 0x57) == 0)),
            "values_compared": int(compared[0]), "bytes_compared": int(compared[0]) * 8,
            "max_abs_d": {k: float(worst[i]) for i, k in enumerate("qvaj")},
            "plans_beyond_tolerance": int(np.sum(maxd.max(axis=1) > TOL)),

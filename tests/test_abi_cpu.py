@@ -118,3 +118,28 @@ def test_cmake_package_resolves_like_the_reference(abi, tmp_path):
         assert p.returncode == 3 and "no device" in p.stdout
     else:
         assert p.returncode == 0 and "planTrajectory: true" in p.stdout
+
+
+def test_a_touched_header_makes_the_library_stale():
+    """_abi.build() takes its inputs from the Makefile (`make print-deps`), so an edit of ANY header the kernels
+    include — the public include/ltp_run_tables.hpp, which holds the sampler's arithmetic, among them — requests a rebuild."""
+    import os
+    from longtermplanner_amd import _abi
+    deps = _abi.build_inputs()
+    names = {os.path.relpath(d, ROOT) for d in deps}
+    for must in ("include/ltp_run_tables.hpp", "include/ltp_hip.h", "longtermplanner_amd/csrc/ltp_libm_pow.hpp",
+                 "longtermplanner_amd/csrc/ltp_libm_pow_tables.inc", "longtermplanner_amd/csrc/ltp_sampler.hip", "longtermplanner_amd/csrc/Makefile"):
+        assert must in names, must
+    csrc = os.path.join(ROOT, "longtermplanner_amd", "csrc")
+    listed = {os.path.basename(d) for d in deps}
+    assert all(f in listed for f in os.listdir(csrc) if f.endswith((".hip", ".hpp", ".inc"))), "a source file is missing from the Makefile's lists"
+    _abi.build()
+    assert not _abi.stale()
+    hdr = os.path.join(ROOT, "include", "ltp_run_tables.hpp")
+    st = os.stat(hdr)
+    try:
+        os.utime(hdr, (st.st_atime, os.path.getmtime(_abi.LIB_PATH) + 5))
+        assert _abi.stale()
+    finally:
+        os.utime(hdr, (st.st_atime, st.st_mtime))
+    assert not _abi.stale()

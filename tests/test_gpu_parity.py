@@ -310,3 +310,114 @@ def test_records_are_bit_identical_to_the_oracle_with_the_device_pow_rule(amd, o
     for k in ("mod", "slowest", "traj_len"):
         assert np.array_equal(dev[k][ok], twin[k][ok]) and np.array_equal(dev[k][ok], libm[k][ok]), k
     assert differing > 0, "libm's pow and the exact products never differed on this batch: the test would prove nothing"
+
+
+def test_device_libm_pow_is_the_host_libm_pow(amd, oracle_mod):
+    """The pow rule LTP_POW_LIBM is glibc's pow restated operation for operation (csrc/ltp_libm_pow.hpp): on the device it returns the
+    bits of the HOST's libm for the planner's exponents on planner-like, arbitrary, negative, subnormal, huge and non-finite x, for
+    arbitrary y, and where the result under- or overflows. (The same header against the same libm on the host, 1.7e10 inputs:
+    tests/test_libm_pow.py, profiles/r05_libm_pow_host_soak.json.)"""
+    D, lim, ltp, _ = _mk(amd, oracle_mod, "panda")
+    rng = np.random.default_rng(5)
+    n = 400_000
+    xs, ys = [], []
+    mag = 10.0 ** rng.uniform(-9, 6, n) * rng.choice([-1.0, 1.0], n)
+    anyx = rng.integers(0, 2**64, n, dtype=np.uint64).view(np.float64)
+    for y in (0.5, 2.0, 3.0, 4.0, 6.0):
+        xs += [mag, anyx]
+        ys += [np.full(n, y), np.full(n, y)]
+    xs.append(10.0 ** rng.uniform(-20, 20, n) * rng.choice([-1.0, 1.0, 1.0, 1.0], n))
+    yy = 10.0 ** rng.uniform(-3, 3, n) * rng.choice([-1.0, 1.0], n)
+    ys.append(np.where(rng.random(n) < 0.5, np.rint(yy), yy))
+    xs.append(10.0 ** rng.uniform(-20, 20, n))
+    ys.append(rng.integers(0, 2**64, n, dtype=np.uint64).view(np.float64))          # any y bit pattern
+    xe = 10.0 ** rng.uniform(-10, 10, n)                                             # results in the subnormal / overflow range
+    xs.append(xe)
+    ys.append(rng.uniform(960, 1080, n) * rng.choice([-1.0, 1.0], n) / np.log2(xe))
+    edge = np.array([0.0, -0.0, 1.0, -1.0, 0.5, -0.5, 2.0, -2.0, 3.0, -3.0, np.inf, -np.inf, np.nan, 5e-324, -5e-324, 2.2250738585072014e-308,
+                     1.7976931348623157e308, -1.7976931348623157e308, 2.0 ** -65, 2.0 ** 63, 2.0 ** -66, 2.0 ** 64, 1e-300, 1e300, 1074.0, -1075.0])
+    ex, ey = np.meshgrid(edge, edge)
+    xs.append(ex.ravel())
+    ys.append(ey.ravel())
+    x, y = np.concatenate(xs), np.concatenate(ys)
+    got = ltp.debugLibmPow(x, y)
+    with np.errstate(all="ignore"):
+        ref = oracle_mod.libm_pow(x, y)
+    same = (got.view(np.uint64) == ref.view(np.uint64)) | (np.isnan(got) & np.isnan(ref))
+    bad = np.nonzero(~same)[0]
+    assert bad.size == 0, [(float(x[i]).hex(), float(y[i]).hex(), float(got[i]).hex(), float(ref[i]).hex()) for i in bad[:5]]
+    # and the rule matters: libm's pow(x, 3) is not always the correctly rounded cube (the default rule)
+    cube = ltp.debugMathProbe(mag, np.ones(n))[:, 2]
+    assert 0 < int(np.sum(cube != oracle_mod.libm_pow(mag, 3.0))) < n // 100
+
+
+@pytest.mark.parametrize("name,n,semantics", [("panda", 300_000, "cpp"), ("ref", 300_000, "cpp"), ("ref30", 40_000, "cpp"), ("ref", 150_000, "matlab")])
+def test_records_are_bit_identical_to_the_libm_oracle_under_the_libm_pow_rule(amd, oracle_mod, name, n, semantics):
+    """VERDICT r4 item 2, the mirror of the test above: with ltp_set_pow_rule(LTP_POW_LIBM) every switching time, v_drive, t_required
+    and every integer field of the device's records has the bits of the DEFAULT oracle — the parity reference, whose powers are the
+    host libm's pow — on 640 k C++-semantics plans (and 150 k in MATLAB semantics). No tolerance."""
+    from concurrent.futures import ThreadPoolExecutor
+    D, lim = amd.limit_set(name)
+    ltp = amd.LongTermPlanner(D, 0.001, device=0, **lim)
+    ltp.setSemantics(semantics)
+    ltp.setPowRule("libm")
+    q = amd.generate_queries(n, lim, seed=424242)
+    dev = ltp.planBatchHost(*q, sample=False)
+    parts = 16
+    cuts = [n * i // parts for i in range(parts + 1)]
+    orc = oracle_mod.Oracle(D, 0.001, semantics=semantics, **lim)
+    with ThreadPoolExecutor(parts) as ex:
+        outs = list(ex.map(lambda i: orc.plan_batch(*[x[cuts[i]:cuts[i + 1]] for x in q], sample=False), range(parts)))
+    libm = {k: np.concatenate([o[k] for o in outs]) for k in outs[0] if k != "n_ok"}
+    ok = (dev["status"] & ~amd.STATUS_MATLAB_COMPLEX & ~amd.STATUS_END_LIMIT) == 0     # planned (the end-limit check was not run: no rows)
+    assert np.array_equal(ok, libm["status"] != 0)
+    for k in ("t_opt", "t_scaled", "v_drive", "t_required", "dir"):
+        d, l = (np.ascontiguousarray(x[k][ok]) for x in (dev, libm))
+        same = (d.view(np.uint64) == l.view(np.uint64)) | (np.isnan(d) & np.isnan(l))
+        assert same.all(), (k, int((~same).sum()), float(np.nanmax(np.abs(d - l))))
+    for k in ("mod", "slowest", "traj_len"):
+        assert np.array_equal(dev[k][ok], libm[k][ok]), k
+    # the default rule on the same batch does differ from the libm oracle in some last bits: the rule is what closes them
+    ltp.setPowRule("exact")
+    dflt = ltp.planBatchHost(*q, sample=False)
+    assert sum(int((np.ascontiguousarray(dflt[k][ok]).view(np.uint64) != np.ascontiguousarray(libm[k][ok]).view(np.uint64)).sum())
+               for k in ("t_opt", "t_scaled", "v_drive")) > 0
+
+
+def test_dense_trajectories_strict_under_the_libm_pow_rule(amd, oracle_mod, capsys):
+    """The dense test above WITHOUT its exception clause: with ltp_set_pow_rule(LTP_POW_LIBM) every q/v/a/j sample of >= 200 k dense
+    trajectories (the same sets: panda, the reference's limits, 30-DoF, 24 wide-fuzzed limit sets) is within 1e-9 of the libm
+    oracle's planTrajectory, no plan excepted, and the jerk rows are bit-identical in every sampled plan."""
+    import json
+    import os
+    import dense_compare as dc
+    bufs = dc.pinned_buffers()
+    sets = {}
+    for name, n in [("panda", 110_000), ("ref", 60_000), ("ref30", 8_000)]:
+        D, lim = amd.limit_set(name)
+        sets[name] = dc.soak(name, D, lim, 0.001, n, 777, bufs, quiet=True, pow_rule="libm")
+    rng = np.random.default_rng(31337)
+    for trial in range(24):
+        D, ts, lim = dc.fuzz_limits(rng, trial, wide=True)
+        sets[f"fuzz{trial}"] = dc.soak(f"fuzz{trial}", D, lim, ts, 1_100, 9000 + trial, bufs, quiet=True, pow_rule="libm")
+    total = sum(s["dense_plans"] for s in sets.values())
+    line = {"device_pow_rule": "libm", "dense_trajectories": total, "values_compared": sum(s["values_compared"] for s in sets.values()), "tolerance": TOL,
+            "max_abs_d": {k: max(s["max_abs_d"][k] for s in sets.values()) for k in "qvaj"},
+            "plans_beyond_tolerance": sum(s["plans_beyond_tolerance"] for s in sets.values()),
+            "sampled_plans": sum(s["sampled"] for s in sets.values()),
+            "plans_with_bit_identical_jerk_rows": sum(s["plans_with_bit_identical_jerk_rows"] for s in sets.values())}
+    with capsys.disabled():
+        print("\nparity report (dense, pow rule libm): " + json.dumps(line))
+    try:
+        out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "parity_report_dense_libm_test.json"), "w") as f:
+            json.dump({"line": line, "sets": sets}, f, indent=1)
+    except OSError:
+        pass
+    assert total >= 200_000
+    for name, s in sets.items():
+        assert s["verdict_mismatches"] == 0 and s["length_mismatches"] == 0 and s["end_limit_flag_mismatches"] == 0, (name, s)
+        assert s["plans_beyond_tolerance"] == 0, (name, s["outliers"])
+        assert max(s["max_abs_d"].values()) <= TOL, (name, s["max_abs_d"])
+        assert s["plans_with_bit_identical_jerk_rows"] == s["sampled"], (name, s["sampled"] - s["plans_with_bit_identical_jerk_rows"])
