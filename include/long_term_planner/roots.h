@@ -13,8 +13,10 @@
 // For users who DO have Eigen: when <Eigen/Dense> is on the include path (and LTP_ROOTS_NO_EIGEN is not defined) the reference's
 // exact signatures exist as well — roots<T>(Eigen::Matrix<T, Dynamic, 1>) returning an n x 1 complex Eigen matrix and
 // getSmallestPositiveNonComplexRoot<T>(Eigen::Matrix<std::complex<T>, Dynamic, Dynamic>) — delegating to the same device call, so
-// the reference's tests/src/roots_tests.cc:9-32 compiles against this header unchanged. NOTE: that block has never been
-// compiled in this repository's build image (Eigen is not installed there); it is provided as is.
+// the reference's tests/src/roots_tests.cc:9-32 compiles against this header unchanged. Eigen is not installed in this repository's
+// build image: the block is compiled there against tests/cpp/not_eigen — a container-only stand-in for the type names, NOT Eigen —
+// which proves syntax and overload resolution (tests/cpp/roots_eigen_signature_test.cc) and lets the reference's roots_tests.cc run
+// against the device (tests/test_gpu_kat.py); against the real Eigen headers it is untested.
 #ifndef roots_H
 #define roots_H
 

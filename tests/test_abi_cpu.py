@@ -143,3 +143,16 @@ def test_a_touched_header_makes_the_library_stale():
     finally:
         os.utime(hdr, (st.st_atime, st.st_mtime))
     assert not _abi.stale()
+
+
+def test_eigen_typed_roots_overloads_compile_and_resolve():
+    """The Eigen-typed overloads of include/long_term_planner/roots.h against tests/cpp/not_eigen (a container-only stand-in: NOT
+    Eigen): syntax and overload resolution (static_asserts in tests/cpp/roots_eigen_signature_test.cc), no GPU needed. Without the
+    stand-in on the include path the same header compiles with the std::vector signatures only."""
+    cpp = os.path.join(ROOT, "tests", "cpp")
+    inc = os.path.join(ROOT, "include")
+    subprocess.check_call(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-Werror", "-I" + os.path.join(cpp, "not_eigen"), "-I" + inc,
+                           os.path.join(cpp, "roots_eigen_signature_test.cc")])
+    p = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-I" + inc, "-x", "c++", "-"], input='#include "long_term_planner/roots.h"\n'
+                       'int main() { return (int)long_term_planner::roots<double>(std::vector<double>{1.0, -3.0, 2.0}).size(); }\n', text=True, capture_output=True)
+    assert p.returncode == 0, p.stderr

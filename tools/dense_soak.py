@@ -5,11 +5,13 @@ chunk's rows are copied to pinned host memory, and 16 host threads run the oracl
 same queries and compare sample by sample (oracle/ltp_oracle.c: ltpo_compare_dense). Plans beyond the tolerance are listed
 with a cause class, as SURVEY.md §8(d) asks: root-classification, window-test flip, sample-index flip, else rounding.
 
-  python tools/dense_soak.py [--exact-pow] [--wide-fuzz] [--matlab] [panda_plans] [ref_plans] [ref30_plans] [fuzz_sets] [plans_per_fuzz_set] [out.json] [seed_shift]
+  python tools/dense_soak.py [--exact-pow] [--wide-fuzz] [--matlab] [--pow-rule-libm] [panda_plans] [ref_plans] [ref30_plans] [fuzz_sets] [plans_per_fuzz_set] [out.json] [seed_shift]
 
 --exact-pow: compare against the oracle's DIAGNOSTIC twin (-DLTPO_EXACT_POW: the device's rule for pow(x, 3 | 4 | 6) and
 pow(x, 0.5) restated in C) instead of the libm oracle. If libm's pow is the only source of last-bit differences, the jerk rows
 are then bit-identical in every plan and nothing lies beyond the tolerance (tools/pow_experiment.py has the records' side).
+--pow-rule-libm: the device under the pow rule LTP_POW_LIBM (glibc's pow restated): against the libm oracle nothing may lie beyond
+the tolerance and every jerk row must be bit-identical.
 --matlab: device and oracle in MATLAB semantics (LTPlanner.m); the device's rows come from k_sample_walk_matlab_*.
 --wide-fuzz: limit sets with j_max / Ts up to 1e9, Ts down to 0.1 ms and slow-jerk sets whose trajectories have 1e4-1e5 samples.
 """
@@ -27,6 +29,7 @@ from dense_compare import THREADS, TOL, fuzz_limits, pinned_buffers, soak as _so
 EXACT = "--exact-pow" in sys.argv[1:]
 WIDE = "--wide-fuzz" in sys.argv[1:]
 MATLAB = "--matlab" in sys.argv[1:]
+LIBM_RULE = "--pow-rule-libm" in sys.argv[1:]      # the device forms its powers as glibc's pow does (ltp_set_pow_rule(LTP_POW_LIBM))
 argv = [a for a in sys.argv[1:] if not a.startswith("--")]
 n_panda = int(argv[0]) if len(argv) > 0 else 600_000
 n_ref = int(argv[1]) if len(argv) > 1 else 300_000
@@ -38,14 +41,14 @@ seed_shift = int(argv[6]) if len(argv) > 6 else 0          # other query sets th
 
 
 def soak(name, D, lim, Ts, n, seed, bufs):
-    return _soak(name, D, lim, Ts, n, seed, bufs, exact=EXACT, matlab=MATLAB)
+    return _soak(name, D, lim, Ts, n, seed, bufs, exact=EXACT, matlab=MATLAB, pow_rule="libm" if LIBM_RULE else "exact")
 
 
 
 
 def main():
     bufs = pinned_buffers()
-    report = {"tolerance": TOL, "host_threads": THREADS, "semantics": "matlab" if MATLAB else "cpp",
+    report = {"tolerance": TOL, "host_threads": THREADS, "semantics": "matlab" if MATLAB else "cpp", "device_pow_rule": "libm" if LIBM_RULE else "exact",
               "oracle": "exact-pow twin (diagnostic)" if EXACT else "libm (the parity reference)",
               "what": "every q/v/a/j sample of the device's dense rows vs the oracle's planTrajectory", "sets": {}}
     for name, n in (("panda", n_panda), ("ref", n_ref), ("ref30", n_ref30)):
