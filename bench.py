@@ -30,6 +30,51 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+# binary64 vector peak: half the 157.3 TFLOP/s binary32 vector rate of the same guide = 256 CUs x 4 SIMDs x 16 lanes/clk x 2 flop x 2.4 GHz
+# (tools/f64_issue_probe.hip measures ~2200 binary64 wave instructions per us and CU = 72 TFLOP/s of fused multiply-adds)
+F64_VALU_PEAK_TFLOPS = 78.6
+
+
+def workload_key(wl, n):
+    """Names a workload for profiles/bench_counters.json (the committed rocprofv3 --pmc passes a line may quote)."""
+    parts = [wl.limits, str(n), "f32" if wl.f32 else "f64"]
+    if wl.switch_only:
+        parts.append("switch_only" + ("+end_limit" if wl.end_limit else ""))
+    if wl.max_samples:
+        parts.append(f"first{wl.max_samples}")
+    if wl.sample_stride > 1:
+        parts.append(f"stride{wl.sample_stride}")
+    if wl.envelope:
+        parts.append(f"envelope{wl.envelope}" + ("+analytic" if getattr(wl, "envelope_analytic", False) else ""))
+    if wl.receding:
+        parts.append(f"receding{wl.receding}")
+    if wl.in_flight > 1:
+        parts.append(f"inflight{wl.in_flight}")
+    if wl.walk is not None:
+        parts.append("walk" if wl.walk else "nowalk")
+    if wl.direct is not None:
+        parts.append("direct" if wl.direct else "nodirect")
+    if wl.table_pass != "auto":
+        parts.append(f"tablepass_{wl.table_pass}")
+    if wl.semantics != "cpp":
+        parts.append(wl.semantics)
+    if wl.pow_rule != "libm":
+        parts.append(f"pow_{wl.pow_rule}")
+    return ":".join(parts)
+
+
+def committed_counters(key):
+    """The entry of profiles/bench_counters.json for this workload, or None. These are PMC measurements of separate rocprofv3 passes
+    (counters cannot be read inside this process); a line quotes them with their provenance and never as measured in this run."""
+    path = os.path.join(ROOT, "profiles", "bench_counters.json")
+    try:
+        d = json.load(open(path))
+        e = d["workloads"].get(key)
+        if e is None:
+            return None
+        return dict(e, source=f"profiles/bench_counters.json ({d.get('collected', '?')}; committed rocprofv3 passes of this workload, NOT measured in this run)")
+    except Exception:
+        return None
 
 
 def shard_range(n_total, rank, world):
@@ -141,6 +186,8 @@ def parse_args(argv=None):
                     help="where the sampler's run tables are built: by the table pass (a kernel of its own) or inside the sampler kernel (ltp_set_table_pass)")
     ap.add_argument("--no-walk", action="store_true", help="A/B: capped rows of <= 256 samples through the table pass instead of k_sample_walk_* (tables kept in the compute unit)")
     ap.add_argument("--walk", action="store_true", help="A/B: force k_sample_walk_* (also for rows it is not chosen for automatically: whole rows, float64 caps beyond 256)")
+    ap.add_argument("--direct", action="store_true", help="A/B: force k_sample_direct_* (lane = (plan, joint), no LDS) for any capped rows")
+    ap.add_argument("--no-direct", action="store_true", help="A/B: forbid k_sample_direct_* (rows of at most 256 bytes then take k_sample_walk_*)")
     ap.add_argument("--in-flight", type=int, default=1, help="switching times only: steps alternate between this many planner handles, each on its own stream "
                     "(two batches in flight: the latency-bound queue-B kernel of one step runs under the next step's stages); 1 = one batch at a time")
     ap.add_argument("--table-gib", type=float, default=0.0, help="upper bound of the table-pass workspace (default: library default, 1/16 of device memory)")
@@ -148,9 +195,9 @@ def parse_args(argv=None):
     ap.add_argument("--gather", action="store_true", help="also all_gather t_required over RCCL each step (optional path)")
     ap.add_argument("--semantics", default="cpp", choices=["cpp", "matlab"],
                     help="VARIANT (SURVEY §8(f).4): 'matlab' follows LTPlanner.m where the C++ translation diverges (ltp_set_semantics); rows then take the table pass")
-    ap.add_argument("--pow-rule", default="exact", choices=["exact", "libm"],
-                    help="VARIANT: how the reference's pow(x, 3 | 4 | 6 | 1/2) calls are formed (ltp_set_pow_rule): 'exact' = one rounding of the exact "
-                         "product (default), 'libm' = glibc's pow restated operation for operation (the bits of a gcc + glibc build of the reference)")
+    ap.add_argument("--pow-rule", default="libm", choices=["libm", "exact"],
+                    help="how the reference's pow(x, 3 | 4 | 6 | 1/2) calls are formed (ltp_set_pow_rule): 'libm' = glibc's pow restated operation for operation "
+                         "(the library's default: the bits of a gcc + glibc build of the reference), 'exact' = one rounding of the exact product (VARIANT: faster stage kernels)")
     ap.add_argument("--one-process", action="store_true",
                     help="--gpus N from ONE process: one planner handle, stream and host thread per device, device-resident shards "
                          "(ltp_plan_switch_times_multi / ltp_envelope_multi / ltp_state_at_multi), no torch.distributed. Workloads without dense "
@@ -237,6 +284,7 @@ class Workload:
         self.sample_blocks, self.gather, self.checksum, self.seed = args.sample_blocks, args.gather, args.checksum, args.seed
         self.table_pass, self.table_gib = args.table_pass, args.table_gib
         self.walk = False if args.no_walk else (True if args.walk else None)
+        self.direct = False if args.no_direct else (True if args.direct else None)
         self.end_limit = args.end_limit
         self.in_flight = args.in_flight
         self.semantics = args.semantics
@@ -328,7 +376,7 @@ def run_workload(wl, ctx):
                 if timed:
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record()
-                ltp.sampleBatch(batch, 0, n, tile, streaming=not wl.plain_stores, spread=wl.spread, walk=wl.walk)
+                ltp.sampleBatch(batch, 0, n, tile, streaming=not wl.plain_stores, spread=wl.spread, walk=wl.walk, direct=wl.direct)
                 if timed:
                     e1.record()
                     ev_pairs.append((e0, e1))
@@ -362,7 +410,7 @@ def run_workload(wl, ctx):
             if timed:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-            ltp.sampleBatch(batch, first, end - first, view, streaming=not wl.plain_stores, dry=wl.dry, spread=wl.spread, walk=wl.walk)
+            ltp.sampleBatch(batch, first, end - first, view, streaming=not wl.plain_stores, dry=wl.dry, spread=wl.spread, walk=wl.walk, direct=wl.direct)
             if timed:
                 e1.record()
                 ev_pairs.append((e0, e1))
@@ -415,7 +463,25 @@ def run_workload(wl, ctx):
         dist.all_reduce(counts, op=dist.ReduceOp.SUM)
     ok_total, len_total, bytes_total = (float(x) for x in counts.tolist())
     roofline = None
-    if ev_pairs:
+    key = workload_key(wl, n)
+    pmc = committed_counters(key)
+    if ev_pairs and env_spec:
+        # the envelope consumer writes 16 bytes per window: its bound is the binary64 vector rate. Counted work: the cubic q(m) of every
+        # sample it looks at, 3 fused multiply-adds = 6 flop (index conversion, min and max are issue slots too but not flops)
+        kern_ms = sum(a.elapsed_time(b) for a, b in ev_pairs)
+        evals = float(dof) * float(np.minimum(traj_len, env_spec[0] * env_spec[1]).sum())
+        if getattr(wl, "envelope_analytic", False):
+            evals = None
+        tflops = (evals * 6.0 * wl.steps / (kern_ms * 1e-3) / 1e12) if evals else None
+        roofline = {"kernel": "k_envelope", "bound": "valu_f64", "achieved": round(tflops, 2) if tflops else None, "peak": F64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(tflops / F64_VALU_PEAK_TFLOPS, 4) if tflops else None,
+                    "counted": "6 flop (the 3 fused multiply-adds of q(m)) per sample inside the windows" if evals else
+                               "analytic form: a few candidate samples per run and window instead of every sample; no flop count claimed",
+                    "bytes_written_per_launch": alg_bytes_per_step, "avg_launch_ms": round(kern_ms / len(ev_pairs), 4), "launches_timed": len(ev_pairs),
+                    "traffic": None, "measured_on": f"rank 0 of {world}" if world > 1 else "rank 0"}
+        if pmc:
+            roofline["counters_from_profile"] = pmc
+    elif ev_pairs:
         kern_ms = sum(a.elapsed_time(b) for a, b in ev_pairs)
         launches = len(ev_pairs)
         rounds = rec_spec[0] if rec_spec else 1    # receding variant: the lengths of the last round stand for all rounds
@@ -428,16 +494,18 @@ def run_workload(wl, ctx):
                     "algorithmic_bytes_per_launch": alg_bytes_per_step // max(n_chunks, 1),
                     "avg_launch_ms": round(kern_ms / launches, 4), "launches_timed": launches,
                     "measured_on": f"rank 0 of {world}" if world > 1 else "rank 0"}
-        pmc = os.path.join(ROOT, "profiles", "sampler_write_bytes.json")
-        if os.path.exists(pmc) and not (env_spec or rec_spec or wl.f32 or wl.max_samples or wl.sample_stride > 1):
-            try:
-                rec = json.load(open(pmc))
-                if rec.get("limits") == wl.limits and rec.get("batch") == n and rec.get("tile_gib") == tile_gib:
-                    roofline["traffic_from_profile"] = {"write_bytes_per_launch": rec.get("write_bytes_per_launch"),
-                                                        "source": "profiles/sampler_write_bytes.json (committed rocprofv3 --pmc WRITE_SIZE pass of this workload; NOT measured in this run)",
-                                                        "collected": rec.get("collected", "round 1")}
-            except Exception:
-                pass
+        if rec_spec:
+            roofline["rows"] = "written by the sampler every cycle; the restart states are recomputed from the records (k_replan_walk), not read back from the rows"
+        if pmc and pmc.get("write_bytes_per_launch"):
+            roofline["traffic_from_profile"] = {"write_bytes_per_launch": pmc["write_bytes_per_launch"], "source": pmc["source"]}
+    elif wl.switch_only or rec_direct:
+        # stages 1-3 move ~750 bytes and ~10^4 flop per plan: neither HBM nor the flop rate bounds them. What does: the
+        # binary64 issue rate of the waves in flight and the latency of the deferred eigen-solves. The share of the vector
+        # issue slots in use is a PMC figure: quoted from the committed pass, if there is one for this workload.
+        roofline = {"kernel": "k_opt_fast + k_opt_slow + k_reduce_scale + k_scaling_slow" + (" + k_end_limit" if wl.end_limit else "") + (" + k_state_at" if rec_direct else ""),
+                    "bound": "latency/valu_f64", "achieved": None, "peak": None, "unit": None, "frac": None, "traffic": None,
+                    "valu_issue_frac": pmc.get("valu_issue_frac") if pmc else None,
+                    "counters_from_profile": pmc}
 
     if rank != 0:
         return None
@@ -458,7 +526,7 @@ def run_workload(wl, ctx):
         "config": {
             "workload": ((f"{wl.global_batch} x {dof}-DoF queries per step sharded over {world} GPU(s) ({n} on rank 0)" if wl.global_batch else
                           f"{n} x {dof}-DoF queries per GPU per step") + f", limits '{wl.limits}', Tsample {wl.t_sample} s, "
-                         + (f"{rec_spec[0]} receding-horizon cycles per step on the device (plan, " + ("state at sample" if rec_direct else f"first {wl.max_samples} samples, replan from stored sample") + f" {rec_spec[1]}); value counts replans; " if rec_spec else "")
+                         + (f"{rec_spec[0]} receding-horizon cycles per step on the device (plan, " + ("state at sample" if rec_direct else f"first {wl.max_samples} samples written, replan from the state at stored sample") + f" {rec_spec[1]}" + ("" if rec_direct else ", recomputed from the records") + "); value counts replans; " if rec_spec else "")
                          + (("switching times only (stages 1-3" + (" + end-limit check" if wl.end_limit else "; status = pre-sampling verdict") + ", no rows)"
                              + (f"; {wl.in_flight} batches in flight (steps alternate between {wl.in_flight} handles and streams)" if wl.in_flight > 1 else "")) if wl.switch_only else
                             "no rows stored (ltp_state_at_batch)" if rec_direct else
@@ -467,7 +535,7 @@ def run_workload(wl, ctx):
                              f"q/v/a/j rows: every {wl.sample_stride}-th sample" + (f", first {wl.max_samples} stored" if wl.max_samples else ""))
                             + f" into a reused {tile_gib} GiB tile ({n_chunks} chunks per step)")),
             "batch_per_gpu": n if not wl.global_batch else None, "global_batch": total_queries, "dof": dof, "t_sample": wl.t_sample,
-            "limits": wl.limits, "input_layout": wl.layout, "table_pass": wl.table_pass, "batches_in_flight": wl.in_flight, "semantics": wl.semantics, "pow_rule": wl.pow_rule,
+            "workload_key": key, "limits": wl.limits, "input_layout": wl.layout, "table_pass": wl.table_pass, "batches_in_flight": wl.in_flight, "semantics": wl.semantics, "pow_rule": wl.pow_rule,
             "sharding": "contiguous query ranges per rank, no data-path collective" + (", all_gather of t_required through the process group every step" if gather_buf else ""),
             "backend": ctx["backend"], "rank_devices": ctx["rank_devices"],
             "plans_ok_frac": round(ok_total / total_queries, 5),
@@ -614,8 +682,8 @@ def main():
             print(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE {world} rank(s)", file=sys.stderr)
         return 2
 
-    variant = (args.no_walk or args.walk or args.switch_only or args.end_limit or args.f32 or args.max_samples or args.sample_stride > 1 or args.envelope or args.receding or args.dry_sampler
-               or args.in_flight > 1 or args.semantics != "cpp" or args.pow_rule != "exact" or args.table_pass != "auto" or args.limits != "panda" or args.batch != 1_000_000 or args.global_batch or args.window_gib or args.layout != "query_major")
+    variant = (args.no_walk or args.walk or args.direct or args.no_direct or args.switch_only or args.end_limit or args.f32 or args.max_samples or args.sample_stride > 1 or args.envelope or args.receding or args.dry_sampler
+               or args.in_flight > 1 or args.semantics != "cpp" or args.pow_rule != "libm" or args.table_pass != "auto" or args.limits != "panda" or args.batch != 1_000_000 or args.global_batch or args.window_gib or args.layout != "query_major")
     rccl_world1 = None
     if not grouped and not variant and not args.no_secondary and not args.no_rccl_check and args.backend == "nccl":
         rccl_world1 = rccl_self_check(args)     # a child process, BEFORE this one imports torch or touches the GPU
@@ -697,7 +765,7 @@ def main():
                  dict(limits="ref30", steps=few, warmup=1)),
                 ("first 256 samples of every row (SURVEY §8(f).2): k_sample_walk, run tables kept in the compute unit",
                  dict(max_samples=256, steps=max(args.steps, 5), warmup=1)),
-                ("receding horizon (SURVEY §8(f).1): 10 cycles per step through 128-sample rows, replan from stored sample 100",
+                ("receding horizon (SURVEY §8(f).1): 10 cycles per step, 128-sample rows WRITTEN every cycle, restart states = stored sample 100 RECOMPUTED from the records (the rows are not read back)",
                  dict(receding="10:100", max_samples=128, steps=few, warmup=1)),
                 ("every 4th sample of every row (SURVEY §8(f).2, strided rows): k_sample_walk, long-row form",
                  dict(sample_stride=4, steps=max(args.steps, 5), warmup=1)),

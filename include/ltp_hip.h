@@ -77,12 +77,13 @@ typedef enum {
  * (pow(x, 2) is x * x in every build: gcc folds it). Both rules are IEEE binary64; they differ in the last bit of about one
  * power in a thousand, which timeScaling's cancelling v_drive formulas (cc:378-446) turn into up to ~5e-11 s of a switching
  * time and the sampler's jerk corrections (cc:768-807) into |dt| * j_max / Ts of single jerk samples.
+ * LTP_POW_LIBM   THE DEFAULT. glibc's pow (>= 2.28; the build glibc selects on x86-64 hosts with FMA) restated operation for
+ *                operation (csrc/ltp_libm_pow.hpp, bit-identical to the installed libm on 1.7e10 inputs): every record has the
+ *                bits a reference built with gcc + glibc computes on such a host and every sample is within 1e-9 of it, no plan
+ *                excepted (tests/test_gpu_parity.py; 14.6 M dense trajectories in profiles/r05_parity_report.json). Costs ~45 fp64
+ *                operations and 3 table reads per power: +1.4 % on a full-sampling batch, +35 % on switching times only.
  * LTP_POW_EXACT  one rounding of the exact product, sqrt for the power 1/2: what a correctly rounded pow returns; within
- *                1 ulp of ANY libm; the faster rule and the default.
- * LTP_POW_LIBM   glibc's pow (>= 2.28; the build glibc selects on x86-64 hosts with FMA) restated operation for operation
- *                (csrc/ltp_libm_pow.hpp, bit-identical to the installed libm on 1.7e10 inputs): with it every record and
- *                every sample has the bits a reference built with gcc + glibc computes on such a host — no 1e-9 exceptions
- *                (tests/test_gpu_parity.py). Costs ~30 fp64 operations and 5 table reads per power in the stage kernels. */
+ *                1 ulp of ANY libm (so within the differences between two libm builds of the reference); the faster rule. */
 #define LTP_POW_EXACT 0
 #define LTP_POW_LIBM 1
 
@@ -157,7 +158,7 @@ int ltp_get_goal_check(const ltp_planner* p);
  * path; ltp_end_limit_batch does nothing. */
 int ltp_set_semantics(ltp_planner* p, int semantics);
 int ltp_get_semantics(const ltp_planner* p);
-/* LTP_POW_EXACT (default) or LTP_POW_LIBM, see above. Applies to the calls that plan (switching times, single-joint entry
+/* LTP_POW_LIBM (default) or LTP_POW_EXACT, see above. Applies to the calls that plan (switching times, single-joint entry
  * points, the one-launch single call); samplers and consumers form no powers and do not depend on it. */
 int ltp_set_pow_rule(ltp_planner* p, int rule);
 int ltp_get_pow_rule(const ltp_planner* p);

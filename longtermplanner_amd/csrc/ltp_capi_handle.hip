@@ -185,6 +185,12 @@ bool want_walk(const ltp_planner* p, int max_samples, int stride, bool f32)
     return f32 || stride >= 3 || (max_samples > 0 && max_samples <= 768);
 }
 
+// k_sample_direct (lane = (plan, joint), no LDS) for rows this short: one 256-byte line set per array and joint at most
+bool want_direct(int max_samples, bool f32)
+{
+    return max_samples > 0 && (unsigned long long)max_samples * (f32 ? 4 : 8) <= 256ull;
+}
+
 // plans per piece so that the tables of a piece fit the workspace; grows the workspace (up to tables_cap) if needed.
 // While a stream is being captured into a hipGraph nothing may be allocated or freed (and a graph that was already
 // instantiated keeps the old pointer): then the range is cut into pieces that fit the workspace as it is

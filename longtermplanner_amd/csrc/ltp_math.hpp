@@ -9,10 +9,10 @@
 //     correctly rounded f64 sequences on gfx950;
 //   * pow(x, n) for the integer exponents the reference uses (3, 4, 6; gcc folds pow(x, 2) to x * x) and its one
 //     pow(x, 1.0 / 2) follow one of two POW RULES (ltp_set_pow_rule):
-//       LTP_POW_EXACT (default)  one rounding of the exact product (error-free products through fma), sqrt for 1/2:
-//                                what a correctly rounded pow returns; within 1 ulp of any libm;
-//       LTP_POW_LIBM             glibc's pow restated operation for operation (ltp_libm_pow.hpp): the bits a reference built
-//                                with gcc + glibc (>= 2.28, FMA host) computes.
+//       LTP_POW_LIBM (default)   glibc's pow restated operation for operation (ltp_libm_pow.hpp): the bits a reference built
+//                                with gcc + glibc (>= 2.28, FMA host) computes;
+//       LTP_POW_EXACT            one rounding of the exact product (error-free products through fma), sqrt for 1/2:
+//                                what a correctly rounded pow returns; within 1 ulp of any libm; ~1/4 fewer stage-kernel cycles.
 //     The rule rides in the template parameter SEM of ltp_profile.hpp next to the semantics: SEM = semantics | kPowLibm.
 #pragma once
 #include <hip/hip_runtime.h>

@@ -972,7 +972,8 @@ def test_walk_sampler_keeps_its_tables_in_the_compute_unit_and_gives_the_same_ro
             full = torch.full((total,), 3.0, dtype=dt, device="cuda")
             ltp.sampleBatch(b, 0, n, full, **kw)
             kern = ltp.lastSamplerKernel()
-            assert ("walk" in kern) == (mode != "fused"), (mode, kern, cap)          # automatic choice: the walk kernel for these caps
+            # automatic choice: the walk kernel for these caps; k_sample_direct for rows of at most 256 bytes (round 5)
+            assert (("walk" in kern) or (mode == "auto" and "direct" in kern and cap * (4 if f32 else 8) <= 256)) == (mode != "fused"), (mode, kern, cap)
             sub = torch.full((int((b.offsets[n - 2] - b.offsets[13]).item()) + 8,), 3.0, dtype=dt, device="cuda")
             ltp.sampleBatch(b, 13, n - 15, sub, spread=48, **kw)
             b2 = ltp.planSwitchTimesBatch(qg, q0, v0, a0)
@@ -1160,3 +1161,50 @@ def test_walk_sampler_beyond_63_joints(amd, dof):
         for k, (got, want) in enumerate(zip(res["walk"], res["fused"])):
             assert torch.equal(got, want), (cap, stride, f32, k)
         assert int((res["walk"][3] > 0).sum().item()) >= n - 1
+
+
+@pytest.mark.parametrize("limits,dof,n,semantics", [("panda", None, 2000, "cpp"), ("ref", 3, 700, "cpp"), ("ref", 30, 90, "cpp"), ("ref", 70, 40, "cpp"),
+                                                    ("panda", None, 900, "matlab")])
+def test_direct_sampler_gives_the_rows_of_the_other_samplers(amd, limits, dof, n, semantics):
+    """k_sample_direct_* (round 5: lane = (plan, joint), runs walked in registers, the lane stores its own samples; what the library
+    takes by itself for capped rows of at most 256 bytes) against the walk kernel and the fused sampler / the table pass: rows, statuses
+    and lengths bit for bit — caps 1-32 (automatic) and beyond (forced), strides, both element types, sub-ranges, tiles too small for
+    the last plans, rejected plans, trajectories that end inside the cap, any number of joints, both semantics."""
+    import torch
+    D, lim = amd.limit_set(limits, dof)
+    ltp = amd.LongTermPlanner(D, 0.001, device=0, **lim)
+    ltp.setSemantics(semantics)
+    qg, q0, v0, a0 = (x.clone() for x in ltp.generateQueries(n, seed=31))
+    v0[7, 0] = 99.0; v0[8, D - 1] = 99.0                        # rejected plans
+    short = torch.arange(20, min(n, 600), 5, device=qg.device)  # short moves from rest: trajectories that end inside the cap
+    qg[short] = q0[short] + 0.004 * torch.sign(qg[short] - q0[short] + 1e-9)
+    v0[short] = 0.0
+    a0[short] = 0.0
+    qg[short] = torch.minimum(torch.maximum(qg[short], torch.tensor(lim["q_min"], dtype=torch.float64, device=qg.device)),
+                              torch.tensor(lim["q_max"], dtype=torch.float64, device=qg.device))
+    other = dict(walk=False) if semantics == "matlab" else dict(tables=False, walk=False)       # the table pass / the fused sampler
+    for cap, stride, f32 in ((16, 1, False), (32, 1, False), (1, 1, False), (2, 1, False), (3, 1, True), (31, 2, False), (64, 1, True), (17, 3, True),
+                             (33, 1, False), (200, 1, False), (130, 4, True)):
+        ltp.setMaxSamples(cap); ltp.setSampleStride(stride)
+        dt = torch.float32 if f32 else torch.float64
+        automatic = cap * (4 if f32 else 8) <= 256
+        res = {}
+        for mode in ("other", "walk", "direct", "auto"):
+            kw = other if mode == "other" else (dict(walk=True) if mode == "walk" else (dict(direct=True) if mode == "direct" else {}))
+            b = ltp.planSwitchTimesBatch(qg, q0, v0, a0)
+            full = torch.full((int(b.offsets[-1].item()),), 3.0, dtype=dt, device="cuda")
+            ltp.sampleBatch(b, 0, n, full, **kw)
+            kern = ltp.lastSamplerKernel()
+            assert ("direct" in kern) == (mode == "direct" or (mode == "auto" and automatic)), (mode, kern, cap, f32)
+            assert ("matlab" in kern) == (semantics == "matlab") or "tab" in kern
+            sub = torch.full((int((b.offsets[n - 2] - b.offsets[13]).item()) + 8,), 3.0, dtype=dt, device="cuda")
+            ltp.sampleBatch(b, 13, n - 15, sub, **kw)
+            b2 = ltp.planSwitchTimesBatch(qg, q0, v0, a0)
+            small = torch.full((int(b2.offsets[n // 2 + 3].item()) + 5,), 3.0, dtype=dt, device="cuda")
+            ltp.sampleBatch(b2, 0, n, small, streaming=False, **kw)
+            torch.cuda.synchronize()
+            res[mode] = (full, sub, small, b.status.clone(), b.traj_len.clone(), b2.status.clone())
+        for mode in ("walk", "direct", "auto"):
+            for k, (got, want) in enumerate(zip(res[mode], res["other"])):
+                assert torch.equal(got, want), (cap, stride, f32, mode, k)
+        assert (res["other"][5] & 32).any(), "the small tile did not leave any plan out"

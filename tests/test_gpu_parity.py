@@ -215,7 +215,9 @@ def test_device_roots_all_eigenvalues_in_eigen_order(amd, oracle_mod, kat):
 
 
 def test_dense_trajectories_parity_budget(amd, oracle_mod, capsys):
-    """EVERY q/v/a/j sample of >= 200 k dense trajectories against the oracle's planTrajectory (cc:7-63 incl. getTrajectory
+    """The OPT-IN pow rule LTP_POW_EXACT (correctly rounded powers; the default rule is tested without any exception clause in
+    test_dense_trajectories_strict_under_the_libm_pow_rule below).
+    EVERY q/v/a/j sample of >= 200 k dense trajectories against the oracle's planTrajectory (cc:7-63 incl. getTrajectory
     cc:706-841): panda, the reference's limits, 30-DoF and 24 fuzzed limit sets (dof 1-12, Ts 0.1-10 ms, j_max / Ts up to 1e9,
     slow-jerk sets with 1e4-1e5 samples per trajectory). The bar and its one stated exception:
       * verdicts, trajectory lengths and end-limit flags equal everywhere; q and v within 1e-9 everywhere;
@@ -283,6 +285,7 @@ def test_records_are_bit_identical_to_the_oracle_with_the_device_pow_rule(amd, o
     from concurrent.futures import ThreadPoolExecutor
     D, lim = amd.limit_set(name)
     ltp = amd.LongTermPlanner(D, 0.001, device=0, **lim)
+    ltp.setPowRule("exact")
     q = amd.generate_queries(n, lim, seed=424242)
     dev = ltp.planBatchHost(*q, sample=False)
     parts = 16

@@ -118,6 +118,7 @@ def site_report(D, lim, Ts, q, dev, ol, oe, cap=12):
 def run_set(name, D, lim, Ts, n, seed):
     t0 = time.time()
     ltp = amd.LongTermPlanner(D, Ts, device=0, **lim)
+    ltp.setPowRule("exact")                       # this experiment is about the correctly rounded powers (the opt-in rule)
     q = amd.generate_queries(n, lim, seed=seed)
     dev = ltp.planBatchHost(*q, sample=False)
     t1 = time.time()
