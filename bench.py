@@ -52,8 +52,6 @@ def workload_key(wl, n):
         parts.append(f"inflight{wl.in_flight}")
     if wl.walk is not None:
         parts.append("walk" if wl.walk else "nowalk")
-    if wl.direct is not None:
-        parts.append("direct" if wl.direct else "nodirect")
     if wl.table_pass != "auto":
         parts.append(f"tablepass_{wl.table_pass}")
     if wl.semantics != "cpp":
@@ -179,6 +177,8 @@ def parse_args(argv=None):
     ap.add_argument("--device", type=int, default=None, help="HIP device ordinal for every rank (default: LOCAL_RANK)")
     ap.add_argument("--envelope", default="", metavar="WINDOW:COUNT",
                     help="VARIANT: instead of dense rows, reduce each plan on the device to per-joint [min q, max q] over COUNT windows of WINDOW samples (ltp_envelope_batch)")
+    ap.add_argument("--envelope-analytic", action="store_true",
+                    help="with --envelope: ltp_set_envelope_mode(LTP_ENVELOPE_ANALYTIC) — the extreme samples from the roots of q'(m) per run instead of every sample")
     ap.add_argument("--receding", default="", metavar="ROUNDS:K",
                     help="VARIANT (SURVEY §8(f).1): per step ROUNDS receding-horizon cycles on the device — plan, sample the first "
                          "--max-samples samples, restart every query from stored sample K (ltp_replan_states_batch); value counts every replan")
@@ -186,8 +186,6 @@ def parse_args(argv=None):
                     help="where the sampler's run tables are built: by the table pass (a kernel of its own) or inside the sampler kernel (ltp_set_table_pass)")
     ap.add_argument("--no-walk", action="store_true", help="A/B: capped rows of <= 256 samples through the table pass instead of k_sample_walk_* (tables kept in the compute unit)")
     ap.add_argument("--walk", action="store_true", help="A/B: force k_sample_walk_* (also for rows it is not chosen for automatically: whole rows, float64 caps beyond 256)")
-    ap.add_argument("--direct", action="store_true", help="A/B: force k_sample_direct_* (lane = (plan, joint), no LDS) for any capped rows")
-    ap.add_argument("--no-direct", action="store_true", help="A/B: forbid k_sample_direct_* (rows of at most 256 bytes then take k_sample_walk_*)")
     ap.add_argument("--in-flight", type=int, default=1, help="switching times only: steps alternate between this many planner handles, each on its own stream "
                     "(two batches in flight: the latency-bound queue-B kernel of one step runs under the next step's stages); 1 = one batch at a time")
     ap.add_argument("--table-gib", type=float, default=0.0, help="upper bound of the table-pass workspace (default: library default, 1/16 of device memory)")
@@ -280,11 +278,11 @@ class Workload:
         self.switch_only, self.f32 = args.switch_only, args.f32
         self.max_samples, self.sample_stride = args.max_samples, args.sample_stride
         self.envelope, self.receding = args.envelope, args.receding
+        self.envelope_analytic = args.envelope_analytic
         self.plain_stores, self.dry, self.spread, self.window_gib = args.plain_stores, args.dry_sampler, args.spread, args.window_gib
         self.sample_blocks, self.gather, self.checksum, self.seed = args.sample_blocks, args.gather, args.checksum, args.seed
         self.table_pass, self.table_gib = args.table_pass, args.table_gib
         self.walk = False if args.no_walk else (True if args.walk else None)
-        self.direct = False if args.no_direct else (True if args.direct else None)
         self.end_limit = args.end_limit
         self.in_flight = args.in_flight
         self.semantics = args.semantics
@@ -308,6 +306,8 @@ def run_workload(wl, ctx):
     if wl.semantics != "cpp":
         ltp.setSemantics(wl.semantics)
     ltp.setPowRule(wl.pow_rule)
+    if wl.envelope_analytic:
+        ltp.setEnvelopeMode("analytic")
     if wl.global_batch:
         first_query, n = shard_range(wl.global_batch, rank, world)
         total_queries = wl.global_batch
@@ -376,7 +376,7 @@ def run_workload(wl, ctx):
                 if timed:
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record()
-                ltp.sampleBatch(batch, 0, n, tile, streaming=not wl.plain_stores, spread=wl.spread, walk=wl.walk, direct=wl.direct)
+                ltp.sampleBatch(batch, 0, n, tile, streaming=not wl.plain_stores, spread=wl.spread, walk=wl.walk)
                 if timed:
                     e1.record()
                     ev_pairs.append((e0, e1))
@@ -410,7 +410,7 @@ def run_workload(wl, ctx):
             if timed:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-            ltp.sampleBatch(batch, first, end - first, view, streaming=not wl.plain_stores, dry=wl.dry, spread=wl.spread, walk=wl.walk, direct=wl.direct)
+            ltp.sampleBatch(batch, first, end - first, view, streaming=not wl.plain_stores, dry=wl.dry, spread=wl.spread, walk=wl.walk)
             if timed:
                 e1.record()
                 ev_pairs.append((e0, e1))
@@ -530,7 +530,7 @@ def run_workload(wl, ctx):
                          + (("switching times only (stages 1-3" + (" + end-limit check" if wl.end_limit else "; status = pre-sampling verdict") + ", no rows)"
                              + (f"; {wl.in_flight} batches in flight (steps alternate between {wl.in_flight} handles and streams)" if wl.in_flight > 1 else "")) if wl.switch_only else
                             "no rows stored (ltp_state_at_batch)" if rec_direct else
-                            f"on-device envelope consumer: [min q, max q] over {env_spec[1]} windows of {env_spec[0]} samples per joint, no dense rows" if env_spec else
+                            f"on-device envelope consumer ({'analytic: the candidates of each run' if wl.envelope_analytic else 'every sample'}): [min q, max q] over {env_spec[1]} windows of {env_spec[0]} samples per joint, no dense rows" if env_spec else
                             ("full q/v/a/j sampling" if not (wl.max_samples or wl.sample_stride > 1) else
                              f"q/v/a/j rows: every {wl.sample_stride}-th sample" + (f", first {wl.max_samples} stored" if wl.max_samples else ""))
                             + f" into a reused {tile_gib} GiB tile ({n_chunks} chunks per step)")),
@@ -682,7 +682,7 @@ def main():
             print(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE {world} rank(s)", file=sys.stderr)
         return 2
 
-    variant = (args.no_walk or args.walk or args.direct or args.no_direct or args.switch_only or args.end_limit or args.f32 or args.max_samples or args.sample_stride > 1 or args.envelope or args.receding or args.dry_sampler
+    variant = (args.no_walk or args.walk or args.switch_only or args.end_limit or args.f32 or args.max_samples or args.sample_stride > 1 or args.envelope or args.receding or args.dry_sampler
                or args.in_flight > 1 or args.semantics != "cpp" or args.pow_rule != "libm" or args.table_pass != "auto" or args.limits != "panda" or args.batch != 1_000_000 or args.global_batch or args.window_gib or args.layout != "query_major")
     rccl_world1 = None
     if not grouped and not variant and not args.no_secondary and not args.no_rccl_check and args.backend == "nccl":

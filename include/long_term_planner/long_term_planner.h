@@ -116,6 +116,7 @@ class LongTermPlanner {
   bool goal_check_ = false;
   int semantics_ = LTP_SEMANTICS_CPP;
   int pow_rule_ = LTP_POW_LIBM;
+  int envelope_mode_ = LTP_ENVELOPE_EXHAUSTIVE;
 
   static void raise(const ltp_planner* h, int rc, const char* what) {
     throw std::runtime_error(std::string("long_term_planner (MI355X): ") + what + " failed with code " + std::to_string(rc) +
@@ -147,6 +148,7 @@ class LongTermPlanner {
       if ((rc = ltp_set_goal_check(t.h, goal_check_ ? 1 : 0)) != LTP_OK) raise(t.h, rc, "ltp_set_goal_check");
       if ((rc = ltp_set_semantics(t.h, semantics_)) != LTP_OK) raise(t.h, rc, "ltp_set_semantics");
       if ((rc = ltp_set_pow_rule(t.h, pow_rule_)) != LTP_OK) raise(t.h, rc, "ltp_set_pow_rule");
+      if ((rc = ltp_set_envelope_mode(t.h, envelope_mode_)) != LTP_OK) raise(t.h, rc, "ltp_set_envelope_mode");
       t.dirty = false;
     }
     return t.h;
@@ -207,12 +209,12 @@ class LongTermPlanner {
   LongTermPlanner(const LongTermPlanner& o)
       : dof_(o.dof_), t_sample_(o.t_sample_), q_min_(o.q_min_), q_max_(o.q_max_), v_max_(o.v_max_), a_max_(o.a_max_),
         j_max_(o.j_max_), device_(o.device_), max_samples_(o.max_samples_), sample_stride_(o.sample_stride_),
-        goal_check_(o.goal_check_), semantics_(o.semantics_), pow_rule_(o.pow_rule_) {}
+        goal_check_(o.goal_check_), semantics_(o.semantics_), pow_rule_(o.pow_rule_), envelope_mode_(o.envelope_mode_) {}
   LongTermPlanner& operator=(const LongTermPlanner& o) {
     if (this != &o) {
       dof_ = o.dof_; t_sample_ = o.t_sample_; q_min_ = o.q_min_; q_max_ = o.q_max_; v_max_ = o.v_max_; a_max_ = o.a_max_;
       j_max_ = o.j_max_; device_ = o.device_; max_samples_ = o.max_samples_; sample_stride_ = o.sample_stride_;
-      goal_check_ = o.goal_check_; semantics_ = o.semantics_; pow_rule_ = o.pow_rule_; markDirty();
+      goal_check_ = o.goal_check_; semantics_ = o.semantics_; pow_rule_ = o.pow_rule_; envelope_mode_ = o.envelope_mode_; markDirty();
     }
     return *this;
   }
@@ -379,6 +381,10 @@ class LongTermPlanner {
    * pow forms them, operation for operation: every switching time and every sample has the bits of the reference built with gcc +
    * glibc (>= 2.28) on a host with FMA (ltp_hip.h LTP_POW_LIBM). false: the correctly rounded powers instead (LTP_POW_EXACT: within
    * 1 ulp of any libm, switching times within 5e-11 s of the above, stage kernels ~1/4 faster). */
+  /** @brief NEW, default false: the envelope calls evaluate only the samples at the ends of each run stretch and
+   * either side of the real roots of q'(m) instead of every sample (ltp_hip.h LTP_ENVELOPE_ANALYTIC): within ulps of the exhaustive result. */
+  inline void setAnalyticEnvelopes(bool enabled) { envelope_mode_ = enabled ? LTP_ENVELOPE_ANALYTIC : LTP_ENVELOPE_EXHAUSTIVE; markDirty(); }
+
   inline void setLibmPow(bool enabled) { pow_rule_ = enabled ? LTP_POW_LIBM : LTP_POW_EXACT; markDirty(); }
 
 

@@ -241,6 +241,16 @@ int ltp_sample_batch_f32(ltp_planner* p, long long first, long long count, const
  * sample_stride do not apply. env: device, count*dof*n_windows*2 doubles, 16-byte aligned. */
 int ltp_envelope_batch(ltp_planner* p, long long first, long long count, const ltp_queries* in, const ltp_records* rec,
                        int window, int n_windows, double* env, void* stream);
+/* How the envelope calls (ltp_envelope_batch, ltp_envelope_multi, ltp_plan_envelope*_host) find a window's extreme samples.
+ * LTP_ENVELOPE_EXHAUSTIVE (default)  every sample of the window is evaluated: min / max have the BITS of the same reduction of the rows.
+ * LTP_ENVELOPE_ANALYTIC              inside a run q is one cubic in the sample index, so only the samples at the ends of each (run,
+ *                                    window) stretch and either side of the real roots of its derivative are evaluated (they ARE samples
+ *                                    of the row): a few evaluations per run instead of `window`; the result can differ from the exhaustive
+ *                                    one where a neighbouring sample undercuts by rounding alone, i.e. by a few ulps of q (tested: <= 1e-12). */
+#define LTP_ENVELOPE_EXHAUSTIVE 0
+#define LTP_ENVELOPE_ANALYTIC 1
+int ltp_set_envelope_mode(ltp_planner* p, int mode);
+int ltp_get_envelope_mode(const ltp_planner* p);
 
 /* SURVEY.md §8(f).2 consumer HOOK: the run tables of plans [first, first+count) of a planned batch in a CALLER buffer, for
  * consumers of the caller's own (include/ltp_run_tables.hpp: the format, run_coef / run_eval, for_each_run / for_each_sample, and

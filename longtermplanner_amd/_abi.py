@@ -118,6 +118,8 @@ _SIGNATURES = {
                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_longlong, C.c_void_p]),
     "ltp_set_semantics": (C.c_int, [C.c_void_p, C.c_int]),
     "ltp_get_semantics": (C.c_int, [C.c_void_p]),
+    "ltp_set_envelope_mode": (C.c_int, [C.c_void_p, C.c_int]),
+    "ltp_get_envelope_mode": (C.c_int, [C.c_void_p]),
     "ltp_set_pow_rule": (C.c_int, [C.c_void_p, C.c_int]),
     "ltp_get_pow_rule": (C.c_int, [C.c_void_p]),
     "ltp_debug_libm_pow_host": (C.c_int, [C.c_void_p, C.c_longlong, _dp, _dp, _dp]),

@@ -83,17 +83,6 @@ static int sample_batch_any(ltp_planner* p, long long first, long long count, co
     // (capped, float32, sparse) and for every row format in MATLAB semantics; flags bit 6 forces it, bit 5 forbids it, bit 2 = "the
     // table-pass kernels" and bit 3 = "the fused build" keep their meaning. (Diagnostic runs — dry stores, stamps — stay with the
     // kernels that implement them.)
-    // k_sample_direct — rows of at most one 256-byte line set per array (first-32 float64 / first-64 float32 samples or fewer): issue-bound
-    // in every other sampler; flags bit 7 forces it for any capped rows, bit 24 forbids it (A/B runs); an explicit choice
-    // of another sampler (bits 2, 3, 5, 6) is honoured
-    if (!p->dbg_stamps && !(flags & (2 | 4 | 8 | 32 | 64 | (1 << 24))) && ltp::sample_direct_applies(p->dof, rows) &&
-        ((flags & 128) || (p->table_pass == 0 && want_direct(rows.max_samples, f32)))) {
-        ltp::launch_sample_direct(s, first, count, p->dof, p->t_sample, dev_limits(p), to_dev(in), to_dev(rec), offsets, out, f32, capacity, rows,
-                                  matlab ? ltp::kSemMatlab : ltp::kSemCpp);
-        LTP_HIP_TRY(p, hipGetLastError());
-        p->last_kernel = matlab ? (f32 ? "k_sample_direct_matlab_f32" : "k_sample_direct_matlab_f64") : (f32 ? "k_sample_direct_f32" : "k_sample_direct_f64");
-        return LTP_OK;
-    }
     if (!p->dbg_stamps && !(flags & (2 | 32)) && ltp::sample_walk_applies(p->dof, rows) &&
         ((flags & 64) || (!(flags & (4 | 8)) && (matlab || want_walk(p, rows.max_samples, rows.stride, f32))))) {
         if (p->walk_blocks[f32 ? 1 : 0] == 0) p->walk_blocks[f32 ? 1 : 0] = ltp::sample_walk_resident_blocks(p->device, f32);
@@ -171,17 +160,17 @@ int ltp_envelope_batch(ltp_planner* p, long long first, long long count, const l
             LTP_HIP_TRY(p, hipMemsetAsync(head, 0, sizeof(unsigned long long), s));
             ltp::launch_build_tables(s, f, c, p->dof, p->t_sample, dev_limits(p), to_dev(in), to_dev(rec), ltp::RowSpec{0, 1}, true, nullptr, f, p->d_tables, p->semantics);
             ltp::launch_envelope(s, f, c, first, p->dof, p->t_sample, dev_limits(p), to_dev(in), to_dev(rec), window, n_windows, env, head,
-                                 blocks, nullptr, p->d_tables);
+                                 blocks, nullptr, p->d_tables, p->envelope_mode == LTP_ENVELOPE_ANALYTIC);
         }
         LTP_HIP_TRY(p, hipGetLastError());
-        p->last_kernel = "k_envelope (run tables from k_build_tables)";
+        p->last_kernel = p->envelope_mode == LTP_ENVELOPE_ANALYTIC ? "k_envelope analytic (run tables from k_build_tables)" : "k_envelope (run tables from k_build_tables)";
         return workspace_release(p, s, capturing);
     }
     unsigned long long* head = p->d_sample_next + (p->sample_next_slot++ & 63u);
     LTP_HIP_TRY(p, hipMemsetAsync(head, 0, sizeof(unsigned long long), s));
-    p->last_kernel = "k_envelope";
+    p->last_kernel = p->envelope_mode == LTP_ENVELOPE_ANALYTIC && !p->dbg_stamps ? "k_envelope analytic" : "k_envelope";
     ltp::launch_envelope(s, first, count, first, p->dof, p->t_sample, dev_limits(p), to_dev(in), to_dev(rec), window,
-                         n_windows, env, head, blocks, p->dbg_stamps);
+                         n_windows, env, head, blocks, p->dbg_stamps, nullptr, p->envelope_mode == LTP_ENVELOPE_ANALYTIC);
     LTP_HIP_TRY(p, hipGetLastError());
     return LTP_OK;
 }

@@ -185,12 +185,6 @@ bool want_walk(const ltp_planner* p, int max_samples, int stride, bool f32)
     return f32 || stride >= 3 || (max_samples > 0 && max_samples <= 768);
 }
 
-// k_sample_direct (lane = (plan, joint), no LDS) for rows this short: one 256-byte line set per array and joint at most
-bool want_direct(int max_samples, bool f32)
-{
-    return max_samples > 0 && (unsigned long long)max_samples * (f32 ? 4 : 8) <= 256ull;
-}
-
 // plans per piece so that the tables of a piece fit the workspace; grows the workspace (up to tables_cap) if needed.
 // While a stream is being captured into a hipGraph nothing may be allocated or freed (and a graph that was already
 // instantiated keeps the old pointer): then the range is cut into pieces that fit the workspace as it is
@@ -347,6 +341,14 @@ int ltp_set_semantics(ltp_planner* p, int semantics)
     return LTP_OK;
 }
 int ltp_get_semantics(const ltp_planner* p) { return p ? p->semantics : -1; }
+int ltp_set_envelope_mode(ltp_planner* p, int mode)
+{
+    if (!p || (mode != LTP_ENVELOPE_EXHAUSTIVE && mode != LTP_ENVELOPE_ANALYTIC)) return fail(p, LTP_ERR_INVALID_ARGUMENT, "envelope mode must be LTP_ENVELOPE_EXHAUSTIVE or LTP_ENVELOPE_ANALYTIC");
+    std::lock_guard<std::mutex> g(p->mu);
+    p->envelope_mode = mode;
+    return LTP_OK;
+}
+int ltp_get_envelope_mode(const ltp_planner* p) { return p ? p->envelope_mode : -1; }
 int ltp_set_pow_rule(ltp_planner* p, int rule)
 {
     if (!p || (rule != LTP_POW_EXACT && rule != LTP_POW_LIBM)) return fail(p, LTP_ERR_INVALID_ARGUMENT, "pow rule must be LTP_POW_EXACT or LTP_POW_LIBM");

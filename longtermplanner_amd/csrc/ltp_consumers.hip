@@ -16,7 +16,13 @@ namespace ltp {
 // hold its last position (the joint rests there); plans without a trajectory (traj_len 0) get NaN.
 // Item = plan x joint group as in k_sample; lane -> (joint, window) task, each walking its samples in order.
 // ---------------------------------------------------------------------------------------
-template <bool PROBE, bool TABLES>
+// ANALYTIC (ltp_set_envelope_mode(p, LTP_ENVELOPE_ANALYTIC), round 5): inside a run q(m) is ONE cubic in the run-local index m, so its
+// extreme samples over a stretch of the run are the stretch's two end samples or the samples either side of a real root of
+// q'(m) = c1 + 2 c2 m + 3 c3 m^2. The task evaluates those <= 6 candidates per (run, window) stretch — with run_eval_q, i.e. they ARE
+// samples of the row, bit for bit — instead of every sample. What it can miss is a sample that undercuts its neighbour by rounding
+// alone: the result is within a few ulps of q (~1e-15) of the exhaustive form's, not bit-identical, which is why the exhaustive form
+// stays the default (tests: 1e-9 against the oracle's reduced rows, 1e-12 against the exhaustive form).
+template <bool PROBE, bool TABLES, bool ANALYTIC = false>
 __global__ void __launch_bounds__(kSampleThreads, kSampleBlocksPerCU)
 k_envelope(long long first, long long count, long long base_first, int dof, double t_sample, Limits lim, Queries in, Records rec, int window,
            int n_windows, int lg, double* __restrict__ env, unsigned long long* __restrict__ next_item,
@@ -88,6 +94,50 @@ k_envelope(long long first, long long count, long long base_first, int dof, doub
                 RunCursor cu(jt);
                 // the four q coefficients of the current run stay in registers; they are re-read at a run boundary only
                 double c4[4] = {jt.c[0][0], jt.c[0][1], jt.c[0][2], jt.c[0][3]};
+                if constexpr (ANALYTIC) {
+                    // (one lane per task: the host launches this form with lg = 0)
+                    const int e_task = past ? len : e;
+                    auto fold = [&](int m) {
+                        const double q = run_eval_q(c4, m);
+                        lo = __builtin_fmin(lo, q);
+                        hi = __builtin_fmax(hi, q);
+                    };
+                    while (i < e_task) {
+                        if (cu.advance(jt, i)) {
+#pragma unroll
+                            for (int x = 0; x < 4; ++x) c4[x] = jt.c[cu.run][x];
+                        }
+                        const int stretch_end = cu.nxt < e_task ? cu.nxt : e_task;     // samples [i, stretch_end) lie in this run
+                        const int m0 = i - cu.cur + 1, m1 = stretch_end - cu.cur;      // their run-local positions m0 .. m1
+                        fold(m0);
+                        if (m1 > m0) fold(m1);
+                        if (m1 - m0 > 1) {
+                            const double A = 3.0 * c4[3], B = 2.0 * c4[2], C = c4[1];
+                            double r1 = __builtin_nan(""), r2 = r1;
+                            if (A == 0.0) {
+                                if (B != 0.0) r1 = -C / B;
+                            } else {
+                                const double disc = B * B - 4.0 * A * C;
+                                if (disc >= 0.0) {
+                                    const double sq = __builtin_sqrt(disc);
+                                    const double qq = -0.5 * (B + (B < 0.0 ? -sq : sq));   // the cancellation-free root first
+                                    r1 = qq / A;
+                                    r2 = qq != 0.0 ? C / qq : r1;
+                                }
+                            }
+#pragma unroll
+                            for (int which = 0; which < 2; ++which) {
+                                const double rho = which ? r2 : r1;
+                                if (rho > (double)m0 - 1.0 && rho < (double)m1 + 1.0) {   // false for NaN
+                                    const int k = (int)__builtin_floor(rho);
+                                    if (k > m0 && k < m1) fold(k);
+                                    if (k + 1 > m0 && k + 1 < m1) fold(k + 1);
+                                }
+                            }
+                        }
+                        i = stretch_end;
+                    }
+                } else
                 for (; i < e; i += g) {
                     if (cu.advance(jt, i)) {
 #pragma unroll
@@ -350,7 +400,7 @@ void launch_build_tables(hipStream_t s, long long first, long long count, int do
 
 void launch_envelope(hipStream_t s, long long first, long long count, long long base_first, int dof, double t_sample, Limits lim, Queries in,
                      Records rec, int window, int n_windows, double* env, unsigned long long* next_item, int resident_blocks,
-                     unsigned long long* probe, const unsigned long long* tables)
+                     unsigned long long* probe, const unsigned long long* tables, bool analytic)
 {
     if (count <= 0 || n_windows <= 0) return;
     const int ngroups = (dof + kSampleJointGroup - 1) / kSampleJointGroup;
@@ -360,6 +410,16 @@ void launch_envelope(hipStream_t s, long long first, long long count, long long 
     const long long tasks = (long long)(dof < kSampleJointGroup ? dof : kSampleJointGroup) * n_windows;
     int lg = 0;
     while (lg < 6 && (tasks << (lg + 1)) <= kSampleThreads && (2 << lg) <= window) ++lg;
+    if (analytic && !probe) {
+        // the analytic form looks at a handful of samples per run and window: one lane per (joint, window) task
+        if (tables)
+            hipLaunchKernelGGL((k_envelope<false, true, true>), dim3((unsigned)blocks), dim3(kSampleThreads), 0, s, first, count, base_first, dof, t_sample, lim, in,
+                               rec, window, n_windows, 0, env, next_item, probe, tables);
+        else
+            hipLaunchKernelGGL((k_envelope<false, false, true>), dim3((unsigned)blocks), dim3(kSampleThreads), 0, s, first, count, base_first, dof, t_sample, lim, in,
+                               rec, window, n_windows, 0, env, next_item, probe, tables);
+        return;
+    }
     if (probe)
         hipLaunchKernelGGL((k_envelope<true, false>), dim3((unsigned)blocks), dim3(kSampleThreads), 0, s, first, count, base_first, dof, t_sample, lim, in,
                            rec, window, n_windows, lg, env, next_item, probe, tables);

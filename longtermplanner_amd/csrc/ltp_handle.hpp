@@ -50,6 +50,7 @@ struct ltp_planner {
     bool small_dirty = false;              // a fused small-batch call failed: k_plan_small's arrival word may be non-zero
     const char* last_kernel = "";          // row / envelope kernel of the latest ltp_sample_batch* / ltp_envelope_batch
     int semantics = 0;                     // LTP_SEMANTICS_CPP (the reference's C++, default) or LTP_SEMANTICS_MATLAB
+    int envelope_mode = 0;                 // LTP_ENVELOPE_EXHAUSTIVE (default, bit-identical to the reduced rows) or LTP_ENVELOPE_ANALYTIC
     int pow_rule = LTP_POW_LIBM;           // LTP_POW_LIBM (default) or LTP_POW_EXACT: how pow(x, 3 | 4 | 6 | 1/2) is formed (ltp_math.hpp)
     int last_matlab_flags = 0;             // MATLAB semantics: flags of the latest one-lane call (1 = complex intermediate, 2 = error)
     unsigned long long* dbg_stamps = nullptr; // diagnostic: per-block start/end stamps of k_sample (caller-owned)
@@ -98,7 +99,6 @@ int workspace_release(ltp_planner* p, hipStream_t s, bool capturing);
 void capture_geometry(ltp_planner* p);
 int check_geometry(ltp_planner* p);
 bool want_table_pass(const ltp_planner* p, unsigned long long row_bytes, bool f32);
-bool want_direct(int max_samples, bool f32);
 bool want_walk(const ltp_planner* p, int max_samples, int stride, bool f32);
 int ensure_tables(ltp_planner* p, long long count, bool capturing, long long* plans_per_piece);
 

@@ -130,11 +130,6 @@ void launch_sample_tab(hipStream_t s, long long first, long long count, long lon
 // Rows without any table traffic (every row format, both semantics, any number of joints; taken by itself for capped, float32 and
 // sparse rows and in MATLAB semantics): a builder wave per block walks the runs into LDS, seven streaming waves write the rows
 // (ltp_sampler_walk.hip).
-// Very short capped rows (ltp_sampler_direct.hip): lane = (plan, joint) walks its runs in registers and stores its own samples,
-// 16 bytes at a time — no LDS, no hand-over, every wave walks; rows bit-identical to the other samplers
-bool sample_direct_applies(int dof, RowSpec rows);
-void launch_sample_direct(hipStream_t s, long long first, long long count, int dof, double t_sample, Limits lim, Queries in, Records rec,
-                          const unsigned long long* offsets, void* out, bool f32, unsigned long long capacity, RowSpec rows, int semantics);
 bool sample_walk_applies(int dof, RowSpec rows);
 int sample_walk_resident_blocks(int device, bool f32);
 void launch_sample_walk(hipStream_t s, long long first, long long count, int dof, double t_sample, Limits lim, Queries in, Records rec,
@@ -146,7 +141,8 @@ int envelope_resident_blocks(int device);
 void launch_envelope(hipStream_t s, long long first, long long count, long long base_first, int dof, double t_sample, Limits lim, Queries in,
                      Records rec, int window, int n_windows, double* env, unsigned long long* next_item /* zeroed on the same stream */,
                      int resident_blocks, unsigned long long* probe = nullptr /* diagnostic: 16 stamps per item */,
-                     const unsigned long long* tables = nullptr);
+                     const unsigned long long* tables = nullptr,
+                     bool analytic = false /* extreme samples from the roots of q'(m) per run instead of every sample: 1e-15, not bit-identical */);
 void launch_replan_states(hipStream_t s, long long first, long long count, int dof, RowSpec rows, Queries in, Records rec,
                           const unsigned long long* offsets, const void* tile, bool f32, unsigned long long capacity,
                           const int* sample_index, int uniform_index,

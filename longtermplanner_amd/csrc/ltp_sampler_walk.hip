@@ -270,7 +270,11 @@ LTP_DEV bool walk_lane(Slot& W, const WalkLaneIn& L, long long needed_end, doubl
         } else if (last_b == L.len) {
             last_b = b;                                                          // first run that is not needed: it ends the last stored one
         }
+#ifdef LTP_EXP_SKIP_TAIL
+        return (long long)b >= needed_end;                                       // EXPERIMENT ONLY (never built into the product): no end-limit walk
+#else
         return false;                                                            // the walk goes to the last sample: end-limit check
+#endif
     }, last_joint);
     W.start[runs] = last_b;
     W.nseg = runs;

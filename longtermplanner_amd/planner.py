@@ -124,6 +124,12 @@ class LongTermPlanner:
         code = {"cpp": _abi.SEMANTICS_CPP, "matlab": _abi.SEMANTICS_MATLAB}.get(semantics, semantics)
         self._check(self._lib.ltp_set_semantics(self._h, int(code)))
 
+    def setEnvelopeMode(self, mode):
+        """NEW: "exhaustive" (default: every sample of a window, bit-identical to the reduced rows) or "analytic" (the
+        samples at the ends of each run stretch and either side of the roots of q'(m): a few evaluations per run; within ulps of q)."""
+        code = {"exhaustive": 0, "analytic": 1}.get(mode, mode)
+        self._check(self._lib.ltp_set_envelope_mode(self._h, int(code)))
+
     def setPowRule(self, rule):
         """NEW: how the reference's pow(x, 3 | 4 | 6) and pow(x, 1.0 / 2) are formed — "libm" (default: glibc's pow restated operation
         for operation: the bits of a reference built with gcc + glibc on an FMA host; include/ltp_hip.h LTP_POW_LIBM) or "exact"
@@ -421,19 +427,18 @@ class LongTermPlanner:
         rec = batch.c_records()
         self._check(self._lib.ltp_end_limit_batch(self._h, first, count, C.byref(batch.queries), C.byref(rec), self._stream()))
 
-    def sampleBatch(self, batch: DeviceBatch, first, count, out, streaming=True, dry=False, spread=0, tables=None, walk=None, direct=None):
+    def sampleBatch(self, batch: DeviceBatch, first, count, out, streaming=True, dry=False, spread=0, tables=None, walk=None):
         """getTrajectory for plans [first, first+count) into the float64 CUDA tensor `out` (ltp_sample_batch).
         dry=True is a diagnostic: same stores, no arithmetic (ceiling of the store pattern). tables: None = automatic, True / False =
         force the table pass / the fused build; walk: None = automatic, True / False = force / forbid k_sample_walk_* (run tables built
-        inside the sampler's block: by itself for capped, float32 and sparse rows and in MATLAB semantics); direct: None = automatic
-        (capped rows of at most 256 bytes), True / False = force / forbid k_sample_direct_* (lane = (plan, joint), no LDS)."""
+        inside the sampler's block: by itself for capped, float32 and sparse rows and in MATLAB semantics)."""
         import torch
         rec = batch.c_records()
         fn = self._lib.ltp_sample_batch_f32 if out.dtype == torch.float32 else self._lib.ltp_sample_batch   # float32 tile -> float rows
         assert out.dtype in (torch.float32, torch.float64)
         self._check(fn(self._h, first, count, C.byref(batch.queries), C.byref(rec), batch.offsets.data_ptr(),
                        out.data_ptr(), out.numel(), (1 if streaming else 0) | (2 if dry else 0) | (int(spread) << 8)
-                       | (0 if tables is None else (4 if tables else 8)) | (0 if walk is None else (64 if walk else 32)) | (0 if direct is None else (128 if direct else (1 << 24))), self._stream()))
+                       | (0 if tables is None else (4 if tables else 8)) | (0 if walk is None else (64 if walk else 32)), self._stream()))
 
     def envelopeBatch(self, batch: DeviceBatch, first, count, window, n_windows, out=None):
         """NEW (on-device consumer): [count, dof, n_windows, 2] = min / max of q over windows of `window`

@@ -228,11 +228,11 @@ def test_matlab_walk_sampler_equals_the_table_pass(amd, limits, dof, n):
         for mode in ("walk", "tables"):
             b = ltp.planSwitchTimesBatch(qg, q0, v0, a0)
             full = torch.full((int(b.offsets[-1].item()),), 3.0, dtype=dt, device="cuda")
-            ltp.sampleBatch(b, 0, n, full, **((dict(walk=True) if 0 < cap * (4 if f32 else 8) <= 256 else {}) if mode == "walk" else dict(walk=False)))
+            ltp.sampleBatch(b, 0, n, full, **({} if mode == "walk" else dict(walk=False)))
             kern = ltp.lastSamplerKernel()
             assert kern.startswith("k_sample_walk_matlab" if mode == "walk" else "k_sample_tab"), (mode, kern)
             sub = torch.full((int((b.offsets[n - 2] - b.offsets[9]).item()) + 8,), 3.0, dtype=dt, device="cuda")
-            ltp.sampleBatch(b, 9, n - 11, sub, spread=5, **((dict(walk=True) if 0 < cap * (4 if f32 else 8) <= 256 else {}) if mode == "walk" else dict(walk=False)))
+            ltp.sampleBatch(b, 9, n - 11, sub, spread=5, **({} if mode == "walk" else dict(walk=False)))
             torch.cuda.synchronize()
             res[mode] = (full, sub, b.status.clone(), b.traj_len.clone())
         for k, (got, want) in enumerate(zip(res["walk"], res["tables"])):
