@@ -192,7 +192,9 @@ int ltp_set_table_workspace(ltp_planner* p, unsigned long long bytes);
 int ltp_reserve_batch(ltp_planner* p, long long n);
 /* Allocates the table-pass workspace for ranges of up to n plans (at most ltp_set_table_workspace bytes; longer ranges
  * are processed in pieces). Needed before capturing a call that takes the table pass — ltp_envelope_batch by default,
- * ltp_build_tables_batch's callers with the library's workspace, ltp_sample_batch* only when flag bit 2 is set: while a stream is
+ * ltp_build_tables_batch's callers with the library's workspace, ltp_sample_batch* when flag bit 2 is set, or when flag bit 5 forbids
+ * the walk kernel for rows of at most 8 KB (float64) / 16 KB (float32) per joint under a cap (those then take the table pass), and
+ * every ltp_sample_batch* call in MATLAB semantics with more than the walk kernel forbidden: while a stream is
  * being captured the library neither allocates nor frees; it cuts the range into pieces that fit the workspace it has
  * and returns LTP_ERR_INVALID_ARGUMENT if it has none. */
 int ltp_reserve_tables(ltp_planner* p, long long n);
@@ -219,7 +221,8 @@ int ltp_end_limit_batch(ltp_planner* p, long long first, long long count, const 
  * `capacity` doubles get LTP_STATUS_OVERFLOW and are skipped.
  * flags: bit 0 = non-temporal stores (recommended); bit 1 = diagnostic dry run (stores without arithmetic);
  * bit 2 = force the table pass (k_build_tables + k_sample_tab_*: kept as the sampler that reads the packed run tables of
- * include/ltp_run_tables.hpp; nothing takes it by itself any more), bit 3 = force the fused table build; bit 4 = reserved;
+ * include/ltp_run_tables.hpp; the library takes it by itself only where bit 5 has forbidden the walk kernel for capped rows of at most
+ * 8 KB / 16 KB per joint, and in MATLAB semantics with the walk kernel forbidden), bit 3 = force the fused table build; bit 4 = reserved;
  * bit 5 = never k_sample_walk_* (rows under a cap of <= 768 samples, float32 rows, rows of every 3rd sample or sparser, and every
  * row format in MATLAB semantics take it by themselves: the run tables then stay in the compute unit, no table pass at all; same
  * rows), bit 6 = force it (any row format);
@@ -271,9 +274,12 @@ int ltp_build_tables_batch(ltp_planner* p, long long first, long long count, con
  * (then uniform_index for all); k is clamped to the stored samples; plans that were not sampled — traj_len 0,
  * LTP_STATUS_OVERFLOW, or rows that would end beyond `capacity` elements of `tile` (the capacity given to
  * ltp_sample_batch) — keep the start state they had in `in`; nothing outside the tile is read. Output element (local plan i, joint j) at
- * ptr[i*query_stride + j*joint_stride]. The float64 form does not read the tile at all: a stored float64 sample has the bits of the
- * closed-form run evaluation, so the state is recomputed from the records (a quarter of the time of 8-byte gathers from the tile);
- * the float32 form returns the ROUNDED values the tile holds. */
+ * ptr[i*query_stride + j*joint_stride]. The float64 form IGNORES THE CONTENT of `tile` (only its capacity rule applies; the pointer
+ * must still be non-NULL): a stored float64 sample has the bits of the closed-form run evaluation, so the state is recomputed from
+ * the records (a quarter of the time of 8-byte gathers from the tile). It therefore returns what ltp_sample_batch WOULD have stored:
+ * `rec` and `in` must be unchanged since the batch was planned, and a tile that was written by a dry run (flags bit 1), edited by the
+ * caller or never sampled is not noticed. Callers that post-process the tile and want the edited values use the float32 form (which
+ * reads the ROUNDED values the tile holds) or gather themselves. */
 int ltp_replan_states_batch(ltp_planner* p, long long first, long long count, const ltp_queries* in, const ltp_records* rec,
                             const unsigned long long* offsets, const double* tile, unsigned long long capacity,
                             const int* sample_index, int uniform_index,

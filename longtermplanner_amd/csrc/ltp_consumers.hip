@@ -21,7 +21,7 @@ namespace ltp {
 // q'(m) = c1 + 2 c2 m + 3 c3 m^2. The task evaluates those <= 6 candidates per (run, window) stretch — with run_eval_q, i.e. they ARE
 // samples of the row, bit for bit — instead of every sample. What it can miss is a sample that undercuts its neighbour by rounding
 // alone: the result is within a few ulps of q (~1e-15) of the exhaustive form's, not bit-identical, which is why the exhaustive form
-// stays the default (tests: 1e-9 against the oracle's reduced rows, 1e-12 against the exhaustive form).
+// stays the default (tests: 1e-12 against the exhaustive form, 1e-9 against the CPU checker's reduced rows).
 template <bool PROBE, bool TABLES, bool ANALYTIC = false>
 __global__ void __launch_bounds__(kSampleThreads, kSampleBlocksPerCU)
 k_envelope(long long first, long long count, long long base_first, int dof, double t_sample, Limits lim, Queries in, Records rec, int window,

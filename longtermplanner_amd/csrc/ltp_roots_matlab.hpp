@@ -32,7 +32,7 @@ struct LdsMat {                           // this thread's matrix inside the blo
     LTP_DEV double& operator()(int i, int j) const { return p[(i * kMaxN + j) * stride]; }
 };
 // dynamic shared memory a launch of `threads` threads per block must provide for the matrices
-inline unsigned matrix_lds_bytes(int threads) { return (unsigned)(kMaxN * kMaxN * threads) * (unsigned)sizeof(double); }
+__host__ __device__ inline unsigned matrix_lds_bytes(int threads) { return (unsigned)(kMaxN * kMaxN * threads) * (unsigned)sizeof(double); }
 
 LTP_DEV double fsign(double a, double b) { return __builtin_signbit(b) ? -dabs(a) : dabs(a); }   // Fortran SIGN(a, b)
 
@@ -385,6 +385,10 @@ LTP_DEV int roots(const double* c, int deg, double* re, double* im, int& nroots)
 {
     extern __shared__ double ltp_mr_matrices[];               // matrix_lds_bytes(threads per block), passed by every launch that gets here
     const int threads = (int)(blockDim.x * blockDim.y * blockDim.z);
+    // (round-4 advisor) the convention is checked, not assumed: the launch's LDS allocation (dispatch packet, group_segment_size) must hold
+    // the kernel's static LDS plus this block's matrices — a launch that forgot the dynamic size traps instead of overwriting LDS data
+    const unsigned group_bytes = ((const unsigned __attribute__((address_space(4)))*)__builtin_amdgcn_dispatch_ptr())[7];   // byte 28
+    if (__builtin_amdgcn_groupstaticsize() + matrix_lds_bytes(threads) > group_bytes) __builtin_trap();
     const int tid = ((int)threadIdx.z * (int)blockDim.y + (int)threadIdx.y) * (int)blockDim.x + (int)threadIdx.x;
     LdsMat H{ltp_mr_matrices + tid, threads};
     return roots_with(H, c, deg, re, im, nroots);

@@ -71,7 +71,15 @@ static_assert(kWalkBuffers * sizeof(WalkBatch) <= 53 * 1024, "three blocks per c
 // one plan at a time beyond that; a wide batch whole plans up to 28 joints, 28 joints of one plan at a time beyond)
 bool sample_walk_applies(int dof, RowSpec rows)
 {
-    return dof >= 1 && rows.max_samples >= 0;
+    if (dof < 1 || rows.max_samples < 0) return false;
+    // capped rows up to kWalkBatchCap samples go through walk_stream, whose offsets inside a batch are 32-bit BYTE offsets behind one
+    // buffer descriptor: the four arrays of a plan (4 * dof * row stride elements of at most 8 bytes) must stay below 2 GiB (round-4
+    // advisor). That holds up to dof ~ 65 000 at a 1024-sample cap; beyond, the fused sampler / the table pass take the rows.
+    if (rows.max_samples > 0 && rows.max_samples <= 1024) {
+        const unsigned long long stride = ((unsigned long long)rows.max_samples + (kRowAlign - 1)) / kRowAlign * kRowAlign;
+        if (4ull * (unsigned long long)dof * stride * 8ull >= (1ull << 31)) return false;
+    }
+    return true;
 }
 
 // LONG rows — no cap, or a cap beyond kWalkBatchCap samples: wide batches only, one row per wave pass (walk_stream_rows). Short rows: compact

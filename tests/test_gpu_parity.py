@@ -274,6 +274,18 @@ def test_dense_trajectories_parity_budget(amd, oracle_mod, capsys):
         budget = max(3, int(np.ceil((1e-3 if name == "fuzzed" else 2e-5) * s["dense_plans"])))
         assert s["plans_beyond_tolerance"] <= budget, (name, s["plans_beyond_tolerance"], budget)
     assert report["sets"]["fuzzed"]["sampled"] >= 15_000
+    # (round-4 advisor) so that a sampler regression cannot hide inside the budget: the SAME plans against the oracle's exact-pow twin
+    # (the rule the device ran with, restated in C) hold the strict bar — nothing beyond 1e-9, every jerk row bit-identical
+    rng = np.random.default_rng(31337)
+    twin = {name: dc.soak(name, *amd.limit_set(name), 0.001, n, 777, bufs, quiet=True, exact=True, pow_rule="exact") for name, n in named}
+    for trial in range(24):
+        D, ts, lim = dc.fuzz_limits(rng, trial, wide=True)
+        twin[f"fuzz{trial}"] = dc.soak(f"fuzz{trial}", D, lim, ts, 1_100, 9000 + trial, bufs, quiet=True, exact=True, pow_rule="exact")
+    assert sum(s["dense_plans"] for s in twin.values()) == total
+    for name, s in twin.items():
+        assert s["verdict_mismatches"] == 0 and s["length_mismatches"] == 0 and s["end_limit_flag_mismatches"] == 0, (name, s)
+        assert s["plans_beyond_tolerance"] == 0 and max(s["max_abs_d"].values()) <= TOL, (name, s["max_abs_d"], s["outliers"])
+        assert s["plans_with_bit_identical_jerk_rows"] == s["sampled"], (name, s["sampled"] - s["plans_with_bit_identical_jerk_rows"])
 
 
 @pytest.mark.parametrize("name,n", [("panda", 300_000), ("ref", 300_000), ("ref30", 40_000)])
