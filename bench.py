@@ -757,10 +757,14 @@ def main():
                  dict(batch=100_000, switch_only=True, in_flight=2, steps=max(args.steps, 40), warmup=4)),
                 ("configs[1] with the reference's limits",
                  dict(limits="ref", batch=100_000, switch_only=True, steps=max(args.steps, 20), warmup=2)),
+                ("configs[1] under the opt-in pow rule LTP_POW_EXACT (correctly rounded powers instead of glibc's pow restated: within 1 ulp of any libm)",
+                 dict(batch=100_000, switch_only=True, pow_rule="exact", steps=max(args.steps, 20), warmup=2)),
                 ("switching times only, 1 M x 7-DoF",
                  dict(switch_only=True, steps=max(args.steps, 10), warmup=2)),
                 ("switching times only, 1 M x 7-DoF, two batches in flight",
                  dict(switch_only=True, in_flight=2, steps=max(args.steps, 20), warmup=4)),
+                ("switching times only, 1 M x 7-DoF, under the opt-in pow rule LTP_POW_EXACT",
+                 dict(switch_only=True, pow_rule="exact", steps=max(args.steps, 10), warmup=2)),
                 ("configs[4]: 1 M x 30-DoF (S-ref30), full sampling through the reused tile",
                  dict(limits="ref30", steps=few, warmup=1)),
                 ("first 256 samples of every row (SURVEY §8(f).2): k_sample_walk, run tables kept in the compute unit",
@@ -771,6 +775,10 @@ def main():
                  dict(sample_stride=4, steps=max(args.steps, 5), warmup=1)),
                 ("float32 rows (SURVEY §8(f).2): the same binary64 results rounded once, k_sample_walk in sample pairs",
                  dict(f32=True, steps=few, warmup=1)),
+                ("on-device envelope consumer (SURVEY §8(f).2): [min q, max q] over 32 windows of 64 samples per joint, every sample evaluated (bit-identical to the reduced rows)",
+                 dict(envelope="64:32", steps=max(args.steps, 5), warmup=1)),
+                ("the same envelopes, analytic form (ltp_set_envelope_mode: the candidates of each run instead of every sample)",
+                 dict(envelope="64:32", envelope_analytic=True, steps=max(args.steps, 5), warmup=1)),
             ]
         else:
             plans = [(f"configs[3]: 10 M x 7-DoF queries sharded over {world} GPUs, full sampling",

@@ -70,6 +70,7 @@ __global__ void k_check_inputs(int dof, Limits lim, const double* q_0, const dou
 template <int SEM>
 __global__ void k_single_opt_braking(int joint, double t_sample, Limits lim, double v_0, double a_0, double* out)
 {
+    if constexpr (sem_libm(SEM)) libm::stage_tables();
     const JointLimits L = load_limits(lim, joint);
     double r[7] = {out[0], out[1], out[2], out[3], out[4], out[5], out[6]};
     double q, dir;
@@ -86,6 +87,7 @@ template <int SEM>
 __global__ void k_single_opt_switch(int joint, double t_sample, Limits lim, double q_goal, double q_0, double v_0, double a_0,
                                     double v_drive, double* io)
 {
+    if constexpr (sem_libm(SEM)) libm::stage_tables();
     const JointLimits L = load_limits(lim, joint);
     double t[7] = {io[0], io[1], io[2], io[3], io[4], io[5], io[6]};
     double dir = 0.0;
@@ -104,6 +106,7 @@ template <int SEM>
 __global__ void k_single_time_scaling(int joint, double t_sample, Limits lim, double q_goal, double q_0, double v_0, double a_0,
                                       double dir, double tr, double* io)
 {
+    if constexpr (sem_libm(SEM)) libm::stage_tables();
     const JointLimits L = load_limits(lim, joint);
     double ts[7] = {io[0], io[1], io[2], io[3], io[4], io[5], io[6]};
     double vd;
@@ -154,6 +157,7 @@ __global__ void k_math_probe(long long n, const double* x, const double* y, doub
 // the restated glibc pow (ltp_libm_pow.hpp, pow rule LTP_POW_LIBM) on arbitrary (x, y): tests compare it with the host's libm bit for bit
 __global__ void k_libm_pow_probe(long long n, const double* x, const double* y, double* out)
 {
+    libm::stage_tables();
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     out[i] = libm::pow(x[i], y[i]);

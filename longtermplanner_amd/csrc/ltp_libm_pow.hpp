@@ -42,6 +42,29 @@ namespace libm {
 
 typedef unsigned long long u64;
 
+// Where the kernels read the two tables from. On the device every block keeps a copy in LDS (5 KB: a kernel that forms libm powers calls
+// stage_tables() once, all threads, before its first power): a lane's table row is a data-dependent address, i.e. 64 different lines
+// per wave instruction, which LDS serves at a fraction of the latency of the vector L1. On the host (tests) the arrays themselves.
+#if defined(__HIPCC__)
+LTP_LIBM_FN double* lds_log_tab() { __shared__ double t[128 * 3]; return t; }
+LTP_LIBM_FN u64* lds_exp_tab() { __shared__ u64 t[256]; return t; }
+__device__ __forceinline__ void stage_tables()
+{
+    const int threads = (int)(blockDim.x * blockDim.y * blockDim.z);
+    const int tid = ((int)threadIdx.z * (int)blockDim.y + (int)threadIdx.y) * (int)blockDim.x + (int)threadIdx.x;
+    double* lt = lds_log_tab();
+    u64* et = lds_exp_tab();
+    for (int i = tid; i < 128 * 3; i += threads) lt[i] = (&kPowLogTab[0][0])[i];
+    for (int i = tid; i < 256; i += threads) et[i] = kExpTab[i];
+    __syncthreads();
+}
+#define LTP_LIBM_LOG_ROW(i, k) lds_log_tab()[(i) * 3 + (k)]
+#define LTP_LIBM_EXP(i) lds_exp_tab()[(i)]
+#else
+#define LTP_LIBM_LOG_ROW(i, k) kPowLogTab[(i)][(k)]
+#define LTP_LIBM_EXP(i) kExpTab[(i)]
+#endif
+
 LTP_LIBM_FN u64 bits(double x) { return __builtin_bit_cast(u64, x); }
 LTP_LIBM_FN double from_bits(u64 u) { return __builtin_bit_cast(double, u); }
 LTP_LIBM_FN unsigned top12(double x) { return (unsigned)(bits(x) >> 52); }
@@ -64,7 +87,7 @@ LTP_LIBM_FN double log_inline(u64 ix, double& tail)
     const int k = (int)((long long)tmp >> 52);
     const double z = from_bits(ix - (tmp & (0xfffull << 52)));
     const double kd = (double)k;
-    const double invc = kPowLogTab[i][0], logc = kPowLogTab[i][1], logctail = kPowLogTab[i][2];
+    const double invc = LTP_LIBM_LOG_ROW(i, 0), logc = LTP_LIBM_LOG_ROW(i, 1), logctail = LTP_LIBM_LOG_ROW(i, 2);
     const double r = __builtin_fma(z, invc, -1.0);                 // exact: 1/c has 9 significant bits
     const double t1 = __builtin_fma(kd, kLn2hi, logc);             // k ln2 + log c + r in two pieces
     const double t2 = t1 + r;
@@ -130,8 +153,8 @@ LTP_LIBM_FN double exp_inline(double x, double xtail, unsigned sign_bias)
     r += xtail;
     const unsigned idx = 2 * (unsigned)(ki % 128);
     const u64 top = (ki + sign_bias) << (52 - 7);
-    const double tail = from_bits(kExpTab[idx]);
-    const u64 sbits = kExpTab[idx + 1] + top;
+    const double tail = from_bits(kExpTab[idx]);                    // (this general form reads the arrays themselves: it is also what the
+    const u64 sbits = kExpTab[idx + 1] + top;                       // out-of-line exp_large runs, where a block's LDS copy is out of reach)
     const double r2 = r * r;
     // tmp = tail + r + r2 (C2 + r C3) + r2 r2 (C4 + r C5), fused from the inside out
     const double tmp = __builtin_fma(__builtin_fma(r, kC5, kC4), r2 * r2, __builtin_fma(__builtin_fma(r, kC3, kC2), r2, tail + r));
@@ -236,8 +259,8 @@ LTP_LIBM_FN double pow_fixed(double x)
     double r = __builtin_fma(kd, kNegLn2loN, __builtin_fma(kd, kNegLn2hiN, ehi));
     r += elo;
     const unsigned idx = 2 * (unsigned)(ki % 128);
-    const u64 sbits = kExpTab[idx + 1] + ((ki + sign_bias) << (52 - 7));
-    const double tail = from_bits(kExpTab[idx]);
+    const u64 sbits = LTP_LIBM_EXP(idx + 1) + ((ki + sign_bias) << (52 - 7));
+    const double tail = from_bits(LTP_LIBM_EXP(idx));
     const double r2 = r * r;
     const double tmp = __builtin_fma(__builtin_fma(r, kC5, kC4), r2 * r2, __builtin_fma(__builtin_fma(r, kC3, kC2), r2, tail + r));
     const double scale = from_bits(sbits);

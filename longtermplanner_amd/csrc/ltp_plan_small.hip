@@ -52,6 +52,7 @@ template <bool GIVEN, int SEM>
 LTP_DEV void plan_small_body(int n, int dof, double t_sample, int goal_check, RowSpec rows, const Limits& lim, const SmallHost& io,
                              SmallShared& sh)
 {
+    if constexpr (sem_libm(SEM)) libm::stage_tables();        // the block's LDS copy of glibc's pow tables (ltp_libm_pow.hpp)
     SegTable& tab = sh.tab;
     double (&s_t_opt)[kSmallPairs][7] = sh.t_opt;
     double (&s_t_scaled)[kSmallPairs][7] = sh.t_scaled;

@@ -118,6 +118,7 @@ __global__ void __launch_bounds__(kQueriesPerBlock* kMaxJointSlots)
 k_opt_fast(long long n, int dof, double t_sample, int goal_check, Limits lim, Queries in, Records out,
            signed char* __restrict__ lane_flags, Queue queue)
 {
+    if constexpr (sem_libm(SEM)) libm::stage_tables();        // the block's LDS copy of glibc's pow tables (ltp_libm_pow.hpp)
     __shared__ unsigned long long s_cnt[kMaxJointSlots + 1];
     const int x = threadIdx.x, y = threadIdx.y, JB = blockDim.y;
     const long long q = (long long)blockIdx.x * kQueriesPerBlock + x;
@@ -161,6 +162,7 @@ template <int SEM>
 __global__ void __launch_bounds__(64)
 k_opt_slow(int dof, double t_sample, Limits lim, Queries in, Records out, signed char* __restrict__ lane_flags, Queue queue)
 {
+    if constexpr (sem_libm(SEM)) libm::stage_tables();        // the block's LDS copy of glibc's pow tables (ltp_libm_pow.hpp)
     unsigned long long cnt[kQueueShards];
     const unsigned long long count = queue_total(queue, cnt);
     for (unsigned long long it = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; it < count;
@@ -190,6 +192,7 @@ __global__ void __launch_bounds__(kQueriesPerBlock* kMaxJointSlots)
 k_reduce_scale(long long n, int dof, double t_sample, Limits lim, Queries in, Records out,
                const signed char* __restrict__ lane_flags, Queue queue)
 {
+    if constexpr (sem_libm(SEM)) libm::stage_tables();        // the block's LDS copy of glibc's pow tables (ltp_libm_pow.hpp)
     __shared__ double s_t[kMaxJointSlots][kQueriesPerBlock];
     __shared__ int s_j[kMaxJointSlots][kQueriesPerBlock];
     __shared__ int s_f[kMaxJointSlots][kQueriesPerBlock];
@@ -359,6 +362,7 @@ template <int SEM>
 __global__ void __launch_bounds__(kQueriesPerBlock * 8)
 k_scaling_slow(int dof, double t_sample, Limits lim, Queries in, Records out, Queue queue)
 {
+    if constexpr (sem_libm(SEM)) libm::stage_tables();        // the block's LDS copy of glibc's pow tables (ltp_libm_pow.hpp)
     __shared__ int s_acc[8][kQueriesPerBlock];
     const int x = threadIdx.x;
     const int c = __builtin_amdgcn_readfirstlane(threadIdx.y);

@@ -300,7 +300,10 @@ int main()
         int slow, ln, stt;
         unsigned long long o2[2];
         ltp_records hr{t_o.data(), t_s.data(), d.data(), vd.data(), md.data(), &treq, &slow, &ln, &stt};
-        for (int with_rows = 0; with_rows < 2; ++with_rows) {
+        for (int variant = 0; variant < 4; ++variant) {
+            // both pow rules (ltp_set_pow_rule): the default restates glibc's pow (~25 of them per joint through two table reads each)
+            const int with_rows = variant & 1;
+            CHECK(ltp_set_pow_rule(h, variant < 2 ? LTP_POW_LIBM : LTP_POW_EXACT) == LTP_OK);
             float best = 1e30f, sum = 0;
             const int reps = 200;
             for (int i = 0; i < reps + 20; ++i) {
@@ -316,9 +319,10 @@ int main()
                 const float us = (t1.tv_sec - t0.tv_sec) * 1e6f + (t1.tv_nsec - t0.tv_nsec) * 1e-3f;
                 if (i >= 20) { best = us < best ? us : best; sum += us; }
             }
-            std::printf("one 7-DoF call through ltp_plan_batch_host, %s: mean %.1f us, best %.1f us\n",
-                        with_rows ? "switching times + sampled trajectory" : "switching times only", sum / reps, best);
+            std::printf("one 7-DoF call through ltp_plan_batch_host, %s, pow rule %s: mean %.1f us, best %.1f us\n",
+                        with_rows ? "switching times + sampled trajectory" : "switching times only", variant < 2 ? "libm (default)" : "exact", sum / reps, best);
         }
+        CHECK(ltp_set_pow_rule(h, LTP_POW_LIBM) == LTP_OK);
     }
 
     // ---- 7. one handle, several host threads: single planTrajectory-sized calls, the one-joint entry points, checkInputs and

@@ -1,6 +1,6 @@
 #!/bin/bash
 # After `gpurun -- bash tools/refresh_profiles.sh TAG` has merged its output into gpurun_out/: condense it into profiles/.
-TAG=${1:-r04}
+TAG=${1:-r05}
 cd "$(dirname "$0")/.."
 python profiles/summarize.py $TAG gpurun_out/prof_stats gpurun_out/prof_write gpurun_out/prof_fetch || exit 1
 cp gpurun_out/bench_default.json profiles/${TAG}_bench.json
@@ -54,4 +54,55 @@ for f in ["profiles/${TAG}_bench_variants.jsonl", "profiles/${TAG}_dry_sampler_c
         print("  %-80s | %9.3f M | %8.3f ms | %s | tp=%s" % (c["workload"][48:128], d["value"] / 1e6, d["ms_per_step"], r.get("achieved"), c.get("table_pass")))
 for r in list(csv.DictReader(open("profiles/${TAG}_table_pass_first256_kernel_stats.csv")))[:3]:
     print("  ", r["Name"][:30], r["Calls"], round(float(r["AverageNs"]) / 1e3, 1))
+PY
+
+# profiles/bench_counters.json: the PMC figures bench.py's roofline blocks quote (keyed by config.workload_key), with how they were made
+python - <<PY
+import csv, glob, json, os, collections
+G = "gpurun_out"
+def latest(pattern):
+    g = glob.glob(pattern, recursive=True)
+    return max(g, key=os.path.getmtime) if g else None
+def counters(d, want):
+    f = latest(f"{G}/{d}/**/*_counter_collection.csv")
+    acc = collections.defaultdict(lambda: collections.defaultdict(lambda: collections.defaultdict(float)))
+    if f:
+        for r in csv.DictReader(open(f)):
+            acc[r["Kernel_Name"].split("(")[0].replace("void ", "")][r["Counter_Name"]][r["Dispatch_Id"]] += float(r["Counter_Value"])
+    return {k: {c: sum(v.values()) / len(v) for c, v in cs.items()} for k, cs in acc.items() if want(k)}
+def stats(d, want):
+    f = latest(f"{G}/{d}/**/*_kernel_stats.csv")
+    return {r["Name"].split("(")[0].replace("void ", ""): float(r["AverageNs"]) / 1e3 for r in csv.DictReader(open(f)) if want(r["Name"])} if f else {}
+out = {"collected": "round 5, tools/refresh_profiles.sh ${TAG} + tools/collect_profiles.sh ${TAG}",
+       "how": "separate rocprofv3 passes of `python3 bench.py --no-secondary --no-cpu-baseline <workload>`: --pmc WRITE_SIZE (KiB, exact for 16-byte-per-lane stores per "
+              "MI355X_MICROARCH.md) for the row writers; --pmc SQ_INSTS_VALU ... and --kernel-trace --stats for the stage / envelope kernels. valu_issue_frac = "
+              "SQ_INSTS_VALU (wave instructions) x 4 issue cycles / (1024 SIMDs x 2.4 GHz x kernel time): the share of the chip's vector issue slots the kernel used",
+       "workloads": {}}
+def writer(key, d, kernel_part):
+    c = counters(d, lambda k: kernel_part in k)
+    for k, v in c.items():
+        if "WRITE_SIZE" in v:
+            out["workloads"][key] = {"sampler_kernel": k, "write_bytes_per_launch": int(v["WRITE_SIZE"] * 1024)}
+writer("panda:1000000:f64", "prof_write", "k_sample")
+writer("panda:1000000:f64:first256", "prof_write_first256", "k_sample")
+writer("panda:1000000:f64:stride4", "prof_write_stride4", "k_sample")
+writer("panda:1000000:f32", "prof_write_f32", "k_sample")
+def stages(key, dsq, dstats, names=("k_opt_fast", "k_opt_slow", "k_reduce_scale", "k_scaling_slow", "k_envelope", "k_build_tables")):
+    c = counters(dsq, lambda k: any(n in k for n in names))
+    t = stats(dstats, lambda k: any(n in k for n in names))
+    e, ins, tot = {}, 0.0, 0.0
+    for k, v in c.items():
+        if k in t and "SQ_INSTS_VALU" in v:
+            frac = v["SQ_INSTS_VALU"] * 4.0 / (1024 * 2.4e9 * t[k] * 1e-6)
+            e[k] = {"avg_us": round(t[k], 2), "valu_wave_insts": int(v["SQ_INSTS_VALU"]), "valu_issue_frac": round(frac, 3),
+                    "wait_any_frac": round(v.get("SQ_WAIT_ANY", 0.0) / v["SQ_WAVE_CYCLES"], 3) if v.get("SQ_WAVE_CYCLES") else None}
+            ins += v["SQ_INSTS_VALU"]; tot += t[k]
+    if e:
+        out["workloads"][key] = {"kernels": e, "valu_issue_frac": round(ins * 4.0 / (1024 * 2.4e9 * tot * 1e-6), 3), "kernel_time_us": round(tot, 2)}
+stages("panda:100000:f64:switch_only", "prof_sq_switch100k", "prof_switch_100000")
+stages("panda:1000000:f64:switch_only", "prof_sq_switch1M", "prof_switch_1000000")
+stages("panda:100000:f64:switch_only:pow_exact", "prof_sq_switch100k_exact", "prof_switch_100000_exact")
+stages("panda:1000000:f64:envelope64:32", "prof_sq_envelope", "prof_env_stats")
+json.dump(out, open("profiles/bench_counters.json", "w"), indent=1)
+print(json.dumps(out, indent=1)[:2500])
 PY
