@@ -184,8 +184,8 @@ def parse_args(argv=None):
                          "--max-samples samples, restart every query from stored sample K (ltp_replan_states_batch); value counts every replan")
     ap.add_argument("--table-pass", default="auto", choices=["auto", "on", "off"],
                     help="where the sampler's run tables are built: by the table pass (a kernel of its own) or inside the sampler kernel (ltp_set_table_pass)")
-    ap.add_argument("--no-walk", action="store_true", help="A/B: capped rows of <= 256 samples through the table pass instead of k_sample_walk_* (tables kept in the compute unit)")
-    ap.add_argument("--walk", action="store_true", help="A/B: force k_sample_walk_* (also for rows it is not chosen for automatically: whole rows, float64 caps beyond 256)")
+    ap.add_argument("--no-walk", action="store_true", help="A/B: forbid k_sample_walk_* (the automatic choice for caps <= 768 samples, float32 rows, every 3rd sample or sparser): capped rows of at most 8 KB float64 / 16 KB float32 per joint then take the table pass, the rest the fused k_sample")
+    ap.add_argument("--walk", action="store_true", help="A/B: force k_sample_walk_* (also for rows it is not chosen for automatically: whole or long float64 rows at stride 1-2)")
     ap.add_argument("--in-flight", type=int, default=1, help="switching times only: steps alternate between this many planner handles, each on its own stream "
                     "(two batches in flight: the latency-bound queue-B kernel of one step runs under the next step's stages); 1 = one batch at a time")
     ap.add_argument("--table-gib", type=float, default=0.0, help="upper bound of the table-pass workspace (default: library default, 1/16 of device memory)")
