@@ -174,8 +174,11 @@ LTP_DEV void walk_stream(const WalkBatch& B, const Slot* __restrict__ slots, int
     const int total = nplans * nj;
     // lanes per row: the cap bounds every row of the call (wave-uniform, the same in every batch)
     const int max_slots = (rows.max_samples + N - 1) / N;
-    const int lg = max_slots > 32 ? 6 : (max_slots > 16 ? 5 : 4);
+    // (round 5: down to one lane per row — at a cap of 16 samples the old floor of 16 lanes per row left half of every pass idle)
+    const int lg = max_slots > 32 ? 6 : (max_slots > 16 ? 5 : (max_slots > 8 ? 4 : (max_slots > 4 ? 3 : (max_slots > 2 ? 2 : (max_slots > 1 ? 1 : 0)))));
     const int rows_per_pass = 64 >> lg;
+    // s / nj for s < 64, nj <= 63 without the integer-division sequence: (s + 0.5) / nj is at least 0.5 / 63 away from every integer
+    const float inv_nj = 1.0f / (float)nj;
     // one buffer descriptor over the batch's rows (they are neighbours in the tile; at most 63 rows x 4 arrays of <= 1024 samples)
     // (rel0 and span are the same for the whole wave: made scalar, or every store gets a loop that checks its descriptor for uniformity)
     const unsigned long long rel0 = walk_uniform(B.rel0), span = walk_uniform(B.span);
@@ -183,7 +186,7 @@ LTP_DEV void walk_stream(const WalkBatch& B, const Slot* __restrict__ slots, int
     for (int s0 = wave * rows_per_pass; s0 < total; s0 += kWalkStreamWaves * rows_per_pass) {
         const int s = s0 + (lane >> lg);                                          // this lane's (plan, joint) slot
         const bool in = s < total;
-        const int pl = in ? s / nj : 0, j = in ? j0 + (s - pl * nj) : 0;
+        const int pl = in ? (int)(((float)s + 0.5f) * inv_nj) : 0, j = in ? j0 + (s - pl * nj) : 0;
         const int slen = in ? B.slen[pl] : 0;
         if (__builtin_amdgcn_ballot_w64(slen > 0) == 0ull) continue;
         const unsigned stride = ((unsigned)slen + (kRowAlign - 1)) / kRowAlign * kRowAlign;

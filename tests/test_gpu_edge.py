@@ -1216,3 +1216,50 @@ def test_analytic_envelopes_agree_with_the_exhaustive_form(amd, oracle_mod, limi
                 worst_oracle = max(worst_oracle, float(np.max(np.abs(an[p - 3, :, :, 0] - wo.min(axis=2)))), float(np.max(np.abs(an[p - 3, :, :, 1] - wo.max(axis=2)))))
     print(f"analytic vs exhaustive envelopes: worst |d| {worst:.2e}, identical in {same} of {total} values; vs the oracle's reduced rows {worst_oracle:.2e}")
     assert worst <= 1e-12 and same >= 0.999 * total and worst_oracle <= TOL
+
+
+@pytest.mark.parametrize("limits,n", [("panda", 1200), ("ref", 500), ("ref30", 60)])
+def test_walk_and_table_samplers_against_the_oracle_directly(amd, oracle_mod, limits, n):
+    """k_sample_walk_* and the table-pass sampler were proven by a chain (== the fused sampler bit for bit, which is
+    compared with the oracle). Here they meet the oracle's getTrajectory (cc:706-841) themselves: whole float64 rows, every 4th sample,
+    float32 rows (the oracle's value rounded once, give or take the float32 ulp a 1e-12 difference can flip) and capped rows, each through
+    the walk kernel and through the table pass, every sample of every plan, bar 1e-9."""
+    import torch
+    D, lim = amd.limit_set(limits)
+    ltp = amd.LongTermPlanner(D, 0.001, device=0, **lim)
+    orc = oracle_mod.Oracle(D, 0.001, **lim)
+    qg, q0, v0, a0 = amd.generate_queries(n, lim, seed=1234)
+    dev = [torch.from_numpy(x).cuda() for x in (qg, q0, v0, a0)]
+    o = orc.plan_batch(qg, q0, v0, a0, sample=False)
+    ref = {}
+    for p in range(n):
+        if o["status"][p] != 0:
+            ref[p] = orc.get_trajectory(o["t_scaled"][p], o["dir"][p], o["mod"][p], q0[p], v0[p], a0[p], o["v_drive"][p])
+    worst = {}
+    for cap, stride, f32 in ((0, 1, False), (0, 4, False), (0, 1, True), (100, 1, False), (40, 3, True)):
+        ltp.setMaxSamples(cap); ltp.setSampleStride(stride)
+        for mode, kw in (("walk", dict(walk=True)), ("tables", dict(tables=True, walk=False))):
+            b = ltp.planSwitchTimesBatch(*dev)
+            tile = torch.zeros(int(b.offsets[-1].item()), dtype=torch.float32 if f32 else torch.float64, device="cuda")
+            ltp.sampleBatch(b, 0, n, tile, **kw)
+            kern = ltp.lastSamplerKernel()
+            assert ("walk" in kern) if mode == "walk" else ("tab" in kern), (mode, kern)
+            torch.cuda.synchronize()
+            off = b.offsets.cpu().numpy().view(np.uint64)
+            lens = b.traj_len.cpu().numpy()
+            host = tile.cpu().numpy()
+            w = 0.0
+            for p, (L, q, v, a, j) in ref.items():
+                assert lens[p] == L
+                stored = -(-L // stride)
+                stored = min(stored, cap) if cap else stored
+                got = amd.unpack_trajectory(host, int(off[p]), D, stored)
+                for g, r in zip(got, (q, v, a, j)):
+                    want = r[:, ::stride][:, :stored]
+                    d = np.abs(g.astype(np.float64) - want)
+                    if f32:
+                        d = np.maximum(d - np.spacing(np.abs(want).astype(np.float32)).astype(np.float64), 0.0)   # one float32 ulp of rounding
+                    w = max(w, float(d.max()))
+            worst[(cap, stride, f32, mode)] = w
+    print("walk / table samplers vs the oracle:", {k: f"{v:.1e}" for k, v in worst.items()})
+    assert max(worst.values()) <= TOL
