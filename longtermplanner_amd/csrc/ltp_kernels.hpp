@@ -132,7 +132,8 @@ void launch_sample_tab(hipStream_t s, long long first, long long count, long lon
 // (ltp_sampler_walk.hip).
 bool sample_walk_applies(int dof, RowSpec rows);
 int sample_walk_resident_blocks(int device, bool f32);
-void launch_sample_walk(hipStream_t s, long long first, long long count, int dof, double t_sample, Limits lim, Queries in, Records rec,
+// returns true if the autonomous-wave form took the rows (caps of at most 16 samples; flags bit 7 forbids it)
+bool launch_sample_walk(hipStream_t s, long long first, long long count, int dof, double t_sample, Limits lim, Queries in, Records rec,
                         const unsigned long long* offsets, void* out, bool f32, unsigned long long capacity, int flags, RowSpec rows,
                         unsigned long long* next_item /* zeroed on the same stream */, int resident_blocks, int semantics = kSemCpp);
 int sample_tab_resident_blocks(int device, bool f32);

@@ -163,7 +163,8 @@ LTP_DEV void walk_store(V o, __amdgpu_buffer_rsrc_t rsrc, unsigned voff)
 
 // CAPPED rows: several rows per wave pass when they are short, every row of the batch behind one descriptor
 template <bool STREAMING, typename T, class Slot>
-LTP_DEV void walk_stream(const WalkBatch& B, const Slot* __restrict__ slots, int dof, T* __restrict__ out, RowSpec rows, double Ts, int wave)
+LTP_DEV void walk_stream(const WalkBatch& B, const Slot* __restrict__ slots, int dof, T* __restrict__ out, RowSpec rows, double Ts, int wave,
+                         int stream_waves = kWalkStreamWaves /* waves that share the batch's rows; 1: the calling wave writes them all */)
 {
     constexpr int N = 2;
     typedef T V __attribute__((ext_vector_type(N)));                                  // what a lane stores per array and slot: 16 or 8 bytes
@@ -183,7 +184,7 @@ LTP_DEV void walk_stream(const WalkBatch& B, const Slot* __restrict__ slots, int
     // (rel0 and span are the same for the whole wave: made scalar, or every store gets a loop that checks its descriptor for uniformity)
     const unsigned long long rel0 = walk_uniform(B.rel0), span = walk_uniform(B.span);
     __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(out + rel0, 0, (int)(unsigned)(span * sizeof(T)), 0x00020000);
-    for (int s0 = wave * rows_per_pass; s0 < total; s0 += kWalkStreamWaves * rows_per_pass) {
+    for (int s0 = wave * rows_per_pass; s0 < total; s0 += stream_waves * rows_per_pass) {
         const int s = s0 + (lane >> lg);                                          // this lane's (plan, joint) slot
         const bool in = s < total;
         const int pl = in ? (int)(((float)s + 0.5f) * inv_nj) : 0, j = in ? j0 + (s - pl * nj) : 0;
@@ -294,6 +295,100 @@ LTP_DEV bool walk_lane(Slot& W, const WalkLaneIn& L, long long needed_end, doubl
     return too_many;
 }
 
+// everything a wave needs to build batches of one launch
+struct WalkCtx {
+    long long first, count;
+    int dof;
+    double t_sample;
+    Limits lim;
+    Queries in;
+    Records rec;
+    const unsigned long long* offsets;
+    unsigned long long off0, capacity;
+    RowSpec rows;
+    long long needed_end;                                      // runs that start at or after this trajectory sample are not needed
+    int lane;
+};
+
+// Builds one batch — joints [j0, j0 + nj) of np plans from local plan pb — into B: record loads, the walk of every lane into its slot
+// (compact: the first kWalkRuns runs inside the cap; WIDE: every run), the end-limit verdict (cc:59-61) and the tile-capacity rule, the
+// plan-level header. The calling wave owns B. Returns false without a valid header if a compact batch does not do: a lane has more
+// runs inside the cap than a slot holds, or a plan lies wholly inside the cap (nearly always more than kWalkRuns runs: wide at once).
+template <int SEM, bool WIDE>
+LTP_DEV bool walk_build(const WalkCtx& c, WalkBatch& B, long long pb, int np, int j0, int nj)
+{
+    const int lane = c.lane;
+    // the loads of lane (plan pb + lane / nj, joint j0 + lane % nj); nothing here waits
+    WalkLaneIn L;
+    const int pl = lane / nj, jl = lane - pl * nj;
+    const bool mine = pl < np;
+    L.len = 0;
+    if (mine) {
+        const int j = j0 + jl;
+        const long long p = c.first + pb + pl;
+        const long long ix = p * c.in.sq + (long long)j * c.in.sj;
+        L.len = c.rec.traj_len[p];
+        L.rel = c.offsets[p] - c.off0;
+        L.R = load_joint_record(c.rec, p * c.dof + j);
+        L.q0 = c.in.q_0[ix]; L.v0 = c.in.v_0[ix]; L.a0 = c.in.a_0[ix];
+        L.j_max = c.lim.j_max[j]; L.q_min = c.lim.q_min[j]; L.q_max = c.lim.q_max[j];
+    }
+    if constexpr (!WIDE) {
+        // (the lengths arrive with the rest of the records: no round trip of their own)
+        if (__builtin_amdgcn_ballot_w64(L.len > 0 && (long long)L.len <= c.needed_end) != 0ull) return false;
+    }
+    const long long p = c.first + pb + (mine ? pl : 0);
+    int slen = mine ? stored_len(L.len, c.rows) : 0;
+    const unsigned long long stride = ((unsigned long long)slen + (kRowAlign - 1)) / kRowAlign * kRowAlign;
+    if (slen > 0 && L.rel + 4ull * c.dof * stride > c.capacity) {
+        if (jl == 0) atomicOr(&c.rec.status[p], kStatusOverflow);
+        slen = 0;
+    }
+    bool too_many = false;
+    if (slen > 0) {
+        double q_end;
+        if constexpr (WIDE) too_many = walk_lane<SEM>(B.wslot[lane], L, c.needed_end, c.t_sample, q_end, j0 + jl == c.dof - 1);
+        else too_many = walk_lane<SEM>(B.slot[lane], L, c.needed_end, c.t_sample, q_end, j0 + jl == c.dof - 1);
+        if constexpr (SEM == kSemCpp) {                                                      // (LTPlanner.m has no position limits)
+            if (q_end < L.q_min || q_end > L.q_max) atomicOr(&c.rec.status[p], kStatusEndLimit);   // cc:59-61: the last sample
+        }
+    }
+    if (__builtin_amdgcn_ballot_w64(too_many) != 0ull) return false;
+    // plan-level header: lane (plan pl, first joint of the batch) holds the plan's stored length and row offset
+    if (lane < kWalkMaxPlans) { B.slen[lane] = 0; B.rel[lane] = 0u; }
+    wave_sync();
+    if (mine && jl == 0) B.slen[pl] = slen;
+    wave_sync();
+    // the span of rows this batch writes: from the first sampled plan to the end of the last one (plans are neighbours in the tile)
+    const int sl = lane < np ? B.slen[lane] : 0;
+    const unsigned long long mask = __builtin_amdgcn_ballot_w64(sl > 0);
+    const int src = lane < np ? lane * nj : 0;                                                // lane k < np takes plan k's row offset from the plan's first lane
+    const unsigned long long my_rel = ((unsigned long long)(unsigned)__shfl((int)(unsigned)(L.rel >> 32), src) << 32) |
+                                      (unsigned long long)(unsigned)__shfl((int)(unsigned)L.rel, src);
+    unsigned long long r_lo = 0ull, span = 0ull;
+    if (mask != 0ull) {
+        const int firstp = __builtin_amdgcn_readfirstlane(__builtin_ctzll(mask)), lastp = __builtin_amdgcn_readfirstlane(63 - __builtin_clzll(mask));
+        r_lo = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(my_rel >> 32), firstp) << 32) |
+               (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)my_rel, firstp);
+        const unsigned long long r_hi = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(my_rel >> 32), lastp) << 32) |
+                                        (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)my_rel, lastp);
+        const int s_hi = __builtin_amdgcn_readlane(sl, lastp);
+        const unsigned long long stride_hi = ((unsigned long long)s_hi + (kRowAlign - 1)) / kRowAlign * kRowAlign;
+        span = r_hi + 4ull * c.dof * stride_hi - r_lo;
+    }
+    if (lane < np && sl > 0) B.rel[lane] = (unsigned)((my_rel - r_lo) / kRowAlign);
+    if (lane == 0) {
+        B.rel0 = r_lo;
+        B.span = span;
+        B.nplans = np;
+        B.j0 = j0;
+        B.nj = nj;
+        B.done = 0;
+        B.wide = WIDE ? 1 : 0;
+    }
+    return true;
+}
+
 template <bool STREAMING, typename T, int SEM>
 LTP_DEV void sample_walk_body(long long first, long long count, int dof, double t_sample, Limits lim, Queries in, Records rec,
                               const unsigned long long* __restrict__ offsets, T* __restrict__ out, unsigned long long capacity, int spread, RowSpec rows,
@@ -363,85 +458,12 @@ LTP_DEV void sample_walk_body(long long first, long long count, int dof, double 
         pb = bi * ppb;
         np = bi < nbatches ? (int)((count - pb) < ppb ? (count - pb) : ppb) : 0;
     };
-    // issues the loads of lane (plan pb + lane / nj, joint j0 + lane % nj) of a batch of np plans; nothing here waits
-    auto load_lane = [&](long long pb, int np, int j0, int nj) -> WalkLaneIn {
-        WalkLaneIn L;
-        const int pl = lane / nj, j = j0 + (lane - pl * nj);
-        L.len = 0;
-        if (pl < np) {
-            const long long p = first + pb + pl;
-            const long long ix = p * in.sq + (long long)j * in.sj;
-            L.len = rec.traj_len[p];
-            L.rel = offsets[p] - off0;
-            L.R = load_joint_record(rec, p * dof + j);
-            L.q0 = in.q_0[ix]; L.v0 = in.v_0[ix]; L.a0 = in.a_0[ix];
-            L.j_max = lim.j_max[j]; L.q_min = lim.q_min[j]; L.q_max = lim.q_max[j];
-        }
-        return L;
-    };
-    // builds and publishes one batch (joints [j0, j0 + nj) of np plans from local plan pb; L = load_lane() of the same arguments)
-    // into the buffer the caller has waited for. Returns false without publishing if a lane of a compact batch has too many runs.
+    const WalkCtx ctx{first, count, dof, t_sample, lim, in, rec, offsets, off0, capacity, rows, needed_end, lane};
+    // builds and publishes one batch into the buffer the builder has waited for; false (nothing published) if a compact batch does not do
     auto build = [&](long long pb, int np, int j0, int nj, auto wide_tag) -> bool {
         constexpr bool WIDE = decltype(wide_tag)::value;
         wait_buffer_free();
-        const WalkLaneIn L = load_lane(pb, np, j0, nj);
-        if constexpr (!WIDE) {
-            // a plan whose whole trajectory lies inside the cap has (nearly always) more than kWalkRuns runs there: straight to wide
-            // batches (the lengths arrive with the rest of the records: no round trip of their own)
-            if (__builtin_amdgcn_ballot_w64(L.len > 0 && (long long)L.len <= needed_end) != 0ull) return false;
-        }
-        WalkBatch& B = buf[seq % kWalkBuffers];
-        const int pl = lane / nj, jl = lane - pl * nj;
-        const bool mine = pl < np;
-        const long long p = first + pb + (mine ? pl : 0);
-        int slen = mine ? stored_len(L.len, rows) : 0;
-        const unsigned long long stride = ((unsigned long long)slen + (kRowAlign - 1)) / kRowAlign * kRowAlign;
-        if (slen > 0 && L.rel + 4ull * dof * stride > capacity) {
-            if (jl == 0) atomicOr(&rec.status[p], kStatusOverflow);
-            slen = 0;
-        }
-        bool too_many = false;
-        if (slen > 0) {
-            double q_end;
-            if constexpr (WIDE) too_many = walk_lane<SEM>(B.wslot[lane], L, needed_end, t_sample, q_end, j0 + jl == dof - 1);
-            else too_many = walk_lane<SEM>(B.slot[lane], L, needed_end, t_sample, q_end, j0 + jl == dof - 1);
-            if constexpr (SEM == kSemCpp) {                                                      // (LTPlanner.m has no position limits)
-                if (q_end < L.q_min || q_end > L.q_max) atomicOr(&rec.status[p], kStatusEndLimit);   // cc:59-61: the last sample
-            }
-        }
-        if (__builtin_amdgcn_ballot_w64(too_many) != 0ull) return false;
-        // plan-level header: lane (plan pl, first joint of the batch) holds the plan's stored length and row offset
-        if (lane < kWalkMaxPlans) { B.slen[lane] = 0; B.rel[lane] = 0u; }
-        wave_sync();
-        if (mine && jl == 0) B.slen[pl] = slen;
-        wave_sync();
-        // the span of rows this batch writes: from the first sampled plan to the end of the last one (plans are neighbours in the tile)
-        const int sl = lane < np ? B.slen[lane] : 0;
-        const unsigned long long mask = __builtin_amdgcn_ballot_w64(sl > 0);
-        const int src = lane < np ? lane * nj : 0;                                                // lane k < np takes plan k's row offset from the plan's first lane
-        const unsigned long long my_rel = ((unsigned long long)(unsigned)__shfl((int)(unsigned)(L.rel >> 32), src) << 32) |
-                                          (unsigned long long)(unsigned)__shfl((int)(unsigned)L.rel, src);
-        unsigned long long r_lo = 0ull, span = 0ull;
-        if (mask != 0ull) {
-            const int firstp = __builtin_amdgcn_readfirstlane(__builtin_ctzll(mask)), lastp = __builtin_amdgcn_readfirstlane(63 - __builtin_clzll(mask));
-            r_lo = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(my_rel >> 32), firstp) << 32) |
-                   (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)my_rel, firstp);
-            const unsigned long long r_hi = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(my_rel >> 32), lastp) << 32) |
-                                            (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)my_rel, lastp);
-            const int s_hi = __builtin_amdgcn_readlane(sl, lastp);
-            const unsigned long long stride_hi = ((unsigned long long)s_hi + (kRowAlign - 1)) / kRowAlign * kRowAlign;
-            span = r_hi + 4ull * dof * stride_hi - r_lo;
-        }
-        if (lane < np && sl > 0) B.rel[lane] = (unsigned)((my_rel - r_lo) / kRowAlign);
-        if (lane == 0) {
-            B.rel0 = r_lo;
-            B.span = span;
-            B.nplans = np;
-            B.j0 = j0;
-            B.nj = nj;
-            B.done = 0;
-            B.wide = WIDE ? 1 : 0;
-        }
+        if (!walk_build<SEM, WIDE>(ctx, buf[seq % kWalkBuffers], pb, np, j0, nj)) return false;
         // publish: everything above is LDS traffic of this one wave, in order
         __hip_atomic_store(&s_ready[seq % kWalkBuffers], seq + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         ++seq;
@@ -476,6 +498,95 @@ LTP_DEV void sample_walk_body(long long first, long long count, int dof, double 
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// AUTONOMOUS waves (round 5), for caps of at most kWalkAutoCap samples. The counters (profiles/EXPERIMENTS.md E7.1) showed rows this
+// short bound by the ONE builder wave of a block: the kernel above takes a fixed ~2 ms per 1 M plans at every cap from 4 to 16 samples
+// — 145 batches per builder at ~10 us each (record loads, the walk to the last sample for the end-limit verdict, hand-over) — while
+// its seven streaming waves have next to nothing to write. Here every wave is builder AND writer of its own batches: it draws an item,
+// walks its 63 (plan, joint) lanes into its OWN batch buffer (walk_build, the same function), and streams the batch's rows itself
+// (walk_stream with one streaming wave); no flags, no hand-over, nothing shared between waves but the work queue. Six waves per block
+// (6 x 24.3 KB of LDS: one block per compute unit), i.e. six builders per compute unit instead of three. Rows bit-identical (same
+// functions); plans with more runs inside the cap than a compact slot holds are rebuilt as wide batches by the same wave.
+// Measured (profiles/r05_auto_waves_ab.jsonl, sampler kernel per 1 M plans, against the builder / streaming-wave form): first-4 1.45 vs
+// 1.95 ms, first-16 1.81 vs 2.03, receding horizon through 16-sample rows 1.54 vs 1.89; first-32 2.54 vs 2.24 — a wave that also
+// writes 7 KB of rows per plan no longer hides its stores behind another wave's walk — hence the cap of 16. What remains is the walk
+// itself: ~5000 vector instructions per batch (15 divisions of set-up, ~200 instructions per run, every run to the last sample for the
+// end-limit verdict), i.e. the vector issue rate of the chip (E7.1).
+// ---------------------------------------------------------------------------------------
+constexpr int kWalkAutoWaves = 6;
+constexpr int kWalkAutoThreads = kWalkAutoWaves * 64;
+constexpr int kWalkAutoCap = 16;
+__host__ __device__ inline bool walk_auto_rows(RowSpec rows) { return rows.max_samples > 0 && rows.max_samples <= kWalkAutoCap; }
+
+template <bool STREAMING, typename T, int SEM>
+LTP_DEV void sample_walk_auto_body(long long first, long long count, int dof, double t_sample, Limits lim, Queries in, Records rec,
+                                   const unsigned long long* __restrict__ offsets, T* __restrict__ out, unsigned long long capacity, int spread, RowSpec rows,
+                                   unsigned long long* __restrict__ next_item)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char ltp_walk_auto_lds[];           // kWalkAutoWaves batch buffers (dynamic: beyond 64 KB)
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = (int)(threadIdx.x & 63);
+    WalkBatch& B = reinterpret_cast<WalkBatch*>(ltp_walk_auto_lds)[wave];
+    const int ppb = walk_plans_per_item(dof, rows);
+    const int wpb = kWideLanes / dof > 1 ? kWideLanes / dof : 1;
+    const int wide_nj = dof < kWideLanes ? dof : kWideLanes;
+    const long long nbatches = (count + ppb - 1) / ppb;
+    const long long per = (nbatches + spread - 1) / spread;
+    const unsigned long long total = (unsigned long long)per * (unsigned long long)spread;
+    const int sstride = rows.stride > 1 ? rows.stride : 1;
+    const WalkCtx ctx{first, count, dof, t_sample, lim, in, rec, offsets, offsets[first], capacity, rows, (long long)rows.max_samples * sstride, lane};
+    auto draw_issue = [&]() -> unsigned long long {
+        unsigned long long item = 0ull;
+        if (lane == 0) item = atomicAdd(next_item, 1ull);
+        return item;
+    };
+    // the wave's batch is complete in LDS (its own stores, in order): write its rows
+    auto stream = [&](bool wide) {
+        wave_sync();
+        if (wide) walk_stream<STREAMING, T, WideSlot>(B, B.wslot, dof, out, rows, t_sample, 0, 1);
+        else walk_stream<STREAMING, T, WalkSlot>(B, B.slot, dof, out, rows, t_sample, 0, 1);
+        wave_sync();                                                                              // the rows' LDS reads before the next batch's stores
+    };
+    unsigned long long drawn = draw_issue();                                                     // one item ahead, as the builder wave above
+    for (;;) {
+        const unsigned long long item = walk_uniform(drawn);
+        if (item >= total) break;
+        drawn = draw_issue();
+        const long long bi = (long long)(item % (unsigned long long)spread) * per + (long long)(item / (unsigned long long)spread);
+        const long long pb = bi * ppb;
+        const int np = bi < nbatches ? (int)((count - pb) < ppb ? (count - pb) : ppb) : 0;
+        if (np <= 0) continue;                                                                   // a hole of the interleave
+        for (int jc = 0; jc < dof; jc += kWalkLanes) {
+            const int jc_end = dof - jc < kWalkLanes ? dof : jc + kWalkLanes;
+            if (walk_build<SEM, false>(ctx, B, pb, np, jc, jc_end - jc)) { stream(false); continue; }
+            for (int sub = 0; sub < np; sub += wpb)
+                for (int j0 = jc; j0 < jc_end; j0 += wide_nj) {
+                    const int npw = np - sub < wpb ? np - sub : wpb, njw = jc_end - j0 < wide_nj ? jc_end - j0 : wide_nj;
+                    (void)walk_build<SEM, true>(ctx, B, pb + sub, npw, j0, njw);
+                    stream(true);
+                }
+        }
+    }
+}
+
+#define LTP_WALK_AUTO_KERNEL(NAME, ST, TY, SEM)                                                                                     \
+    __global__ void __launch_bounds__(kWalkAutoThreads)                                                                               \
+    NAME(long long first, long long count, int dof, double t_sample, Limits lim, Queries in, Records rec,                             \
+         const unsigned long long* __restrict__ offsets, TY* __restrict__ out, unsigned long long capacity, int spread, RowSpec rows, \
+         unsigned long long* __restrict__ next_item)                                                                                  \
+    {                                                                                                                                 \
+        sample_walk_auto_body<ST, TY, SEM>(first, count, dof, t_sample, lim, in, rec, offsets, out, capacity, spread, rows, next_item);    \
+    }
+LTP_WALK_AUTO_KERNEL(k_sample_walk_auto_f64, false, double, kSemCpp)
+LTP_WALK_AUTO_KERNEL(k_sample_walk_auto_f64_nt, true, double, kSemCpp)
+LTP_WALK_AUTO_KERNEL(k_sample_walk_auto_f32, false, float, kSemCpp)
+LTP_WALK_AUTO_KERNEL(k_sample_walk_auto_f32_nt, true, float, kSemCpp)
+LTP_WALK_AUTO_KERNEL(k_sample_walk_matlab_auto_f64, false, double, kSemMatlab)
+LTP_WALK_AUTO_KERNEL(k_sample_walk_matlab_auto_f64_nt, true, double, kSemMatlab)
+LTP_WALK_AUTO_KERNEL(k_sample_walk_matlab_auto_f32, false, float, kSemMatlab)
+LTP_WALK_AUTO_KERNEL(k_sample_walk_matlab_auto_f32_nt, true, float, kSemMatlab)
+#undef LTP_WALK_AUTO_KERNEL
+
 #define LTP_WALK_KERNEL(NAME, ST, TY, SEM)                                                                                          \
     __global__ void __launch_bounds__(kWalkThreads) __attribute__((amdgpu_waves_per_eu(6, 8)))                                    \
     NAME(long long first, long long count, int dof, double t_sample, Limits lim, Queries in, Records rec,                             \
@@ -504,16 +615,46 @@ int sample_walk_resident_blocks(int device, bool f32)
     return cus * per_cu;
 }
 
-void launch_sample_walk(hipStream_t s, long long first, long long count, int dof, double t_sample, Limits lim, Queries in, Records rec,
+bool launch_sample_walk(hipStream_t s, long long first, long long count, int dof, double t_sample, Limits lim, Queries in, Records rec,
                         const unsigned long long* offsets, void* out, bool f32, unsigned long long capacity, int flags, RowSpec rows,
                         unsigned long long* next_item, int resident_blocks, int semantics)
 {
-    if (count <= 0) return;
+    if (count <= 0) return false;
     const int ppb = walk_plans_per_item(dof, rows);
     const long long nbatches = (count + ppb - 1) / ppb;
     int spread = (flags >> 8) & 0xFFFF;
     if (spread == 0) spread = kSampleSpread;
     if ((long long)spread > nbatches) spread = (int)nbatches;
+    if (walk_auto_rows(rows) && !(flags & 128)) {
+        // autonomous waves (one block per compute unit); flags bit 7 keeps the builder / streaming-wave form (A/B runs)
+        static int cus = 0;
+        const unsigned lds = (unsigned)(kWalkAutoWaves * sizeof(WalkBatch));
+        if (cus == 0) {
+            int dev = 0;
+            (void)hipGetDevice(&dev);
+            if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        }
+        long long ablocks = cus;
+        if (ablocks * kWalkAutoWaves > nbatches) ablocks = (nbatches + kWalkAutoWaves - 1) / kWalkAutoWaves;
+        const dim3 agrid((unsigned)ablocks), ablock(kWalkAutoThreads);
+#define LTP_WALK_AUTO_CASE(K, TY)                                                                                                    \
+    do {                                                                                                                              \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(K), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                \
+        hipLaunchKernelGGL(K, agrid, ablock, lds, s, first, count, dof, t_sample, lim, in, rec, offsets, (TY*)out, capacity, spread, rows, next_item); \
+    } while (0)
+        switch ((flags & 1) | (f32 ? 2 : 0) | (semantics == kSemMatlab ? 4 : 0)) {
+        case 0: LTP_WALK_AUTO_CASE(k_sample_walk_auto_f64, double); break;
+        case 1: LTP_WALK_AUTO_CASE(k_sample_walk_auto_f64_nt, double); break;
+        case 2: LTP_WALK_AUTO_CASE(k_sample_walk_auto_f32, float); break;
+        case 3: LTP_WALK_AUTO_CASE(k_sample_walk_auto_f32_nt, float); break;
+        case 4: LTP_WALK_AUTO_CASE(k_sample_walk_matlab_auto_f64, double); break;
+        case 5: LTP_WALK_AUTO_CASE(k_sample_walk_matlab_auto_f64_nt, double); break;
+        case 6: LTP_WALK_AUTO_CASE(k_sample_walk_matlab_auto_f32, float); break;
+        default: LTP_WALK_AUTO_CASE(k_sample_walk_matlab_auto_f32_nt, float); break;
+        }
+#undef LTP_WALK_AUTO_CASE
+        return true;
+    }
     long long blocks = resident_blocks > 0 ? resident_blocks : 768;
     if (blocks > nbatches) blocks = nbatches;
     const dim3 grid((unsigned)blocks), block(kWalkThreads);
@@ -529,6 +670,7 @@ void launch_sample_walk(hipStream_t s, long long first, long long count, int dof
     default: LTP_WALK_CASE(k_sample_walk_matlab_f32_nt, float); break;
     }
 #undef LTP_WALK_CASE
+    return false;
 }
 
 }  // namespace ltp

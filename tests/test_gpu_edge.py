@@ -1263,3 +1263,45 @@ def test_walk_and_table_samplers_against_the_oracle_directly(amd, oracle_mod, li
             worst[(cap, stride, f32, mode)] = w
     print("walk / table samplers vs the oracle:", {k: f"{v:.1e}" for k, v in worst.items()})
     assert max(worst.values()) <= TOL
+
+
+@pytest.mark.parametrize("limits,dof,n,semantics", [("panda", None, 3000, "cpp"), ("ref", 30, 120, "cpp"), ("ref", 9, 500, "matlab")])
+def test_autonomous_waves_write_the_rows_of_the_builder_form(amd, limits, dof, n, semantics):
+    """Round 5: for caps of at most 16 samples the walk kernel runs as k_sample_walk_auto_* — every wave builds AND writes its own
+    batches (six builders per compute unit instead of three). Same walk_build / walk_stream functions: rows, statuses and lengths are
+    those of the builder / streaming-wave form (flag bit 7) and of the fused sampler / table pass, bit for bit — caps 1-16, strides,
+    both element types, sub-ranges, small tiles, rejected plans, trajectories that end inside the cap (wide batches)."""
+    import torch
+    D, lim = amd.limit_set(limits, dof)
+    ltp = amd.LongTermPlanner(D, 0.001, device=0, **lim)
+    ltp.setSemantics(semantics)
+    qg, q0, v0, a0 = (x.clone() for x in ltp.generateQueries(n, seed=51))
+    v0[7, 0] = 99.0; v0[8, D - 1] = 99.0
+    short = torch.arange(20, min(n, 700), 5, device=qg.device)
+    qg[short] = q0[short] + 0.002 * torch.sign(qg[short] - q0[short] + 1e-9)
+    v0[short] = 0.0
+    a0[short] = 0.0
+    qg[short] = torch.minimum(torch.maximum(qg[short], torch.tensor(lim["q_min"], dtype=torch.float64, device=qg.device)),
+                              torch.tensor(lim["q_max"], dtype=torch.float64, device=qg.device))
+    other = dict(walk=False) if semantics == "matlab" else dict(tables=False, walk=False)
+    for cap, stride, f32 in ((16, 1, False), (1, 1, False), (4, 1, True), (15, 2, False), (16, 3, True), (17, 1, False)):
+        ltp.setMaxSamples(cap); ltp.setSampleStride(stride)
+        dt = torch.float32 if f32 else torch.float64
+        res = {}
+        for mode, kw in (("other", other), ("builder", dict(walk=True, auto_waves=False)), ("auto", {})):
+            b = ltp.planSwitchTimesBatch(qg, q0, v0, a0)
+            full = torch.full((int(b.offsets[-1].item()),), 3.0, dtype=dt, device="cuda")
+            ltp.sampleBatch(b, 0, n, full, **kw)
+            kern = ltp.lastSamplerKernel()
+            assert ("auto" in kern) == (mode == "auto" and cap <= 16), (mode, kern, cap)
+            sub = torch.full((int((b.offsets[n - 2] - b.offsets[13]).item()) + 8,), 3.0, dtype=dt, device="cuda")
+            ltp.sampleBatch(b, 13, n - 15, sub, spread=11, **kw)
+            b2 = ltp.planSwitchTimesBatch(qg, q0, v0, a0)
+            small = torch.full((int(b2.offsets[n // 2 + 3].item()) + 5,), 3.0, dtype=dt, device="cuda")
+            ltp.sampleBatch(b2, 0, n, small, streaming=False, **kw)
+            torch.cuda.synchronize()
+            res[mode] = (full, sub, small, b.status.clone(), b.traj_len.clone(), b2.status.clone())
+        for mode in ("builder", "auto"):
+            for k, (got, want) in enumerate(zip(res[mode], res["other"])):
+                assert torch.equal(got, want), (cap, stride, f32, mode, k)
+        assert (res["other"][5] & 32).any(), "the small tile did not leave any plan out"
