@@ -481,6 +481,9 @@ def run_workload(wl, ctx):
                     "traffic": None, "measured_on": f"rank 0 of {world}" if world > 1 else "rank 0"}
         if pmc:
             roofline["counters_from_profile"] = pmc
+            env_k = [v for k, v in (pmc.get("kernels") or {}).items() if "k_envelope" in k]
+            if env_k:       # what the kernel is bound by: vector issue slots (index conversion, run lookup, min, max are slots, not flops)
+                roofline["issue_slots_used_frac_from_profile"] = env_k[0].get("valu_issue_frac")
     elif ev_pairs:
         kern_ms = sum(a.elapsed_time(b) for a, b in ev_pairs)
         launches = len(ev_pairs)

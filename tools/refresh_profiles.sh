@@ -88,4 +88,4 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/pro
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_env_stats -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary --envelope 64:32 > $O/prof_env_stats.log 2>&1 || exit 1
 echo "SQ counter passes done"
 # keep only the small CSVs
-find $O/prof_write_first256 $O/prof_write_stride4 $O/prof_write_f32 $O/prof_sq_switch1M $O/prof_env_stats $O/prof_sq_switch100k_exact $O/prof_switch_100000_exact $O/prof_stats $O/prof_write $O/prof_fetch $O/prof_tab_stats $O/prof_switch_100000 $O/prof_switch_1000000 $O/prof_sq_first256 $O/prof_sq_first256_tab $O/prof_sq_first64 $O/prof_sq_first64_tab $O/prof_sq_switch100k $O/prof_sq_f32 $O/prof_sq_envelope $O/prof_f32_stats -type f ! -name "*_kernel_stats.csv" ! -name "*_counter_collection.csv" -delete
+find $O/prof_write_first256 $O/prof_write_stride4 $O/prof_write_f32 $O/prof_sq_switch1M $O/prof_env_stats $O/prof_sq_switch100k_exact $O/prof_switch_100000_exact $O/prof_stats $O/prof_write $O/prof_fetch $O/prof_tab_stats $O/prof_switch_100000 $O/prof_switch_1000000 $O/prof_sq_first256 $O/prof_sq_first256_tab $O/prof_sq_first64 $O/prof_sq_first64_tab $O/prof_sq_switch100k $O/prof_sq_f32 $O/prof_sq_envelope $O/prof_f32_stats -type f ! -name "*_kernel_stats.csv" ! -name "*_counter_collection.csv" -delete 2>/dev/null || true
