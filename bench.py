@@ -473,7 +473,7 @@ def run_workload(wl, ctx):
         if getattr(wl, "envelope_analytic", False):
             evals = None
         tflops = (evals * 6.0 * wl.steps / (kern_ms * 1e-3) / 1e12) if evals else None
-        roofline = {"kernel": "k_envelope", "bound": "valu_f64", "achieved": round(tflops, 2) if tflops else None, "peak": F64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+        roofline = {"kernel": ltp.lastSamplerKernel(), "bound": "valu_f64", "achieved": round(tflops, 2) if tflops else None, "peak": F64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(tflops / F64_VALU_PEAK_TFLOPS, 4) if tflops else None,
                     "counted": "6 flop (the 3 fused multiply-adds of q(m)) per sample inside the windows" if evals else
                                "analytic form: a few candidate samples per run and window instead of every sample; no flop count claimed",
@@ -780,7 +780,7 @@ def main():
                  dict(f32=True, steps=few, warmup=1)),
                 ("on-device envelope consumer (SURVEY §8(f).2): [min q, max q] over 32 windows of 64 samples per joint, every sample evaluated (bit-identical to the reduced rows)",
                  dict(envelope="64:32", steps=max(args.steps, 5), warmup=1)),
-                ("the same envelopes, analytic form (ltp_set_envelope_mode: the candidates of each run instead of every sample)",
+                ("the same envelopes, analytic form (ltp_set_envelope_mode: per run and window the end samples and the samples at the roots of q'(m) instead of every sample; k_envelope_walk: lane = (plan, joint), no run tables)",
                  dict(envelope="64:32", envelope_analytic=True, steps=max(args.steps, 5), warmup=1)),
             ]
         else:

@@ -153,6 +153,14 @@ int ltp_envelope_batch(ltp_planner* p, long long first, long long count, const l
     if ((rc = reserve(p, 0)) != LTP_OK) return rc;
     const hipStream_t s = (hipStream_t)stream;
     const int blocks = p->sample_blocks_override > 0 ? p->sample_blocks_override : p->sample_blocks[2];
+    // analytic envelopes: the register walk (no tables, no workspace); ltp_set_table_pass(p, 1 | -1) asks for the block-cooperative kernel's
+    // analytic form instead (through the table pass / with the build inside the kernel) — same values, A/B runs
+    if (p->envelope_mode == LTP_ENVELOPE_ANALYTIC && p->table_pass == 0 && !p->dbg_stamps) {
+        ltp::launch_envelope_walk(s, first, count, first, p->dof, p->t_sample, dev_limits(p), to_dev(in), to_dev(rec), window, n_windows, env, p->semantics);
+        LTP_HIP_TRY(p, hipGetLastError());
+        p->last_kernel = p->semantics == LTP_SEMANTICS_MATLAB ? "k_envelope_walk_matlab analytic" : "k_envelope_walk analytic";
+        return LTP_OK;
+    }
     if (p->semantics == LTP_SEMANTICS_MATLAB || (!p->dbg_stamps && (p->table_pass > 0 || (p->table_pass == 0 && kEnvelopeTablePassByDefault)))) {
         bool capturing = false;
         if ((rc = workspace_acquire(p, s, capturing)) != LTP_OK) return rc;

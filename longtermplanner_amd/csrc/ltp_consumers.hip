@@ -161,6 +161,94 @@ k_envelope(long long first, long long count, long long base_first, int dof, doub
     }
 }
 
+// The analytic envelopes WITHOUT run tables (round 5): lane = (plan, joint) walks its runs in registers — the walk of k_state_at /
+// k_end_limit — and while a run lasts folds the candidates of each window it crosses: the two end samples of the stretch and the
+// samples either side of the real roots of q'(m) (computed once per run: they do not depend on the window), evaluated with
+// run_eval_q on the coefficients for_each_run hands over, i.e. the values k_envelope's analytic form folds, bit for bit. A window
+// is stored (16 bytes) when the walk leaves it; the walk goes on to the last sample, which also gives planTrajectory's end-limit
+// verdict (cc:59-61) and the content of the windows past the end. No table pass, no workspace, no LDS, no per-item latency: what
+// the block-cooperative kernel spends on fetching and installing seven joints' tables per plan (E7.4) is not there.
+template <int SEM>
+__global__ void __launch_bounds__(256)
+k_envelope_walk(long long first, long long count, long long base_first, int dof, double t_sample, Limits lim, Queries in, Records rec,
+                int window, int n_windows, double* __restrict__ env)
+{
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= count * dof) return;
+    const long long local = idx / dof;
+    const int j = (int)(idx - local * dof);
+    const long long p = first + local;
+    double2_t* const dst = reinterpret_cast<double2_t*>(env) + ((unsigned long long)(p - base_first) * dof + j) * n_windows;
+    const int len = rec.traj_len[p];
+    if (len <= 0) {
+        const double nan = __builtin_nan("");
+        for (int w = 0; w < n_windows; ++w) dst[w] = double2_t{nan, nan};
+        return;
+    }
+    const long long ix = p * in.sq + (long long)j * in.sj;
+    double q = in.q_0[ix], v = in.v_0[ix], a = in.a_0[ix];
+    int w = 0;                                                  // the window under construction: samples [w_end - window, w_end)
+    long long w_end = window;
+    double lo = __builtin_huge_val(), hi = -__builtin_huge_val();
+    for_each_run<SEM>(lim, rec, p * dof + j, j, len, t_sample, q, v, a, [&](int b, int e, const RunCoef& rc) {
+        if (w >= n_windows) return false;                       // every window written: the walk only continues for the end-limit verdict
+        const double* c4 = rc.c;                                // q(m) = c0 + c1 m + c2 m^2 + c3 m^3, m = sample - b + 1 (run_eval_q)
+        auto fold = [&](int m) {
+            const double x = run_eval_q(c4, m);
+            lo = __builtin_fmin(lo, x);
+            hi = __builtin_fmax(hi, x);
+        };
+        // the real roots of q'(m) = c1 + 2 c2 m + 3 c3 m^2 (the same expressions as k_envelope's analytic form)
+        const double A = 3.0 * c4[3], B = 2.0 * c4[2], C = c4[1];
+        double r1 = __builtin_nan(""), r2 = r1;
+        if (A == 0.0) {
+            if (B != 0.0) r1 = -C / B;
+        } else {
+            const double disc = B * B - 4.0 * A * C;
+            if (disc >= 0.0) {
+                const double sq = __builtin_sqrt(disc);
+                const double qq = -0.5 * (B + (B < 0.0 ? -sq : sq));
+                r1 = qq / A;
+                r2 = qq != 0.0 ? C / qq : r1;
+            }
+        }
+        int i = b;
+        while (i < e && w < n_windows) {
+            const int stretch_end = (long long)e < w_end ? e : (int)w_end;      // samples [i, stretch_end) of this run lie in window w
+            const int m0 = i - b + 1, m1 = stretch_end - b;
+            fold(m0);
+            if (m1 > m0) fold(m1);
+            if (m1 - m0 > 1) {
+#pragma unroll
+                for (int which = 0; which < 2; ++which) {
+                    const double rho = which ? r2 : r1;
+                    if (rho > (double)m0 - 1.0 && rho < (double)m1 + 1.0) {     // false for NaN
+                        const int k = (int)__builtin_floor(rho);
+                        if (k > m0 && k < m1) fold(k);
+                        if (k + 1 > m0 && k + 1 < m1) fold(k + 1);
+                    }
+                }
+            }
+            i = stretch_end;
+            if ((long long)i == w_end) {                                        // the window is complete
+                dst[w] = double2_t{lo, hi};
+                ++w;
+                w_end += window;
+                lo = __builtin_huge_val();
+                hi = -__builtin_huge_val();
+            }
+        }
+        return false;
+    }, j == dof - 1);
+    // q now holds the last trajectory sample. A window the trajectory ended in holds the samples that exist; windows that start at or
+    // after the end hold the last position twice (as k_envelope)
+    if (w < n_windows && lo <= hi) { dst[w] = double2_t{lo, hi}; ++w; }
+    for (; w < n_windows; ++w) dst[w] = double2_t{q, q};
+    if constexpr (SEM == kSemCpp) {
+        if (q < lim.q_min[j] || q > lim.q_max[j]) atomicOr(&rec.status[p], kStatusEndLimit);   // cc:59-61
+    }
+}
+
 // ---------------------------------------------------------------------------------------
 // Receding horizon (reference README.md:10-13): the start state of the next plan is the state
 // at sample k of the previous trajectory, gathered on the device without a host round trip.
@@ -429,6 +517,18 @@ void launch_envelope(hipStream_t s, long long first, long long count, long long 
     else
         hipLaunchKernelGGL((k_envelope<false, false>), dim3((unsigned)blocks), dim3(kSampleThreads), 0, s, first, count, base_first, dof, t_sample, lim, in,
                            rec, window, n_windows, lg, env, next_item, probe, tables);
+}
+
+void launch_envelope_walk(hipStream_t s, long long first, long long count, long long base_first, int dof, double t_sample, Limits lim, Queries in,
+                          Records rec, int window, int n_windows, double* env, int semantics)
+{
+    if (count <= 0 || n_windows <= 0 || dof <= 0) return;
+    const long long total = count * dof;
+    const dim3 grid((unsigned)((total + 255) / 256)), block(256);
+    if (semantics == kSemMatlab)
+        hipLaunchKernelGGL(k_envelope_walk<kSemMatlab>, grid, block, 0, s, first, count, base_first, dof, t_sample, lim, in, rec, window, n_windows, env);
+    else
+        hipLaunchKernelGGL(k_envelope_walk<kSemCpp>, grid, block, 0, s, first, count, base_first, dof, t_sample, lim, in, rec, window, n_windows, env);
 }
 
 void launch_replan_states(hipStream_t s, long long first, long long count, int dof, RowSpec rows, Queries in, Records rec,

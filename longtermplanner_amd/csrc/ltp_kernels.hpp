@@ -139,6 +139,9 @@ bool launch_sample_walk(hipStream_t s, long long first, long long count, int dof
 int sample_tab_resident_blocks(int device, bool f32);
 int sample_resident_blocks(int device, int which /* 0 k_sample f64, 1 k_sample f32, 2 k_envelope */);
 int envelope_resident_blocks(int device);
+// the analytic envelopes by a lane-per-(plan, joint) register walk: no run tables, no workspace (ltp_consumers.hip: k_envelope_walk)
+void launch_envelope_walk(hipStream_t s, long long first, long long count, long long base_first, int dof, double t_sample, Limits lim, Queries in,
+                          Records rec, int window, int n_windows, double* env, int semantics);
 void launch_envelope(hipStream_t s, long long first, long long count, long long base_first, int dof, double t_sample, Limits lim, Queries in,
                      Records rec, int window, int n_windows, double* env, unsigned long long* next_item /* zeroed on the same stream */,
                      int resident_blocks, unsigned long long* probe = nullptr /* diagnostic: 16 stamps per item */,

@@ -1184,7 +1184,9 @@ def test_analytic_envelopes_agree_with_the_exhaustive_form(amd, oracle_mod, limi
                               torch.tensor(lim["q_max"], dtype=torch.float64, device=qg.device))
     orc = oracle_mod.Oracle(D, 0.001, **lim) if semantics == "cpp" else None
     worst, same, total, worst_oracle = 0.0, 0, 0, 0.0
-    for window, n_windows, table_pass in ((64, 32, 0), (1, 40, 0), (2, 64, 0), (3, 50, -1), (700, 4, 0), (129, 20, -1), (4000, 2, 0)):
+    # table_pass 0: the analytic form is the register walk k_envelope_walk (no tables); 1 / -1: the block-cooperative k_envelope's analytic
+    # form through the table pass / with the build inside the kernel
+    for window, n_windows, table_pass in ((64, 32, 0), (1, 40, 0), (2, 64, 0), (3, 50, -1), (700, 4, 0), (129, 20, -1), (4000, 2, 0), (64, 32, 1), (5, 300, 0), (37, 9, 1)):
         if semantics == "matlab" and table_pass < 0:
             continue                                             # MATLAB semantics: envelopes always take the table pass
         ltp.setTablePass(table_pass)
@@ -1194,6 +1196,7 @@ def test_analytic_envelopes_agree_with_the_exhaustive_form(amd, oracle_mod, limi
             b = ltp.planSwitchTimesBatch(qg, q0, v0, a0)
             env = ltp.envelopeBatch(b, 3, n - 7, window, n_windows)
             assert ("analytic" in ltp.lastSamplerKernel()) == (mode == "analytic"), ltp.lastSamplerKernel()
+            assert ("k_envelope_walk" in ltp.lastSamplerKernel()) == (mode == "analytic" and table_pass == 0), ltp.lastSamplerKernel()
             torch.cuda.synchronize()
             res[mode] = (env.cpu().numpy(), b.status.cpu().numpy(), b.traj_len.cpu().numpy())
         ex, an = res["exhaustive"][0], res["analytic"][0]
