@@ -161,6 +161,14 @@ LTP_DEV void walk_store(V o, __amdgpu_buffer_rsrc_t rsrc, unsigned voff)
     else __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), rsrc, voff, 0, STREAMING ? /*nt | sc1*/ (2 | 16) : 0);
 }
 
+// lanes per row (as a power of two) of a capped row format: the cap bounds every row of the call
+__host__ __device__ inline int walk_row_lanes_log2(RowSpec rows)
+{
+    const int max_slots = (rows.max_samples + 1) / 2;
+    // (round 5: down to one lane per row — at a cap of 16 samples the old floor of 16 lanes per row left half of every pass idle)
+    return max_slots > 32 ? 6 : (max_slots > 16 ? 5 : (max_slots > 8 ? 4 : (max_slots > 4 ? 3 : (max_slots > 2 ? 2 : (max_slots > 1 ? 1 : 0)))));
+}
+
 // CAPPED rows: several rows per wave pass when they are short, every row of the batch behind one descriptor
 template <bool STREAMING, typename T, class Slot>
 LTP_DEV void walk_stream(const WalkBatch& B, const Slot* __restrict__ slots, int dof, T* __restrict__ out, RowSpec rows, double Ts, int wave,
@@ -174,9 +182,7 @@ LTP_DEV void walk_stream(const WalkBatch& B, const Slot* __restrict__ slots, int
     const int nj = __builtin_amdgcn_readfirstlane(B.nj), j0 = __builtin_amdgcn_readfirstlane(B.j0);
     const int total = nplans * nj;
     // lanes per row: the cap bounds every row of the call (wave-uniform, the same in every batch)
-    const int max_slots = (rows.max_samples + N - 1) / N;
-    // (round 5: down to one lane per row — at a cap of 16 samples the old floor of 16 lanes per row left half of every pass idle)
-    const int lg = max_slots > 32 ? 6 : (max_slots > 16 ? 5 : (max_slots > 8 ? 4 : (max_slots > 4 ? 3 : (max_slots > 2 ? 2 : (max_slots > 1 ? 1 : 0)))));
+    const int lg = walk_row_lanes_log2(rows);
     const int rows_per_pass = 64 >> lg;
     // s / nj for s < 64, nj <= 63 without the integer-division sequence: (s + 0.5) / nj is at least 0.5 / 63 away from every integer
     const float inv_nj = 1.0f / (float)nj;
