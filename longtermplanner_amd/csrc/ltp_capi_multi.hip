@@ -27,7 +27,8 @@ int check_shard_planners(ltp_planner* const* planners, int k)
     for (int g = 1; g < k; ++g) {
         const ltp_planner* pg = planners[g];
         bool same = pg && pg->dof == p0->dof && pg->t_sample == p0->t_sample && pg->max_samples == p0->max_samples &&
-                    pg->sample_stride == p0->sample_stride && pg->goal_check == p0->goal_check && pg->semantics == p0->semantics;
+                    pg->sample_stride == p0->sample_stride && pg->goal_check == p0->goal_check && pg->semantics == p0->semantics &&
+                    pg->pow_rule == p0->pow_rule && pg->envelope_mode == p0->envelope_mode;
         for (int l = 0; same && l < 5; ++l) {
             same = (int)pg->h_lim[l].size() >= p0->dof && (int)p0->h_lim[l].size() >= p0->dof;
             for (int j = 0; same && j < p0->dof; ++j) same = pg->h_lim[l][j] == p0->h_lim[l][j];

@@ -313,3 +313,47 @@ def test_bench_never_reports_fewer_gpus_than_requested():
         return
     p = _bench("--gpus", "2", "--batch", "1000")
     assert p.returncode != 0 and not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_default_bench_line_says_what_bounds_every_line():
+    """the line the driver records (`python bench.py`, here with --steps 1) — headline AND every secondary entry carry a
+    roofline block that names the bound that applies to THAT workload: `hbm` with a kernel, algorithmic GB/s and a fraction of 8 TB/s for the
+    row writers; `valu_f64` for the envelope consumer (flop rate against the binary64 vector peak, the committed issue-slot share beside it);
+    `latency/valu_f64` without a fraction for the switching-times lines, quoting the committed PMC figures (profiles/bench_counters.json,
+    with provenance) where the workload has them. And `rccl_world1`: the nccl branch ran at world size 1 in a child process."""
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "1"], capture_output=True, text=True, timeout=1200, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    out = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(out) == 1, p.stdout[-2000:]
+    line = json.loads(out[0])
+    assert line["n_gpus"] == 1 and line["config"]["pow_rule"] == "libm" and line["config"]["workload_key"] == "panda:1000000:f64"
+    r = line["roofline"]
+    assert r["bound"] == "hbm" and r["kernel"] == "k_sample" and 0.5 < r["frac"] < 1.0 and r["traffic"] is None
+    assert r["traffic_from_profile"]["write_bytes_per_launch"] > 1.9e11 and "NOT measured in this run" in r["traffic_from_profile"]["source"]
+    w1 = line["rccl_world1"]
+    assert w1["ok"] and w1["backend"].startswith("nccl") and w1["rank_devices"] == [0]
+    assert line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline"]["value"] > 0
+    sec = line["secondary"]
+    assert len(sec) >= 16 and not [s_ for s_ in sec if "error" in s_], [s_.get("error") for s_ in sec]
+    bounds = {"hbm": 0, "valu_f64": 0, "latency/valu_f64": 0}
+    for s_ in sec:
+        rr = s_["roofline"]
+        bounds[rr["bound"]] += 1
+        key = s_["config"]["workload_key"]
+        if rr["bound"] == "hbm":
+            assert rr["unit"] == "GB/s" and rr["peak"] == 8000.0 and 0.0 < rr["frac"] < 1.0 and rr["kernel"].startswith("k_sample"), (key, rr)
+            assert abs(rr["frac"] - rr["achieved"] / rr["peak"]) < 1e-3
+        elif rr["bound"] == "valu_f64":
+            assert rr["unit"] == "TFLOP/s" and rr["peak"] == 78.6 and "envelope" in key and "k_envelope" in rr["kernel"], (key, rr)
+            if "analytic" not in key:
+                assert 0.0 < rr["frac"] < 0.5 and 0.5 < rr["issue_slots_used_frac_from_profile"] <= 1.0, rr
+        else:
+            assert rr["frac"] is None and rr["achieved"] is None and "switch_only" in key, (key, rr)
+            if key in ("panda:100000:f64:switch_only", "panda:1000000:f64:switch_only", "panda:100000:f64:switch_only:pow_exact"):
+                assert 0.0 < rr["valu_issue_frac"] < 1.0 and "NOT measured in this run" in rr["counters_from_profile"]["source"], (key, rr)
+    assert bounds["hbm"] >= 6 and bounds["valu_f64"] == 2 and bounds["latency/valu_f64"] >= 8, bounds
+    walk = [s_ for s_ in sec if s_["config"]["workload_key"] in ("panda:1000000:f64:first256", "panda:1000000:f64:stride4", "panda:1000000:f32")]
+    assert len(walk) == 3 and all(w["roofline"]["traffic_from_profile"]["write_bytes_per_launch"] > 0 for w in walk)
