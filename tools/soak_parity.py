@@ -27,7 +27,7 @@ for seed in seeds:
       with ThreadPoolExecutor(parts) as ex:
           outs = list(ex.map(lambda i: orc.plan_batch(qg[i::parts], q0[i::parts], v0[i::parts], a0[i::parts], sample=False), range(parts)))
       t2 = time.time()
-      worst, flips, over = 0.0, 0, 0
+      worst, flips, over, bits = 0.0, 0, 0, 0
       for i, o in enumerate(outs):
           sl = slice(i, None, parts)
           ok = o["status"] != 0
@@ -41,5 +41,7 @@ for seed in seeds:
           for k in ("t_opt", "t_scaled", "v_drive", "t_required"):
               d = np.abs(r[k][sl][ok] - o[k][ok]); d = d[np.isfinite(d)]
               worst = max(worst, float(d.max())); over += int(np.sum(d > 1e-9))
-      print(("MATLAB semantics " if matlab else "") + f"seed {seed} {name:6s} {nn:8d} queries ({nn * D} joint lanes): integer mismatches {flips}, values beyond 1e-9: {over}, worst |d| {worst:.3e}"
+              x, y = np.ascontiguousarray(r[k][sl][ok]), np.ascontiguousarray(o[k][ok])
+              bits += int(np.sum((x.view(np.uint64) != y.view(np.uint64)) & ~(np.isnan(x) & np.isnan(y))))   # entries whose BITS differ (default pow rule: none)
+      print(("MATLAB semantics " if matlab else "") + f"seed {seed} {name:6s} {nn:8d} queries ({nn * D} joint lanes): integer mismatches {flips}, values beyond 1e-9: {over}, worst |d| {worst:.3e}, entries with other bits {bits}"
             f"  [gpu+copies {t1 - t0:.1f} s, oracle x16 threads {t2 - t1:.1f} s]", flush=True)
