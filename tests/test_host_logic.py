@@ -169,3 +169,42 @@ def test_dense_comparator_of_the_soak_tool(oracle_mod):
     cnt, maxd, flag = run()
     assert abs(maxd[5, 0] - 1e-6) < 1e-12 and not maxd[5, 1:].any() and flag[5] == 0 and flag[6] == 4 and flag[7] == 2 and flag[3] == 1 and flag[8] == 8
     assert np.count_nonzero(maxd) == 2 and np.count_nonzero(flag) == 4
+
+
+def test_bench_workload_keys_and_committed_counters():
+    """bench.py names every workload (config.workload_key) and quotes the committed PMC passes of profiles/bench_counters.json under that
+    name, with their provenance — never as measured in the run. Pure host logic: the keys of the lines the default run prints exist in
+    the committed file where a pass was made, the entries have the fields the roofline blocks read, and unknown workloads get nothing."""
+    import json
+    import types
+    sys.path.insert(0, ROOT)
+    import bench
+    args = bench.parse_args([])
+    wl = bench.Workload(args)
+    assert bench.workload_key(wl, 1_000_000) == "panda:1000000:f64"
+    cases = [(dict(batch=100_000, switch_only=True), 100_000, "panda:100000:f64:switch_only"),
+             (dict(batch=100_000, switch_only=True, end_limit=True), 100_000, "panda:100000:f64:switch_only+end_limit"),
+             (dict(batch=100_000, switch_only=True, pow_rule="exact"), 100_000, "panda:100000:f64:switch_only:pow_exact"),
+             (dict(switch_only=True, in_flight=2), 1_000_000, "panda:1000000:f64:switch_only:inflight2"),
+             (dict(max_samples=256), 1_000_000, "panda:1000000:f64:first256"),
+             (dict(sample_stride=4), 1_000_000, "panda:1000000:f64:stride4"),
+             (dict(f32=True), 1_000_000, "panda:1000000:f32"),
+             (dict(envelope="64:32"), 1_000_000, "panda:1000000:f64:envelope64:32"),
+             (dict(envelope="64:32", envelope_analytic=True), 1_000_000, "panda:1000000:f64:envelope64:32+analytic"),
+             (dict(receding="10:100", max_samples=128), 1_000_000, "panda:1000000:f64:first128:receding10:100"),
+             (dict(limits="ref", semantics="matlab"), 1_000_000, "ref:1000000:f64:matlab")]
+    for over, n, want in cases:
+        assert bench.workload_key(bench.Workload(args, **over), n) == want, (over, bench.workload_key(bench.Workload(args, **over), n))
+    d = json.load(open(os.path.join(ROOT, "profiles", "bench_counters.json")))
+    assert "rocprofv3" in d["how"] and d["collected"]
+    for key in ("panda:1000000:f64", "panda:1000000:f64:first256", "panda:1000000:f64:stride4", "panda:1000000:f32"):
+        e = bench.committed_counters(key)
+        assert e["write_bytes_per_launch"] > 1e10 and "k_sample" in e["sampler_kernel"] and "NOT measured in this run" in e["source"], key
+    # the headline's HBM write bytes: within 0.2 % of the algorithmic 192.9 GB per launch
+    assert abs(bench.committed_counters("panda:1000000:f64")["write_bytes_per_launch"] / 192906497168 - 1.0) < 2e-3
+    for key in ("panda:100000:f64:switch_only", "panda:1000000:f64:switch_only", "panda:100000:f64:switch_only:pow_exact", "panda:1000000:f64:envelope64:32"):
+        e = bench.committed_counters(key)
+        assert 0.0 < e["valu_issue_frac"] < 1.0 and e["kernel_time_us"] > 0, key
+        for name, k in e["kernels"].items():
+            assert k["avg_us"] > 0 and k["valu_wave_insts"] > 0 and 0.0 <= k["valu_issue_frac"] <= 1.0, (key, name)
+    assert bench.committed_counters("panda:123:f64:first7") is None
