@@ -187,6 +187,8 @@ k_opt_slow(int dof, double t_sample, Limits lim, Queries in, Records out, signed
     }
 }
 
+// (with glibc's pow the kernel has 155 VGPRs = one 7-wave block per compute unit; held to 128 for two blocks it spills 80 bytes and is
+// 2 % slower on the same box: left alone. Same for k_opt_fast at 80 registers, -15 %.)
 template <int SEM>
 __global__ void __launch_bounds__(kQueriesPerBlock* kMaxJointSlots)
 k_reduce_scale(long long n, int dof, double t_sample, Limits lim, Queries in, Records out,
