@@ -45,7 +45,7 @@ typedef unsigned long long u64;
 // Where the kernels read the two tables from. On the device every block keeps a copy in LDS (5 KB: a kernel that forms libm powers calls
 // stage_tables() once, all threads, before its first power): a lane's table row is a data-dependent address, i.e. 64 different lines
 // per wave instruction, which LDS serves at a fraction of the latency of the vector L1. On the host (tests) the arrays themselves.
-#if defined(__HIPCC__)
+#if defined(__HIPCC__) && !defined(LTP_LIBM_GLOBAL_TABLES)
 LTP_LIBM_FN double* lds_log_tab() { __shared__ double t[128 * 3]; return t; }
 LTP_LIBM_FN u64* lds_exp_tab() { __shared__ u64 t[256]; return t; }
 __device__ __forceinline__ void stage_tables()
@@ -61,6 +61,9 @@ __device__ __forceinline__ void stage_tables()
 #define LTP_LIBM_LOG_ROW(i, k) lds_log_tab()[(i) * 3 + (k)]
 #define LTP_LIBM_EXP(i) lds_exp_tab()[(i)]
 #else
+#if defined(__HIPCC__)
+__device__ __forceinline__ void stage_tables() {}      // (-DLTP_LIBM_GLOBAL_TABLES: A/B builds that read the arrays in global memory)
+#endif
 #define LTP_LIBM_LOG_ROW(i, k) kPowLogTab[(i)][(k)]
 #define LTP_LIBM_EXP(i) kExpTab[(i)]
 #endif
