@@ -52,6 +52,8 @@ def workload_key(wl, n):
         parts.append(f"inflight{wl.in_flight}")
     if wl.walk is not None:
         parts.append("walk" if wl.walk else "nowalk")
+    if wl.auto_waves is False:
+        parts.append("builder_form")
     if wl.table_pass != "auto":
         parts.append(f"tablepass_{wl.table_pass}")
     if wl.semantics != "cpp":
@@ -186,6 +188,7 @@ def parse_args(argv=None):
                     help="where the sampler's run tables are built: by the table pass (a kernel of its own) or inside the sampler kernel (ltp_set_table_pass)")
     ap.add_argument("--no-walk", action="store_true", help="A/B: forbid k_sample_walk_* (the automatic choice for caps <= 768 samples, float32 rows, every 3rd sample or sparser): capped rows of at most 8 KB float64 / 16 KB float32 per joint then take the table pass, the rest the fused k_sample")
     ap.add_argument("--walk", action="store_true", help="A/B: force k_sample_walk_* (also for rows it is not chosen for automatically: whole or long float64 rows at stride 1-2)")
+    ap.add_argument("--no-auto-waves", action="store_true", help="A/B: caps of at most 16 samples through the walk kernel's builder / streaming-wave form instead of k_sample_walk_auto_*")
     ap.add_argument("--in-flight", type=int, default=1, help="switching times only: steps alternate between this many planner handles, each on its own stream "
                     "(two batches in flight: the latency-bound queue-B kernel of one step runs under the next step's stages); 1 = one batch at a time")
     ap.add_argument("--table-gib", type=float, default=0.0, help="upper bound of the table-pass workspace (default: library default, 1/16 of device memory)")
@@ -283,6 +286,7 @@ class Workload:
         self.sample_blocks, self.gather, self.checksum, self.seed = args.sample_blocks, args.gather, args.checksum, args.seed
         self.table_pass, self.table_gib = args.table_pass, args.table_gib
         self.walk = False if args.no_walk else (True if args.walk else None)
+        self.auto_waves = False if args.no_auto_waves else None
         self.end_limit = args.end_limit
         self.in_flight = args.in_flight
         self.semantics = args.semantics
@@ -376,7 +380,7 @@ def run_workload(wl, ctx):
                 if timed:
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record()
-                ltp.sampleBatch(batch, 0, n, tile, streaming=not wl.plain_stores, spread=wl.spread, walk=wl.walk)
+                ltp.sampleBatch(batch, 0, n, tile, streaming=not wl.plain_stores, spread=wl.spread, walk=wl.walk, auto_waves=wl.auto_waves)
                 if timed:
                     e1.record()
                     ev_pairs.append((e0, e1))
@@ -410,7 +414,7 @@ def run_workload(wl, ctx):
             if timed:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-            ltp.sampleBatch(batch, first, end - first, view, streaming=not wl.plain_stores, dry=wl.dry, spread=wl.spread, walk=wl.walk)
+            ltp.sampleBatch(batch, first, end - first, view, streaming=not wl.plain_stores, dry=wl.dry, spread=wl.spread, walk=wl.walk, auto_waves=wl.auto_waves)
             if timed:
                 e1.record()
                 ev_pairs.append((e0, e1))
@@ -685,7 +689,7 @@ def main():
             print(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE {world} rank(s)", file=sys.stderr)
         return 2
 
-    variant = (args.no_walk or args.walk or args.switch_only or args.end_limit or args.f32 or args.max_samples or args.sample_stride > 1 or args.envelope or args.receding or args.dry_sampler
+    variant = (args.no_walk or args.walk or args.no_auto_waves or args.switch_only or args.end_limit or args.f32 or args.max_samples or args.sample_stride > 1 or args.envelope or args.receding or args.dry_sampler
                or args.in_flight > 1 or args.semantics != "cpp" or args.pow_rule != "libm" or args.table_pass != "auto" or args.limits != "panda" or args.batch != 1_000_000 or args.global_batch or args.window_gib or args.layout != "query_major")
     rccl_world1 = None
     if not grouped and not variant and not args.no_secondary and not args.no_rccl_check and args.backend == "nccl":

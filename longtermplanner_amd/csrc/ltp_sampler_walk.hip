@@ -513,8 +513,9 @@ LTP_DEV void sample_walk_body(long long first, long long count, int dof, double 
 // (walk_stream with one streaming wave); no flags, no hand-over, nothing shared between waves but the work queue. Six waves per block
 // (6 x 24.3 KB of LDS: one block per compute unit), i.e. six builders per compute unit instead of three. Rows bit-identical (same
 // functions); plans with more runs inside the cap than a compact slot holds are rebuilt as wide batches by the same wave.
-// Measured (profiles/r05_auto_waves_ab.jsonl, sampler kernel per 1 M plans, against the builder / streaming-wave form): first-4 1.45 vs
-// 1.95 ms, first-16 1.81 vs 2.03, receding horizon through 16-sample rows 1.54 vs 1.89; first-32 2.54 vs 2.24 — a wave that also
+// Measured (profiles/r05_auto_waves_ab.jsonl, sampler kernel per 1 M plans, against the builder / streaming-wave form — flags bit 7 —
+// on one box, two rounds): first-4 1.42 vs 1.95 ms, first-8 1.45 vs 2.00, first-16 1.81 vs 2.05 (float32: 1.80 vs 2.02), receding
+// horizon through 16-sample rows 1.53 vs 1.89; first-32 2.54 vs 2.24 — a wave that also
 // writes 7 KB of rows per plan no longer hides its stores behind another wave's walk — hence the cap of 16. What remains is the walk
 // itself: ~5000 vector instructions per batch (15 divisions of set-up, ~200 instructions per run, every run to the last sample for the
 // end-limit verdict), i.e. the vector issue rate of the chip (E7.1).
