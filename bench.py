@@ -258,7 +258,7 @@ def rccl_self_check(args):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     t0 = time.perf_counter()
     try:
-        p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+        p = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=env)
     except Exception as e:
         return {"ok": False, "error": f"{type(e).__name__}: {e}"}
     wall = round(time.perf_counter() - t0, 1)

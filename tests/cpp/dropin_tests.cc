@@ -314,6 +314,49 @@ static void testShardedBatch()
   EXPECT_TRUE(env9.size() == 3u * 6 * 9 * 2 && std::memcmp(env9.data(), env1.data(), sizeof(double) * env9.size()) == 0);
 }
 
+// Round 5 options of the drop-in class: the pow rule (default: glibc's pow restated; setLibmPow(false): correctly rounded powers) and
+// the analytic envelopes. Copies inherit both; the rules agree to well within 1e-9 and differ in some last bits; the analytic envelopes
+// equal the exhaustive ones (their candidates are samples of the row).
+static void testRound5Options()
+{
+  const int n = 400;
+  std::vector<double> qg(n * 6), q0(n * 6), v0(n * 6, 0.0), a0(n * 6, 0.0);
+  unsigned long long st = 88172645463325252ull;
+  auto u = [&]() { st ^= st << 13; st ^= st >> 7; st ^= st << 17; return (double)(st >> 11) * (1.0 / 9007199254740992.0); };
+  for (int i = 0; i < n * 6; ++i) { qg[i] = -3.0 + 6.0 * u(); q0[i] = -3.0 + 6.0 * u(); v0[i] = -0.9 + 1.8 * u(); }
+  ltpn::LongTermPlanner libm(6, 0.004, std::vector<double>(6, -3.14), std::vector<double>(6, 3.14), std::vector<double>(6, 1.0), std::vector<double>(6, 2.0),
+                            std::vector<double>(6, 15.0));
+  ltpn::LongTermPlanner exact = libm;                       // copies carry the options
+  exact.setLibmPow(false);
+  ltpn::LongTermPlanner exact2 = exact;
+  ltpn::BatchTrajectory a, b, c;
+  const long long oa = libm.planTrajectoryBatch(n, qg.data(), q0.data(), v0.data(), a0.data(), a, false);
+  const long long ob = exact.planTrajectoryBatch(n, qg.data(), q0.data(), v0.data(), a0.data(), b, false);
+  const long long oc = exact2.planTrajectoryBatch(n, qg.data(), q0.data(), v0.data(), a0.data(), c, false);
+  EXPECT_TRUE(oa == ob && ob == oc && a.status == b.status && a.length == b.length);
+  EXPECT_TRUE(b.t_scaled.size() == c.t_scaled.size() && std::memcmp(b.t_scaled.data(), c.t_scaled.data(), sizeof(double) * b.t_scaled.size()) == 0);
+  double worst = 0.0;
+  size_t other_bits = 0;
+  for (size_t i = 0; i < a.t_scaled.size(); ++i) {
+    const double d = std::fabs(a.t_scaled[i] - b.t_scaled[i]);
+    if (d == d && d > worst) worst = d;
+    other_bits += std::memcmp(&a.t_scaled[i], &b.t_scaled[i], sizeof(double)) != 0;
+  }
+  std::printf("pow rules, %d plans: switching times differ by at most %.3e s, %zu of %zu entries in their bits\n", n, worst, other_bits, a.t_scaled.size());
+  EXPECT_TRUE(worst < 1e-9);
+  std::vector<double> e_all, e_ana;
+  const long long e1 = libm.planEnvelopeBatch(n, qg.data(), q0.data(), v0.data(), a0.data(), 20, 12, e_all);
+  libm.setAnalyticEnvelopes(true);
+  const long long e2 = libm.planEnvelopeBatch(n, qg.data(), q0.data(), v0.data(), a0.data(), 20, 12, e_ana);
+  EXPECT_TRUE(e1 == e2 && e_all.size() == e_ana.size() && e_all.size() == (size_t)n * 6 * 12 * 2);
+  double wenv = 0.0;
+  for (size_t i = 0; i < e_all.size(); ++i) {
+    if (e_all[i] != e_all[i]) { EXPECT_TRUE(e_ana[i] != e_ana[i]); continue; }
+    wenv = std::fmax(wenv, std::fabs(e_all[i] - e_ana[i]));
+  }
+  EXPECT_TRUE(wenv <= 1e-12);
+}
+
 int main()
 {
   try {
@@ -326,6 +369,7 @@ int main()
     testRootsHeader();
     testConcurrentFirstCall();
     testShardedBatch();
+    testRound5Options();
   } catch (const std::exception& e) {
     std::printf("EXCEPTION: %s\n", e.what());
     return 2;
