@@ -1,12 +1,12 @@
 #!/bin/bash
 # A/B of two builds of the library on the short-row bench lines, in ONE run (boxes differ by up to 15 % on these):
-# tools/ab/base.so against the library in the tree. usage: bash tools/short_ab.sh ["bench args" ...]
+# every tools/ab/*.so (base.so, ...) against the library in the tree. usage: bash tools/short_ab.sh ["bench args" ...]
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
 cp longtermplanner_amd/libltp_hip.so tools/ab/new.so
 if [ $# -eq 0 ]; then set -- "--max-samples 64" "--receding 10:100 --max-samples 128" "--max-samples 256" "--max-samples 16"; fi
 for rep in 1 2; do
-for lib in base new; do
+for lib in $(cd tools/ab && ls *.so | sed s/.so// | grep -v "^new$") new; do
 cp tools/ab/$lib.so longtermplanner_amd/libltp_hip.so
 for v in "$@"; do
 python bench.py --no-cpu-baseline --no-secondary --steps 5 --warmup 2 $v 2>/dev/null | python -c "
