@@ -15,8 +15,9 @@
 //     they read LDS and issue stores only, as in k_sample_tab;
 //   * buffers change hands through LDS flags (s_ready / s_consumed), no block barrier in the loop; a final "done" batch lets every
 //     wave leave.
-// No table traffic, no table launch; the only global reads are the 13 record words per (plan, joint). A batch is normally COMPACT
-// (9 consecutive 7-DoF plans, the first kWalkRuns = 8 runs per lane); when one of its lanes has more runs inside the cap —
+// No table traffic, no table launch; the only global reads are the 13 record words per (plan, joint) and a plan's length. A batch is
+// normally COMPACT (9 7-DoF plans — the next LIVE ones of the queue item in hand, walk_plans_per_item: rejected plans take no lane
+// of a walk — the first kWalkRuns = 8 runs per lane); when one of its lanes has more runs inside the cap —
 // a few per million of random queries, up to 4 % of the plans (a third of the batches) in the later cycles of a receding-horizon
 // loop, tools/wide_batch_fraction.py —
 // the builder rebuilds the same plans as WIDE batches (4 plans, all 20 runs per lane; beyond 28 joints: 28 joints of one plan at a
@@ -87,14 +88,60 @@ bool sample_walk_applies(int dof, RowSpec rows)
 constexpr int kWalkBatchCap = 1024;
 __host__ __device__ inline bool walk_long_rows(RowSpec rows) { return rows.max_samples <= 0 || rows.max_samples > kWalkBatchCap; }
 
-// plans per queue item: a compact batch; for long rows two wide batches
-__host__ __device__ inline int walk_plans_per_item(int dof, RowSpec rows)
+// plans per batch: a compact batch; for long rows two wide batches
+__host__ __device__ inline int walk_plans_per_batch(int dof, RowSpec rows)
 {
     if (dof > kWalkLanes) return 1;                                                // one plan, kWalkLanes joints at a time
     const int compact = (kWalkLanes / dof) < kWalkMaxPlans ? (kWalkLanes / dof) : kWalkMaxPlans;
     if (!walk_long_rows(rows)) return compact;
     const int two_wide = 2 * (kWideLanes / dof) > 1 ? 2 * (kWideLanes / dof) : 1;
     return two_wide < compact ? two_wide : compact;
+}
+// plans per QUEUE ITEM. Rows of at most kWalkGatherCap samples — where the builder's walks are what a block waits for — take
+// kWalkGather batches' worth of consecutive plans per item, and a batch is made of the item's LIVE plans — the ones that store
+// samples — walk_plans_per_batch at a time: plans that were rejected (traj_len 0) have no rows and take no lane of a walk. (Round 5:
+// in the later cycles of a receding-horizon loop a third of the random plans are dead; a batch of nine consecutive plans then walked
+// six. Rows of the live plans of an item are neighbours in the tile whatever lies between them. Longer rows are bound by their
+// stores: an item stays one batch there — gathered items cost first-256 1.3 % on one box, profiles/EXPERIMENTS.md E7.7.)
+constexpr int kWalkGather = 3;
+constexpr int kWalkGatherCap = 64;
+__host__ __device__ inline int walk_plans_per_item(int dof, RowSpec rows)
+{
+    const int ppb = walk_plans_per_batch(dof, rows);
+    if (rows.max_samples <= 0 || rows.max_samples > kWalkGatherCap) return ppb;
+    const int g = 64 / ppb < kWalkGather ? (64 / ppb > 1 ? 64 / ppb : 1) : kWalkGather;     // (one traj_len load per lane)
+    return g * ppb;
+}
+// The work queue of a launch: items of walk_plans_per_item consecutive plans, interleaved over `spread` stripes of the call's plans
+// (item -> stripe item % spread, place item / spread; holes included).
+struct WalkQueue {
+    int ipp, ppb, spread;
+    long long count, items, per;
+    unsigned long long total;
+};
+__host__ __device__ inline WalkQueue walk_queue(long long count, int dof, RowSpec rows, int spread)
+{
+    WalkQueue q;
+    q.ppb = walk_plans_per_batch(dof, rows);
+    q.ipp = walk_plans_per_item(dof, rows);
+    q.spread = spread > 0 ? spread : 1;
+    q.count = count;
+    q.items = (count + q.ipp - 1) / q.ipp;
+    q.per = (q.items + q.spread - 1) / q.spread;
+    q.total = (unsigned long long)q.per * (unsigned long long)q.spread;
+    return q;
+}
+// first plan (local number) and plan count of a queue item; 0 plans: a hole of the interleave, or the end of the queue
+__host__ __device__ inline void walk_queue_item(const WalkQueue& q, unsigned long long item, long long& pb, int& np)
+{
+    pb = 0;
+    np = 0;
+    if (item >= q.total) return;
+    const long long bi = (long long)(item % (unsigned long long)q.spread) * q.per + (long long)(item / (unsigned long long)q.spread);
+    if (bi < q.items) {
+        pb = bi * q.ipp;
+        np = (int)(q.count - pb < q.ipp ? q.count - pb : q.ipp);
+    }
 }
 
 LTP_DEV unsigned long long walk_uniform(unsigned long long x)     // a value every lane holds alike -> scalar registers
@@ -316,22 +363,43 @@ struct WalkCtx {
     int lane;
 };
 
-// Builds one batch — joints [j0, j0 + nj) of np plans from local plan pb — into B: record loads, the walk of every lane into its slot
+// The trajectory lengths of an item's plans: lane k < np_item loads plan pb + k's (issued one item ahead by the callers: nothing waits)
+LTP_DEV int walk_item_len_load(const WalkCtx& c, long long pb, int np_item)
+{
+    return c.lane < np_item ? c.rec.traj_len[c.first + pb + c.lane] : 0;
+}
+// The live plans of one queue item (np_item consecutive plans; len: what walk_item_len_load returned for it). Returns in lane r the
+// item-relative index of the r-th live plan; nlive: their number.
+LTP_DEV int walk_item_plans(const WalkCtx& c, int len, int np_item, int& nlive)
+{
+    const bool live = c.lane < np_item && stored_len(len, c.rows) > 0;
+    const unsigned long long mask = walk_uniform(__builtin_amdgcn_ballot_w64(live));
+    nlive = __builtin_popcountll(mask);
+    if (nlive == np_item) return c.lane;                                           // every plan is live (wave-uniform)
+    // lane i of a live plan knows its rank (live plans below it); the inverse — rank -> lane — is one forward permute. Dead lanes
+    // push to lane 63, which is no rank here (nlive < np_item <= 64).
+    const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+    return __builtin_amdgcn_ds_permute((live ? rank : 63) << 2, c.lane);
+}
+
+// Builds one batch — joints [j0, j0 + nj) of np live plans of an item, entries [base, base + np) of its plan list (walk_item_plans;
+// local plan = pb + entry) — into B: record loads, the walk of every lane into its slot
 // (compact: the first kWalkRuns runs inside the cap; WIDE: every run), the end-limit verdict (cc:59-61) and the tile-capacity rule, the
 // plan-level header. The calling wave owns B. Returns false without a valid header if a compact batch does not do: a lane has more
 // runs inside the cap than a slot holds, or a plan lies wholly inside the cap (nearly always more than kWalkRuns runs: wide at once).
 template <int SEM, bool WIDE>
-LTP_DEV bool walk_build(const WalkCtx& c, WalkBatch& B, long long pb, int np, int j0, int nj)
+LTP_DEV bool walk_build(const WalkCtx& c, WalkBatch& B, long long pb, int plist, int base, int np, int j0, int nj)
 {
     const int lane = c.lane;
-    // the loads of lane (plan pb + lane / nj, joint j0 + lane % nj); nothing here waits
+    // the loads of lane (batch plan lane / nj, joint j0 + lane % nj); nothing here waits
     WalkLaneIn L;
     const int pl = lane / nj, jl = lane - pl * nj;
     const bool mine = pl < np;
+    const long long pmine = c.first + pb + __shfl(plist, base + (mine ? pl : 0));   // this lane's plan
     L.len = 0;
     if (mine) {
         const int j = j0 + jl;
-        const long long p = c.first + pb + pl;
+        const long long p = pmine;
         const long long ix = p * c.in.sq + (long long)j * c.in.sj;
         L.len = c.rec.traj_len[p];
         L.rel = c.offsets[p] - c.off0;
@@ -343,7 +411,7 @@ LTP_DEV bool walk_build(const WalkCtx& c, WalkBatch& B, long long pb, int np, in
         // (the lengths arrive with the rest of the records: no round trip of their own)
         if (__builtin_amdgcn_ballot_w64(L.len > 0 && (long long)L.len <= c.needed_end) != 0ull) return false;
     }
-    const long long p = c.first + pb + (mine ? pl : 0);
+    const long long p = pmine;
     int slen = mine ? stored_len(L.len, c.rows) : 0;
     const unsigned long long stride = ((unsigned long long)slen + (kRowAlign - 1)) / kRowAlign * kRowAlign;
     if (slen > 0 && L.rel + 4ull * c.dof * stride > c.capacity) {
@@ -421,18 +489,18 @@ LTP_DEV void sample_walk_body(long long first, long long count, int dof, double 
         }
         return;
     }
-    // ---- builder wave: ordinary loads and LDS stores. A queue item is a COMPACT batch of ppb consecutive plans; if one of its lanes
-    // has more than kWalkRuns runs inside the cap (plans that restart mid-motion close to their goal, trajectories that end inside
-    // the cap), the same plans are built again as WIDE batches of wpb plans each, every run kept. The walk is one long dependent chain
-    // on a SIMD it shares with streaming waves that wait for the memory system anyway: it runs at raised issue priority. ----
+    // ---- builder wave: ordinary loads and LDS stores. A queue item is walk_plans_per_item consecutive plans; its live plans are
+    // built walk_plans_per_batch at a time as COMPACT batches; if a lane of one has more than kWalkRuns runs inside the cap (plans that
+    // restart mid-motion close to their goal, trajectories that end inside the cap), the same plans are built again as WIDE batches of
+    // wpb plans each, every run kept. The walk is one long dependent chain on a SIMD it shares with streaming waves that wait for the
+    // memory system anyway: it runs at raised issue priority. ----
     __builtin_amdgcn_s_setprio(3);
     const int lane = (int)(threadIdx.x & 63);
-    const int ppb = walk_plans_per_item(dof, rows);                                               // plans per queue item = per compact batch
+    const WalkQueue queue = walk_queue(count, dof, rows, spread);
+    const int ppb = queue.ppb;                                                                    // live plans per compact batch
     const int wpb = kWideLanes / dof > 1 ? kWideLanes / dof : 1;                                  // plans per wide batch
     const int wide_nj = dof < kWideLanes ? dof : kWideLanes;                                      // joints per plan of a wide batch
-    const long long nbatches = (count + ppb - 1) / ppb;
-    const long long per = (nbatches + spread - 1) / spread;
-    const unsigned long long total = (unsigned long long)per * (unsigned long long)spread;
+    const unsigned long long total = queue.total;
     const unsigned long long off0 = offsets[first];
     const int sstride = rows.stride > 1 ? rows.stride : 1;
     const bool long_rows = walk_long_rows(rows);
@@ -448,28 +516,19 @@ LTP_DEV void sample_walk_body(long long first, long long count, int dof, double 
         }
     };
     // the queue is drawn ONE ITEM AHEAD: the atomic's round trip (1-2 us behind the block's own row stores) runs beside the walk
-    // of the current item; its result is first looked at when the next item starts
+    // of the current item, and so does the load of the next item's trajectory lengths (what its plan list is made from)
     auto draw_issue = [&]() -> unsigned long long {
         unsigned long long item = 0ull;
         if (lane == 0) item = atomicAdd(next_item, 1ull);
         return item;
     };
-    auto draw_result = [&](unsigned long long item) -> unsigned long long {
-        return ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(item >> 32)) << 32) |
-               (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)item);
-    };
-    // first plan (local number) and plan count of a queue item; 0 plans: a hole of the interleave
-    auto item_plans = [&](unsigned long long item, long long& pb, int& np) {
-        const long long bi = (long long)(item % (unsigned long long)spread) * per + (long long)(item / (unsigned long long)spread);
-        pb = bi * ppb;
-        np = bi < nbatches ? (int)((count - pb) < ppb ? (count - pb) : ppb) : 0;
-    };
+    auto item_plans = [&](unsigned long long item, long long& pb, int& np) { walk_queue_item(queue, item, pb, np); };
     const WalkCtx ctx{first, count, dof, t_sample, lim, in, rec, offsets, off0, capacity, rows, needed_end, lane};
     // builds and publishes one batch into the buffer the builder has waited for; false (nothing published) if a compact batch does not do
-    auto build = [&](long long pb, int np, int j0, int nj, auto wide_tag) -> bool {
+    auto build = [&](long long pb, int plist, int base, int np, int j0, int nj, auto wide_tag) -> bool {
         constexpr bool WIDE = decltype(wide_tag)::value;
         wait_buffer_free();
-        if (!walk_build<SEM, WIDE>(ctx, buf[seq % kWalkBuffers], pb, np, j0, nj)) return false;
+        if (!walk_build<SEM, WIDE>(ctx, buf[seq % kWalkBuffers], pb, plist, base, np, j0, nj)) return false;
         // publish: everything above is LDS traffic of this one wave, in order
         __hip_atomic_store(&s_ready[seq % kWalkBuffers], seq + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         ++seq;
@@ -478,28 +537,39 @@ LTP_DEV void sample_walk_body(long long first, long long count, int dof, double 
     typedef std::integral_constant<bool, false> CompactTag;
     typedef std::integral_constant<bool, true> WideTag;
 
+    unsigned long long item = walk_uniform(draw_issue());
+    long long pb = 0;
+    int np_item = 0;
+    item_plans(item, pb, np_item);
+    int len = walk_item_len_load(ctx, pb, np_item);
     unsigned long long drawn = draw_issue();
     for (;;) {
-        const unsigned long long item = draw_result(drawn);
         if (item >= total) {
             wait_buffer_free();
             if (lane == 0) buf[seq % kWalkBuffers].done = 1;
             __hip_atomic_store(&s_ready[seq % kWalkBuffers], seq + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
             break;
         }
+        int nlive = 0;
+        const int plist = walk_item_plans(ctx, len, np_item, nlive);
+        const long long pb_now = pb;
+        // the next item: its number has been on its way since the current one started; its lengths travel beside this item's walks
+        item = walk_uniform(drawn);
+        item_plans(item, pb, np_item);
+        len = walk_item_len_load(ctx, pb, np_item);
         drawn = draw_issue();
-        long long pb = 0;
-        int np = 0;
-        item_plans(item, pb, np);
-        // (beyond kWalkLanes joints an item is one plan, taken kWalkLanes joints at a time)
-        for (int jc = 0; jc < dof; jc += kWalkLanes) {
-            const int jc_end = dof - jc < kWalkLanes ? dof : jc + kWalkLanes;
-            if (!long_rows && build(pb, np, jc, jc_end - jc, CompactTag{})) continue;
-            for (int sub = 0; sub < np; sub += wpb)
-                for (int j0 = jc; j0 < jc_end; j0 += wide_nj) {
-                    const int npw = np - sub < wpb ? np - sub : wpb, njw = jc_end - j0 < wide_nj ? jc_end - j0 : wide_nj;
-                    (void)build(pb + sub, npw, j0, njw, WideTag{});
-                }
+        for (int base = 0; base < nlive; base += ppb) {
+            const int np = nlive - base < ppb ? nlive - base : ppb;
+            // (beyond kWalkLanes joints a batch is one plan, taken kWalkLanes joints at a time)
+            for (int jc = 0; jc < dof; jc += kWalkLanes) {
+                const int jc_end = dof - jc < kWalkLanes ? dof : jc + kWalkLanes;
+                if (!long_rows && build(pb_now, plist, base, np, jc, jc_end - jc, CompactTag{})) continue;
+                for (int sub = 0; sub < np; sub += wpb)
+                    for (int j0 = jc; j0 < jc_end; j0 += wide_nj) {
+                        const int npw = np - sub < wpb ? np - sub : wpb, njw = jc_end - j0 < wide_nj ? jc_end - j0 : wide_nj;
+                        (void)build(pb_now, plist, base + sub, npw, j0, njw, WideTag{});
+                    }
+            }
         }
     }
 }
@@ -534,12 +604,11 @@ LTP_DEV void sample_walk_auto_body(long long first, long long count, int dof, do
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = (int)(threadIdx.x & 63);
     WalkBatch& B = reinterpret_cast<WalkBatch*>(ltp_walk_auto_lds)[wave];
-    const int ppb = walk_plans_per_item(dof, rows);
+    const WalkQueue queue = walk_queue(count, dof, rows, spread);
+    const int ppb = queue.ppb;
     const int wpb = kWideLanes / dof > 1 ? kWideLanes / dof : 1;
     const int wide_nj = dof < kWideLanes ? dof : kWideLanes;
-    const long long nbatches = (count + ppb - 1) / ppb;
-    const long long per = (nbatches + spread - 1) / spread;
-    const unsigned long long total = (unsigned long long)per * (unsigned long long)spread;
+    const unsigned long long total = queue.total;
     const int sstride = rows.stride > 1 ? rows.stride : 1;
     const WalkCtx ctx{first, count, dof, t_sample, lim, in, rec, offsets, offsets[first], capacity, rows, (long long)rows.max_samples * sstride, lane};
     auto draw_issue = [&]() -> unsigned long long {
@@ -547,6 +616,7 @@ LTP_DEV void sample_walk_auto_body(long long first, long long count, int dof, do
         if (lane == 0) item = atomicAdd(next_item, 1ull);
         return item;
     };
+    auto item_plans = [&](unsigned long long item, long long& pb, int& np) { walk_queue_item(queue, item, pb, np); };
     // the wave's batch is complete in LDS (its own stores, in order): write its rows
     auto stream = [&](bool wide) {
         wave_sync();
@@ -554,24 +624,33 @@ LTP_DEV void sample_walk_auto_body(long long first, long long count, int dof, do
         else walk_stream<STREAMING, T, WalkSlot>(B, B.slot, dof, out, rows, t_sample, 0, 1);
         wave_sync();                                                                              // the rows' LDS reads before the next batch's stores
     };
-    unsigned long long drawn = draw_issue();                                                     // one item ahead, as the builder wave above
-    for (;;) {
-        const unsigned long long item = walk_uniform(drawn);
-        if (item >= total) break;
+    // one item ahead, as the builder wave above: the next item's number and trajectory lengths travel beside this item's walks
+    unsigned long long item = walk_uniform(draw_issue());
+    long long pb = 0;
+    int np_item = 0;
+    item_plans(item, pb, np_item);
+    int len = walk_item_len_load(ctx, pb, np_item);
+    unsigned long long drawn = draw_issue();
+    while (item < total) {
+        int nlive = 0;
+        const int plist = walk_item_plans(ctx, len, np_item, nlive);
+        const long long pb_now = pb;
+        item = walk_uniform(drawn);
+        item_plans(item, pb, np_item);
+        len = walk_item_len_load(ctx, pb, np_item);
         drawn = draw_issue();
-        const long long bi = (long long)(item % (unsigned long long)spread) * per + (long long)(item / (unsigned long long)spread);
-        const long long pb = bi * ppb;
-        const int np = bi < nbatches ? (int)((count - pb) < ppb ? (count - pb) : ppb) : 0;
-        if (np <= 0) continue;                                                                   // a hole of the interleave
-        for (int jc = 0; jc < dof; jc += kWalkLanes) {
-            const int jc_end = dof - jc < kWalkLanes ? dof : jc + kWalkLanes;
-            if (walk_build<SEM, false>(ctx, B, pb, np, jc, jc_end - jc)) { stream(false); continue; }
-            for (int sub = 0; sub < np; sub += wpb)
-                for (int j0 = jc; j0 < jc_end; j0 += wide_nj) {
-                    const int npw = np - sub < wpb ? np - sub : wpb, njw = jc_end - j0 < wide_nj ? jc_end - j0 : wide_nj;
-                    (void)walk_build<SEM, true>(ctx, B, pb + sub, npw, j0, njw);
-                    stream(true);
-                }
+        for (int base = 0; base < nlive; base += ppb) {
+            const int np = nlive - base < ppb ? nlive - base : ppb;
+            for (int jc = 0; jc < dof; jc += kWalkLanes) {
+                const int jc_end = dof - jc < kWalkLanes ? dof : jc + kWalkLanes;
+                if (walk_build<SEM, false>(ctx, B, pb_now, plist, base, np, jc, jc_end - jc)) { stream(false); continue; }
+                for (int sub = 0; sub < np; sub += wpb)
+                    for (int j0 = jc; j0 < jc_end; j0 += wide_nj) {
+                        const int npw = np - sub < wpb ? np - sub : wpb, njw = jc_end - j0 < wide_nj ? jc_end - j0 : wide_nj;
+                        (void)walk_build<SEM, true>(ctx, B, pb_now, plist, base + sub, npw, j0, njw);
+                        stream(true);
+                    }
+            }
         }
     }
 }
@@ -627,10 +706,9 @@ bool launch_sample_walk(hipStream_t s, long long first, long long count, int dof
                         unsigned long long* next_item, int resident_blocks, int semantics)
 {
     if (count <= 0) return false;
-    const int ppb = walk_plans_per_item(dof, rows);
-    const long long nbatches = (count + ppb - 1) / ppb;
     int spread = (flags >> 8) & 0xFFFF;
     if (spread == 0) spread = kSampleSpread;
+    const long long nbatches = walk_queue(count, dof, rows, 1).items;                 // queue items
     if ((long long)spread > nbatches) spread = (int)nbatches;
     if (walk_auto_rows(rows) && !(flags & 128)) {
         // autonomous waves (one block per compute unit); flags bit 7 keeps the builder / streaming-wave form (A/B runs)

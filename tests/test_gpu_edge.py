@@ -1308,3 +1308,51 @@ def test_autonomous_waves_write_the_rows_of_the_builder_form(amd, limits, dof, n
             for k, (got, want) in enumerate(zip(res[mode], res["other"])):
                 assert torch.equal(got, want), (cap, stride, f32, mode, k)
         assert (res["other"][5] & 32).any(), "the small tile did not leave any plan out"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("limits,dof,n,semantics", [("panda", None, 5003, "cpp"), ("ref", 30, 333, "cpp"), ("ref", 2, 4000, "cpp"), ("ref", 64, 400, "cpp"),
+                                                     ("panda", None, 2500, "matlab")])
+def test_walk_sampler_gathers_the_live_plans_of_an_item(amd, limits, dof, n, semantics):
+    """Round 5: for caps of at most 64 samples a queue item of the walk kernels is three batches' worth of consecutive plans and a
+    batch is made of the item's LIVE plans only (rejected plans have no rows and take no lane of a walk). With a third of the plans
+    dead at random, long dead stretches (whole items, item tails and heads) and single survivors, rows, statuses and lengths are
+    those of the fused sampler / table pass bit for bit — both kernel forms, sub-ranges that start and end inside dead stretches,
+    small interleaves, a tile too small for the last plans."""
+    import torch
+    D, lim = amd.limit_set(limits, dof)
+    ltp = amd.LongTermPlanner(D, 0.001, device=0, **lim)
+    ltp.setSemantics(semantics)
+    qg, q0, v0, a0 = (x.clone() for x in ltp.generateQueries(n, seed=77))
+    g = torch.Generator(device="cpu").manual_seed(5)
+    dead = torch.rand(n, generator=g) < 0.33
+    dead[100:190] = True                        # several whole items
+    dead[200:230] = True; dead[214] = False     # a single survivor in a dead stretch
+    dead[n - 40:] = True                        # the call ends in dead plans
+    dead[:3] = True                             # and starts with some
+    dead[300:330] = False                       # a stretch without any
+    dead = dead.to(qg.device)
+    v0[dead, 0] = 99.0                          # checkInputs rejects the plan (cc:63-80): traj_len 0, no rows
+    other = dict(walk=False) if semantics == "matlab" else dict(tables=False, walk=False)
+    for cap, stride, f32 in ((64, 1, False), (32, 1, False), (16, 1, False), (5, 1, True), (20, 3, False), (65, 1, False)):
+        ltp.setMaxSamples(cap); ltp.setSampleStride(stride)
+        dt = torch.float32 if f32 else torch.float64
+        res = {}
+        for mode, kw in (("other", other), ("builder", dict(walk=True, auto_waves=False)), ("default walk", dict(walk=True))):
+            b = ltp.planSwitchTimesBatch(qg, q0, v0, a0)
+            assert int((b.traj_len == 0).sum().item()) >= int(dead.sum().item())
+            full = torch.full((int(b.offsets[-1].item()) + 8,), 3.0, dtype=dt, device="cuda")
+            ltp.sampleBatch(b, 0, n, full, **kw)
+            assert ("walk" in ltp.lastSamplerKernel()) == (mode != "other")
+            lo, hi = 105, n - 20                # starts and ends inside dead stretches
+            sub = torch.full((int((b.offsets[hi] - b.offsets[lo]).item()) + 8,), 3.0, dtype=dt, device="cuda")
+            ltp.sampleBatch(b, lo, hi - lo, sub, spread=7, **kw)
+            b2 = ltp.planSwitchTimesBatch(qg, q0, v0, a0)
+            small = torch.full((int(b2.offsets[n // 2 + 3].item()) + 5,), 3.0, dtype=dt, device="cuda")
+            ltp.sampleBatch(b2, 0, n, small, streaming=False, **kw)
+            torch.cuda.synchronize()
+            res[mode] = (full, sub, small, b.status.clone(), b.traj_len.clone(), b2.status.clone())
+        for mode in ("builder", "default walk"):
+            for k, (got, want) in enumerate(zip(res[mode], res["other"])):
+                assert torch.equal(got, want), (cap, stride, f32, mode, k)
+        assert (res["other"][5] & 32).any(), "the small tile did not leave any plan out"

@@ -6,7 +6,8 @@ D, lim = amd.limit_set("panda")
 N = 200_000
 ltp = amd.LongTermPlanner(D, 0.001, device=0, **lim)
 qg, q0, v0, a0 = ltp.generateQueries(N, seed=4711)
-ltp.setMaxSamples(128)
+CAP = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+ltp.setMaxSamples(CAP)
 s0, s1, s2 = q0, v0, a0
 def frac_wide(b, cap):
     tab = ltp.buildRunTables(b, 0, N)
@@ -24,7 +25,7 @@ def frac_wide(b, cap):
     return float((per_plan > 8).mean()), float(per_plan.mean())
 for cycle in range(10):
     b = ltp.planSwitchTimesBatch(qg, s0, s1, s2)
-    f, m = frac_wide(b, 128)
+    f, m = frac_wide(b, CAP)
     ln = b.traj_len.cpu().numpy()
-    print(f"cycle {cycle}: plans with a joint of > 8 runs inside 128 samples: {f:.4f}; mean max runs inside {m:.2f}; traj_len <= 128: {(ln[ln>0] <= 128).mean():.4f}, mean len {ln.mean():.0f}", flush=True)
+    print(f"cycle {cycle}: plans with a joint of > 8 runs inside {CAP} samples: {f:.4f}; mean max runs inside {m:.2f}; traj_len <= cap: {(ln[ln>0] <= CAP).mean():.4f} of the live plans, live {(ln>0).mean():.4f}, mean len {ln.mean():.0f}", flush=True)
     s0, s1, s2 = ltp.stateAt(b, 0, N, 100)
