@@ -188,7 +188,7 @@ def parse_args(argv=None):
                     help="where the sampler's run tables are built: by the table pass (a kernel of its own) or inside the sampler kernel (ltp_set_table_pass)")
     ap.add_argument("--no-walk", action="store_true", help="A/B: forbid k_sample_walk_* (the automatic choice for caps <= 768 samples, float32 rows, every 3rd sample or sparser): capped rows of at most 8 KB float64 / 16 KB float32 per joint then take the table pass, the rest the fused k_sample")
     ap.add_argument("--walk", action="store_true", help="A/B: force k_sample_walk_* (also for rows it is not chosen for automatically: whole or long float64 rows at stride 1-2)")
-    ap.add_argument("--no-auto-waves", action="store_true", help="A/B: caps of at most 16 samples through the walk kernel's builder / streaming-wave form instead of k_sample_walk_auto_*")
+    ap.add_argument("--no-auto-waves", action="store_true", help="A/B: caps of at most 32 samples through the walk kernel's builder / streaming-wave form instead of k_sample_walk_auto_*")
     ap.add_argument("--in-flight", type=int, default=1, help="switching times only: steps alternate between this many planner handles, each on its own stream "
                     "(two batches in flight: the latency-bound queue-B kernel of one step runs under the next step's stages); 1 = one batch at a time")
     ap.add_argument("--table-gib", type=float, default=0.0, help="upper bound of the table-pass workspace (default: library default, 1/16 of device memory)")

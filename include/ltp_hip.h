@@ -225,7 +225,7 @@ int ltp_end_limit_batch(ltp_planner* p, long long first, long long count, const 
  * 8 KB / 16 KB per joint, and in MATLAB semantics with the walk kernel forbidden), bit 3 = force the fused table build; bit 4 = reserved;
  * bit 5 = never k_sample_walk_* (rows under a cap of <= 768 samples, float32 rows, rows of every 3rd sample or sparser, and every
  * row format in MATLAB semantics take it by themselves: the run tables then stay in the compute unit, no table pass at all; same
- * rows), bit 6 = force it (any row format); bit 7 = keep its builder / streaming-wave form also for caps of at most 16 samples, which
+ * rows), bit 6 = force it (any row format); bit 7 = keep its builder / streaming-wave form also for caps of at most 32 samples, which
  * otherwise take the autonomous-wave form of the same kernel (k_sample_walk_auto_*: every wave builds and writes its own batches);
  * bits 8..23 = block interleave factor (0 = default 64, 1 = blocks in plan order). Large tiles (>= 64 GiB)
  * written with the default interleave reach the HBM fill ceiling; see DESIGN.md. */

@@ -128,11 +128,11 @@ void launch_sample_tab(hipStream_t s, long long first, long long count, long lon
                        double t_sample /* the one the tables were built with */,
                        unsigned long long* stamps = nullptr /* diagnostic: 8 per (plan, joint group) item */);
 // Rows without any table traffic (every row format, both semantics, any number of joints; taken by itself for capped, float32 and
-// sparse rows and in MATLAB semantics): a builder wave per block walks the runs into LDS, seven streaming waves write the rows
+// sparse rows and in MATLAB semantics): a builder wave per block walks the runs into LDS, five streaming waves write the rows
 // (ltp_sampler_walk.hip).
 bool sample_walk_applies(int dof, RowSpec rows);
 int sample_walk_resident_blocks(int device, bool f32);
-// returns true if the autonomous-wave form took the rows (caps of at most 16 samples; flags bit 7 forbids it)
+// returns true if the autonomous-wave form took the rows (caps of at most 32 samples; flags bit 7 forbids it)
 bool launch_sample_walk(hipStream_t s, long long first, long long count, int dof, double t_sample, Limits lim, Queries in, Records rec,
                         const unsigned long long* offsets, void* out, bool f32, unsigned long long capacity, int flags, RowSpec rows,
                         unsigned long long* next_item /* zeroed on the same stream */, int resident_blocks, int semantics = kSemCpp);

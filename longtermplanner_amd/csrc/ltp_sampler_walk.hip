@@ -6,11 +6,11 @@
 // lines read back — and the reads cost the write stream more than their bytes: that mixed pattern tops out at 5.3-5.6 TB/s of total
 // traffic against 7.07 TB/s for pure row writes (profiles/EXPERIMENTS.md E6.3). Here one persistent block of 8 waves keeps the
 // tables in LDS:
-//   * the BUILDER wave (wave 7) walks the runs of up to 63 (plan, joint) lanes at a time — a batch of consecutive plans — with
+//   * the BUILDER wave (the last one) walks the runs of up to 63 (plan, joint) lanes at a time — a batch of consecutive plans — with
 //     for_each_run (ltp_runs.hpp: the register walk of k_build_tables / k_state_at), leaves per lane the state before each of the
 //     first kWalkRuns runs that start inside the row cap in one of two LDS batch buffers, applies the end-limit check (cc:59-61) and
 //     the capacity rule, and publishes the batch;
-//   * the seven STREAMING waves take the (plan, joint) slots of the published batch, expand a run's coefficients on the fly
+//   * the five STREAMING waves take the (plan, joint) slots of the published batch, expand a run's coefficients on the fly
 //     (run_coef: six LDS reads and ~15 operations per run instead of ten reads of an expanded table) and store the rows —
 //     they read LDS and issue stores only, as in k_sample_tab;
 //   * buffers change hands through LDS flags (s_ready / s_consumed), no block barrier in the loop; a final "done" batch lets every
@@ -34,26 +34,56 @@ namespace ltp {
 constexpr int kWalkRuns = 8;                                  // runs per (plan, joint) of a COMPACT batch
 constexpr int kWalkLanes = 63;                                // (plan, joint) lanes of a compact batch: 9 plans of 7 joints
 constexpr int kWalkMaxPlans = 9;
-constexpr int kWideLanes = 28;                                // lanes of a WIDE batch (all kMaxSegments runs per lane): 4 plans of 7 joints
-constexpr int kWalkStreamWaves = 7;
+constexpr int kWideLanes = 21;                                // lanes of a WIDE batch (all kMaxSegments runs per lane): 3 plans of 7 joints
+constexpr int kWalkStreamWaves = 5;
 constexpr int kWalkThreads = (kWalkStreamWaves + 1) * 64;
 constexpr int kWalkBuffers = 2;
-template <int RUNS>
-struct WalkSlotT {
-    int nseg;                                                 // runs stored (<= RUNS)
-    int pad0;
-    int start[RUNS + 2];                                      // first sample of run r; start[nseg] = first sample NOT covered (>= the cap, or traj_len)
+// COMPACT slot, 76 words: a run is four doubles (a, v, q before the run, its jerk); its mode bits (kMode*, 3 of them) ride in the
+// top four bits of its start sample, so every stored start — and the cap times the sample stride — must stay below 2^28
+// (kWalkCompactEnd; rows beyond that are built wide). Round 5: 384 -> 304 bytes per lane, i.e. two batch buffers in 38.5 KB and FOUR
+// blocks — four builder waves, one per SIMD — on a compute unit instead of three (profiles/EXPERIMENTS.md E7.9).
+constexpr unsigned kWalkStartMask = 0x0fffffffu;
+constexpr long long kWalkCompactEnd = 0x0fffffffll;
+struct WalkSlot {
+    static constexpr int kRuns = kWalkRuns;
+    int nseg;                                                 // runs stored (<= kRuns)
+    unsigned start[kWalkRuns + 1];                            // low 28 bits: first sample of run r; start[nseg]: first sample NOT covered (>= the cap, or traj_len); top 4 bits: run r's mode
     double vsnap;                                             // v_drive * dir (cc:823)
-    double pad1;
-    double run[RUNS][kPackedRunWords];                        // a, v, q before the run, its jerk, its mode bits (as in the packed tables)
+    double run[kWalkRuns][4];                                 // a, v, q before the run, its jerk
+    LTP_DEV int first(int r) const { return (int)(start[r] & kWalkStartMask); }
+    LTP_DEV int mode(int r) const { return (int)(start[r] >> 28); }
+    LTP_DEV void put(int r, int b, int m, double a, double v, double q, double J)
+    {
+        start[r] = (unsigned)b | ((unsigned)m << 28);
+        run[r][0] = a; run[r][1] = v; run[r][2] = q; run[r][3] = J;
+    }
+    LTP_DEV void close(int runs, int last_b) { start[runs] = (unsigned)(last_b < (int)kWalkStartMask ? last_b : (int)kWalkStartMask); nseg = runs; }
 };
-typedef WalkSlotT<kWalkRuns> WalkSlot;                        // 48 words
-typedef WalkSlotT<kMaxSegments> WideSlot;                     // 114 words
-static_assert(sizeof(WalkSlot) == 384 && sizeof(WideSlot) == 912, "48 / 114 words");
+// WIDE slot, 114 words: every run of the lane, the layout of the packed tables (mode as a fifth word; starts use all 31 bits)
+struct WideSlot {
+    static constexpr int kRuns = kMaxSegments;
+    int nseg;
+    int pad0;
+    int start[kMaxSegments + 2];
+    double vsnap;
+    double pad1;
+    double run[kMaxSegments][kPackedRunWords];
+    LTP_DEV int first(int r) const { return start[r]; }
+    LTP_DEV int mode(int r) const { return (int)(unsigned)__builtin_bit_cast(unsigned long long, run[r][4]); }
+    LTP_DEV void put(int r, int b, int m, double a, double v, double q, double J)
+    {
+        start[r] = b;
+        run[r][0] = a; run[r][1] = v; run[r][2] = q; run[r][3] = J;
+        run[r][4] = __builtin_bit_cast(double, (unsigned long long)(unsigned)m);
+    }
+    LTP_DEV void close(int runs, int last_b) { start[runs] = last_b; nseg = runs; }
+};
+static_assert(sizeof(WalkSlot) == 304 && sizeof(WideSlot) == 912, "76 / 114 words");
+static_assert(kWalkLanes * sizeof(WalkSlot) == kWideLanes * sizeof(WideSlot), "both kinds of batch fill the buffer");
 struct WalkBatch {
     union {
-        WalkSlot slot[kWalkLanes];                            // compact batch: up to 9 consecutive plans, 8 runs per lane
-        WideSlot wslot[kWideLanes];                           // wide batch: up to 4 consecutive plans, every run of every lane
+        WalkSlot slot[kWalkLanes];                            // compact batch: up to 9 plans, 8 runs per lane
+        WideSlot wslot[kWideLanes];                           // wide batch: up to 3 plans, every run of every lane
     };
     unsigned long long rel0;                                  // element offset in `out` of the first row of the batch's first sampled plan
     unsigned long long span;                                  // elements from rel0 to the end of the batch's last sampled plan
@@ -61,12 +91,12 @@ struct WalkBatch {
     int done;                                                 // 1 = the queue is exhausted
     int wide;                                                 // which member of the union holds the batch
     int j0, nj;                                               // the batch holds joints [j0, j0 + nj) of each of its plans (slots = nplans * nj):
-                                                              // all of them up to 63 (compact) / 28 (wide) joints, a part of ONE plan beyond
+                                                              // all of them up to 63 (compact) / 21 (wide) joints, a part of ONE plan beyond
     int pad;
     int slen[kWalkMaxPlans];                                  // stored samples per row of plan k of the batch; 0 = nothing to stream
     unsigned rel[kWalkMaxPlans];                              // row offset of plan k relative to rel0, in units of kRowAlign elements
 };
-static_assert(kWalkBuffers * sizeof(WalkBatch) <= 53 * 1024, "three blocks per compute unit");
+static_assert(kWalkBuffers * sizeof(WalkBatch) + 64 <= 40 * 1024, "four blocks per compute unit (160 KB of LDS)");
 
 // rows this kernel takes: every format, any number of joints (a compact batch holds whole plans up to 63 joints and 63 joints of
 // one plan at a time beyond that; a wide batch whole plans up to 28 joints, 28 joints of one plan at a time beyond)
@@ -161,19 +191,18 @@ struct WalkCursor {
 template <typename T, class Slot>
 LTP_DEV void walk_eval_slot(const Slot& W, int nruns, WalkCursor& c, int i0, int sstride, int slen, double Ts, T __attribute__((ext_vector_type(2))) (&o)[4])
 {
-    constexpr int RUNS = (int)(sizeof(Slot::run) / sizeof(double) / kPackedRunWords);
+    constexpr int RUNS = Slot::kRuns;
     const int t0 = i0 * sstride;
     while (c.nxt <= t0) {
         ++c.kr;
         c.cur = c.nxt;
-        c.nxt = c.kr + 1 < nruns ? W.start[c.kr + 1] : 0x7fffffff;
+        c.nxt = c.kr + 1 < nruns ? W.first(c.kr + 1) : 0x7fffffff;
     }
     // sample by sample when a run boundary or the end of the row lies inside the pair (the tail of the last slot is row padding:
     // zero); otherwise one run, its coefficients expanded once
     const bool single = !(t0 + sstride >= c.nxt || i0 + 2 > slen);
     int kh = c.kr, ch = c.cur, nh = c.nxt;
-    RunCoef rc = run_coef<kSemMatlab>((int)(unsigned)__builtin_bit_cast(unsigned long long, W.run[kh][4]), W.run[kh][3], W.run[kh][0], W.run[kh][1],
-                                      W.run[kh][2], W.vsnap, Ts);
+    RunCoef rc = run_coef<kSemMatlab>(W.mode(kh), W.run[kh][3], W.run[kh][0], W.run[kh][1], W.run[kh][2], W.vsnap, Ts);
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         const int i = t0 + h * sstride;
@@ -182,13 +211,12 @@ LTP_DEV void walk_eval_slot(const Slot& W, int nruns, WalkCursor& c, int i0, int
             while (nh <= i) {
                 ++kh;
                 ch = nh;
-                nh = kh + 1 < nruns ? W.start[kh + 1] : 0x7fffffff;
+                nh = kh + 1 < nruns ? W.first(kh + 1) : 0x7fffffff;
                 moved = true;
             }
             if (moved) {
                 const int kk = kh < RUNS ? kh : RUNS - 1;
-                rc = run_coef<kSemMatlab>((int)(unsigned)__builtin_bit_cast(unsigned long long, W.run[kk][4]), W.run[kk][3], W.run[kk][0], W.run[kk][1],
-                                          W.run[kk][2], W.vsnap, Ts);
+                rc = run_coef<kSemMatlab>(W.mode(kk), W.run[kk][3], W.run[kk][0], W.run[kk][1], W.run[kk][2], W.vsnap, Ts);
             }
         }
         const bool pad = i0 + h >= slen;
@@ -250,7 +278,7 @@ LTP_DEV void walk_stream(const WalkBatch& B, const Slot* __restrict__ slots, int
         const int nslots = slen > 0 ? (slen + NF - 1) / NF * (NF / N) : 0;
         const Slot& W = slots[in ? s : 0];
         const int nruns = W.nseg;
-        WalkCursor c = {0, 0, nruns > 1 ? W.start[1] : 0x7fffffff};
+        WalkCursor c = {0, 0, nruns > 1 ? W.first(1) : 0x7fffffff};
         for (int slot = lane & ((1 << lg) - 1); slot < nslots; slot += 1 << lg) {
             V o[4];
             walk_eval_slot<T, Slot>(W, nruns, c, N * slot, sstride, slen, Ts, o);
@@ -286,7 +314,7 @@ LTP_DEV void walk_stream_rows(const WalkBatch& B, int dof, T* __restrict__ out, 
         const int nslots = (slen + NF - 1) / NF * (NF / N);
         const WideSlot& W = B.wslot[s];
         const int nruns = __builtin_amdgcn_readfirstlane(W.nseg);
-        WalkCursor c = {0, 0, nruns > 1 ? W.start[1] : 0x7fffffff};
+        WalkCursor c = {0, 0, nruns > 1 ? W.first(1) : 0x7fffffff};
         for (int wbase = 0; wbase < nslots; wbase += kWalkWindowSlots) {
             const int wend = nslots - wbase < kWalkWindowSlots ? nslots : wbase + kWalkWindowSlots;
             __amdgpu_buffer_rsrc_t rsrc[4];
@@ -317,7 +345,7 @@ struct WalkLaneIn {
 template <int SEM, class Slot>
 LTP_DEV bool walk_lane(Slot& W, const WalkLaneIn& L, long long needed_end, double Ts, double& q_end, bool last_joint)
 {
-    constexpr int RUNS = (int)(sizeof(Slot::run) / sizeof(double) / kPackedRunWords);
+    constexpr int RUNS = Slot::kRuns;
     double q = L.q0, v = L.v0, a = L.a0;
     int runs = 0, last_b = L.len;
     bool too_many = false;
@@ -325,9 +353,7 @@ LTP_DEV bool walk_lane(Slot& W, const WalkLaneIn& L, long long needed_end, doubl
         if ((long long)b < needed_end) {
             if (runs < RUNS) {
                 // q, v, a still hold the state before this run: the walk advances them after the visit
-                W.start[runs] = b;
-                W.run[runs][0] = a; W.run[runs][1] = v; W.run[runs][2] = q; W.run[runs][3] = rc.c[9];
-                W.run[runs][4] = __builtin_bit_cast(double, (unsigned long long)(unsigned)rc.mode);
+                W.put(runs, b, rc.mode, a, v, q, rc.c[9]);
                 ++runs;
             } else {
                 too_many = true;
@@ -341,8 +367,7 @@ LTP_DEV bool walk_lane(Slot& W, const WalkLaneIn& L, long long needed_end, doubl
         return false;                                                            // the walk goes to the last sample: end-limit check
 #endif
     }, last_joint);
-    W.start[runs] = last_b;
-    W.nseg = runs;
+    W.close(runs, last_b);
     W.vsnap = L.R.v_drive * L.R.dir;                                             // as the walk forms it (cc:823)
     q_end = q;
     return too_many;
@@ -503,8 +528,9 @@ LTP_DEV void sample_walk_body(long long first, long long count, int dof, double 
     const unsigned long long total = queue.total;
     const unsigned long long off0 = offsets[first];
     const int sstride = rows.stride > 1 ? rows.stride : 1;
-    const bool long_rows = walk_long_rows(rows);
     const long long needed_end = rows.max_samples > 0 ? (long long)rows.max_samples * sstride : 0x7fffffffffffffffll;   // runs that start at or after this sample are not needed
+    const bool long_rows = walk_long_rows(rows);
+    const bool no_compact = long_rows || needed_end >= kWalkCompactEnd;                          // (a compact slot's starts have 28 bits)
     int seq = 0;
     auto wait_buffer_free = [&]() {
         if (seq < kWalkBuffers) return;
@@ -563,7 +589,7 @@ LTP_DEV void sample_walk_body(long long first, long long count, int dof, double 
             // (beyond kWalkLanes joints a batch is one plan, taken kWalkLanes joints at a time)
             for (int jc = 0; jc < dof; jc += kWalkLanes) {
                 const int jc_end = dof - jc < kWalkLanes ? dof : jc + kWalkLanes;
-                if (!long_rows && build(pb_now, plist, base, np, jc, jc_end - jc, CompactTag{})) continue;
+                if (!no_compact && build(pb_now, plist, base, np, jc, jc_end - jc, CompactTag{})) continue;
                 for (int sub = 0; sub < np; sub += wpb)
                     for (int j0 = jc; j0 < jc_end; j0 += wide_nj) {
                         const int npw = np - sub < wpb ? np - sub : wpb, njw = jc_end - j0 < wide_nj ? jc_end - j0 : wide_nj;
@@ -576,24 +602,31 @@ LTP_DEV void sample_walk_body(long long first, long long count, int dof, double 
 
 // ---------------------------------------------------------------------------------------
 // AUTONOMOUS waves (round 5), for caps of at most kWalkAutoCap samples. The counters (profiles/EXPERIMENTS.md E7.1) showed rows this
-// short bound by the ONE builder wave of a block: the kernel above takes a fixed ~2 ms per 1 M plans at every cap from 4 to 16 samples
-// — 145 batches per builder at ~10 us each (record loads, the walk to the last sample for the end-limit verdict, hand-over) — while
-// its seven streaming waves have next to nothing to write. Here every wave is builder AND writer of its own batches: it draws an item,
-// walks its 63 (plan, joint) lanes into its OWN batch buffer (walk_build, the same function), and streams the batch's rows itself
-// (walk_stream with one streaming wave); no flags, no hand-over, nothing shared between waves but the work queue. Six waves per block
-// (6 x 24.3 KB of LDS: one block per compute unit), i.e. six builders per compute unit instead of three. Rows bit-identical (same
-// functions); plans with more runs inside the cap than a compact slot holds are rebuilt as wide batches by the same wave.
-// Measured (profiles/r05_auto_waves_ab.jsonl, sampler kernel per 1 M plans, against the builder / streaming-wave form — flags bit 7 —
-// on one box, two rounds): first-4 1.42 vs 1.95 ms, first-8 1.45 vs 2.00, first-16 1.81 vs 2.05 (float32: 1.80 vs 2.02), receding
-// horizon through 16-sample rows 1.53 vs 1.89; first-32 2.54 vs 2.24 — a wave that also
-// writes 7 KB of rows per plan no longer hides its stores behind another wave's walk — hence the cap of 16. What remains is the walk
-// itself: ~5000 vector instructions per batch (15 divisions of set-up, ~200 instructions per run, every run to the last sample for the
-// end-limit verdict), i.e. the vector issue rate of the chip (E7.1).
+// short bound by the builder waves: the kernel above takes a fixed ~2 ms per 1 M plans at every cap from 4 to 16 samples (record
+// loads, the walk to the last sample for the end-limit verdict, hand-over) while its streaming waves have next to nothing to write.
+// Here every wave is builder AND writer of its own batches: it draws an item, walks its 63 (plan, joint) lanes into its OWN batch
+// buffer (walk_build, the same function), and streams the batch's rows itself (walk_stream with one streaming wave); no flags, no
+// hand-over, nothing shared between waves but the work queue. Eight waves per block (8 x 19.3 KB of LDS: one block per compute
+// unit, two walks per SIMD — six waves of 24.3 KB until the compact slot shrank, E7.9). Rows bit-identical (same functions); plans
+// with more runs inside the cap than a compact slot holds are rebuilt as wide batches by the same wave.
+// Measured against the builder / streaming-wave form — flags bit 7 — on one box, two rounds (profiles/r05_auto_waves_ab.jsonl: six
+// waves against three builders; profiles/r05_four_blocks_ab.txt: eight waves against four builders, sampler kernel in TB/s):
+// first-4 0.58 vs 0.55 (both forms of E7.9), first-16 2.42 vs 1.84, first-24 2.63 vs 2.49, first-32 3.46 vs 3.25, receding horizon
+// through 32-sample rows 2.68 vs 2.50; first-48 3.40 vs 4.18, first-64 4.36 vs 5.10 — a wave that also writes 10-14 KB of rows per
+// plan no longer hides its stores behind another wave's walk — hence the cap of 32. What remains is the walk itself: ~4 500 vector
+// instructions per batch (15 divisions of set-up, ~150 vector instructions per run, every run to the last sample for the end-limit
+// verdict), i.e. the vector issue rate of the chip (E7.1, E7.6).
 // ---------------------------------------------------------------------------------------
-constexpr int kWalkAutoWaves = 6;
+constexpr int kWalkAutoWaves = 8;
 constexpr int kWalkAutoThreads = kWalkAutoWaves * 64;
-constexpr int kWalkAutoCap = 16;
-__host__ __device__ inline bool walk_auto_rows(RowSpec rows) { return rows.max_samples > 0 && rows.max_samples <= kWalkAutoCap; }
+#ifndef LTP_WALK_AUTO_CAP
+#define LTP_WALK_AUTO_CAP 32
+#endif
+constexpr int kWalkAutoCap = LTP_WALK_AUTO_CAP;
+__host__ __device__ inline bool walk_auto_rows(RowSpec rows)
+{
+    return rows.max_samples > 0 && rows.max_samples <= kWalkAutoCap && (long long)rows.max_samples * (rows.stride > 1 ? rows.stride : 1) < kWalkCompactEnd;
+}
 
 template <bool STREAMING, typename T, int SEM>
 LTP_DEV void sample_walk_auto_body(long long first, long long count, int dof, double t_sample, Limits lim, Queries in, Records rec,
@@ -697,7 +730,7 @@ int sample_walk_resident_blocks(int device, bool f32)
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus <= 0) cus = 256;
     hipError_t e = f32 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_sample_walk_f32_nt, kWalkThreads, 0)
                        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_sample_walk_f64_nt, kWalkThreads, 0);
-    if (e != hipSuccess || per_cu <= 0) per_cu = 3;
+    if (e != hipSuccess || per_cu <= 0) per_cu = 4;
     return cus * per_cu;
 }
 
@@ -740,7 +773,7 @@ bool launch_sample_walk(hipStream_t s, long long first, long long count, int dof
 #undef LTP_WALK_AUTO_CASE
         return true;
     }
-    long long blocks = resident_blocks > 0 ? resident_blocks : 768;
+    long long blocks = resident_blocks > 0 ? resident_blocks : 1024;
     if (blocks > nbatches) blocks = nbatches;
     const dim3 grid((unsigned)blocks), block(kWalkThreads);
 #define LTP_WALK_CASE(K, TY) hipLaunchKernelGGL(K, grid, block, 0, s, first, count, dof, t_sample, lim, in, rec, offsets, (TY*)out, capacity, spread, rows, next_item)

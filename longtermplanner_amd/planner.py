@@ -432,7 +432,7 @@ class LongTermPlanner:
         dry=True is a diagnostic: same stores, no arithmetic (ceiling of the store pattern). tables: None = automatic, True / False =
         force the table pass / the fused build; walk: None = automatic, True / False = force / forbid k_sample_walk_* (run tables built
         inside the sampler's block: by itself for capped, float32 and sparse rows and in MATLAB semantics); auto_waves=False keeps
-        the walk kernel's builder / streaming-wave form also for caps of at most 16 samples (flag bit 7; by itself: k_sample_walk_auto_*)."""
+        the walk kernel's builder / streaming-wave form also for caps of at most 32 samples (flag bit 7; by itself: k_sample_walk_auto_*)."""
         import torch
         rec = batch.c_records()
         fn = self._lib.ltp_sample_batch_f32 if out.dtype == torch.float32 else self._lib.ltp_sample_batch   # float32 tile -> float rows

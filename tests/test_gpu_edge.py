@@ -1270,9 +1270,9 @@ def test_walk_and_table_samplers_against_the_oracle_directly(amd, oracle_mod, li
 
 @pytest.mark.parametrize("limits,dof,n,semantics", [("panda", None, 3000, "cpp"), ("ref", 30, 120, "cpp"), ("ref", 9, 500, "matlab")])
 def test_autonomous_waves_write_the_rows_of_the_builder_form(amd, limits, dof, n, semantics):
-    """Round 5: for caps of at most 16 samples the walk kernel runs as k_sample_walk_auto_* — every wave builds AND writes its own
-    batches (six builders per compute unit instead of three). Same walk_build / walk_stream functions: rows, statuses and lengths are
-    those of the builder / streaming-wave form (flag bit 7) and of the fused sampler / table pass, bit for bit — caps 1-16, strides,
+    """Round 5: for caps of at most 32 samples the walk kernel runs as k_sample_walk_auto_* — every wave builds AND writes its own
+    batches (eight walks per compute unit instead of four). Same walk_build / walk_stream functions: rows, statuses and lengths are
+    those of the builder / streaming-wave form (flag bit 7) and of the fused sampler / table pass, bit for bit — caps 1-33, strides,
     both element types, sub-ranges, small tiles, rejected plans, trajectories that end inside the cap (wide batches)."""
     import torch
     D, lim = amd.limit_set(limits, dof)
@@ -1287,7 +1287,7 @@ def test_autonomous_waves_write_the_rows_of_the_builder_form(amd, limits, dof, n
     qg[short] = torch.minimum(torch.maximum(qg[short], torch.tensor(lim["q_min"], dtype=torch.float64, device=qg.device)),
                               torch.tensor(lim["q_max"], dtype=torch.float64, device=qg.device))
     other = dict(walk=False) if semantics == "matlab" else dict(tables=False, walk=False)
-    for cap, stride, f32 in ((16, 1, False), (1, 1, False), (4, 1, True), (15, 2, False), (16, 3, True), (17, 1, False)):
+    for cap, stride, f32 in ((16, 1, False), (1, 1, False), (4, 1, True), (15, 2, False), (16, 3, True), (17, 1, False), (32, 1, False), (31, 2, True), (33, 1, False)):
         ltp.setMaxSamples(cap); ltp.setSampleStride(stride)
         dt = torch.float32 if f32 else torch.float64
         res = {}
@@ -1296,7 +1296,7 @@ def test_autonomous_waves_write_the_rows_of_the_builder_form(amd, limits, dof, n
             full = torch.full((int(b.offsets[-1].item()),), 3.0, dtype=dt, device="cuda")
             ltp.sampleBatch(b, 0, n, full, **kw)
             kern = ltp.lastSamplerKernel()
-            assert ("auto" in kern) == (mode == "auto" and cap <= 16), (mode, kern, cap)
+            assert ("auto" in kern) == (mode == "auto" and cap <= 32), (mode, kern, cap)
             sub = torch.full((int((b.offsets[n - 2] - b.offsets[13]).item()) + 8,), 3.0, dtype=dt, device="cuda")
             ltp.sampleBatch(b, 13, n - 15, sub, spread=11, **kw)
             b2 = ltp.planSwitchTimesBatch(qg, q0, v0, a0)
