@@ -198,32 +198,29 @@ LTP_DEV void walk_eval_slot(const Slot& W, int nruns, WalkCursor& c, int i0, int
         c.cur = c.nxt;
         c.nxt = c.kr + 1 < nruns ? W.first(c.kr + 1) : 0x7fffffff;
     }
-    // sample by sample when a run boundary or the end of the row lies inside the pair (the tail of the last slot is row padding:
-    // zero); otherwise one run, its coefficients expanded once
-    const bool single = !(t0 + sstride >= c.nxt || i0 + 2 > slen);
+    // first sample: the cursor's run
     int kh = c.kr, ch = c.cur, nh = c.nxt;
     RunCoef rc = run_coef<kSemMatlab>(W.mode(kh), W.run[kh][3], W.run[kh][0], W.run[kh][1], W.run[kh][2], W.vsnap, Ts);
+    double x0[4], x1[4];
+    run_eval(rc.c, t0 - ch + 1, x0[0], x0[1], x0[2], x0[3]);
+    // second sample: the same run unless a boundary lies between the two (its coefficients then replace the first one's)
+    const int i1 = t0 + sstride;
+    if (nh <= i1) {
+        do {
+            ++kh;
+            ch = nh;
+            nh = kh + 1 < nruns ? W.first(kh + 1) : 0x7fffffff;
+        } while (nh <= i1);
+        const int kk = kh < RUNS ? kh : RUNS - 1;
+        rc = run_coef<kSemMatlab>(W.mode(kk), W.run[kk][3], W.run[kk][0], W.run[kk][1], W.run[kk][2], W.vsnap, Ts);
+    }
+    run_eval(rc.c, i1 - ch + 1, x1[0], x1[1], x1[2], x1[3]);
+    // (the tail of the last slot is row padding: zero)
+    const bool pad0 = i0 >= slen, pad1 = i0 + 1 >= slen;
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const int i = t0 + h * sstride;
-        if (!single) {
-            bool moved = false;
-            while (nh <= i) {
-                ++kh;
-                ch = nh;
-                nh = kh + 1 < nruns ? W.first(kh + 1) : 0x7fffffff;
-                moved = true;
-            }
-            if (moved) {
-                const int kk = kh < RUNS ? kh : RUNS - 1;
-                rc = run_coef<kSemMatlab>(W.mode(kk), W.run[kk][3], W.run[kk][0], W.run[kk][1], W.run[kk][2], W.vsnap, Ts);
-            }
-        }
-        const bool pad = i0 + h >= slen;
-        double x4[4];
-        run_eval(rc.c, i - ch + 1, x4[0], x4[1], x4[2], x4[3]);
-#pragma unroll
-        for (int x = 0; x < 4; ++x) o[x][h] = pad ? (T)0 : (T)x4[x];
+    for (int x = 0; x < 4; ++x) {
+        o[x][0] = pad0 ? (T)0 : (T)x0[x];
+        o[x][1] = pad1 ? (T)0 : (T)x1[x];
     }
 }
 

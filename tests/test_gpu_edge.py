@@ -1005,7 +1005,9 @@ def test_walk_sampler_random_configurations_against_the_fused_sampler(amd):
     """A randomized differential test of k_sample_walk_* (the default writer of capped rows) against the fused sampler: 48 random
     combinations of joints (1-63), sample time, cap (1-2500), stride (1-6), element type, batch size, sub-range, block interleave and
     tile size, on random limit sets (fast and slow jerk, i.e. many and few runs inside the cap) with rejected plans and short moves
-    mixed in; every 7th configuration in MATLAB semantics (against the table pass). Rows, statuses and lengths must agree bit for bit."""
+    mixed in; every 7th configuration in MATLAB semantics (against the table pass). Rows, statuses and lengths must agree bit for bit.
+    (Round 5: 2 %, 30 % or 70 % of the plans rejected and dead stretches of several queue items — gathered batches — and caps either
+    side of the autonomous form's and the gathered items' limits.)"""
     import torch
     # (a soak: LTP_WALK_TRIALS=3000 LTP_WALK_SEED=1 python -m pytest tests/test_gpu_edge.py -k random_configurations)
     rng = np.random.default_rng(20260401 + int(os.environ.get("LTP_WALK_SEED", "0")))
@@ -1023,15 +1025,18 @@ def test_walk_sampler_random_configurations_against_the_fused_sampler(amd):
             ltp.setSemantics("matlab")
         n = int(rng.integers(1, 900))
         qg, q0, v0, a0 = (x.clone() for x in ltp.generateQueries(n, seed=1000 + trial))
-        for p in rng.integers(0, n, size=max(1, n // 50)):
+        # rejected plans: a few, a third or most of them (round 5: the walk kernels build their batches from an item's live plans)
+        for p in rng.integers(0, n, size=max(1, int(n * float(rng.choice([0.02, 0.02, 0.3, 0.7]))))):
             q0[int(p), 0] = 99.0
+        if trial % 5 == 2 and n > 120:
+            q0[40:120, 0] = 99.0                                 # a dead stretch of several queue items
         short = torch.as_tensor(rng.integers(0, n, size=max(1, n // 6)), device=qg.device)
         qg[short] = torch.clamp(q0[short] + float(rng.choice([0.01, 0.03, 0.1])) * torch.sign(qg[short] - q0[short] + 1e-9), -99.0, 99.0)
         qg[short] = torch.minimum(torch.maximum(qg[short], torch.tensor(lim["q_min"], dtype=torch.float64, device=qg.device)),
                                   torch.tensor(lim["q_max"], dtype=torch.float64, device=qg.device))
         v0[short] = 0.0
         a0[short] = 0.0
-        cap = int(rng.choice([1, 2, 7, 16, 31, 64, 100, 128, 255, 256, 500, 1024, 1025, 2500]))
+        cap = int(rng.choice([1, 2, 7, 16, 17, 31, 32, 33, 48, 64, 65, 100, 128, 255, 256, 500, 1024, 1025, 2500]))
         stride = int(rng.integers(1, 7))
         f32 = bool(rng.integers(0, 2))
         spread = int(rng.choice([0, 1, 3, 48, 5000]))
