@@ -1292,7 +1292,8 @@ def test_autonomous_waves_write_the_rows_of_the_builder_form(amd, limits, dof, n
     qg[short] = torch.minimum(torch.maximum(qg[short], torch.tensor(lim["q_min"], dtype=torch.float64, device=qg.device)),
                               torch.tensor(lim["q_max"], dtype=torch.float64, device=qg.device))
     other = dict(walk=False) if semantics == "matlab" else dict(tables=False, walk=False)
-    for cap, stride, f32 in ((16, 1, False), (1, 1, False), (4, 1, True), (15, 2, False), (16, 3, True), (17, 1, False), (32, 1, False), (31, 2, True), (33, 1, False)):
+    for cap, stride, f32 in ((16, 1, False), (1, 1, False), (4, 1, True), (15, 2, False), (16, 3, True), (17, 1, False), (32, 1, False), (31, 2, True), (33, 1, False),
+                             (4, 1 << 27, False)):      # cap x stride beyond 2^28: a compact slot's start has 28 bits -> wide batches, builder form
         ltp.setMaxSamples(cap); ltp.setSampleStride(stride)
         dt = torch.float32 if f32 else torch.float64
         res = {}
@@ -1301,7 +1302,7 @@ def test_autonomous_waves_write_the_rows_of_the_builder_form(amd, limits, dof, n
             full = torch.full((int(b.offsets[-1].item()),), 3.0, dtype=dt, device="cuda")
             ltp.sampleBatch(b, 0, n, full, **kw)
             kern = ltp.lastSamplerKernel()
-            assert ("auto" in kern) == (mode == "auto" and cap <= 32), (mode, kern, cap)
+            assert ("auto" in kern) == (mode == "auto" and cap <= 32 and cap * stride < (1 << 28)), (mode, kern, cap)
             sub = torch.full((int((b.offsets[n - 2] - b.offsets[13]).item()) + 8,), 3.0, dtype=dt, device="cuda")
             ltp.sampleBatch(b, 13, n - 15, sub, spread=11, **kw)
             b2 = ltp.planSwitchTimesBatch(qg, q0, v0, a0)
