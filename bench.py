@@ -54,6 +54,8 @@ def workload_key(wl, n):
         parts.append("walk" if wl.walk else "nowalk")
     if wl.auto_waves is False:
         parts.append("builder_form")
+    if not getattr(wl, "row_verdict", True):
+        parts.append("no_row_verdict")
     if wl.table_pass != "auto":
         parts.append(f"tablepass_{wl.table_pass}")
     if wl.semantics != "cpp":
@@ -188,6 +190,7 @@ def parse_args(argv=None):
                     help="where the sampler's run tables are built: by the table pass (a kernel of its own) or inside the sampler kernel (ltp_set_table_pass)")
     ap.add_argument("--no-walk", action="store_true", help="A/B: forbid k_sample_walk_* (the automatic choice for caps <= 768 samples, float32 rows, every 3rd sample or sparser): capped rows of at most 8 KB float64 / 16 KB float32 per joint then take the table pass, the rest the fused k_sample")
     ap.add_argument("--walk", action="store_true", help="A/B: force k_sample_walk_* (also for rows it is not chosen for automatically: whole or long float64 rows at stride 1-2)")
+    ap.add_argument("--no-row-verdict", action="store_true", help="capped rows WITHOUT the end-limit verdict (ltp_sample_batch flags bit 4): the walk kernels stop at the cap; status is then planTrajectory's verdict before its last check (cc:59-61)")
     ap.add_argument("--no-auto-waves", action="store_true", help="A/B: caps of at most 32 samples through the walk kernel's builder / streaming-wave form instead of k_sample_walk_auto_*")
     ap.add_argument("--in-flight", type=int, default=1, help="switching times only: steps alternate between this many planner handles, each on its own stream "
                     "(two batches in flight: the latency-bound queue-B kernel of one step runs under the next step's stages); 1 = one batch at a time")
@@ -287,6 +290,7 @@ class Workload:
         self.table_pass, self.table_gib = args.table_pass, args.table_gib
         self.walk = False if args.no_walk else (True if args.walk else None)
         self.auto_waves = False if args.no_auto_waves else None
+        self.row_verdict = not args.no_row_verdict
         self.end_limit = args.end_limit
         self.in_flight = args.in_flight
         self.semantics = args.semantics
@@ -380,7 +384,7 @@ def run_workload(wl, ctx):
                 if timed:
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record()
-                ltp.sampleBatch(batch, 0, n, tile, streaming=not wl.plain_stores, spread=wl.spread, walk=wl.walk, auto_waves=wl.auto_waves)
+                ltp.sampleBatch(batch, 0, n, tile, streaming=not wl.plain_stores, spread=wl.spread, walk=wl.walk, auto_waves=wl.auto_waves, verdict=wl.row_verdict)
                 if timed:
                     e1.record()
                     ev_pairs.append((e0, e1))
@@ -414,7 +418,7 @@ def run_workload(wl, ctx):
             if timed:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-            ltp.sampleBatch(batch, first, end - first, view, streaming=not wl.plain_stores, dry=wl.dry, spread=wl.spread, walk=wl.walk, auto_waves=wl.auto_waves)
+            ltp.sampleBatch(batch, first, end - first, view, streaming=not wl.plain_stores, dry=wl.dry, spread=wl.spread, walk=wl.walk, auto_waves=wl.auto_waves, verdict=wl.row_verdict)
             if timed:
                 e1.record()
                 ev_pairs.append((e0, e1))
@@ -533,13 +537,14 @@ def run_workload(wl, ctx):
         "config": {
             "workload": ((f"{wl.global_batch} x {dof}-DoF queries per step sharded over {world} GPU(s) ({n} on rank 0)" if wl.global_batch else
                           f"{n} x {dof}-DoF queries per GPU per step") + f", limits '{wl.limits}', Tsample {wl.t_sample} s, "
-                         + (f"{rec_spec[0]} receding-horizon cycles per step on the device (plan, " + ("state at sample" if rec_direct else f"first {wl.max_samples} samples written, replan from the state at stored sample") + f" {rec_spec[1]}" + ("" if rec_direct else ", recomputed from the records") + "); value counts replans; " if rec_spec else "")
+                         + (f"{rec_spec[0]} receding-horizon cycles per step on the device (plan, " + ("state at sample" if rec_direct else f"first {wl.max_samples} samples written" + ("" if wl.row_verdict else " WITHOUT the end-limit verdict (opt-in, flags bit 4)") + ", replan from the state at stored sample") + f" {rec_spec[1]}" + ("" if rec_direct else ", recomputed from the records") + "); value counts replans; " if rec_spec else "")
                          + (("switching times only (stages 1-3" + (" + end-limit check" if wl.end_limit else "; status = pre-sampling verdict") + ", no rows)"
                              + (f"; {wl.in_flight} batches in flight (steps alternate between {wl.in_flight} handles and streams)" if wl.in_flight > 1 else "")) if wl.switch_only else
                             "no rows stored (ltp_state_at_batch)" if rec_direct else
                             f"on-device envelope consumer ({'analytic: the candidates of each run' if wl.envelope_analytic else 'every sample'}): [min q, max q] over {env_spec[1]} windows of {env_spec[0]} samples per joint, no dense rows" if env_spec else
                             ("full q/v/a/j sampling" if not (wl.max_samples or wl.sample_stride > 1) else
-                             f"q/v/a/j rows: every {wl.sample_stride}-th sample" + (f", first {wl.max_samples} stored" if wl.max_samples else ""))
+                             f"q/v/a/j rows: every {wl.sample_stride}-th sample" + (f", first {wl.max_samples} stored" if wl.max_samples else "")
+                             + ("" if wl.row_verdict or not wl.max_samples else " (OPT-IN: the sampler does not form the end-limit verdict cc:59-61, ltp_sample_batch flags bit 4)"))
                             + f" into a reused {tile_gib} GiB tile ({n_chunks} chunks per step)")),
             "batch_per_gpu": n if not wl.global_batch else None, "global_batch": total_queries, "dof": dof, "t_sample": wl.t_sample,
             "workload_key": key, "limits": wl.limits, "input_layout": wl.layout, "table_pass": wl.table_pass, "batches_in_flight": wl.in_flight, "semantics": wl.semantics, "pow_rule": wl.pow_rule,
@@ -689,7 +694,7 @@ def main():
             print(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE {world} rank(s)", file=sys.stderr)
         return 2
 
-    variant = (args.no_walk or args.walk or args.no_auto_waves or args.switch_only or args.end_limit or args.f32 or args.max_samples or args.sample_stride > 1 or args.envelope or args.receding or args.dry_sampler
+    variant = (args.no_walk or args.walk or args.no_auto_waves or args.no_row_verdict or args.switch_only or args.end_limit or args.f32 or args.max_samples or args.sample_stride > 1 or args.envelope or args.receding or args.dry_sampler
                or args.in_flight > 1 or args.semantics != "cpp" or args.pow_rule != "libm" or args.table_pass != "auto" or args.limits != "panda" or args.batch != 1_000_000 or args.global_batch or args.window_gib or args.layout != "query_major")
     rccl_world1 = None
     if not grouped and not variant and not args.no_secondary and not args.no_rccl_check and args.backend == "nccl":

@@ -222,7 +222,10 @@ int ltp_end_limit_batch(ltp_planner* p, long long first, long long count, const 
  * flags: bit 0 = non-temporal stores (recommended); bit 1 = diagnostic dry run (stores without arithmetic);
  * bit 2 = force the table pass (k_build_tables + k_sample_tab_*: kept as the sampler that reads the packed run tables of
  * include/ltp_run_tables.hpp; the library takes it by itself only where bit 5 has forbidden the walk kernel for capped rows of at most
- * 8 KB / 16 KB per joint, and in MATLAB semantics with the walk kernel forbidden), bit 3 = force the fused table build; bit 4 = reserved;
+ * 8 KB / 16 KB per joint, and in MATLAB semantics with the walk kernel forbidden), bit 3 = force the fused table build; bit 4 = the caller does
+ * not need the end-limit verdict (cc:59-61) from THIS call: for capped rows (ltp_set_max_samples) the walk kernels then stop at the cap
+ * instead of walking every joint to its last sample, and LTP_STATUS_END_LIMIT is left unspecified by the call (it is formed by
+ * ltp_plan_switch_times_batch with end_limit = 1 / ltp_end_limit_batch, or by a call without this bit; rows are the same);
  * bit 5 = never k_sample_walk_* (rows under a cap of <= 768 samples, float32 rows, rows of every 3rd sample or sparser, and every
  * row format in MATLAB semantics take it by themselves: the run tables then stay in the compute unit, no table pass at all; same
  * rows), bit 6 = force it (any row format); bit 7 = keep its builder / streaming-wave form also for caps of at most 32 samples, which

@@ -91,7 +91,11 @@ static int sample_batch_any(ltp_planner* p, long long first, long long count, co
         const bool autonomous = ltp::launch_sample_walk(s, first, count, p->dof, p->t_sample, dev_limits(p), to_dev(in), to_dev(rec), offsets, out, f32, capacity, flags, rows, head,
                                 p->sample_blocks_override > 0 ? p->sample_blocks_override : p->walk_blocks[f32 ? 1 : 0], matlab ? ltp::kSemMatlab : ltp::kSemCpp);
         LTP_HIP_TRY(p, hipGetLastError());
-        if (autonomous)     // caps of at most 32 samples: every wave builds and writes its own batches (ltp_sampler_walk.hip)
+        const bool nv = !matlab && (flags & 16) && rows.max_samples > 0;     // flags bit 4: capped rows without the end-limit verdict
+        if (nv)
+            p->last_kernel = autonomous ? (f32 ? ((flags & 1) ? "k_sample_walk_auto_f32_nt_nv" : "k_sample_walk_auto_f32_nv") : ((flags & 1) ? "k_sample_walk_auto_f64_nt_nv" : "k_sample_walk_auto_f64_nv"))
+                                        : (f32 ? ((flags & 1) ? "k_sample_walk_f32_nt_nv" : "k_sample_walk_f32_nv") : ((flags & 1) ? "k_sample_walk_f64_nt_nv" : "k_sample_walk_f64_nv"));
+        else if (autonomous)     // caps of at most 32 samples: every wave builds and writes its own batches (ltp_sampler_walk.hip)
             p->last_kernel = matlab ? (f32 ? ((flags & 1) ? "k_sample_walk_matlab_auto_f32_nt" : "k_sample_walk_matlab_auto_f32") : ((flags & 1) ? "k_sample_walk_matlab_auto_f64_nt" : "k_sample_walk_matlab_auto_f64"))
                                     : (f32 ? ((flags & 1) ? "k_sample_walk_auto_f32_nt" : "k_sample_walk_auto_f32") : ((flags & 1) ? "k_sample_walk_auto_f64_nt" : "k_sample_walk_auto_f64"));
         else

@@ -338,9 +338,11 @@ struct WalkLaneIn {
 };
 
 // The walk of one lane into its slot of the batch under construction. Returns true if the lane has more runs inside the cap than
-// the slot holds (compact batches only: the batch is then rebuilt wide). q_end receives the last trajectory sample (cc:59-61).
+// the slot holds (compact batches only: the batch is then rebuilt wide). q_end receives the last trajectory sample (cc:59-61) —
+// unless stop_at_cap: the walk then ends at the first run that is not needed (no end-limit verdict: LTPlanner.m has none, and a
+// caller of the C++ semantics may ask for rows without it, ltp_sample_batch flags bit 4).
 template <int SEM, class Slot>
-LTP_DEV bool walk_lane(Slot& W, const WalkLaneIn& L, long long needed_end, double Ts, double& q_end, bool last_joint)
+LTP_DEV bool walk_lane(Slot& W, const WalkLaneIn& L, long long needed_end, bool stop_at_cap, double Ts, double& q_end, bool last_joint)
 {
     constexpr int RUNS = Slot::kRuns;
     double q = L.q0, v = L.v0, a = L.a0;
@@ -358,11 +360,7 @@ LTP_DEV bool walk_lane(Slot& W, const WalkLaneIn& L, long long needed_end, doubl
         } else if (last_b == L.len) {
             last_b = b;                                                          // first run that is not needed: it ends the last stored one
         }
-#ifdef LTP_EXP_SKIP_TAIL
-        return (long long)b >= needed_end;                                       // EXPERIMENT ONLY (never built into the product): no end-limit walk
-#else
-        return false;                                                            // the walk goes to the last sample: end-limit check
-#endif
+        return stop_at_cap && (long long)b >= needed_end;                        // otherwise the walk goes to the last sample: end-limit check
     }, last_joint);
     W.close(runs, last_b);
     W.vsnap = L.R.v_drive * L.R.dir;                                             // as the walk forms it (cc:823)
@@ -409,7 +407,7 @@ LTP_DEV int walk_item_plans(const WalkCtx& c, int len, int np_item, int& nlive)
 // (compact: the first kWalkRuns runs inside the cap; WIDE: every run), the end-limit verdict (cc:59-61) and the tile-capacity rule, the
 // plan-level header. The calling wave owns B. Returns false without a valid header if a compact batch does not do: a lane has more
 // runs inside the cap than a slot holds, or a plan lies wholly inside the cap (nearly always more than kWalkRuns runs: wide at once).
-template <int SEM, bool WIDE>
+template <int SEM, bool WIDE, bool STOP>
 LTP_DEV bool walk_build(const WalkCtx& c, WalkBatch& B, long long pb, int plist, int base, int np, int j0, int nj)
 {
     const int lane = c.lane;
@@ -443,9 +441,9 @@ LTP_DEV bool walk_build(const WalkCtx& c, WalkBatch& B, long long pb, int plist,
     bool too_many = false;
     if (slen > 0) {
         double q_end;
-        if constexpr (WIDE) too_many = walk_lane<SEM>(B.wslot[lane], L, c.needed_end, c.t_sample, q_end, j0 + jl == c.dof - 1);
-        else too_many = walk_lane<SEM>(B.slot[lane], L, c.needed_end, c.t_sample, q_end, j0 + jl == c.dof - 1);
-        if constexpr (SEM == kSemCpp) {                                                      // (LTPlanner.m has no position limits)
+        if constexpr (WIDE) too_many = walk_lane<SEM>(B.wslot[lane], L, c.needed_end, STOP, c.t_sample, q_end, j0 + jl == c.dof - 1);
+        else too_many = walk_lane<SEM>(B.slot[lane], L, c.needed_end, STOP, c.t_sample, q_end, j0 + jl == c.dof - 1);
+        if constexpr (SEM == kSemCpp && !STOP) {                                             // (LTPlanner.m has no position limits)
             if (q_end < L.q_min || q_end > L.q_max) atomicOr(&c.rec.status[p], kStatusEndLimit);   // cc:59-61: the last sample
         }
     }
@@ -485,11 +483,12 @@ LTP_DEV bool walk_build(const WalkCtx& c, WalkBatch& B, long long pb, int plist,
     return true;
 }
 
-template <bool STREAMING, typename T, int SEM>
+template <bool STREAMING, typename T, int SEM, bool NV>
 LTP_DEV void sample_walk_body(long long first, long long count, int dof, double t_sample, Limits lim, Queries in, Records rec,
                               const unsigned long long* __restrict__ offsets, T* __restrict__ out, unsigned long long capacity, int spread, RowSpec rows,
                               unsigned long long* __restrict__ next_item)
 {
+    constexpr bool STOP = NV || SEM == kSemMatlab;             // the walk ends at the cap: no end-limit verdict from this launch
     __shared__ WalkBatch buf[kWalkBuffers];
     __shared__ int s_ready[kWalkBuffers];
     __shared__ int s_consumed[kWalkStreamWaves];
@@ -551,7 +550,7 @@ LTP_DEV void sample_walk_body(long long first, long long count, int dof, double 
     auto build = [&](long long pb, int plist, int base, int np, int j0, int nj, auto wide_tag) -> bool {
         constexpr bool WIDE = decltype(wide_tag)::value;
         wait_buffer_free();
-        if (!walk_build<SEM, WIDE>(ctx, buf[seq % kWalkBuffers], pb, plist, base, np, j0, nj)) return false;
+        if (!walk_build<SEM, WIDE, STOP>(ctx, buf[seq % kWalkBuffers], pb, plist, base, np, j0, nj)) return false;
         // publish: everything above is LDS traffic of this one wave, in order
         __hip_atomic_store(&s_ready[seq % kWalkBuffers], seq + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         ++seq;
@@ -625,11 +624,12 @@ __host__ __device__ inline bool walk_auto_rows(RowSpec rows)
     return rows.max_samples > 0 && rows.max_samples <= kWalkAutoCap && (long long)rows.max_samples * (rows.stride > 1 ? rows.stride : 1) < kWalkCompactEnd;
 }
 
-template <bool STREAMING, typename T, int SEM>
+template <bool STREAMING, typename T, int SEM, bool NV>
 LTP_DEV void sample_walk_auto_body(long long first, long long count, int dof, double t_sample, Limits lim, Queries in, Records rec,
                                    const unsigned long long* __restrict__ offsets, T* __restrict__ out, unsigned long long capacity, int spread, RowSpec rows,
                                    unsigned long long* __restrict__ next_item)
 {
+    constexpr bool STOP = NV || SEM == kSemMatlab;
     extern __shared__ __attribute__((aligned(16))) unsigned char ltp_walk_auto_lds[];           // kWalkAutoWaves batch buffers (dynamic: beyond 64 KB)
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = (int)(threadIdx.x & 63);
@@ -673,11 +673,11 @@ LTP_DEV void sample_walk_auto_body(long long first, long long count, int dof, do
             const int np = nlive - base < ppb ? nlive - base : ppb;
             for (int jc = 0; jc < dof; jc += kWalkLanes) {
                 const int jc_end = dof - jc < kWalkLanes ? dof : jc + kWalkLanes;
-                if (walk_build<SEM, false>(ctx, B, pb_now, plist, base, np, jc, jc_end - jc)) { stream(false); continue; }
+                if (walk_build<SEM, false, STOP>(ctx, B, pb_now, plist, base, np, jc, jc_end - jc)) { stream(false); continue; }
                 for (int sub = 0; sub < np; sub += wpb)
                     for (int j0 = jc; j0 < jc_end; j0 += wide_nj) {
                         const int npw = np - sub < wpb ? np - sub : wpb, njw = jc_end - j0 < wide_nj ? jc_end - j0 : wide_nj;
-                        (void)walk_build<SEM, true>(ctx, B, pb_now, plist, base + sub, npw, j0, njw);
+                        (void)walk_build<SEM, true, STOP>(ctx, B, pb_now, plist, base + sub, npw, j0, njw);
                         stream(true);
                     }
             }
@@ -685,40 +685,48 @@ LTP_DEV void sample_walk_auto_body(long long first, long long count, int dof, do
     }
 }
 
-#define LTP_WALK_AUTO_KERNEL(NAME, ST, TY, SEM)                                                                                     \
+#define LTP_WALK_AUTO_KERNEL(NAME, ST, TY, SEM, NV)                                                                                     \
     __global__ void __launch_bounds__(kWalkAutoThreads)                                                                               \
     NAME(long long first, long long count, int dof, double t_sample, Limits lim, Queries in, Records rec,                             \
          const unsigned long long* __restrict__ offsets, TY* __restrict__ out, unsigned long long capacity, int spread, RowSpec rows, \
          unsigned long long* __restrict__ next_item)                                                                                  \
     {                                                                                                                                 \
-        sample_walk_auto_body<ST, TY, SEM>(first, count, dof, t_sample, lim, in, rec, offsets, out, capacity, spread, rows, next_item);    \
+        sample_walk_auto_body<ST, TY, SEM, NV>(first, count, dof, t_sample, lim, in, rec, offsets, out, capacity, spread, rows, next_item); \
     }
-LTP_WALK_AUTO_KERNEL(k_sample_walk_auto_f64, false, double, kSemCpp)
-LTP_WALK_AUTO_KERNEL(k_sample_walk_auto_f64_nt, true, double, kSemCpp)
-LTP_WALK_AUTO_KERNEL(k_sample_walk_auto_f32, false, float, kSemCpp)
-LTP_WALK_AUTO_KERNEL(k_sample_walk_auto_f32_nt, true, float, kSemCpp)
-LTP_WALK_AUTO_KERNEL(k_sample_walk_matlab_auto_f64, false, double, kSemMatlab)
-LTP_WALK_AUTO_KERNEL(k_sample_walk_matlab_auto_f64_nt, true, double, kSemMatlab)
-LTP_WALK_AUTO_KERNEL(k_sample_walk_matlab_auto_f32, false, float, kSemMatlab)
-LTP_WALK_AUTO_KERNEL(k_sample_walk_matlab_auto_f32_nt, true, float, kSemMatlab)
+LTP_WALK_AUTO_KERNEL(k_sample_walk_auto_f64, false, double, kSemCpp, false)
+LTP_WALK_AUTO_KERNEL(k_sample_walk_auto_f64_nv, false, double, kSemCpp, true)      // flags bit 4: no end-limit verdict, the walk stops at the cap
+LTP_WALK_AUTO_KERNEL(k_sample_walk_auto_f64_nt, true, double, kSemCpp, false)
+LTP_WALK_AUTO_KERNEL(k_sample_walk_auto_f64_nt_nv, true, double, kSemCpp, true)      // flags bit 4: no end-limit verdict, the walk stops at the cap
+LTP_WALK_AUTO_KERNEL(k_sample_walk_auto_f32, false, float, kSemCpp, false)
+LTP_WALK_AUTO_KERNEL(k_sample_walk_auto_f32_nv, false, float, kSemCpp, true)      // flags bit 4: no end-limit verdict, the walk stops at the cap
+LTP_WALK_AUTO_KERNEL(k_sample_walk_auto_f32_nt, true, float, kSemCpp, false)
+LTP_WALK_AUTO_KERNEL(k_sample_walk_auto_f32_nt_nv, true, float, kSemCpp, true)      // flags bit 4: no end-limit verdict, the walk stops at the cap
+LTP_WALK_AUTO_KERNEL(k_sample_walk_matlab_auto_f64, false, double, kSemMatlab, false)
+LTP_WALK_AUTO_KERNEL(k_sample_walk_matlab_auto_f64_nt, true, double, kSemMatlab, false)
+LTP_WALK_AUTO_KERNEL(k_sample_walk_matlab_auto_f32, false, float, kSemMatlab, false)
+LTP_WALK_AUTO_KERNEL(k_sample_walk_matlab_auto_f32_nt, true, float, kSemMatlab, false)
 #undef LTP_WALK_AUTO_KERNEL
 
-#define LTP_WALK_KERNEL(NAME, ST, TY, SEM)                                                                                          \
+#define LTP_WALK_KERNEL(NAME, ST, TY, SEM, NV)                                                                                          \
     __global__ void __launch_bounds__(kWalkThreads) __attribute__((amdgpu_waves_per_eu(6, 8)))                                    \
     NAME(long long first, long long count, int dof, double t_sample, Limits lim, Queries in, Records rec,                             \
          const unsigned long long* __restrict__ offsets, TY* __restrict__ out, unsigned long long capacity, int spread, RowSpec rows, \
          unsigned long long* __restrict__ next_item)                                                                                  \
     {                                                                                                                                 \
-        sample_walk_body<ST, TY, SEM>(first, count, dof, t_sample, lim, in, rec, offsets, out, capacity, spread, rows, next_item);         \
+        sample_walk_body<ST, TY, SEM, NV>(first, count, dof, t_sample, lim, in, rec, offsets, out, capacity, spread, rows, next_item);     \
     }
-LTP_WALK_KERNEL(k_sample_walk_f64, false, double, kSemCpp)
-LTP_WALK_KERNEL(k_sample_walk_f64_nt, true, double, kSemCpp)
-LTP_WALK_KERNEL(k_sample_walk_f32, false, float, kSemCpp)
-LTP_WALK_KERNEL(k_sample_walk_f32_nt, true, float, kSemCpp)
-LTP_WALK_KERNEL(k_sample_walk_matlab_f64, false, double, kSemMatlab)      // LTPlanner.m's sampler (ltp_runs.hpp): same batches, same streaming
-LTP_WALK_KERNEL(k_sample_walk_matlab_f64_nt, true, double, kSemMatlab)
-LTP_WALK_KERNEL(k_sample_walk_matlab_f32, false, float, kSemMatlab)
-LTP_WALK_KERNEL(k_sample_walk_matlab_f32_nt, true, float, kSemMatlab)
+LTP_WALK_KERNEL(k_sample_walk_f64, false, double, kSemCpp, false)
+LTP_WALK_KERNEL(k_sample_walk_f64_nv, false, double, kSemCpp, true)      // flags bit 4: no end-limit verdict, the walk stops at the cap
+LTP_WALK_KERNEL(k_sample_walk_f64_nt, true, double, kSemCpp, false)
+LTP_WALK_KERNEL(k_sample_walk_f64_nt_nv, true, double, kSemCpp, true)      // flags bit 4: no end-limit verdict, the walk stops at the cap
+LTP_WALK_KERNEL(k_sample_walk_f32, false, float, kSemCpp, false)
+LTP_WALK_KERNEL(k_sample_walk_f32_nv, false, float, kSemCpp, true)      // flags bit 4: no end-limit verdict, the walk stops at the cap
+LTP_WALK_KERNEL(k_sample_walk_f32_nt, true, float, kSemCpp, false)
+LTP_WALK_KERNEL(k_sample_walk_f32_nt_nv, true, float, kSemCpp, true)      // flags bit 4: no end-limit verdict, the walk stops at the cap
+LTP_WALK_KERNEL(k_sample_walk_matlab_f64, false, double, kSemMatlab, false)      // LTPlanner.m's sampler (ltp_runs.hpp): same batches, same streaming
+LTP_WALK_KERNEL(k_sample_walk_matlab_f64_nt, true, double, kSemMatlab, false)
+LTP_WALK_KERNEL(k_sample_walk_matlab_f32, false, float, kSemMatlab, false)
+LTP_WALK_KERNEL(k_sample_walk_matlab_f32_nt, true, float, kSemMatlab, false)
 #undef LTP_WALK_KERNEL
 
 int sample_walk_resident_blocks(int device, bool f32)
@@ -736,6 +744,8 @@ bool launch_sample_walk(hipStream_t s, long long first, long long count, int dof
                         unsigned long long* next_item, int resident_blocks, int semantics)
 {
     if (count <= 0) return false;
+    // flags bit 4: capped rows without the end-limit verdict — the walk stops at the cap (uncapped rows reach the last sample anyway)
+    const int no_verdict = ((flags & 16) && rows.max_samples > 0) ? 1 : 0;
     int spread = (flags >> 8) & 0xFFFF;
     if (spread == 0) spread = kSampleSpread;
     const long long nbatches = walk_queue(count, dof, rows, 1).items;                 // queue items
@@ -757,7 +767,11 @@ bool launch_sample_walk(hipStream_t s, long long first, long long count, int dof
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(K), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                \
         hipLaunchKernelGGL(K, agrid, ablock, lds, s, first, count, dof, t_sample, lim, in, rec, offsets, (TY*)out, capacity, spread, rows, next_item); \
     } while (0)
-        switch ((flags & 1) | (f32 ? 2 : 0) | (semantics == kSemMatlab ? 4 : 0)) {
+        switch ((flags & 1) | (f32 ? 2 : 0) | (semantics == kSemMatlab ? 4 : (no_verdict ? 8 : 0))) {
+        case 8: LTP_WALK_AUTO_CASE(k_sample_walk_auto_f64_nv, double); break;
+        case 9: LTP_WALK_AUTO_CASE(k_sample_walk_auto_f64_nt_nv, double); break;
+        case 10: LTP_WALK_AUTO_CASE(k_sample_walk_auto_f32_nv, float); break;
+        case 11: LTP_WALK_AUTO_CASE(k_sample_walk_auto_f32_nt_nv, float); break;
         case 0: LTP_WALK_AUTO_CASE(k_sample_walk_auto_f64, double); break;
         case 1: LTP_WALK_AUTO_CASE(k_sample_walk_auto_f64_nt, double); break;
         case 2: LTP_WALK_AUTO_CASE(k_sample_walk_auto_f32, float); break;
@@ -774,7 +788,11 @@ bool launch_sample_walk(hipStream_t s, long long first, long long count, int dof
     if (blocks > nbatches) blocks = nbatches;
     const dim3 grid((unsigned)blocks), block(kWalkThreads);
 #define LTP_WALK_CASE(K, TY) hipLaunchKernelGGL(K, grid, block, 0, s, first, count, dof, t_sample, lim, in, rec, offsets, (TY*)out, capacity, spread, rows, next_item)
-    switch ((flags & 1) | (f32 ? 2 : 0) | (semantics == kSemMatlab ? 4 : 0)) {
+    switch ((flags & 1) | (f32 ? 2 : 0) | (semantics == kSemMatlab ? 4 : (no_verdict ? 8 : 0))) {
+    case 8: LTP_WALK_CASE(k_sample_walk_f64_nv, double); break;
+    case 9: LTP_WALK_CASE(k_sample_walk_f64_nt_nv, double); break;
+    case 10: LTP_WALK_CASE(k_sample_walk_f32_nv, float); break;
+    case 11: LTP_WALK_CASE(k_sample_walk_f32_nt_nv, float); break;
     case 0: LTP_WALK_CASE(k_sample_walk_f64, double); break;
     case 1: LTP_WALK_CASE(k_sample_walk_f64_nt, double); break;
     case 2: LTP_WALK_CASE(k_sample_walk_f32, float); break;

@@ -427,19 +427,21 @@ class LongTermPlanner:
         rec = batch.c_records()
         self._check(self._lib.ltp_end_limit_batch(self._h, first, count, C.byref(batch.queries), C.byref(rec), self._stream()))
 
-    def sampleBatch(self, batch: DeviceBatch, first, count, out, streaming=True, dry=False, spread=0, tables=None, walk=None, auto_waves=None):
+    def sampleBatch(self, batch: DeviceBatch, first, count, out, streaming=True, dry=False, spread=0, tables=None, walk=None, auto_waves=None, verdict=True):
         """getTrajectory for plans [first, first+count) into the float64 CUDA tensor `out` (ltp_sample_batch).
         dry=True is a diagnostic: same stores, no arithmetic (ceiling of the store pattern). tables: None = automatic, True / False =
         force the table pass / the fused build; walk: None = automatic, True / False = force / forbid k_sample_walk_* (run tables built
         inside the sampler's block: by itself for capped, float32 and sparse rows and in MATLAB semantics); auto_waves=False keeps
-        the walk kernel's builder / streaming-wave form also for caps of at most 32 samples (flag bit 7; by itself: k_sample_walk_auto_*)."""
+        the walk kernel's builder / streaming-wave form also for caps of at most 32 samples (flag bit 7; by itself: k_sample_walk_auto_*);
+        verdict=False (flag bit 4): capped rows without the end-limit verdict — the walk kernels stop at the cap, STATUS_END_LIMIT is then
+        not formed by this call (same rows)."""
         import torch
         rec = batch.c_records()
         fn = self._lib.ltp_sample_batch_f32 if out.dtype == torch.float32 else self._lib.ltp_sample_batch   # float32 tile -> float rows
         assert out.dtype in (torch.float32, torch.float64)
         self._check(fn(self._h, first, count, C.byref(batch.queries), C.byref(rec), batch.offsets.data_ptr(),
                        out.data_ptr(), out.numel(), (1 if streaming else 0) | (2 if dry else 0) | (int(spread) << 8)
-                       | (0 if tables is None else (4 if tables else 8)) | (0 if walk is None else (64 if walk else 32)) | (128 if auto_waves is False else 0), self._stream()))
+                       | (0 if tables is None else (4 if tables else 8)) | (0 if walk is None else (64 if walk else 32)) | (128 if auto_waves is False else 0) | (0 if verdict else 16), self._stream()))
 
     def envelopeBatch(self, batch: DeviceBatch, first, count, window, n_windows, out=None):
         """NEW (on-device consumer): [count, dof, n_windows, 2] = min / max of q over windows of `window`

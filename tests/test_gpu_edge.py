@@ -1362,3 +1362,34 @@ def test_walk_sampler_gathers_the_live_plans_of_an_item(amd, limits, dof, n, sem
             for k, (got, want) in enumerate(zip(res[mode], res["other"])):
                 assert torch.equal(got, want), (cap, stride, f32, mode, k)
         assert (res["other"][5] & 32).any(), "the small tile did not leave any plan out"
+
+
+@pytest.mark.gpu
+def test_capped_rows_without_the_end_limit_verdict(amd, ref7):
+    """Round 5: ltp_sample_batch flags bit 4 (sampleBatch(verdict=False)) — capped rows whose caller does not need cc:59-61's verdict
+    from this call: the walk kernels stop at the cap. Rows, lengths and every other status bit are those of the default call, the
+    END_LIMIT bit stays clear; the verdict is still available from planSwitchTimesBatch(end_limit=True). Both kernel forms, float32."""
+    import torch
+    D, lim, _, _ = ref7
+    ltp = amd.LongTermPlanner(D, 0.004, device=0, **lim)       # 4 ms: ~0.5 % of random plans overshoot a joint limit
+    n = 20000
+    qg, q0, v0, a0 = (x.clone() for x in ltp.generateQueries(n, seed=77))
+    v0[5, 0] = 99.0
+    for cap, f32, kw in ((64, False, {}), (16, False, {}), (16, True, dict(auto_waves=False)), (200, False, {})):
+        ltp.setMaxSamples(cap)
+        dt = torch.float32 if f32 else torch.float64
+        b = ltp.planSwitchTimesBatch(qg, q0, v0, a0)
+        full = torch.full((int(b.offsets[-1].item()) + 8,), 3.0, dtype=dt, device="cuda")
+        ltp.sampleBatch(b, 0, n, full, walk=True, **kw)
+        st = b.status.clone()
+        assert int(((st & amd.STATUS_END_LIMIT) != 0).sum().item()) >= 3
+        b2 = ltp.planSwitchTimesBatch(qg, q0, v0, a0)
+        rows = torch.full_like(full, 3.0)
+        ltp.sampleBatch(b2, 0, n, rows, walk=True, verdict=False, **kw)
+        torch.cuda.synchronize()
+        assert torch.equal(rows, full), (cap, f32)
+        assert torch.equal(b2.traj_len, b.traj_len)
+        assert torch.equal(b2.status, st & ~amd.STATUS_END_LIMIT), (cap, f32)
+        b3 = ltp.planSwitchTimesBatch(qg, q0, v0, a0, end_limit=True)
+        torch.cuda.synchronize()
+        assert torch.equal(b3.status, st)
