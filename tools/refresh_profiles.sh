@@ -20,6 +20,7 @@ for a in "--limits ref" "--limits ref30 --batch 200000" "--switch-only --batch 1
          "--max-samples 64" "--max-samples 64 --no-walk" "--max-samples 32" "--max-samples 32 --no-walk" \
          "--max-samples 16" "--max-samples 16 --no-walk" "--max-samples 16 --no-auto-waves" "--max-samples 32 --no-auto-waves" "--max-samples 4" \
          "--receding 10:100 --max-samples 32" "--receding 10:100 --max-samples 16" \
+         "--max-samples 16 --no-row-verdict" "--max-samples 32 --no-row-verdict" "--receding 10:100 --max-samples 32 --no-row-verdict" "--semantics matlab --max-samples 32" \
          "--f32 --max-samples 128" "--f32 --max-samples 128 --no-walk" \
          "--receding 10:100 --max-samples 64" "--receding 10:100 --max-samples 64 --no-walk" "--sample-stride 4" "--sample-stride 4 --no-walk" "--sample-stride 3" \
          "--sample-stride 2" "--max-samples 512" "--max-samples 512 --no-walk" "--f32" "--f32 --no-walk" "--f32 --sample-stride 4" "--f32 --sample-stride 4 --no-walk" "--f32 --limits ref" \
