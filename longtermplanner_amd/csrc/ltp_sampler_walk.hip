@@ -4,9 +4,9 @@
 //
 // The table pass (k_build_tables + k_sample_tab*) pays a round trip through HBM per plan — 3 KB of packed tables written, 3.4 KB of
 // lines read back — and the reads cost the write stream more than their bytes: that mixed pattern tops out at 5.3-5.6 TB/s of total
-// traffic against 7.07 TB/s for pure row writes (profiles/EXPERIMENTS.md E6.3). Here one persistent block of 8 waves keeps the
-// tables in LDS:
-//   * the BUILDER wave (the last one) walks the runs of up to 63 (plan, joint) lanes at a time — a batch of consecutive plans — with
+// traffic against 7.07 TB/s for pure row writes (profiles/EXPERIMENTS.md E6.3). Here one persistent block of 6 waves (four such blocks per
+// compute unit; 8 waves and three blocks until the compact slot shrank in round 5) keeps the tables in LDS:
+//   * the BUILDER wave (the last one) walks the runs of up to 63 (plan, joint) lanes at a time — a batch of plans — with
 //     for_each_run (ltp_runs.hpp: the register walk of k_build_tables / k_state_at), leaves per lane the state before each of the
 //     first kWalkRuns runs that start inside the row cap in one of two LDS batch buffers, applies the end-limit check (cc:59-61) and
 //     the capacity rule, and publishes the batch;
@@ -20,7 +20,7 @@
 // of a walk — the first kWalkRuns = 8 runs per lane); when one of its lanes has more runs inside the cap —
 // a few per million of random queries, up to 4 % of the plans (a third of the batches) in the later cycles of a receding-horizon
 // loop, tools/wide_batch_fraction.py —
-// the builder rebuilds the same plans as WIDE batches (4 plans, all 20 runs per lane; beyond 28 joints: 28 joints of one plan at a
+// the builder rebuilds the same plans as WIDE batches (3 plans, all 20 runs per lane; beyond 21 joints: 21 joints of one plan at a
 // time) in the same buffers. LONG rows (no cap, or a cap beyond 1024 samples) are wide batches from the start and are streamed one
 // row per wave pass (walk_stream_rows). Rows are bit-identical
 // to every other sampler's: same run walk, same run_coef / run_eval (include/ltp_run_tables.hpp).
