@@ -781,6 +781,10 @@ def main():
                  dict(limits="ref30", steps=few, warmup=1)),
                 ("first 256 samples of every row (SURVEY §8(f).2): k_sample_walk, run tables kept in the compute unit",
                  dict(max_samples=256, steps=max(args.steps, 5), warmup=1)),
+                ("first 32 samples of every row: k_sample_walk_auto (caps of at most 32 samples: every wave builds AND writes its own batches; issue-bound, DESIGN.md §4 'Short rows')",
+                 dict(max_samples=32, steps=max(args.steps, 5), warmup=1)),
+                ("receding horizon, 10 cycles per step, 64-sample rows WRITTEN every cycle (from the second cycle on a third of the random restarts are rejected: batches are made of the live plans)",
+                 dict(receding="10:100", max_samples=64, steps=few, warmup=1)),
                 ("receding horizon (SURVEY §8(f).1): 10 cycles per step, 128-sample rows WRITTEN every cycle, restart states = stored sample 100 RECOMPUTED from the records (the rows are not read back)",
                  dict(receding="10:100", max_samples=128, steps=few, warmup=1)),
                 ("every 4th sample of every row (SURVEY §8(f).2, strided rows): k_sample_walk, long-row form",
