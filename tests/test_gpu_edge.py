@@ -1060,6 +1060,20 @@ def test_walk_sampler_random_configurations_against_the_fused_sampler(amd):
             res[mode] = (tile, small, b.status.clone(), b.traj_len.clone(), b2.status.clone())
         for k, (got, want) in enumerate(zip(res["walk"], res["fused"])):
             assert torch.equal(got, want), (trial, D, ts, cap, stride, f32, n, first, count, spread, matlab, k)
+        if trial % 3 == 1:
+            # the same rows without the end-limit verdict (flags bit 4): every status bit but END_LIMIT as before
+            b = ltp.planSwitchTimesBatch(qg, q0, v0, a0)
+            st0 = b.status.clone()
+            need = int((b.offsets[first + count] - b.offsets[first]).item())
+            tile = torch.full((need + 8,), 3.0, dtype=dt, device="cuda")
+            ltp.sampleBatch(b, first, count, tile, spread=spread, walk=True, verdict=False)
+            torch.cuda.synchronize()
+            assert torch.equal(tile, res["walk"][0]), (trial, "no-verdict rows")
+            keep = ~amd.STATUS_END_LIMIT
+            full_st = res["walk"][2]
+            sel = torch.zeros(n, dtype=torch.bool, device=st0.device)
+            sel[first:first + count] = True
+            assert torch.equal(b.status[sel] & keep, full_st[sel] & keep) and torch.equal(b.status[~sel], st0[~sel]), (trial, "no-verdict status")
 
 
 @pytest.mark.parametrize("limits,dof,n", [("panda", None, 1201), ("ref", None, 400), ("ref", 30, 60), ("ref", 3, 500)])
