@@ -251,14 +251,14 @@ void launch_single_opt_braking(hipStream_t s, int joint, double t_sample, Limits
 void launch_roots_matlab(hipStream_t s, long long n, int degree, const double* coef, double* re, double* im, int* nroots, int* status)
 {
     if (n <= 0) return;
-    hipLaunchKernelGGL(k_roots_matlab, dim3((unsigned)((n + 63) / 64)), dim3(64), mr::matrix_lds_bytes(64), s, n, degree, coef, re, im, nroots, status);
+    hipLaunchKernelGGL(k_roots_matlab, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, n, degree, coef, re, im, nroots, status);
 }
 void launch_single_opt_switch(hipStream_t s, int joint, double t_sample, Limits lim, double q_goal, double q_0, double v_0,
                               double a_0, double v_drive, double* io10, int variant)
 {
     dispatch_variant(variant, [&](auto v) {
         constexpr int SEM = decltype(v)::value;
-        hipLaunchKernelGGL(k_single_opt_switch<SEM>, dim3(1), dim3(1), sem_matlab(SEM) ? mr::matrix_lds_bytes(1) : 0, s, joint, t_sample, lim, q_goal, q_0,
+        hipLaunchKernelGGL(k_single_opt_switch<SEM>, dim3(1), dim3(1), 0, s, joint, t_sample, lim, q_goal, q_0,
                            v_0, a_0, v_drive, io10);
     });
 }
@@ -267,7 +267,7 @@ void launch_single_time_scaling(hipStream_t s, int joint, double t_sample, Limit
 {
     dispatch_variant(variant, [&](auto v) {
         constexpr int SEM = decltype(v)::value;
-        hipLaunchKernelGGL(k_single_time_scaling<SEM>, dim3(1), dim3(1), sem_matlab(SEM) ? mr::matrix_lds_bytes(1) : 0, s, joint, t_sample, lim, q_goal, q_0,
+        hipLaunchKernelGGL(k_single_time_scaling<SEM>, dim3(1), dim3(1), 0, s, joint, t_sample, lim, q_goal, q_0,
                            v_0, a_0, dir, t_required, out11);
     });
 }

@@ -113,7 +113,7 @@ __device__ inline double matlab_filtered_root(const double (&c)[N + 1], bool mus
     double re[mr::kMaxN], im[mr::kMaxN];
     int nr = 0;
     const double nan = __builtin_nan("");
-    if (mr::roots(c, N, re, im, nr) != 0) { mc.flags |= kMatlabError; return nan; }
+    if (mr::roots_n<N>(c, re, im, nr) != 0) { mc.flags |= kMatlabError; return nan; }
     double pick = nan, pick_im = 0.0;
     int kept = 0;
     for (int i = 0; i < nr; ++i) {
@@ -140,7 +140,7 @@ __device__ inline double root_squared(const double (&c)[N + 1], int k, MatlabCtx
         double re[mr::kMaxN], im[mr::kMaxN];
         int nr = 0;
         const double nan = __builtin_nan("");
-        if (mr::roots(c, N, re, im, nr) != 0 || k > nr) { mc.flags |= kMatlabError; return nan; }
+        if (mr::roots_n<N>(c, re, im, nr) != 0 || k > nr) { mc.flags |= kMatlabError; return nan; }
         const double rr = re[k - 1] * re[k - 1] - im[k - 1] * im[k - 1];
         const double ri = 2.0 * (re[k - 1] * im[k - 1]);
         return ri != 0.0 ? nan : rr;

@@ -8,15 +8,39 @@
 // nothing on a companion matrix with a non-zero constant coefficient), DGEHRD (the identity on a Hessenberg matrix), DHSEQR ->
 // DLAHQR (double-shift QR with the Ahues-Tisseur deflation test, exceptional shifts every 10 iterations without deflation),
 // DLANV2 for the final 2x2 blocks. The order is checked against numpy.roots — the same driver — through the CPU twin of this file
-// in the test suite (tests/test_matlab_twin.py) and on the device against that twin (tests/test_gpu_matlab.py); against MATLAB's own
-// LAPACK build it is unpinned.
+// in the test suite (tests/test_matlab_twin.py), on the HOST against that twin (tests/cpp/matlab_roots_test.cc compiles this very
+// header with g++: bit-identical on every class of input) and on the device against it (tests/test_gpu_matlab.py); against
+// MATLAB's own LAPACK build it is unpinned.
 //
-// One lane solves one polynomial; unlike the register-resident solver of ltp_roots.hpp the matrix is indexed dynamically. Round 4: it
-// lives in DYNAMIC LDS (element (i, j) of thread t at word (6 i + j) * T + t, T = threads per block: conflict-free whatever the lanes
-// index), not in scratch memory — same operations, same bits. Every launch of a kernel that can reach roots() in this mode passes
-// matrix_lds_bytes(threads per block) of dynamic shared memory (ltp_stage_kernels.hip, ltp_aux_kernels.hip).
+// MI355X design (round 5; rounds 3-4 indexed the matrix dynamically, first in scratch memory, then in 144 KB of dynamic LDS per
+// block): one lane solves one polynomial and its N x N matrix lives in VGPRs, as in the C++-semantics solver of ltp_roots.hpp —
+// every loop over matrix indices is a compile-time loop (static_for: each subscript a constant), and what LAPACK's loops take
+// from the data — the active window [l, i], the start row m of a sweep, whether a reflector spans two or three rows, the order
+// n left after stripping zero coefficients — is a per-lane predicate on those constant positions. Entries outside the n x n
+// matrix are kept at zero, which makes DGEBAL's norms and DLAHQR's neighbour sums come out as LAPACK forms them without a
+// predicate on n. Same operations in the same order on the same elements as the loops of the twin: same bits. No LDS, no
+// scratch, no launch convention.
 #pragma once
+#if defined(__HIPCC__)
 #include "ltp_math.hpp"
+#define LTP_MR_FN LTP_DEV
+// the solver of one degree is ONE out-of-line function per kernel image: a stage kernel has up to six sites that solve a polynomial
+// and ~100 live registers of its own around each; inlined, the 36 matrix registers and the solver's temporaries on top of that spilled
+// 300-480 registers per lane (k_scaling_slow), and the image held nine copies of a 10 k-instruction loop
+#define LTP_MR_SOLVER __device__ __attribute__((noinline))
+#else
+// host build (tests only): the helpers of ltp_math.hpp this file uses
+namespace ltp {
+static inline double dabs(double x) { return __builtin_fabs(x); }
+static inline bool dfinite(double x) { return dabs(x) < __builtin_huge_val(); }
+static inline bool disnan(double x) { return x != x; }
+static inline double dsqrt(double x) { return __builtin_sqrt(x); }
+static inline double dmax(double a, double b) { return a < b ? b : a; }
+static inline double dmin(double a, double b) { return b < a ? b : a; }
+}  // namespace ltp
+#define LTP_MR_FN static inline
+#define LTP_MR_SOLVER static __attribute__((noinline))
+#endif
 
 namespace ltp {
 namespace mr {
@@ -26,17 +50,29 @@ constexpr double kDblMinM = 2.2250738585072014e-308;
 constexpr double kDblEpsM = 2.220446049250313e-16;
 constexpr double kDblMaxM = 1.7976931348623157e+308;
 
-struct LdsMat {                           // this thread's matrix inside the block's LDS image
-    double* p;
-    int stride;                           // threads per block
-    LTP_DEV double& operator()(int i, int j) const { return p[(i * kMaxN + j) * stride]; }
-};
-// dynamic shared memory a launch of `threads` threads per block must provide for the matrices
-__host__ __device__ inline unsigned matrix_lds_bytes(int threads) { return (unsigned)(kMaxN * kMaxN * threads) * (unsigned)sizeof(double); }
+// f(constant I) for I = B .. E-1 (UP) or E-1 .. B (down): the loop index is a constant expression inside f
+template <int I> struct Idx { static constexpr int value = I; };
+template <int B, int E, class F>
+LTP_MR_FN void static_for(F&& f)
+{
+    if constexpr (B < E) {
+        f(Idx<B>{});
+        static_for<B + 1, E>(f);
+    }
+}
+template <int B, int E, class F>
+LTP_MR_FN void static_for_down(F&& f)
+{
+    if constexpr (B < E) {
+        f(Idx<E - 1>{});
+        static_for_down<B, E - 1>(f);
+    }
+}
+#define LTP_MR_I(ic) (decltype(ic)::value)
 
-LTP_DEV double fsign(double a, double b) { return __builtin_signbit(b) ? -dabs(a) : dabs(a); }   // Fortran SIGN(a, b)
+LTP_MR_FN double fsign(double a, double b) { return __builtin_signbit(b) ? -dabs(a) : dabs(a); }   // Fortran SIGN(a, b)
 
-LTP_DEV double lapy2(double x, double y)
+LTP_MR_FN double lapy2(double x, double y)
 {
     const double xa = dabs(x), ya = dabs(y);
     const double w = dmax(xa, ya), z = dmin(xa, ya);
@@ -46,42 +82,26 @@ LTP_DEV double lapy2(double x, double y)
     return w * dsqrt(1.0 + (z / w) * (z / w));
 }
 
-// DNRM2 (scaled sum of squares) of n values with a stride
-LTP_DEV double nrm2(int n, const double* x, int inc)
+// one term of DNRM2's scaled sum of squares
+LTP_MR_FN void nrm2_term(double x, double& scale, double& ssq)
 {
-    double scale = 0.0, ssq = 1.0;
-    for (int i = 0; i < n; ++i) {
-        const double a = dabs(x[i * inc]);
-        if (a != 0.0) {
-            if (scale < a) { ssq = 1.0 + ssq * (scale / a) * (scale / a); scale = a; }
-            else ssq += (a / scale) * (a / scale);
-        }
+    const double a = dabs(x);
+    if (a != 0.0) {
+        if (scale < a) { ssq = 1.0 + ssq * (scale / a) * (scale / a); scale = a; }
+        else ssq += (a / scale) * (a / scale);
     }
-    return scale * dsqrt(ssq);
 }
 
-// DNRM2 of column `col` (ROW == false) or row `row` (ROW == true) of the matrix: nrm2() above with the matrix accessor
-template <bool ROW, class M>
-LTP_DEV double mat_nrm2(int n, M& H, int k)
+// DLARFG on (v[0]; v[1 .. NR-1]), NR = 2 or 3
+template <int NR>
+LTP_MR_FN void larfg(double (&v)[3], double& tau)
 {
-    double scale = 0.0, ssq = 1.0;
-    for (int i = 0; i < n; ++i) {
-        const double a = dabs(ROW ? H(k, i) : H(i, k));
-        if (a != 0.0) {
-            if (scale < a) { ssq = 1.0 + ssq * (scale / a) * (scale / a); scale = a; }
-            else ssq += (a / scale) * (a / scale);
-        }
-    }
-    return scale * dsqrt(ssq);
-}
-
-// DLARFG, nr = 2 or 3
-LTP_DEV void larfg(int nr, double* v, double& tau)
-{
+    static_assert(NR == 2 || NR == 3, "reflectors of a double-shift sweep");
     const double safmin = kDblMinM / (kDblEpsM * 0.5);
     double alpha = v[0];
-    if (nr <= 1) { tau = 0.0; return; }
-    double xnorm = nrm2(nr - 1, v + 1, 1);
+    double scale = 0.0, ssq = 1.0;
+    static_for<1, NR>([&](auto e) { nrm2_term(v[LTP_MR_I(e)], scale, ssq); });
+    double xnorm = scale * dsqrt(ssq);
     if (xnorm == 0.0) { tau = 0.0; return; }
     double beta = -fsign(lapy2(alpha, xnorm), alpha);
     int knt = 0;
@@ -89,22 +109,25 @@ LTP_DEV void larfg(int nr, double* v, double& tau)
         const double rsafmn = 1.0 / safmin;
         do {
             ++knt;
-            for (int i = 1; i < nr; ++i) v[i] *= rsafmn;
+            static_for<1, NR>([&](auto e) { v[LTP_MR_I(e)] *= rsafmn; });
             beta *= rsafmn;
             alpha *= rsafmn;
         } while (dabs(beta) < safmin && knt < 20);
-        xnorm = nrm2(nr - 1, v + 1, 1);
+        scale = 0.0;
+        ssq = 1.0;
+        static_for<1, NR>([&](auto e) { nrm2_term(v[LTP_MR_I(e)], scale, ssq); });
+        xnorm = scale * dsqrt(ssq);
         beta = -fsign(lapy2(alpha, xnorm), alpha);
     }
     tau = (beta - alpha) / beta;
     const double s = 1.0 / (alpha - beta);
-    for (int i = 1; i < nr; ++i) v[i] *= s;
-    for (int i = 0; i < knt; ++i) beta *= safmin;
+    static_for<1, NR>([&](auto e) { v[LTP_MR_I(e)] *= s; });
+    for (int x = 0; x < knt; ++x) beta *= safmin;
     v[0] = beta;
 }
 
 // DLANV2: eigenvalues of [a b; c d]; (rt1r, rt1i) first
-LTP_DEV void lanv2(double a, double b, double c, double d, double& rt1r, double& rt1i, double& rt2r, double& rt2i)
+LTP_MR_FN void lanv2(double a, double b, double c, double d, double& rt1r, double& rt1i, double& rt2r, double& rt2i)
 {
     const double multpl = 4.0, eps = kDblEpsM;
     if (c == 0.0) {
@@ -168,25 +191,34 @@ LTP_DEV void lanv2(double a, double b, double c, double d, double& rt1r, double&
     }
 }
 
-// DGEBAL('B') without the permutation search, in place
-template <class M>
-LTP_DEV void balance(int n, M& H)
+// DGEBAL('B') without the permutation search, in place. Rows and columns beyond the matrix order are zero: LAPACK's loop over
+// i < n is the loop over i < N here (a zero row or column is skipped by DGEBAL's own "c == 0 or r == 0" rule), its sums over j < n
+// the sums over j < N (DNRM2 skips zeros; max with |0| changes nothing).
+template <int N>
+LTP_MR_FN void balance(double (&T)[N][N])
 {
     const double sclfac = 2.0, factor = 0.95;
     const double sfmin1 = kDblMinM / kDblEpsM, sfmax1 = 1.0 / sfmin1;
     const double sfmin2 = sfmin1 * sclfac, sfmax2 = 1.0 / sfmin2;
-    double scalev[kMaxN];
-    for (int i = 0; i < n; ++i) scalev[i] = 1.0;
-    bool noconv = true;
+    double scalev[N];
+    static_for<0, N>([&](auto ic) { scalev[LTP_MR_I(ic)] = 1.0; });
+    bool noconv = true, nan = false;
     for (int guard = 0; noconv && guard < 1000; ++guard) {
         noconv = false;
-        for (int i = 0; i < n; ++i) {
-            double c = mat_nrm2<false>(n, H, i), r = mat_nrm2<true>(n, H, i), ca = 0.0, ra = 0.0;
-            for (int j = 0; j < n; ++j) { ca = dmax(ca, dabs(H(j, i))); ra = dmax(ra, dabs(H(i, j))); }
-            if (c == 0.0 || r == 0.0) continue;
+        static_for<0, N>([&](auto ic) {
+            constexpr int i = LTP_MR_I(ic);
+            if (nan) return;
+            double cs = 0.0, cq = 1.0, rs = 0.0, rq = 1.0, ca = 0.0, ra = 0.0;
+            static_for<0, N>([&](auto jc) { nrm2_term(T[LTP_MR_I(jc)][i], cs, cq); });
+            static_for<0, N>([&](auto jc) { nrm2_term(T[i][LTP_MR_I(jc)], rs, rq); });
+            double c = cs * dsqrt(cq), r = rs * dsqrt(rq);
+            static_for<0, N>([&](auto jc) {
+                ca = dmax(ca, dabs(T[LTP_MR_I(jc)][i]));
+                ra = dmax(ra, dabs(T[i][LTP_MR_I(jc)]));
+            });
+            if (c == 0.0 || r == 0.0) return;
             double g = r / sclfac, f = 1.0;
             const double s = c + r;
-            bool nan = false;
             while (!(c >= g || dmax(f, dmax(c, ca)) >= sfmax2 || dmin(r, dmin(g, ra)) <= sfmin2)) {
                 if (disnan(c + f + ca + r + g + ra)) { nan = true; break; }
                 f *= sclfac; c *= sclfac; ca *= sclfac;
@@ -198,200 +230,330 @@ LTP_DEV void balance(int n, M& H)
                 f /= sclfac; c /= sclfac; g /= sclfac; ca /= sclfac;
                 r *= sclfac; ra *= sclfac;
             }
-            if (c + r >= factor * s) continue;
-            if (f < 1.0 && scalev[i] < 1.0 && f * scalev[i] <= sfmin1) continue;
-            if (f > 1.0 && scalev[i] > 1.0 && scalev[i] >= sfmax1 / f) continue;
+            if (c + r >= factor * s) return;
+            if (f < 1.0 && scalev[i] < 1.0 && f * scalev[i] <= sfmin1) return;
+            if (f > 1.0 && scalev[i] > 1.0 && scalev[i] >= sfmax1 / f) return;
             g = 1.0 / f;
             scalev[i] *= f;
             noconv = true;
-            for (int j = 0; j < n; ++j) H(i, j) *= g;
-            for (int j = 0; j < n; ++j) H(j, i) *= f;
-        }
+            static_for<0, N>([&](auto jc) { T[i][LTP_MR_I(jc)] *= g; });
+            static_for<0, N>([&](auto jc) { T[LTP_MR_I(jc)][i] *= f; });
+        });
+        if (nan) return;
     }
 }
 
-// DLAHQR, eigenvalues only. Returns 0, or i + 1 if the iteration did not converge.
-template <class M>
-LTP_DEV int lahqr(int n, M& H, double* wr, double* wi)
+// DLAHQR, eigenvalues only (WANTT = WANTZ = false), on the leading n x n part of T (upper Hessenberg, zero elsewhere). Returns 0, or
+// i + 1 if the iteration did not converge. LAPACK's two nested loops (over the active block's bottom row i, over the iterations of
+// one block) run as ONE loop here: each pass looks for a negligible sub-diagonal entry in rows l+1 .. i and then either takes the
+// one or two eigenvalues that split off at the bottom or performs one sweep. wr / wi: N entries, those not reached stay untouched.
+template <int N>
+LTP_MR_FN int lahqr(double (&T)[N][N], int n, double (&wr)[N], double (&wi)[N])
 {
     const double dat1 = 3.0 / 4.0, dat2 = -0.4375;
     const int kexsh = 10;
     const double safmin = kDblMinM, ulp = kDblEpsM;
     const double smlnum = safmin * ((double)n / ulp);
-    const int itmax = 30 * (n > 10 ? n : 10);
-    if (n == 0) return 0;
-    if (n == 1) { wr[0] = H(0, 0); wi[0] = 0.0; return 0; }
-    for (int j = 0; j <= n - 4; ++j) { H(j + 2, j) = 0.0; H(j + 3, j) = 0.0; }
-    if (n >= 3) H(n - 1, n - 3) = 0.0;
-    int i = n - 1, kdefl = 0;
+    const int itmax = 30 * 10;                                         // 30 * max(n, 10), n <= 6
+    // (DLAHQR first clears the entries below the sub-diagonal: they are zero by construction and DGEBAL only scales)
+    int i = n - 1, l = 0, kdefl = 0, its = 0;
     while (i >= 0) {
-        bool converged = false;
-        int l = 0;
-        for (int its = 0; its <= itmax; ++its) {
-            int k;
-            for (k = i; k > l; --k) {
-                if (dabs(H(k, k - 1)) <= smlnum) break;
-                double tst = dabs(H(k - 1, k - 1)) + dabs(H(k, k));
-                if (tst == 0.0) {
-                    if (k - 2 >= 0) tst += dabs(H(k - 1, k - 2));
-                    if (k + 1 <= n - 1) tst += dabs(H(k + 1, k));
+        // look for a single small subdiagonal element: LAPACK's k = i, i-1, ..., l+1, the first k that passes a test; else l
+        {
+            int kk = l;
+            bool stop = false;
+            static_for_down<1, N>([&](auto rc) {
+                constexpr int r = LTP_MR_I(rc);
+                if (stop || r > i || r <= l) return;
+                const double sub = dabs(T[r][r - 1]);
+                bool brk = sub <= smlnum;
+                if (!brk) {
+                    double tst = dabs(T[r - 1][r - 1]) + dabs(T[r][r]);
+                    if (tst == 0.0) {
+                        if constexpr (r - 2 >= 0) tst += dabs(T[r - 1][r - 2]);
+                        if constexpr (r + 1 <= N - 1) tst += dabs(T[r + 1][r]);        // zero from row n on
+                    }
+                    if (sub <= ulp * tst) {
+                        const double sup = dabs(T[r - 1][r]);
+                        const double ab = dmax(sub, sup);
+                        const double ba = dmin(sub, sup);
+                        const double dd = dabs(T[r - 1][r - 1] - T[r][r]);
+                        const double aa = dmax(dabs(T[r][r]), dd);
+                        const double bb = dmin(dabs(T[r][r]), dd);
+                        const double ss = aa + ab;
+                        if (ba * (ab / ss) <= dmax(smlnum, ulp * (bb * (aa / ss)))) brk = true;
+                    }
                 }
-                if (dabs(H(k, k - 1)) <= ulp * tst) {
-                    const double ab = dmax(dabs(H(k, k - 1)), dabs(H(k - 1, k)));
-                    const double ba = dmin(dabs(H(k, k - 1)), dabs(H(k - 1, k)));
-                    const double aa = dmax(dabs(H(k, k)), dabs(H(k - 1, k - 1) - H(k, k)));
-                    const double bb = dmin(dabs(H(k, k)), dabs(H(k - 1, k - 1) - H(k, k)));
-                    const double ss = aa + ab;
-                    if (ba * (ab / ss) <= dmax(smlnum, ulp * (bb * (aa / ss)))) break;
-                }
+                if (brk) { kk = r; stop = true; }
+            });
+            l = kk;
+        }
+        static_for<1, N>([&](auto rc) {
+            constexpr int r = LTP_MR_I(rc);
+            if (r == l) T[r][r - 1] = 0.0;
+        });
+        // the bottom 2 x 2 of the active block, wherever it is
+        double hmm = 0.0, hmi = 0.0, him = 0.0, hii = 0.0;
+        static_for<0, N>([&](auto uc) {
+            constexpr int u = LTP_MR_I(uc);
+            if (u == i) {
+                hii = T[u][u];
+                if constexpr (u >= 1) { hmm = T[u - 1][u - 1]; hmi = T[u - 1][u]; him = T[u][u - 1]; }
             }
-            l = k;
-            if (l > 0) H(l, l - 1) = 0.0;
-            if (l >= i - 1) { converged = true; break; }
-            ++kdefl;
-            double h11, h21, h12, h22, s;
+        });
+        if (l >= i - 1) {
+            // one or two eigenvalues have split off
+            double r1r, r1i = 0.0, r2r = 0.0, r2i = 0.0;
+            const bool pair = l != i;
+            if (pair) lanv2(hmm, hmi, him, hii, r1r, r1i, r2r, r2i);
+            else r1r = hii;
+            static_for<0, N>([&](auto uc) {
+                constexpr int u = LTP_MR_I(uc);
+                if (pair) {
+                    if (u == i - 1) { wr[u] = r1r; wi[u] = r1i; }
+                    if (u == i) { wr[u] = r2r; wi[u] = r2i; }
+                } else if (u == i) {
+                    wr[u] = r1r;
+                    wi[u] = 0.0;
+                }
+            });
+            kdefl = 0;
+            its = 0;
+            i = l - 1;
+            l = 0;
+            continue;
+        }
+        ++kdefl;
+        double h11, h21, h12, h22, s;
+        if (kdefl % kexsh == 0) {
+            // exceptional shifts (every 10th / 20th iteration without a deflation)
+            double d0 = 0.0, s0 = 0.0, s1 = 0.0;
             if (kdefl % (2 * kexsh) == 0) {
-                s = dabs(H(i, i - 1)) + dabs(H(i - 1, i - 2));
-                h11 = dat1 * s + H(i, i);
-                h12 = dat2 * s;
-                h21 = s;
-                h22 = h11;
-            } else if (kdefl % kexsh == 0) {
-                s = dabs(H(l + 1, l)) + dabs(H(l + 2, l + 1));
-                h11 = dat1 * s + H(l, l);
-                h12 = dat2 * s;
-                h21 = s;
-                h22 = h11;
+                static_for<2, N>([&](auto uc) {
+                    constexpr int u = LTP_MR_I(uc);
+                    if (u == i) { d0 = T[u][u]; s0 = T[u][u - 1]; s1 = T[u - 1][u - 2]; }
+                });
             } else {
-                h11 = H(i - 1, i - 1);
-                h21 = H(i, i - 1);
-                h12 = H(i - 1, i);
-                h22 = H(i, i);
+                static_for<0, N - 2>([&](auto uc) {
+                    constexpr int u = LTP_MR_I(uc);
+                    if (u == l) { d0 = T[u][u]; s0 = T[u + 1][u]; s1 = T[u + 2][u + 1]; }
+                });
             }
-            s = dabs(h11) + dabs(h12) + dabs(h21) + dabs(h22);
-            double rt1r = 0.0, rt1i = 0.0, rt2r = 0.0, rt2i = 0.0;
-            if (s != 0.0) {
-                h11 /= s; h21 /= s; h12 /= s; h22 /= s;
-                const double tr = (h11 + h22) / 2.0;
-                const double det = (h11 - tr) * (h22 - tr) - h12 * h21;
-                const double rtdisc = dsqrt(dabs(det));
-                if (det >= 0.0) {
-                    rt1r = tr * s; rt2r = rt1r; rt1i = rtdisc * s; rt2i = -rt1i;
-                } else {
-                    rt1r = tr + rtdisc;
-                    rt2r = tr - rtdisc;
-                    if (dabs(rt1r - h22) <= dabs(rt2r - h22)) { rt1r = rt1r * s; rt2r = rt1r; }
-                    else { rt2r = rt2r * s; rt1r = rt2r; }
-                }
-            }
-            double v[3] = {0.0, 0.0, 0.0};
-            int m;
-            for (m = i - 2; m >= l; --m) {
-                double h21s = dabs(H(m + 1, m));
-                s = dabs(H(m, m) - rt2r) + dabs(rt2i) + h21s;
-                h21s = H(m + 1, m) / s;
-                v[0] = h21s * H(m, m + 1) + (H(m, m) - rt1r) * ((H(m, m) - rt2r) / s) - rt1i * (rt2i / s);
-                v[1] = h21s * (H(m, m) + H(m + 1, m + 1) - rt1r - rt2r);
-                v[2] = h21s * H(m + 2, m + 1);
-                s = dabs(v[0]) + dabs(v[1]) + dabs(v[2]);
-                v[0] /= s; v[1] /= s; v[2] /= s;
-                if (m == l) break;
-                const double h00 = dabs(H(m - 1, m - 1)), hh11 = dabs(H(m, m)), hh22 = dabs(H(m + 1, m + 1));
-                if (dabs(H(m, m - 1)) * (dabs(v[1]) + dabs(v[2])) <= ulp * dabs(v[0]) * (h00 + hh11 + hh22)) break;
-            }
-            for (k = m; k <= i - 1; ++k) {
-                const int nr = (3 < i - k + 1) ? 3 : i - k + 1;
-                double t1;
-                if (k > m) for (int e = 0; e < nr; ++e) v[e] = H(k + e, k - 1);
-                larfg(nr, v, t1);
-                if (k > m) {
-                    H(k, k - 1) = v[0];
-                    H(k + 1, k - 1) = 0.0;
-                    if (k < i - 1) H(k + 2, k - 1) = 0.0;
-                } else if (m > l) {
-                    H(k, k - 1) = H(k, k - 1) * (1.0 - t1);
-                }
-                const double v2 = v[1], t2 = t1 * v2;
-                if (nr == 3) {
-                    const double v3 = v[2], t3 = t1 * v3;
-                    const int jend = (k + 3 < i) ? k + 3 : i;
-                    for (int j = k; j <= i; ++j) {
-                        const double sum = H(k, j) + v2 * H(k + 1, j) + v3 * H(k + 2, j);
-                        H(k, j) -= sum * t1;
-                        H(k + 1, j) -= sum * t2;
-                        H(k + 2, j) -= sum * t3;
-                    }
-                    for (int j = l; j <= jend; ++j) {
-                        const double sum = H(j, k) + v2 * H(j, k + 1) + v3 * H(j, k + 2);
-                        H(j, k) -= sum * t1;
-                        H(j, k + 1) -= sum * t2;
-                        H(j, k + 2) -= sum * t3;
-                    }
-                } else if (nr == 2) {
-                    for (int j = k; j <= i; ++j) {
-                        const double sum = H(k, j) + v2 * H(k + 1, j);
-                        H(k, j) -= sum * t1;
-                        H(k + 1, j) -= sum * t2;
-                    }
-                    for (int j = l; j <= i; ++j) {
-                        const double sum = H(j, k) + v2 * H(j, k + 1);
-                        H(j, k) -= sum * t1;
-                        H(j, k + 1) -= sum * t2;
-                    }
-                }
-            }
-        }
-        if (!converged) return i + 1;
-        if (l == i) {
-            wr[i] = H(i, i);
-            wi[i] = 0.0;
+            s = dabs(s0) + dabs(s1);
+            h11 = dat1 * s + d0;
+            h12 = dat2 * s;
+            h21 = s;
+            h22 = h11;
         } else {
-            lanv2(H(i - 1, i - 1), H(i - 1, i), H(i, i - 1), H(i, i), wr[i - 1], wi[i - 1], wr[i], wi[i]);
+            h11 = hmm;
+            h21 = him;
+            h12 = hmi;
+            h22 = hii;
         }
-        kdefl = 0;
-        i = l - 1;
+        s = dabs(h11) + dabs(h12) + dabs(h21) + dabs(h22);
+        double rt1r = 0.0, rt1i = 0.0, rt2r = 0.0, rt2i = 0.0;
+        if (s != 0.0) {
+            h11 /= s; h21 /= s; h12 /= s; h22 /= s;
+            const double tr = (h11 + h22) / 2.0;
+            const double det = (h11 - tr) * (h22 - tr) - h12 * h21;
+            const double rtdisc = dsqrt(dabs(det));
+            if (det >= 0.0) {
+                rt1r = tr * s; rt2r = rt1r; rt1i = rtdisc * s; rt2i = -rt1i;
+            } else {
+                rt1r = tr + rtdisc;
+                rt2r = tr - rtdisc;
+                if (dabs(rt1r - h22) <= dabs(rt2r - h22)) { rt1r = rt1r * s; rt2r = rt1r; }
+                else { rt2r = rt2r * s; rt1r = rt2r; }
+            }
+        }
+        // look for two consecutive small subdiagonal elements: m = i-2, ..., l
+        double v[3] = {0.0, 0.0, 0.0};
+        int m = l;
+        {
+            bool stop = false;
+            static_for_down<0, N - 2>([&](auto mc) {
+                constexpr int mm = LTP_MR_I(mc);
+                if (stop || mm > i - 2 || mm < l) return;
+                double h21s = dabs(T[mm + 1][mm]);
+                double sc = dabs(T[mm][mm] - rt2r) + dabs(rt2i) + h21s;
+                h21s = T[mm + 1][mm] / sc;
+                v[0] = h21s * T[mm][mm + 1] + (T[mm][mm] - rt1r) * ((T[mm][mm] - rt2r) / sc) - rt1i * (rt2i / sc);
+                v[1] = h21s * (T[mm][mm] + T[mm + 1][mm + 1] - rt1r - rt2r);
+                v[2] = h21s * T[mm + 2][mm + 1];
+                sc = dabs(v[0]) + dabs(v[1]) + dabs(v[2]);
+                v[0] /= sc; v[1] /= sc; v[2] /= sc;
+                m = mm;
+                if (mm == l) { stop = true; return; }
+                if constexpr (mm >= 1) {
+                    const double h00 = dabs(T[mm - 1][mm - 1]), hh11 = dabs(T[mm][mm]), hh22 = dabs(T[mm + 1][mm + 1]);
+                    if (dabs(T[mm][mm - 1]) * (dabs(v[1]) + dabs(v[2])) <= ulp * dabs(v[0]) * (h00 + hh11 + hh22)) stop = true;
+                }
+            });
+        }
+        // double-shift QR sweep on rows / columns l .. i (eigenvalues only: i1 = l, i2 = i): k = m .. i-1
+        static_for<0, N - 1>([&](auto kc) {
+            constexpr int k = LTP_MR_I(kc);
+            if (k < m || k > i - 1) return;
+            const bool three = k < i - 1;                              // nr = min(3, i - k + 1)
+            double t1;
+            if constexpr (k >= 1) {
+                if (k > m) {
+                    v[0] = T[k][k - 1];
+                    v[1] = T[k + 1][k - 1];
+                    if constexpr (k + 2 <= N - 1) { if (three) v[2] = T[k + 2][k - 1]; }
+                }
+            }
+            if constexpr (k + 2 <= N - 1) {
+                if (three) larfg<3>(v, t1);
+                else larfg<2>(v, t1);
+            } else {
+                larfg<2>(v, t1);                                       // the last row pair: never three rows
+            }
+            if (k > m) {
+                if constexpr (k >= 1) {
+                    T[k][k - 1] = v[0];
+                    T[k + 1][k - 1] = 0.0;
+                    if constexpr (k + 2 <= N - 1) { if (three) T[k + 2][k - 1] = 0.0; }
+                }
+            } else if (m > l) {
+                if constexpr (k >= 1) T[k][k - 1] = T[k][k - 1] * (1.0 - t1);
+            }
+            const double v2 = v[1], t2 = t1 * v2;
+            if (three) {
+                if constexpr (k + 2 <= N - 1) {
+                    const double v3 = v[2], t3 = t1 * v3;
+                    static_for<k, N>([&](auto jc) {
+                        constexpr int j = LTP_MR_I(jc);
+                        if (j > i) return;
+                        const double sum = T[k][j] + v2 * T[k + 1][j] + v3 * T[k + 2][j];
+                        T[k][j] -= sum * t1;
+                        T[k + 1][j] -= sum * t2;
+                        T[k + 2][j] -= sum * t3;
+                    });
+                    static_for<0, (k + 3 < N - 1 ? k + 3 : N - 1) + 1>([&](auto jc) {
+                        constexpr int j = LTP_MR_I(jc);
+                        if (j < l || j > i) return;                    // j = l .. min(k + 3, i)
+                        const double sum = T[j][k] + v2 * T[j][k + 1] + v3 * T[j][k + 2];
+                        T[j][k] -= sum * t1;
+                        T[j][k + 1] -= sum * t2;
+                        T[j][k + 2] -= sum * t3;
+                    });
+                }
+            } else {
+                // nr == 2: k == i - 1
+                static_for<k, N>([&](auto jc) {
+                    constexpr int j = LTP_MR_I(jc);
+                    if (j > i) return;
+                    const double sum = T[k][j] + v2 * T[k + 1][j];
+                    T[k][j] -= sum * t1;
+                    T[k + 1][j] -= sum * t2;
+                });
+                static_for<0, k + 2>([&](auto jc) {
+                    constexpr int j = LTP_MR_I(jc);
+                    if (j < l) return;                                 // j = l .. i
+                    const double sum = T[j][k] + v2 * T[j][k + 1];
+                    T[j][k] -= sum * t1;
+                    T[j][k + 1] -= sum * t2;
+                });
+            }
+        });
+        ++its;
+        if (its > itmax) return i + 1;
     }
     return 0;
 }
 
-// roots(c) for c[0..deg], deg <= 6, highest coefficient first. re / im: deg entries in MATLAB's output order (zero roots
-// from stripped trailing zero coefficients first); nroots = deg minus the stripped leading zeros. 0 = ok, 1 = no
-// convergence, 2 = NaN / Inf coefficient (MATLAB: error).
-template <class M>
-LTP_DEV int roots_with(M& H, const double* c, int deg, double* re, double* im, int& nroots)
+// roots(c) for c[0 .. N], N <= 6, highest coefficient first. re / im: N entries in MATLAB's output order (zero roots from stripped
+// trailing zero coefficients first); nroots = N minus the stripped leading zeros. 0 = ok, 1 = no convergence, 2 = NaN / Inf
+// coefficient (MATLAB: error).
+template <int N>
+LTP_MR_SOLVER int roots_n(const double (&c)[N + 1], double (&re)[kMaxN], double (&im)[kMaxN], int& nroots)
 {
+    static_assert(N >= 1 && N <= kMaxN, "degree");
     const double nan = __builtin_nan("");
-    for (int i = 0; i < deg; ++i) { re[i] = nan; im[i] = nan; }
+    static_for<0, N>([&](auto ic) { re[LTP_MR_I(ic)] = nan; im[LTP_MR_I(ic)] = nan; });
     nroots = 0;
-    if (deg < 0 || deg > kMaxN) return 2;
-    for (int i = 0; i <= deg; ++i) if (!dfinite(c[i])) return 2;
-    int first = 0, last = deg;
-    while (first <= deg && c[first] == 0.0) ++first;
-    if (first > deg) return 0;
-    while (last > first && c[last] == 0.0) --last;
+    bool finite = true;
+    static_for<0, N + 1>([&](auto ic) { finite = finite && dfinite(c[LTP_MR_I(ic)]); });
+    if (!finite) return 2;
+    int first = 0;
+    {
+        bool lead = true;
+        static_for<0, N + 1>([&](auto ic) {
+            if (lead && c[LTP_MR_I(ic)] == 0.0) ++first;
+            else lead = false;
+        });
+    }
+    if (first > N) return 0;
+    int last = N;
+    {
+        bool trail = true;
+        static_for_down<1, N + 1>([&](auto ic) {
+            if (trail && LTP_MR_I(ic) > first && c[LTP_MR_I(ic)] == 0.0) --last;
+            else trail = false;
+        });
+    }
     const int n = last - first;
-    nroots = deg - first;
-    for (int i = 0; i < kMaxN; ++i) for (int j = 0; j < kMaxN; ++j) H(i, j) = 0.0;
-    for (int i = 1; i < n; ++i) H(i, i - 1) = 1.0;
-    for (int j = 0; j < n; ++j) H(0, j) = -c[first + 1 + j] / c[first];
-    for (int j = 0; j < n; ++j) if (!dfinite(H(0, j))) return 2;
-    balance(n, H);
-    const int nz = nroots - n;
-    for (int i = 0; i < nz; ++i) { re[i] = 0.0; im[i] = 0.0; }
-    return lahqr(n, H, re + nz, im + nz) ? 1 : 0;
+    nroots = N - first;
+    // d[j] = c[first + j]
+    double d[N + 1];
+    static_for<0, N + 1>([&](auto jc) { d[LTP_MR_I(jc)] = 0.0; });
+    static_for<0, N + 1>([&](auto fc) {
+        constexpr int f = LTP_MR_I(fc);
+        if (first == f) static_for<0, N + 1 - f>([&](auto jc) { d[LTP_MR_I(jc)] = c[f + LTP_MR_I(jc)]; });
+    });
+    double T[N][N];
+    static_for<0, N>([&](auto ic) { static_for<0, N>([&](auto jc) { T[LTP_MR_I(ic)][LTP_MR_I(jc)] = 0.0; }); });
+    static_for<1, N>([&](auto ic) {
+        constexpr int i = LTP_MR_I(ic);
+        if (i < n) T[i][i - 1] = 1.0;
+    });
+    static_for<0, N>([&](auto jc) {
+        constexpr int j = LTP_MR_I(jc);
+        if (j < n) {
+            T[0][j] = -d[1 + j] / d[0];
+            finite = finite && dfinite(T[0][j]);
+        }
+    });
+    if (!finite) return 2;
+    balance<N>(T);
+    double wr[N], wi[N];
+    static_for<0, N>([&](auto ic) { wr[LTP_MR_I(ic)] = nan; wi[LTP_MR_I(ic)] = nan; });
+    const int info = lahqr<N>(T, n, wr, wi);
+    const int nz = nroots - n;                                         // zero roots come first: r = [zeros(nnz, 1); eig(A)]
+    static_for<0, N>([&](auto kc) {
+        constexpr int k = LTP_MR_I(kc);
+        if (k < nz) { re[k] = 0.0; im[k] = 0.0; }
+        else {
+            static_for<0, k + 1>([&](auto uc) {
+                constexpr int u = LTP_MR_I(uc);
+                if (k - nz == u && u < n) { re[k] = wr[u]; im[k] = wi[u]; }
+            });
+        }
+    });
+    return info ? 1 : 0;
 }
 
-LTP_DEV int roots(const double* c, int deg, double* re, double* im, int& nroots)
+// the same with the degree as a value (tests)
+LTP_MR_FN int roots(const double* c, int deg, double (&re)[kMaxN], double (&im)[kMaxN], int& nroots)
 {
-    extern __shared__ double ltp_mr_matrices[];               // matrix_lds_bytes(threads per block), passed by every launch that gets here
-    const int threads = (int)(blockDim.x * blockDim.y * blockDim.z);
-    // (round-4 advisor) the convention is checked, not assumed: the launch's LDS allocation (dispatch packet, group_segment_size) must hold
-    // the kernel's static LDS plus this block's matrices — a launch that forgot the dynamic size traps instead of overwriting LDS data
-    const unsigned group_bytes = ((const unsigned __attribute__((address_space(4)))*)__builtin_amdgcn_dispatch_ptr())[7];   // byte 28
-    if (__builtin_amdgcn_groupstaticsize() + matrix_lds_bytes(threads) > group_bytes) __builtin_trap();
-    const int tid = ((int)threadIdx.z * (int)blockDim.y + (int)threadIdx.y) * (int)blockDim.x + (int)threadIdx.x;
-    LdsMat H{ltp_mr_matrices + tid, threads};
-    return roots_with(H, c, deg, re, im, nroots);
+    const double nan = __builtin_nan("");
+    nroots = 0;
+    if (deg < 0 || deg > kMaxN) {
+        for (int i = 0; i < deg && i < kMaxN; ++i) { re[i] = nan; im[i] = nan; }
+        return 2;
+    }
+    if (deg == 0) return dfinite(c[0]) ? 0 : 2;
+    int st = 2;
+    static_for<1, kMaxN + 1>([&](auto dc) {
+        constexpr int D = LTP_MR_I(dc);
+        if (deg == D) {
+            double cc[D + 1];
+            static_for<0, D + 1>([&](auto ic) { cc[LTP_MR_I(ic)] = c[LTP_MR_I(ic)]; });
+            st = roots_n<D>(cc, re, im, nroots);
+        }
+    });
+    return st;
 }
 
 }  // namespace mr

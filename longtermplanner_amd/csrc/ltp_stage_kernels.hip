@@ -589,12 +589,10 @@ void launch_switch_times(hipStream_t s, long long n, int dof, double t_sample, i
     if (b_blocks > 1024) b_blocks = 1024;
     dispatch_variant(variant, [&](auto v) {
         constexpr int SEM = decltype(v)::value;
-        // MATLAB's roots() keeps its matrix in dynamic LDS (ltp_roots_matlab.hpp)
-        const unsigned lds_a = sem_matlab(SEM) ? mr::matrix_lds_bytes(64) : 0, lds_b = sem_matlab(SEM) ? mr::matrix_lds_bytes(kQueriesPerBlock * 8) : 0;
         hipLaunchKernelGGL(k_opt_fast<SEM>, grid, block, 0, s, n, dof, t_sample, goal_check, lim, in, out, lane_flags, qa);
-        hipLaunchKernelGGL(k_opt_slow<SEM>, dim3((unsigned)a_blocks), dim3(64), lds_a, s, dof, t_sample, lim, in, out, lane_flags, qa);
+        hipLaunchKernelGGL(k_opt_slow<SEM>, dim3((unsigned)a_blocks), dim3(64), 0, s, dof, t_sample, lim, in, out, lane_flags, qa);
         hipLaunchKernelGGL(k_reduce_scale<SEM>, grid, block, 0, s, n, dof, t_sample, lim, in, out, lane_flags, qb);
-        hipLaunchKernelGGL(k_scaling_slow<SEM>, dim3((unsigned)b_blocks), dim3(kQueriesPerBlock, 8), lds_b, s, dof, t_sample, lim, in, out, qb);
+        hipLaunchKernelGGL(k_scaling_slow<SEM>, dim3((unsigned)b_blocks), dim3(kQueriesPerBlock, 8), 0, s, dof, t_sample, lim, in, out, qb);
     });
 }
 

@@ -54,6 +54,53 @@ def test_matlab_roots_on_the_device(amd, oracle_mod):
     assert st[0] == 2 and nr[0] == 0
 
 
+def test_matlab_roots_on_the_device_bit_for_bit(amd, oracle_mod):
+    """The register-resident solver (round 5: matrix in VGPRs, every index a constant, one out-of-line function per degree) against the
+    twin's loop form, BIT for bit — status, root count, every re / im entry: ~160 k polynomials of degree 1..6 with uniform and
+    log-uniform coefficients, root clusters and exact multiples (the exceptional shifts of iterations 10 and 20), stripped leading /
+    trailing zeros, magnitudes from 2^-1000 to 2^1000, NaN / Inf coefficients. (The same header against the same twin on the host,
+    2.9 M polynomials: tests/test_matlab_twin.py.)"""
+    D, lim = amd.limit_set("ref")
+    ltp = amd.LongTermPlanner(D, 0.001, device=0, **lim)
+    rng = np.random.default_rng(20251005)
+    n = 6000
+    checked = noconv = 0
+    for deg in (1, 2, 3, 4, 5, 6):
+        sets = [rng.uniform(-1, 1, size=(n, deg + 1)),
+                rng.choice([-1.0, 1.0], size=(n, deg + 1)) * np.exp(rng.uniform(-27.6, 27.6, size=(n, deg + 1)))]
+        # from chosen roots: a cluster of width `spread` around `centre`, exact multiples, a few roots elsewhere
+        centre = rng.uniform(-3, 3, size=(n, 1)); spread = np.exp(-rng.uniform(0, 30, size=(n, 1)))
+        pick = rng.integers(0, 4, size=(n, deg))
+        roots = np.where(pick == 0, centre, np.where(pick == 1, centre + spread * rng.uniform(-1, 1, size=(n, deg)), rng.uniform(-10, 10, size=(n, deg))))
+        c = np.ones((n, 1))
+        for k in range(deg):
+            c = np.concatenate([c, np.zeros((n, 1))], axis=1) - np.concatenate([np.zeros((n, 1)), c * roots[:, k:k + 1]], axis=1)
+        sets.append(c * np.exp(rng.uniform(-10, 10, size=(n, 1))))
+        z = rng.uniform(-1, 1, size=(n, deg + 1))
+        lead0 = rng.integers(0, deg + 2, size=n); trail0 = rng.integers(0, deg + 2, size=n)
+        col = np.arange(deg + 1)[None, :]
+        z[col < lead0[:, None]] = 0.0
+        z[col > deg - trail0[:, None]] = 0.0
+        sets.append(z)
+        sets.append(rng.uniform(-1, 1, size=(n // 2, deg + 1)) * np.exp2(rng.integers(-1000, 1000, size=(n // 2, deg + 1)).astype(np.float64)))
+        bad = rng.uniform(-1, 1, size=(64, deg + 1))
+        bad[np.arange(64), rng.integers(0, deg + 1, size=64)] = np.where(rng.integers(0, 2, size=64) == 1, np.nan, np.inf)
+        sets.append(bad)
+        polys = np.ascontiguousarray(np.concatenate(sets, axis=0))
+        got, nr, st = ltp.matlabRoots(polys)
+        gre = np.ascontiguousarray(got.real).view(np.uint64); gim = np.ascontiguousarray(got.imag).view(np.uint64)
+        for i, c in enumerate(polys):
+            want, wst = oracle_mod.matlab_roots(c)
+            assert st[i] == wst and nr[i] == want.size, (deg, i, c.tolist())
+            k = int(nr[i])
+            wre = np.ascontiguousarray(want.real).view(np.uint64); wim = np.ascontiguousarray(want.imag).view(np.uint64)
+            same = ((gre[i, :k] == wre) | (np.isnan(got.real[i, :k]) & np.isnan(want.real))) & ((gim[i, :k] == wim) | (np.isnan(got.imag[i, :k]) & np.isnan(want.imag)))
+            assert bool(np.all(same)), (deg, i, c.tolist(), got[i, :k].tolist(), want.tolist())
+            checked += 1
+            noconv += int(wst == 1)
+    assert checked > 160_000
+
+
 def test_matlab_unit_tables_on_the_device(amd, kat):
     """tests/unittests/*.m through the one-lane entry points in MATLAB semantics (all seven switching times)."""
     m = kat["matlab_twins"]

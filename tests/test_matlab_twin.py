@@ -203,3 +203,22 @@ def test_matlab_trajectory_semantics(oracle_mod):
     bad = o.plan_batch(qg, q0, np.array([[0.0, 1.6, 0.0]]), z, sample=False)          # |v_0| > v_max: error() in LTPlanner.m:93-95
     assert bad["status"][0] == 0 and bad["matlab_flags"][0] & 2
     assert np.all(rm["mod"][0, rm["slowest"][0]] == 0)
+
+
+def test_device_header_of_matlab_roots_equals_the_twin_on_the_host():
+    """csrc/ltp_roots_matlab.hpp — the header the MATLAB-semantics kernels include: LAPACK's DGEEV path with the matrix in registers and
+    every index a compile-time constant — compiled by plain g++ and compared with the twin's loop form (oracle/matlab_roots.inc) bit for
+    bit: status, root count and every re / im entry on ~2.9 M polynomials of degree 0..6 (uniform and log-uniform coefficients, root
+    clusters / exact multiples / near-real pairs that take both exceptional shifts, stripped leading / trailing zeros, magnitudes from
+    subnormal to 2^1000, NaN / Inf). tests/test_gpu_matlab.py repeats the comparison on the device."""
+    import json
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-C", os.path.join(root, "oracle"), "-s"])
+    subprocess.check_call(["make", "-C", os.path.join(root, "tests", "cpp"), "-s", "matlab_roots_test"])
+    p = subprocess.run([os.path.join(root, "tests", "cpp", "matlab_roots_test"), "120", "20251005"], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = json.loads(p.stdout.strip().splitlines()[-1])
+    assert line["mismatches"] == 0 and line["polynomials"] > 2_500_000
+    assert line["with_both_exceptional_shifts"] > 10_000 and line["with_stripped_zeros"] > 50_000      # the rare paths were taken
