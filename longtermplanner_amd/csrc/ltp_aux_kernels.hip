@@ -84,7 +84,7 @@ __global__ void k_single_opt_braking(int joint, double t_sample, Limits lim, dou
 }
 
 template <int SEM>
-__global__ void k_single_opt_switch(int joint, double t_sample, Limits lim, double q_goal, double q_0, double v_0, double a_0,
+__global__ void __launch_bounds__(64) k_single_opt_switch(int joint, double t_sample, Limits lim, double q_goal, double q_0, double v_0, double a_0,
                                     double v_drive, double* io)
 {
     if constexpr (sem_libm(SEM)) libm::stage_tables();
@@ -103,7 +103,7 @@ __global__ void k_single_opt_switch(int joint, double t_sample, Limits lim, doub
 }
 
 template <int SEM>
-__global__ void k_single_time_scaling(int joint, double t_sample, Limits lim, double q_goal, double q_0, double v_0, double a_0,
+__global__ void __launch_bounds__(64) k_single_time_scaling(int joint, double t_sample, Limits lim, double q_goal, double q_0, double v_0, double a_0,
                                       double dir, double tr, double* io)
 {
     if constexpr (sem_libm(SEM)) libm::stage_tables();

@@ -69,6 +69,14 @@ LTP_MR_FN void static_for_down(F&& f)
     }
 }
 #define LTP_MR_I(ic) (decltype(ic)::value)
+// every loop body is a lambda; left to the inliner's cost model some stayed calls until after the last scalar-replacement pass, and the
+// arrays they capture by reference (a row of the matrix, the eigenvalue arrays) stayed in scratch memory: loads and stores on the
+// critical path of every sweep
+#define LTP_MR_INL __attribute__((always_inline))
+
+// c ? a : b on VALUES. (With two variables as operands the conditional operator yields one of the two OBJECTS — the compiler selects an
+// address and loads through it, which takes the address of a matrix element and keeps it in scratch memory.)
+LTP_MR_FN double pick(bool c, double a, double b) { return c ? a : b; }
 
 LTP_MR_FN double fsign(double a, double b) { return __builtin_signbit(b) ? -dabs(a) : dabs(a); }   // Fortran SIGN(a, b)
 
@@ -82,26 +90,51 @@ LTP_MR_FN double lapy2(double x, double y)
     return w * dsqrt(1.0 + (z / w) * (z / w));
 }
 
-// one term of DNRM2's scaled sum of squares
+// one term of DNRM2's scaled sum of squares: "if (scale < a) { ssq = 1 + ssq (scale / a)^2; scale = a } else ssq += (a / scale)^2" with
+// the quotient of either branch formed by ONE division (lanes of a wave take different branches: two divisions would both be run)
 LTP_MR_FN void nrm2_term(double x, double& scale, double& ssq)
 {
     const double a = dabs(x);
     if (a != 0.0) {
-        if (scale < a) { ssq = 1.0 + ssq * (scale / a) * (scale / a); scale = a; }
-        else ssq += (a / scale) * (a / scale);
+        const bool up = scale < a;
+        const double t = pick(up, scale, a) / pick(up, a, scale);
+        if (up) { ssq = 1.0 + ssq * t * t; scale = a; }
+        else ssq += t * t;
+    }
+}
+// the first term, on (scale, ssq) = (0, 1): a finite or infinite a > 0 gives ssq = 1 + 1 (0 / a)^2 = 1 exactly and scale = a; a NaN
+// fails "scale < a" and makes ssq NaN. No division.
+LTP_MR_FN void nrm2_first_term(double x, double& scale, double& ssq)
+{
+    const double a = dabs(x);
+    if (a != 0.0) {
+        if (a == a) scale = a;
+        else ssq = a;
+    }
+}
+// DNRM2 of v[1 .. NR-1]. One element: scale sqrt(ssq) with (scale, ssq) = (|v1|, 1), (0, 1) or (0, NaN), i.e. |v1| in every case.
+template <int NR>
+LTP_MR_FN double tail_nrm2(double v1, double v2)
+{
+    if constexpr (NR == 2) {
+        return dabs(v1);
+    } else {
+        double scale = 0.0, ssq = 1.0;
+        nrm2_first_term(v1, scale, ssq);
+        nrm2_term(v2, scale, ssq);
+        return scale * dsqrt(ssq);
     }
 }
 
-// DLARFG on (v[0]; v[1 .. NR-1]), NR = 2 or 3
+// DLARFG on (v0; v1 [, v2]), NR = 2 or 3 (the vector as scalars: an array handed down by reference stayed in scratch memory, three
+// loads and stores per reflector on the critical path of every sweep)
 template <int NR>
-LTP_MR_FN void larfg(double (&v)[3], double& tau)
+LTP_MR_FN void larfg(double& v0, double& v1, double& v2, double& tau)
 {
     static_assert(NR == 2 || NR == 3, "reflectors of a double-shift sweep");
     const double safmin = kDblMinM / (kDblEpsM * 0.5);
-    double alpha = v[0];
-    double scale = 0.0, ssq = 1.0;
-    static_for<1, NR>([&](auto e) { nrm2_term(v[LTP_MR_I(e)], scale, ssq); });
-    double xnorm = scale * dsqrt(ssq);
+    double alpha = v0;
+    double xnorm = tail_nrm2<NR>(v1, v2);
     if (xnorm == 0.0) { tau = 0.0; return; }
     double beta = -fsign(lapy2(alpha, xnorm), alpha);
     int knt = 0;
@@ -109,21 +142,20 @@ LTP_MR_FN void larfg(double (&v)[3], double& tau)
         const double rsafmn = 1.0 / safmin;
         do {
             ++knt;
-            static_for<1, NR>([&](auto e) { v[LTP_MR_I(e)] *= rsafmn; });
+            v1 *= rsafmn;
+            if constexpr (NR == 3) v2 *= rsafmn;
             beta *= rsafmn;
             alpha *= rsafmn;
         } while (dabs(beta) < safmin && knt < 20);
-        scale = 0.0;
-        ssq = 1.0;
-        static_for<1, NR>([&](auto e) { nrm2_term(v[LTP_MR_I(e)], scale, ssq); });
-        xnorm = scale * dsqrt(ssq);
+        xnorm = tail_nrm2<NR>(v1, v2);
         beta = -fsign(lapy2(alpha, xnorm), alpha);
     }
     tau = (beta - alpha) / beta;
     const double s = 1.0 / (alpha - beta);
-    static_for<1, NR>([&](auto e) { v[LTP_MR_I(e)] *= s; });
+    v1 *= s;
+    if constexpr (NR == 3) v2 *= s;
     for (int x = 0; x < knt; ++x) beta *= safmin;
-    v[0] = beta;
+    v0 = beta;
 }
 
 // DLANV2: eigenvalues of [a b; c d]; (rt1r, rt1i) first
@@ -201,18 +233,18 @@ LTP_MR_FN void balance(double (&T)[N][N])
     const double sfmin1 = kDblMinM / kDblEpsM, sfmax1 = 1.0 / sfmin1;
     const double sfmin2 = sfmin1 * sclfac, sfmax2 = 1.0 / sfmin2;
     double scalev[N];
-    static_for<0, N>([&](auto ic) { scalev[LTP_MR_I(ic)] = 1.0; });
+    static_for<0, N>([&](auto ic) LTP_MR_INL { scalev[LTP_MR_I(ic)] = 1.0; });
     bool noconv = true, nan = false;
     for (int guard = 0; noconv && guard < 1000; ++guard) {
         noconv = false;
-        static_for<0, N>([&](auto ic) {
+        static_for<0, N>([&](auto ic) LTP_MR_INL {
             constexpr int i = LTP_MR_I(ic);
             if (nan) return;
             double cs = 0.0, cq = 1.0, rs = 0.0, rq = 1.0, ca = 0.0, ra = 0.0;
-            static_for<0, N>([&](auto jc) { nrm2_term(T[LTP_MR_I(jc)][i], cs, cq); });
-            static_for<0, N>([&](auto jc) { nrm2_term(T[i][LTP_MR_I(jc)], rs, rq); });
+            static_for<0, N>([&](auto jc) LTP_MR_INL { nrm2_term(T[LTP_MR_I(jc)][i], cs, cq); });
+            static_for<0, N>([&](auto jc) LTP_MR_INL { nrm2_term(T[i][LTP_MR_I(jc)], rs, rq); });
             double c = cs * dsqrt(cq), r = rs * dsqrt(rq);
-            static_for<0, N>([&](auto jc) {
+            static_for<0, N>([&](auto jc) LTP_MR_INL {
                 ca = dmax(ca, dabs(T[LTP_MR_I(jc)][i]));
                 ra = dmax(ra, dabs(T[i][LTP_MR_I(jc)]));
             });
@@ -236,8 +268,8 @@ LTP_MR_FN void balance(double (&T)[N][N])
             g = 1.0 / f;
             scalev[i] *= f;
             noconv = true;
-            static_for<0, N>([&](auto jc) { T[i][LTP_MR_I(jc)] *= g; });
-            static_for<0, N>([&](auto jc) { T[LTP_MR_I(jc)][i] *= f; });
+            static_for<0, N>([&](auto jc) LTP_MR_INL { T[i][LTP_MR_I(jc)] *= g; });
+            static_for<0, N>([&](auto jc) LTP_MR_INL { T[LTP_MR_I(jc)][i] *= f; });
         });
         if (nan) return;
     }
@@ -262,7 +294,7 @@ LTP_MR_FN int lahqr(double (&T)[N][N], int n, double (&wr)[N], double (&wi)[N])
         {
             int kk = l;
             bool stop = false;
-            static_for_down<1, N>([&](auto rc) {
+            static_for_down<1, N>([&](auto rc) LTP_MR_INL {
                 constexpr int r = LTP_MR_I(rc);
                 if (stop || r > i || r <= l) return;
                 const double sub = dabs(T[r][r - 1]);
@@ -288,34 +320,36 @@ LTP_MR_FN int lahqr(double (&T)[N][N], int n, double (&wr)[N], double (&wi)[N])
             });
             l = kk;
         }
-        static_for<1, N>([&](auto rc) {
+        // (an element at a position only known at run time is read and written as a SELECT of values over the constant positions, never
+        // under a branch: the optimizer merges "if (u == i) x = T[u][u]" over u into one load through a pointer chosen at run time, and an
+        // element whose address is taken that way stays in scratch memory)
+        static_for<1, N>([&](auto rc) LTP_MR_INL {
             constexpr int r = LTP_MR_I(rc);
-            if (r == l) T[r][r - 1] = 0.0;
+            T[r][r - 1] = pick(r == l, 0.0, T[r][r - 1]);
         });
         // the bottom 2 x 2 of the active block, wherever it is
         double hmm = 0.0, hmi = 0.0, him = 0.0, hii = 0.0;
-        static_for<0, N>([&](auto uc) {
+        static_for<0, N>([&](auto uc) LTP_MR_INL {
             constexpr int u = LTP_MR_I(uc);
-            if (u == i) {
-                hii = T[u][u];
-                if constexpr (u >= 1) { hmm = T[u - 1][u - 1]; hmi = T[u - 1][u]; him = T[u][u - 1]; }
+            const bool at = u == i;
+            hii = pick(at, T[u][u], hii);
+            if constexpr (u >= 1) {
+                hmm = pick(at, T[u - 1][u - 1], hmm);
+                hmi = pick(at, T[u - 1][u], hmi);
+                him = pick(at, T[u][u - 1], him);
             }
         });
         if (l >= i - 1) {
             // one or two eigenvalues have split off
-            double r1r, r1i = 0.0, r2r = 0.0, r2i = 0.0;
+            double r1r = 0.0, r1i = 0.0, r2r = 0.0, r2i = 0.0;
             const bool pair = l != i;
             if (pair) lanv2(hmm, hmi, him, hii, r1r, r1i, r2r, r2i);
             else r1r = hii;
-            static_for<0, N>([&](auto uc) {
+            static_for<0, N>([&](auto uc) LTP_MR_INL {
                 constexpr int u = LTP_MR_I(uc);
-                if (pair) {
-                    if (u == i - 1) { wr[u] = r1r; wi[u] = r1i; }
-                    if (u == i) { wr[u] = r2r; wi[u] = r2i; }
-                } else if (u == i) {
-                    wr[u] = r1r;
-                    wi[u] = 0.0;
-                }
+                const bool first = pair ? u == i - 1 : u == i, second = pair && u == i;
+                wr[u] = pick(first, r1r, pick(second, r2r, wr[u]));
+                wi[u] = pick(first, r1i, pick(second, r2i, wi[u]));
             });
             kdefl = 0;
             its = 0;
@@ -329,14 +363,16 @@ LTP_MR_FN int lahqr(double (&T)[N][N], int n, double (&wr)[N], double (&wi)[N])
             // exceptional shifts (every 10th / 20th iteration without a deflation)
             double d0 = 0.0, s0 = 0.0, s1 = 0.0;
             if (kdefl % (2 * kexsh) == 0) {
-                static_for<2, N>([&](auto uc) {
+                static_for<2, N>([&](auto uc) LTP_MR_INL {
                     constexpr int u = LTP_MR_I(uc);
-                    if (u == i) { d0 = T[u][u]; s0 = T[u][u - 1]; s1 = T[u - 1][u - 2]; }
+                    const bool at = u == i;
+                    d0 = pick(at, T[u][u], d0); s0 = pick(at, T[u][u - 1], s0); s1 = pick(at, T[u - 1][u - 2], s1);
                 });
             } else {
-                static_for<0, N - 2>([&](auto uc) {
+                static_for<0, N - 2>([&](auto uc) LTP_MR_INL {
                     constexpr int u = LTP_MR_I(uc);
-                    if (u == l) { d0 = T[u][u]; s0 = T[u + 1][u]; s1 = T[u + 2][u + 1]; }
+                    const bool at = u == l;
+                    d0 = pick(at, T[u][u], d0); s0 = pick(at, T[u + 1][u], s0); s1 = pick(at, T[u + 2][u + 1], s1);
                 });
             }
             s = dabs(s0) + dabs(s1);
@@ -367,73 +403,73 @@ LTP_MR_FN int lahqr(double (&T)[N][N], int n, double (&wr)[N], double (&wi)[N])
             }
         }
         // look for two consecutive small subdiagonal elements: m = i-2, ..., l
-        double v[3] = {0.0, 0.0, 0.0};
+        double v0 = 0.0, v1 = 0.0, v2 = 0.0;
         int m = l;
         {
             bool stop = false;
-            static_for_down<0, N - 2>([&](auto mc) {
+            static_for_down<0, N - 2>([&](auto mc) LTP_MR_INL {
                 constexpr int mm = LTP_MR_I(mc);
                 if (stop || mm > i - 2 || mm < l) return;
                 double h21s = dabs(T[mm + 1][mm]);
                 double sc = dabs(T[mm][mm] - rt2r) + dabs(rt2i) + h21s;
                 h21s = T[mm + 1][mm] / sc;
-                v[0] = h21s * T[mm][mm + 1] + (T[mm][mm] - rt1r) * ((T[mm][mm] - rt2r) / sc) - rt1i * (rt2i / sc);
-                v[1] = h21s * (T[mm][mm] + T[mm + 1][mm + 1] - rt1r - rt2r);
-                v[2] = h21s * T[mm + 2][mm + 1];
-                sc = dabs(v[0]) + dabs(v[1]) + dabs(v[2]);
-                v[0] /= sc; v[1] /= sc; v[2] /= sc;
+                v0 = h21s * T[mm][mm + 1] + (T[mm][mm] - rt1r) * ((T[mm][mm] - rt2r) / sc) - rt1i * (rt2i / sc);
+                v1 = h21s * (T[mm][mm] + T[mm + 1][mm + 1] - rt1r - rt2r);
+                v2 = h21s * T[mm + 2][mm + 1];
+                sc = dabs(v0) + dabs(v1) + dabs(v2);
+                v0 /= sc; v1 /= sc; v2 /= sc;
                 m = mm;
                 if (mm == l) { stop = true; return; }
                 if constexpr (mm >= 1) {
                     const double h00 = dabs(T[mm - 1][mm - 1]), hh11 = dabs(T[mm][mm]), hh22 = dabs(T[mm + 1][mm + 1]);
-                    if (dabs(T[mm][mm - 1]) * (dabs(v[1]) + dabs(v[2])) <= ulp * dabs(v[0]) * (h00 + hh11 + hh22)) stop = true;
+                    if (dabs(T[mm][mm - 1]) * (dabs(v1) + dabs(v2)) <= ulp * dabs(v0) * (h00 + hh11 + hh22)) stop = true;
                 }
             });
         }
         // double-shift QR sweep on rows / columns l .. i (eigenvalues only: i1 = l, i2 = i): k = m .. i-1
-        static_for<0, N - 1>([&](auto kc) {
+        static_for<0, N - 1>([&](auto kc) LTP_MR_INL {
             constexpr int k = LTP_MR_I(kc);
             if (k < m || k > i - 1) return;
             const bool three = k < i - 1;                              // nr = min(3, i - k + 1)
             double t1;
             if constexpr (k >= 1) {
                 if (k > m) {
-                    v[0] = T[k][k - 1];
-                    v[1] = T[k + 1][k - 1];
-                    if constexpr (k + 2 <= N - 1) { if (three) v[2] = T[k + 2][k - 1]; }
+                    v0 = T[k][k - 1];
+                    v1 = T[k + 1][k - 1];
+                    if constexpr (k + 2 <= N - 1) { if (three) v2 = T[k + 2][k - 1]; }
                 }
             }
             if constexpr (k + 2 <= N - 1) {
-                if (three) larfg<3>(v, t1);
-                else larfg<2>(v, t1);
+                if (three) larfg<3>(v0, v1, v2, t1);
+                else larfg<2>(v0, v1, v2, t1);
             } else {
-                larfg<2>(v, t1);                                       // the last row pair: never three rows
+                larfg<2>(v0, v1, v2, t1);                                     // the last row pair: never three rows
             }
             if (k > m) {
                 if constexpr (k >= 1) {
-                    T[k][k - 1] = v[0];
+                    T[k][k - 1] = v0;
                     T[k + 1][k - 1] = 0.0;
                     if constexpr (k + 2 <= N - 1) { if (three) T[k + 2][k - 1] = 0.0; }
                 }
             } else if (m > l) {
                 if constexpr (k >= 1) T[k][k - 1] = T[k][k - 1] * (1.0 - t1);
             }
-            const double v2 = v[1], t2 = t1 * v2;
+            const double w2 = v1, t2 = t1 * w2;
             if (three) {
                 if constexpr (k + 2 <= N - 1) {
-                    const double v3 = v[2], t3 = t1 * v3;
-                    static_for<k, N>([&](auto jc) {
+                    const double w3 = v2, t3 = t1 * w3;
+                    static_for<k, N>([&](auto jc) LTP_MR_INL {
                         constexpr int j = LTP_MR_I(jc);
                         if (j > i) return;
-                        const double sum = T[k][j] + v2 * T[k + 1][j] + v3 * T[k + 2][j];
+                        const double sum = T[k][j] + w2 * T[k + 1][j] + w3 * T[k + 2][j];
                         T[k][j] -= sum * t1;
                         T[k + 1][j] -= sum * t2;
                         T[k + 2][j] -= sum * t3;
                     });
-                    static_for<0, (k + 3 < N - 1 ? k + 3 : N - 1) + 1>([&](auto jc) {
+                    static_for<0, (k + 3 < N - 1 ? k + 3 : N - 1) + 1>([&](auto jc) LTP_MR_INL {
                         constexpr int j = LTP_MR_I(jc);
                         if (j < l || j > i) return;                    // j = l .. min(k + 3, i)
-                        const double sum = T[j][k] + v2 * T[j][k + 1] + v3 * T[j][k + 2];
+                        const double sum = T[j][k] + w2 * T[j][k + 1] + w3 * T[j][k + 2];
                         T[j][k] -= sum * t1;
                         T[j][k + 1] -= sum * t2;
                         T[j][k + 2] -= sum * t3;
@@ -441,17 +477,17 @@ LTP_MR_FN int lahqr(double (&T)[N][N], int n, double (&wr)[N], double (&wi)[N])
                 }
             } else {
                 // nr == 2: k == i - 1
-                static_for<k, N>([&](auto jc) {
+                static_for<k, N>([&](auto jc) LTP_MR_INL {
                     constexpr int j = LTP_MR_I(jc);
                     if (j > i) return;
-                    const double sum = T[k][j] + v2 * T[k + 1][j];
+                    const double sum = T[k][j] + w2 * T[k + 1][j];
                     T[k][j] -= sum * t1;
                     T[k + 1][j] -= sum * t2;
                 });
-                static_for<0, k + 2>([&](auto jc) {
+                static_for<0, k + 2>([&](auto jc) LTP_MR_INL {
                     constexpr int j = LTP_MR_I(jc);
                     if (j < l) return;                                 // j = l .. i
-                    const double sum = T[j][k] + v2 * T[j][k + 1];
+                    const double sum = T[j][k] + w2 * T[j][k + 1];
                     T[j][k] -= sum * t1;
                     T[j][k + 1] -= sum * t2;
                 });
@@ -471,15 +507,15 @@ LTP_MR_SOLVER int roots_n(const double (&c)[N + 1], double (&re)[kMaxN], double 
 {
     static_assert(N >= 1 && N <= kMaxN, "degree");
     const double nan = __builtin_nan("");
-    static_for<0, N>([&](auto ic) { re[LTP_MR_I(ic)] = nan; im[LTP_MR_I(ic)] = nan; });
+    static_for<0, N>([&](auto ic) LTP_MR_INL { re[LTP_MR_I(ic)] = nan; im[LTP_MR_I(ic)] = nan; });
     nroots = 0;
     bool finite = true;
-    static_for<0, N + 1>([&](auto ic) { finite = finite && dfinite(c[LTP_MR_I(ic)]); });
+    static_for<0, N + 1>([&](auto ic) LTP_MR_INL { finite = finite && dfinite(c[LTP_MR_I(ic)]); });
     if (!finite) return 2;
     int first = 0;
     {
         bool lead = true;
-        static_for<0, N + 1>([&](auto ic) {
+        static_for<0, N + 1>([&](auto ic) LTP_MR_INL {
             if (lead && c[LTP_MR_I(ic)] == 0.0) ++first;
             else lead = false;
         });
@@ -488,7 +524,7 @@ LTP_MR_SOLVER int roots_n(const double (&c)[N + 1], double (&re)[kMaxN], double 
     int last = N;
     {
         bool trail = true;
-        static_for_down<1, N + 1>([&](auto ic) {
+        static_for_down<1, N + 1>([&](auto ic) LTP_MR_INL {
             if (trail && LTP_MR_I(ic) > first && c[LTP_MR_I(ic)] == 0.0) --last;
             else trail = false;
         });
@@ -497,18 +533,18 @@ LTP_MR_SOLVER int roots_n(const double (&c)[N + 1], double (&re)[kMaxN], double 
     nroots = N - first;
     // d[j] = c[first + j]
     double d[N + 1];
-    static_for<0, N + 1>([&](auto jc) { d[LTP_MR_I(jc)] = 0.0; });
-    static_for<0, N + 1>([&](auto fc) {
+    static_for<0, N + 1>([&](auto jc) LTP_MR_INL { d[LTP_MR_I(jc)] = 0.0; });
+    static_for<0, N + 1>([&](auto fc) LTP_MR_INL {
         constexpr int f = LTP_MR_I(fc);
-        if (first == f) static_for<0, N + 1 - f>([&](auto jc) { d[LTP_MR_I(jc)] = c[f + LTP_MR_I(jc)]; });
+        if (first == f) static_for<0, N + 1 - f>([&](auto jc) LTP_MR_INL { d[LTP_MR_I(jc)] = c[f + LTP_MR_I(jc)]; });
     });
     double T[N][N];
-    static_for<0, N>([&](auto ic) { static_for<0, N>([&](auto jc) { T[LTP_MR_I(ic)][LTP_MR_I(jc)] = 0.0; }); });
-    static_for<1, N>([&](auto ic) {
+    static_for<0, N>([&](auto ic) LTP_MR_INL { static_for<0, N>([&](auto jc) LTP_MR_INL { T[LTP_MR_I(ic)][LTP_MR_I(jc)] = 0.0; }); });
+    static_for<1, N>([&](auto ic) LTP_MR_INL {
         constexpr int i = LTP_MR_I(ic);
         if (i < n) T[i][i - 1] = 1.0;
     });
-    static_for<0, N>([&](auto jc) {
+    static_for<0, N>([&](auto jc) LTP_MR_INL {
         constexpr int j = LTP_MR_I(jc);
         if (j < n) {
             T[0][j] = -d[1 + j] / d[0];
@@ -518,18 +554,20 @@ LTP_MR_SOLVER int roots_n(const double (&c)[N + 1], double (&re)[kMaxN], double 
     if (!finite) return 2;
     balance<N>(T);
     double wr[N], wi[N];
-    static_for<0, N>([&](auto ic) { wr[LTP_MR_I(ic)] = nan; wi[LTP_MR_I(ic)] = nan; });
+    static_for<0, N>([&](auto ic) LTP_MR_INL { wr[LTP_MR_I(ic)] = nan; wi[LTP_MR_I(ic)] = nan; });
     const int info = lahqr<N>(T, n, wr, wi);
     const int nz = nroots - n;                                         // zero roots come first: r = [zeros(nnz, 1); eig(A)]
-    static_for<0, N>([&](auto kc) {
+    static_for<0, N>([&](auto kc) LTP_MR_INL {
         constexpr int k = LTP_MR_I(kc);
-        if (k < nz) { re[k] = 0.0; im[k] = 0.0; }
-        else {
-            static_for<0, k + 1>([&](auto uc) {
-                constexpr int u = LTP_MR_I(uc);
-                if (k - nz == u && u < n) { re[k] = wr[u]; im[k] = wi[u]; }
-            });
-        }
+        double rk = nan, ik = nan;                                     // (entries behind the last root stay NaN)
+        static_for<0, k + 1>([&](auto uc) LTP_MR_INL {
+            constexpr int u = LTP_MR_I(uc);
+            const bool at = k - nz == u && u < n;
+            rk = pick(at, wr[u], rk);
+            ik = pick(at, wi[u], ik);
+        });
+        re[k] = pick(k < nz, 0.0, rk);
+        im[k] = pick(k < nz, 0.0, ik);
     });
     return info ? 1 : 0;
 }
@@ -545,11 +583,11 @@ LTP_MR_FN int roots(const double* c, int deg, double (&re)[kMaxN], double (&im)[
     }
     if (deg == 0) return dfinite(c[0]) ? 0 : 2;
     int st = 2;
-    static_for<1, kMaxN + 1>([&](auto dc) {
+    static_for<1, kMaxN + 1>([&](auto dc) LTP_MR_INL {
         constexpr int D = LTP_MR_I(dc);
         if (deg == D) {
             double cc[D + 1];
-            static_for<0, D + 1>([&](auto ic) { cc[LTP_MR_I(ic)] = c[LTP_MR_I(ic)]; });
+            static_for<0, D + 1>([&](auto ic) LTP_MR_INL { cc[LTP_MR_I(ic)] = c[LTP_MR_I(ic)]; });
             st = roots_n<D>(cc, re, im, nroots);
         }
     });
