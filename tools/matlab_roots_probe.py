@@ -1,5 +1,5 @@
 """What one MATLAB-semantics eigen-solve costs on the device: k_roots_matlab (the kernel behind LongTermPlanner.matlabRoots) on the
-polynomials a 100 k panda batch really solves (tools/exp/polys100k.npy: rows [degree, c0..c6, root] logged by the oracle), alone and
+polynomials a 100 k panda batch really solves (logged by the oracle while it plans the same batch), alone and
 in company. Run under rocprofv3 --kernel-trace (durations) or --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES (instructions):
 the launches appear in this order — per degree 4, 5, 6: [worst polynomial x 64 lanes = one wave] [worst polynomial x 1 lane]
 [every polynomial of the degree]."""
@@ -11,8 +11,11 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import longtermplanner_amd as amd
 import oracle
 
-rows = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "exp", "polys100k.npy"))
 D, lim = amd.limit_set("panda")
+# the polynomials of bench.py's 100 k panda batch (seed 12345), logged by the oracle's MATLAB-semantics twin: rows [degree, c0..c6, root]
+qg, q0, v0, a0 = amd.generate_queries(100000, lim, seed=12345)
+orc = oracle.Oracle(D, 0.001, semantics="matlab", **lim)
+_, rows = oracle.poly_log(lambda: orc.plan_batch(qg, q0, v0, a0, sample=False), cap=3000000)
 ltp = amd.LongTermPlanner(D, 0.001, device=0, **lim)
 lib = oracle.lib()
 ltp.matlabRoots(np.array([[1.0, -3.0, 2.0]]))      # warm-up launch
