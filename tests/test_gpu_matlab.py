@@ -172,6 +172,28 @@ def test_matlab_records_parity(amd, oracle_mod, name, n, ts):
     assert np.any(np.abs(c["t_scaled"][both] - r["t_scaled"][both]) > 1e-6) or name == "panda"
 
 
+@pytest.mark.parametrize("name", ["panda", "ref", "ref30"])
+def test_matlab_queue_spreading_batch_sizes(amd, oracle_mod, name):
+    """Round 5: in MATLAB semantics the two queue kernels deal their queued lanes to all the blocks that run at once (1 .. 64 lanes per
+    block by the queue's length, ltp_stage_kernels.hip slow_lanes_per_block). Batches whose queues hold fewer lanes than there are
+    blocks, exactly a block's worth, and many rounds' worth: every record entry the twin's BITS (the arithmetic does not depend on
+    which block a lane lands in)."""
+    D, lim, ltp, orc = _pair(amd, oracle_mod, name)
+    sizes = (1, 2, 9, 64, 65, 1000, 4097, 70001) if D == 7 else (1, 3, 64, 513, 9001)
+    for n in sizes:
+        qg, q0, v0, a0 = amd.generate_queries(n, lim, seed=4040 + n)
+        r = ltp.planBatchHost(qg, q0, v0, a0, sample=False)
+        o = orc.plan_batch(qg, q0, v0, a0, sample=False)
+        planned = o["status"] != 0
+        assert np.array_equal((r["status"] & ~amd.STATUS_MATLAB_COMPLEX) == 0, planned), n
+        for k in ("slowest", "traj_len", "mod", "dir"):
+            assert np.array_equal(r[k][planned], o[k][planned]), (n, k)
+        for k in ("t_opt", "t_scaled", "v_drive", "t_required"):
+            a, b = np.ascontiguousarray(r[k][planned]), np.ascontiguousarray(o[k][planned])
+            same = (a.view(np.uint64) == b.view(np.uint64)) | (np.isnan(a) & np.isnan(b))
+            assert bool(np.all(same)), (n, k, float(np.nanmax(np.abs(a - b))))
+
+
 @pytest.mark.parametrize("name,n,ts", [("panda", 600, 0.001), ("ref", 300, 0.001), ("ref30", 40, 0.001), ("ref", 400, 0.004)])
 def test_matlab_dense_trajectory_parity(amd, oracle_mod, name, n, ts):
     import torch
