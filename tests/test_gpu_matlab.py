@@ -65,8 +65,10 @@ def test_matlab_roots_on_the_device_bit_for_bit(amd, oracle_mod):
     rng = np.random.default_rng(20251005)
     n = 6000
     checked = noconv = 0
+    rows = np.load(__import__("os").path.join(__import__("os").path.dirname(__file__), "golden", "planner_polynomials.npz"))["rows"]
     for deg in (1, 2, 3, 4, 5, 6):
-        sets = [rng.uniform(-1, 1, size=(n, deg + 1)),
+        planner = np.array([r[1:2 + deg] for r in rows if int(r[0]) == deg]).reshape(-1, deg + 1)      # what the planner really solves
+        sets = [planner, rng.uniform(-1, 1, size=(n, deg + 1)),
                 rng.choice([-1.0, 1.0], size=(n, deg + 1)) * np.exp(rng.uniform(-27.6, 27.6, size=(n, deg + 1)))]
         # from chosen roots: a cluster of width `spread` around `centre`, exact multiples, a few roots elsewhere
         centre = rng.uniform(-3, 3, size=(n, 1)); spread = np.exp(-rng.uniform(0, 30, size=(n, 1)))
