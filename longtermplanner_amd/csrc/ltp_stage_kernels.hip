@@ -158,9 +158,9 @@ k_opt_fast(long long n, int dof, double t_sample, int goal_check, Limits lim, Qu
     }
 }
 
-// Queue kernels in MATLAB semantics: how many consecutive queue items a block takes per pass. LAPACK's iteration runs 16-30 sweeps on
-// nearly every polynomial with different windows per lane; at 2 waves per SIMD (the kernels' register budget) the machine holds
-// kSlowWavesAtOnce waves, and a queue of a 100 k batch has ~1 300 items: 64 to a wave leaves 98 % of the SIMDs idle and makes every
+// k_scaling_slow in MATLAB semantics: how many consecutive queue items a block takes per pass. LAPACK's iteration runs 16-30 sweeps on
+// nearly every degree-6 polynomial with different windows per lane; at 2 waves per SIMD (the kernel's register budget) the machine holds
+// kSlowWavesAtOnce waves, and the queue of a 100 k batch has ~1 300 items: 64 to a wave leaves 98 % of the SIMDs idle and makes every
 // wave run the union of 64 lanes' branches.
 constexpr unsigned kSlowWavesAtOnce = 256 * 4 * 2;
 constexpr unsigned long long kSlowLanesMin = 1;   // (a floor of 8 lanes per block was measured: slower in every line, profiles/r05_matlab_roots_registers_ab.txt)
@@ -178,14 +178,12 @@ k_opt_slow(int dof, double t_sample, Limits lim, Queries in, Records out, signed
     if constexpr (sem_libm(SEM)) libm::stage_tables();        // the block's LDS copy of glibc's pow tables (ltp_libm_pow.hpp)
     unsigned long long cnt[kQueueShards];
     const unsigned long long count = queue_total(queue, cnt);
-    // MATLAB semantics: a wave pays for the union of what its lanes do, and a queue is short next to the machine — the queued lanes are
-    // dealt to as many blocks as run at once (kSlowWavesAtOnce), 1 .. 64 lanes per block, instead of 64 per block to the first
-    // count / 64 blocks. C++ semantics keeps 64 per block: spread, this kernel was 21 % SLOWER on the reference's limits (88 -> 107 us
-    // per 100 k queries, one box) — one wave's binary64 stream fills its SIMD, and two thin waves per SIMD issue twice the instructions.
-    const unsigned long long per = sem_matlab(SEM) ? slow_lanes_per_block(count, gridDim.x, kSlowWavesAtOnce) : (unsigned long long)kQueriesPerBlock;
-    for (unsigned long long base = (unsigned long long)blockIdx.x * per; base < count; base += (unsigned long long)gridDim.x * per) {
-        const unsigned long long it = base + threadIdx.x;
-        if (threadIdx.x >= per || it >= count) continue;
+    // (64 queued lanes per block in both semantics. Dealt thinly to all the blocks that run at once, as k_scaling_slow does in MATLAB
+    // semantics, this kernel was SLOWER — 88 -> 107 us per 100 k queries of the reference's limits in C++ semantics, 0.560 -> 0.588 ms for
+    // the whole MATLAB-semantics line: its queue is long where it matters, one wave's binary64 stream fills its SIMD, and two thin waves
+    // per SIMD issue twice the instructions for the same lanes.)
+    for (unsigned long long it = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; it < count;
+         it += (unsigned long long)gridDim.x * blockDim.x) {
         const long long rj = (long long)queue_item(queue, cnt, it);
         const long long q = rj / dof;
         const int j = (int)(rj - q * dof);
@@ -389,7 +387,7 @@ k_scaling_slow(int dof, double t_sample, Limits lim, Queries in, Records out, Qu
     const int c = __builtin_amdgcn_readfirstlane(threadIdx.y);
     unsigned long long cnt[kQueueShards];
     const unsigned long long count = queue_total(queue, cnt);
-    // MATLAB semantics: as in k_opt_slow, the queued items spread over the blocks that run at once (one 8-wave block per compute unit),
+    // MATLAB semantics: the queued items spread over the blocks that run at once (one 8-wave block per compute unit),
     // 1 .. 64 per block — LAPACK's iteration takes 16-30 sweeps on nearly every degree-6 polynomial, so a wave of 64 pays the union of
     // 64 lanes' branches in every one of them (100 k queries: 0.476 -> 0.457 ms). C++ semantics keeps 64 per block: there ONE lane's 76
     // Francis steps decide the kernel whatever its company, and 256 blocks instead of 20 were 3 % slower (155.7 -> 160.6 us, one box).
