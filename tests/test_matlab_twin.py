@@ -222,3 +222,24 @@ def test_device_header_of_matlab_roots_equals_the_twin_on_the_host():
     line = json.loads(p.stdout.strip().splitlines()[-1])
     assert line["mismatches"] == 0 and line["polynomials"] > 2_500_000
     assert line["with_both_exceptional_shifts"] > 10_000 and line["with_stripped_zeros"] > 50_000      # the rare paths were taken
+
+
+def test_matlab_solver_stays_in_registers():
+    """Build guard (hipcc cross-compiles here, no GPU): the MATLAB-semantics queue kernels keep the eigen-solve's matrix in registers. Inlined
+    at its call sites the solver once spilled 483 registers per lane (1.7 KB of scratch), and with a dynamically indexed element it kept a
+    matrix row in scratch memory (EXPERIMENTS E7.13): what is left per lane is the argument arrays of the out-of-line solver (c[7], re[6],
+    im[6]) and a call frame."""
+    import os
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "kres.py"), "ltp_stage_kernels", "slow<"], capture_output=True, text=True, timeout=900).stdout
+    seen = 0
+    for line in out.splitlines():
+        m = re.match(r"void ltp::(k_\w+)<(\d)>\s+VGPR\s+(\d+).*scratch\s+(\d+)\s+vspill\s+(\d+).*LDS\s+(\d+)", line)
+        if m and int(m.group(2)) & 1:                       # SEM bit 0: MATLAB semantics
+            seen += 1
+            assert int(m.group(4)) <= 400 and int(m.group(5)) <= 16, line
+            assert int(m.group(6)) <= 8192, line            # (and no 144 KB of matrices in LDS)
+    assert seen == 4, out
