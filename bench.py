@@ -14,10 +14,13 @@ launched plainly with --gpus N > 1, this process spawns the N rank processes its
 touching a GPU, forwards their output, and exits non-zero if any of them fails — it never reports an
 n_gpus: 1 line under an N-GPU request.
 
-The line carries the headline workload (BASELINE.json configs[2]: 1 M x 7-DoF, 1 ms, full sampling) and, in
-"secondary", the other single-GPU configs run back to back in the same process (S-ref limits, configs[1]
-100 k switching times only, configs[4] 1 M x 30-DoF); with N > 1 the secondary entry is configs[3]
-(10 M queries sharded over the N GPUs, strong scaling).
+The line — the LAST and only JSON line on stdout, held under 4 KB (HEADLINE_BUDGET) because the driver parses the tail
+of stdout — carries the headline workload (BASELINE.json configs[2]: 1 M x 7-DoF, 1 ms, full sampling) with its
+`roofline` and `cpu_baseline`. The other single-GPU configs run back to back in the same process (S-ref limits,
+configs[1] 100 k switching times only, configs[4] 1 M x 30-DoF, the short-row / receding / consumer forms; with N > 1:
+configs[3], 10 M queries sharded over the N GPUs, strong scaling): their full records go to --secondary-file
+(gpurun_out/bench_secondary.jsonl, one JSON line each), one short text line each to stderr, and the headline
+names the file and their count.
 """
 import argparse
 import json
@@ -172,6 +175,8 @@ def parse_args(argv=None):
                          "(ltp_end_limit_batch), so that status == 0 is exactly planTrajectory's bool")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="only the primary workload (profiling runs)")
+    ap.add_argument("--secondary-file", default=os.path.join(ROOT, "gpurun_out", "bench_secondary.jsonl"),
+                    help="where the secondary workloads' full records go, one JSON line each (stdout carries the headline line only)")
     ap.add_argument("--plain-stores", action="store_true", help="sampler uses plain instead of non-temporal stores")
     ap.add_argument("--window-gib", type=float, default=0.0, help="DIAGNOSTIC: chunk capacity; chunks rotate through windows of the tile")
     ap.add_argument("--spread", type=int, default=0, help="sampler block->plan interleave factor (0 = library default 64, 1 = plan order)")
@@ -662,6 +667,57 @@ def run_one_process(args):
         out["config"]["records_checksum"] = acc % M
     return out
 
+HEADLINE_BUDGET = 4096      # bytes: the driver keeps the tail of stdout only, so the line it parses must be short and LAST
+
+
+def assemble_lines(out, secondary, rccl_world1, secondary_file):
+    """(headline, side_lines, notes): the ONE JSON line stdout carries, the full secondary records for `secondary_file` (JSON lines), and
+    one short plain-text note per secondary workload for stderr. Round 5's default line carried 18 secondary workloads inline and grew to
+    29 KB; the driver's capture kept its tail only and parsed nothing. The headline is held under HEADLINE_BUDGET bytes whatever the run adds."""
+    head = json.loads(json.dumps(out))      # deep copy: the caller's record is not trimmed
+    side, notes = [], []
+    for s in secondary or []:
+        side.append(dict(s, kind="secondary"))
+        r = s.get("roofline") or {}
+        key = (s.get("config") or {}).get("workload_key", "?")
+        notes.append("bench.py secondary: %s | %s %s | %s ms/step | %s %s" % (
+            key, s.get("value"), s.get("unit", ""), s.get("ms_per_step"), r.get("bound", "-"),
+            ("frac %s (%s)" % (r.get("frac"), r.get("kernel"))) if r.get("frac") is not None else (s.get("error") or "")))
+    if rccl_world1 is not None:
+        side.append(dict(rccl_world1, kind="rccl_world1"))
+        head["rccl_world1"] = {k: rccl_world1[k] for k in ("ok", "value", "unit", "backend", "rank_devices", "roofline_frac", "error") if k in rccl_world1}
+    if side:
+        head["secondary"] = {"count": len(secondary or []), "errors": len([s for s in secondary or [] if "error" in s]), "file": secondary_file,
+                             "note": "one JSON line per secondary workload in `file` (and one short text line each on stderr); this line is the headline only"}
+    line = json.dumps(head)
+    if len(line) > HEADLINE_BUDGET:       # drop prose first, never the numbers
+        for path in (("roofline", "traffic_from_profile"), ("cpu_baseline", "flat_preallocated"), ("cpu_baseline", "cores_rule"), ("rccl_world1", "backend"),
+                     ("secondary", "note"), ("config", "sharding"), ("config", "plans_ok_is"), ("cpu_baseline", "measured_on")):
+            d = head.get(path[0])
+            if isinstance(d, dict) and path[1] in d:
+                del d[path[1]]
+                line = json.dumps(head)
+                if len(line) <= HEADLINE_BUDGET:
+                    break
+    return line, [json.dumps(x) for x in side], notes
+
+
+def emit_result(out, secondary, rccl_world1, secondary_file):
+    line, side, notes = assemble_lines(out, secondary, rccl_world1, secondary_file)
+    if side:
+        try:
+            d = os.path.dirname(secondary_file)
+            if d:
+                os.makedirs(d, exist_ok=True)
+            with open(secondary_file, "w") as f:
+                f.write("\n".join(side) + "\n")
+        except OSError as e:
+            print(f"bench.py: could not write {secondary_file}: {e}", file=sys.stderr)
+    for n in notes:
+        print(n, file=sys.stderr)
+    sys.stderr.flush()
+    print(line, flush=True)
+
 
 def main():
     args = parse_args()
@@ -816,10 +872,6 @@ def main():
                 secondary.append(keep)
 
     if rank == 0:
-        if secondary:
-            out["secondary"] = secondary
-        if rccl_world1 is not None:
-            out["rccl_world1"] = rccl_world1
         if not args.no_cpu_baseline:
             # rank 0 only, outside every timed region; with N > 1 the other ranks wait in the final barrier meanwhile
             from longtermplanner_amd import limit_set
@@ -827,7 +879,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(dof, lim, args.t_sample, args.seed, args.switch_only)
             if world > 1:
                 out["cpu_baseline"]["measured_on"] = f"rank 0 of {world}, after the timed steps, while the other ranks wait in the final barrier"
-        print(json.dumps(out), flush=True)
+        emit_result(out, secondary, rccl_world1, args.secondary_file)
     if grouped:
         dist.barrier()
         dist.destroy_process_group()

@@ -1,9 +1,10 @@
 #!/bin/bash
 # After `gpurun -- bash tools/refresh_profiles.sh TAG` has merged its output into gpurun_out/: condense it into profiles/.
-TAG=${1:-r05}
+TAG=${1:-r06}
 cd "$(dirname "$0")/.."
 python profiles/summarize.py $TAG gpurun_out/prof_stats gpurun_out/prof_write gpurun_out/prof_fetch || exit 1
 cp gpurun_out/bench_default.json profiles/${TAG}_bench.json
+cp gpurun_out/bench_default_secondary.jsonl profiles/${TAG}_bench_secondary.jsonl
 cp gpurun_out/bench_variants.jsonl profiles/${TAG}_bench_variants.jsonl
 cp gpurun_out/bench_dry.jsonl profiles/${TAG}_dry_sampler_ceilings.jsonl
 cp gpurun_out/bench_2ranks_gloo.json profiles/${TAG}_bench_2ranks_one_gpu_gloo.json
@@ -41,7 +42,7 @@ python - <<PY
 import json, csv
 b = json.loads(open("profiles/${TAG}_bench.json").read())
 print("headline", b["value"], b["ms_per_step"], b["roofline"]["achieved"], b["roofline"]["frac"], b["roofline"]["avg_launch_ms"])
-for s in b.get("secondary", []):
+for s in [json.loads(x) for x in open("profiles/${TAG}_bench_secondary.jsonl") if '"kind": "secondary"' in x]:
     print("  ", s["name"][:72], s.get("value"), s.get("ms_per_step"), (s.get("roofline") or {}).get("achieved"), s.get("error"))
 for f in ["profiles/${TAG}_bench_variants.jsonl", "profiles/${TAG}_dry_sampler_ceilings.jsonl", "profiles/${TAG}_bench_2ranks_one_gpu_gloo.json",
           "profiles/${TAG}_bench_4ranks_one_gpu_gloo_global_batch.json", "profiles/${TAG}_bench_config4_10M_4ranks_one_gpu_gloo.json"]:

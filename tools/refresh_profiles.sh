@@ -2,7 +2,7 @@
 # Runs on the GPU box (gpurun -- bash tools/refresh_profiles.sh [tag]): headline bench, workload variants and the rocprofv3
 # passes whose summaries are kept under profiles/. Everything lands in gpurun_out/; profiles/summarize.py condenses it.
 set -o pipefail
-TAG=${1:-r05}
+TAG=${1:-r06}
 PART=${2:-all}      # all | bench (the bench lines) | prof (the rocprofv3 passes, first half) | prof2 (second half): separate gpurun calls, one would run out of time
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$R/gpurun_out
@@ -10,7 +10,7 @@ mkdir -p $O
 if [ "$PART" != bench ]; then rm -rf $O/prof_stats $O/prof_write $O/prof_fetch $O/prof_tab_stats $O/prof_switch_100000 $O/prof_switch_1000000 $O/prof_sq_first256 $O/prof_sq_first256_tab $O/prof_sq_first64 $O/prof_sq_first64_tab $O/prof_sq_switch100k $O/prof_sq_f32 $O/prof_sq_envelope $O/prof_f32_stats $O/prof_write_first256 $O/prof_write_stride4 $O/prof_write_f32 $O/prof_sq_switch1M $O/prof_env_stats $O/prof_sq_switch100k_exact $O/prof_switch_100000_exact; fi
 cd $R
 if [ "$PART" != prof ] && [ "$PART" != prof2 ]; then
-timeout -k 10 400 python bench.py > $O/bench_default.json 2> $O/bench_default.err || exit 1
+timeout -k 10 400 python bench.py --secondary-file $O/bench_default_secondary.jsonl > $O/bench_default.json 2> $O/bench_default.err || exit 1
 echo "default done"; cut -c1-300 $O/bench_default.json
 : > $O/bench_variants.jsonl
 for a in "--limits ref" "--limits ref30 --batch 200000" "--switch-only --batch 100000" "--switch-only --batch 100000 --end-limit" "--switch-only" \
