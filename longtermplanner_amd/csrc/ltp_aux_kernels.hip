@@ -57,6 +57,26 @@ k_generate(long long n, int dof, Limits lim, unsigned long long seed, long long 
 // ---------------------------------------------------------------------------------------
 // One-lane mirrors of the protected member functions (for the reference's KAT-style tests).
 // ---------------------------------------------------------------------------------------
+// LimPow of every joint under one pow rule (ltp_profile.hpp): the same device functions, on the same bits, that the kernels would
+// call — formed once per ltp_set_limits instead of once per lane. One thread per joint; out[j * kLimPowN + ...].
+template <int SEM>
+__global__ void __launch_bounds__(64) k_limit_powers(int dof, const double* a_max, const double* j_max, double* out)
+{
+    if constexpr (sem_libm(SEM)) libm::stage_tables();
+    for (int j = threadIdx.x; j < dof; j += blockDim.x) {
+        const double am = a_max[j], jm = j_max[j];
+        const double tj = am / jm;                     // cc:124, 171, 186: t_rel = a_max / j_max
+        double* w = out + (long long)j * kLimPowN;
+        w[0] = tj;
+        w[1] = pw3<SEM>(tj);
+        w[2] = pw4<SEM>(tj);
+        w[3] = pw3<SEM>(am);
+        w[4] = pw4<SEM>(am);
+        w[5] = pw3<SEM>(jm);
+        w[6] = pw4<SEM>(jm);
+    }
+}
+
 // LongTermPlanner::checkInputs (cc:68-77) for one query
 template <int SEM>
 __global__ void k_check_inputs(int dof, Limits lim, const double* q_0, const double* v_0, const double* a_0, int* ok)
@@ -75,7 +95,7 @@ __global__ void k_single_opt_braking(int joint, double t_sample, Limits lim, dou
     double r[7] = {out[0], out[1], out[2], out[3], out[4], out[5], out[6]};
     double q, dir;
     MatlabCtx mc;
-    opt_braking<SEM>(L.a_max, L.j_max, t_sample, v_0, a_0, q, r, dir, mc);
+    opt_braking<SEM>(L.a_max, L.j_max, L.pw, t_sample, v_0, a_0, q, r, dir, mc);
 #pragma unroll
     for (int k = 0; k < 7; ++k) out[k] = r[k];
     out[7] = q;
@@ -93,7 +113,7 @@ __global__ void __launch_bounds__(64) k_single_opt_switch(int joint, double t_sa
     double dir = 0.0;
     int mod = 0;
     MatlabCtx mc;
-    const bool ok = opt_switch_times<true, SEM>(L.a_max, L.j_max, L.v_max, t_sample, q_goal, q_0, v_0, a_0, v_drive, t, dir, mod, mc) == kOptTrue;
+    const bool ok = opt_switch_times<true, SEM>(L.a_max, L.j_max, L.v_max, L.pw, t_sample, q_goal, q_0, v_0, a_0, v_drive, t, dir, mod, mc) == kOptTrue;
 #pragma unroll
     for (int k = 0; k < 7; ++k) io[k] = t[k];
     io[7] = dir;
@@ -234,6 +254,13 @@ void launch_generate(hipStream_t s, long long n, int dof, Limits lim, unsigned l
     const long long total = n * dof;
     hipLaunchKernelGGL(k_generate, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, n, dof, lim, seed, first_query,
                        q_goal, q_0, v_0, a_0, sq, sj);
+}
+
+void launch_limit_powers(hipStream_t s, int dof, const double* a_max, const double* j_max, double* out_exact, double* out_libm)
+{
+    if (dof <= 0) return;
+    hipLaunchKernelGGL(k_limit_powers<0>, dim3(1), dim3(64), 0, s, dof, a_max, j_max, out_exact);
+    hipLaunchKernelGGL(k_limit_powers<kPowLibm>, dim3(1), dim3(64), 0, s, dof, a_max, j_max, out_libm);
 }
 
 void launch_check_inputs(hipStream_t s, int dof, Limits lim, const double* q_0, const double* v_0, const double* a_0, int* ok, int variant)

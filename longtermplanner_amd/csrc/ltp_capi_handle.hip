@@ -27,13 +27,19 @@ int upload_limits(ltp_planner* p)
     if (n > p->lim_cap) {
         if (p->d_lim) LTP_HIP_TRY(p, hipFree(p->d_lim));
         p->d_lim = nullptr;
-        LTP_HIP_TRY(p, hipMalloc((void**)&p->d_lim, sizeof(double) * 5 * n));
+        // five limit vectors, then the joints' LimPow tables under LTP_POW_EXACT and under LTP_POW_LIBM (dev_limits picks one)
+        LTP_HIP_TRY(p, hipMalloc((void**)&p->d_lim, sizeof(double) * (5 + 2 * ltp::kLimPowN) * n));
         p->lim_cap = n;
     }
     std::vector<double> flat(5 * (size_t)p->lim_cap, 0.0);
     for (int k = 0; k < 5; ++k)
         for (size_t i = 0; i < p->h_lim[k].size(); ++i) flat[(size_t)k * p->lim_cap + i] = p->h_lim[k][i];
     LTP_HIP_TRY(p, hipMemcpy(p->d_lim, flat.data(), sizeof(double) * flat.size(), hipMemcpyHostToDevice));
+    // the powers of the limits, by the kernels' own device functions (never inside a capture: ltp_create / ltp_set_limits are not capturable)
+    double* pw = p->d_lim + 5 * (size_t)p->lim_cap;
+    ltp::launch_limit_powers(nullptr, p->lim_cap, p->d_lim + 3 * (size_t)p->lim_cap, p->d_lim + 4 * (size_t)p->lim_cap, pw, pw + (size_t)ltp::kLimPowN * p->lim_cap);
+    LTP_HIP_TRY(p, hipGetLastError());
+    LTP_HIP_TRY(p, hipStreamSynchronize(nullptr));
     return LTP_OK;
 }
 
@@ -45,6 +51,7 @@ ltp::Limits dev_limits(const ltp_planner* p)
     L.v_max = p->d_lim + 2 * (size_t)p->lim_cap;
     L.a_max = p->d_lim + 3 * (size_t)p->lim_cap;
     L.j_max = p->d_lim + 4 * (size_t)p->lim_cap;
+    L.pw = p->d_lim + (5 + (p->pow_rule == LTP_POW_LIBM ? ltp::kLimPowN : 0)) * (size_t)p->lim_cap;
     return L;
 }
 

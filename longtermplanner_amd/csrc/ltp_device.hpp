@@ -21,6 +21,8 @@ LTP_DEV JointLimits load_limits(const Limits& lim, int j)
     L.v_max = lim.v_max[j];
     L.a_max = lim.a_max[j];
     L.j_max = lim.j_max[j];
+    const double* w = lim.pw + (long long)j * kLimPowN;
+    L.pw = LimPow{w[0], w[1], w[2], w[3], w[4], w[5], w[6]};
     return L;
 }
 

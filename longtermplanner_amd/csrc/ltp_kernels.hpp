@@ -57,7 +57,9 @@ struct Limits {            // device pointers, [dof] each
     const double* v_max;
     const double* a_max;
     const double* j_max;
+    const double* pw;      // [dof][kLimPowN]: LimPow of every joint under the handle's pow rule (k_limit_powers)
 };
+constexpr int kLimPowN = 7;
 
 struct Queries {           // element (query p, joint j) at ptr[p * sq + j * sj]
     const double* q_goal;
@@ -171,6 +173,8 @@ void launch_plan_small(hipStream_t s, int n, int dof, double t_sample, int goal_
 void launch_generate(hipStream_t s, long long n, int dof, Limits lim, unsigned long long seed, long long first_query,
                      double* q_goal, double* q_0, double* v_0, double* a_0, long long sq, long long sj);
 
+// LimPow tables of dof joints under both pow rules ([dof][kLimPowN] each), from the device copies of a_max / j_max
+void launch_limit_powers(hipStream_t s, int dof, const double* a_max, const double* j_max, double* out_exact, double* out_libm);
 void launch_check_inputs(hipStream_t s, int dof, Limits lim, const double* q_0, const double* v_0, const double* a_0, int* ok, int variant = 0);
 // single-joint mirrors of the protected methods (one lane); io[11] receives the lane's MATLAB flags (kMatlabComplex | kMatlabError)
 void launch_single_opt_braking(hipStream_t s, int joint, double t_sample, Limits lim, double v_0, double a_0, double* out10, int variant = 0);

@@ -75,7 +75,7 @@ LTP_DEV void plan_small_body(int n, int dof, double t_sample, int goal_check, Ro
     const int pid = t;
     const bool pair = pid < pairs;
     const int q = pair ? pid / dof : 0, j = pair ? pid - q * dof : 0;
-    JointLimits L = {0.0, 0.0, 0.0, 0.0, 0.0};
+    JointLimits L = {0.0, 0.0, 0.0, 0.0, 0.0, {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0}};
     double qg = 0.0, q0 = 0.0, v0 = 0.0, a0 = 0.0;
     if constexpr (GIVEN) {
         if (t < n) { s_status[t] = 0; s_len[t] = 0; s_treq[t] = 0.0; s_slowest[t] = -1; }
@@ -106,7 +106,7 @@ LTP_DEV void plan_small_body(int n, int dof, double t_sample, int goal_check, Ro
         double dir = 0.0;
         int mod = 0;
         MatlabCtx mc;
-        if (opt_switch_times<true, SEM>(L.a_max, L.j_max, L.v_max, t_sample, qg, q0, v0, a0, L.v_max, tt, dir, mod, mc) == kOptFalse) flags |= kStatusOptFailed;
+        if (opt_switch_times<true, SEM>(L.a_max, L.j_max, L.v_max, L.pw, t_sample, qg, q0, v0, a0, L.v_max, tt, dir, mod, mc) == kOptFalse) flags |= kStatusOptFailed;
 #pragma unroll
         for (int k = 0; k < 7; ++k) s_t_opt[pid][k] = tt[k];
         s_dir[pid] = dir;

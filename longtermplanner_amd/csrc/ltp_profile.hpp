@@ -52,9 +52,34 @@ LTP_DEV double sem_sqrt(double x, MatlabCtx& mc)
     return dsqrt(x);
 }
 
+// Powers of one joint's limits, formed ONCE per ltp_set_limits / pow rule by the same device functions the kernels call
+// (k_limit_powers, ltp_aux_kernels.hip): tj = a_max / j_max is what optSwitchTimes assigns to t_rel[2], [4], [6] whenever a phase of
+// constant acceleration exists (cc:124, 171, 186), i.e. in most lanes; its cube and fourth power, and the cubes / fourth powers of
+// a_max and j_max that timeScaling's candidates use, are the same for every query. Under LTP_POW_LIBM a power is ~100 vector
+// instructions (glibc's pow restated), and half of the stage kernels' instructions were powers.
+struct LimPow {
+    double tj, tj3, tj4, am3, am4, jm3, jm4;
+};
+
 struct JointLimits {
     double q_min, q_max, v_max, a_max, j_max;
+    LimPow pw;
 };
+
+// pw3 / pw4 of a value that is USUALLY the joint's tj: when every active lane of the wave holds exactly tj's bits, the stored power
+// (the same function of the same bits) is the result and the wave skips the evaluation; otherwise all lanes evaluate.
+template <int SEM> LTP_DEV double pw3_tj(double x, const LimPow& P)
+{
+    if constexpr (!sem_libm(SEM)) return pw3<SEM>(x);        // the exact rule's cube is six operations: nothing to skip
+    else if (__builtin_amdgcn_ballot_w64(__builtin_bit_cast(unsigned long long, x) != __builtin_bit_cast(unsigned long long, P.tj)) == 0ull) return P.tj3;
+    return pw3<SEM>(x);
+}
+template <int SEM> LTP_DEV double pw4_tj(double x, const LimPow& P)
+{
+    if constexpr (!sem_libm(SEM)) return pw4<SEM>(x);
+    else if (__builtin_amdgcn_ballot_w64(__builtin_bit_cast(unsigned long long, x) != __builtin_bit_cast(unsigned long long, P.tj)) == 0ull) return P.tj4;
+    return pw4<SEM>(x);
+}
 
 // cc:68-77 for one joint (LTPlanner.m:92-103 has no position limits)
 template <int SEM = kSemCpp>
@@ -70,7 +95,7 @@ LTP_DEV bool check_inputs_joint(const JointLimits& L, double q_0, double v_0, do
 
 // cc:650-701 (LTPlanner.m:435-484). Writes r[0..2] only.
 template <int SEM = kSemCpp>
-LTP_DEV void opt_braking(double am, double jm, double t_sample, double v_0, double a_0,
+LTP_DEV void opt_braking(double am, double jm, const LimPow& P, double t_sample, double v_0, double a_0,
                          double& q, double (&r)[7], double& dir, MatlabCtx& mc)
 {
     if (v_0 * a_0 > 0.0) {
@@ -94,14 +119,9 @@ LTP_DEV void opt_braking(double am, double jm, double t_sample, double v_0, doub
     q = v_0 * (r[0] + r[1] + r[2]) +
         a_0 * (1.0 / 2.0 * pw2(r[0]) + r[0] * (r[1] + r[2]) + 1.0 / 2.0 * pw2(r[2])) +
         jm * (1.0 / 6.0 * pw3<SEM>(r[0]) + 1.0 / 2.0 * pw2(r[0]) * (r[1] + r[2]) -
-              1.0 / 6.0 * pw3<SEM>(r[2]) + 1.0 / 2.0 * r[0] * pw2(r[2])) +
+              1.0 / 6.0 * pw3_tj<SEM>(r[2], P) + 1.0 / 2.0 * r[0] * pw2(r[2])) +
         am * (1.0 / 2.0 * pw2(r[1]) + r[1] * r[2]);
     q = dir * q;
-}
-LTP_DEV void opt_braking(double am, double jm, double t_sample, double v_0, double a_0, double& q, double (&r)[7], double& dir)
-{
-    MatlabCtx mc;
-    opt_braking<kSemCpp>(am, jm, t_sample, v_0, a_0, q, r, dir, mc);
 }
 
 // LTPlanner.m:247-250 / 272-275: root = root(abs(imag(root)) < eps); root = root(root >= 0) — MATLAB compares real parts —
@@ -170,7 +190,7 @@ LTP_DEV void zero7(double (&t)[7])
 constexpr int kOptFalse = 0, kOptTrue = 1, kOptDefer = 2;
 
 template <bool FULL, int SEM = kSemCpp>
-__device__ inline int opt_switch_times(double am, double jm, double vm, double t_sample,
+__device__ inline int opt_switch_times(double am, double jm, double vm, const LimPow& P, double t_sample,
                                        double q_goal, double q_0, double v_0, double a_0, double v_drive,
                                        double (&t)[7], double& dir, int& mod, MatlabCtx& mc)
 {
@@ -186,7 +206,7 @@ __device__ inline int opt_switch_times(double am, double jm, double vm, double t
         }
     }
     double q_stop = 0.0;
-    opt_braking<SEM>(am, jm, t_sample, v_0, a_0, q_stop, r, dir, mc);
+    opt_braking<SEM>(am, jm, P, t_sample, v_0, a_0, q_stop, r, dir, mc);
     const double q_diff = q_goal - (q_0 + q_stop);
     if (dabs(q_diff) < kEps) {
         cumsum7(r, t);
@@ -202,7 +222,7 @@ __device__ inline int opt_switch_times(double am, double jm, double vm, double t
     if (v_0 + 0.5 * a_0 * dabs(a_0) / jm > v_drive) {
         mod = 1;
         double emp;
-        opt_braking<SEM>(am, jm, t_sample, v_0 - v_drive, a_0, q_brake, r, emp, mc);
+        opt_braking<SEM>(am, jm, P, t_sample, v_0 - v_drive, a_0, q_brake, r, emp, mc);
     } else {
         r[0] = (am - a_0) / jm;
         r[2] = am / jm;
@@ -233,23 +253,29 @@ __device__ inline int opt_switch_times(double am, double jm, double vm, double t
             return kOptTrue;
         }
     }
+    // the cubes of t_rel[0], [2], [4] (= [6], cc:186 / 193) are formed once: the re-solve without a cruise phase below (cc:202-243) uses
+    // the same four values again, and a power is the expensive operation here (LimPow)
     double q_part1;
+    double r0_3 = 0.0, r2_3 = 0.0;
     if (mod == 1) {
         q_part1 = q_brake + v_drive * (r[0] + r[1] + r[2]);
     } else {
+        r0_3 = pw3<SEM>(r[0]);
+        r2_3 = pw3_tj<SEM>(r[2], P);
         q_part1 = v_0 * (r[0] + r[1] + r[2]) +
                   a_0 * (1.0 / 2.0 * pw2(r[0]) +
                          r[0] * (r[1] + r[2]) +
                          1.0 / 2.0 * pw2(r[2])) +
-                  jm * (1.0 / 6.0 * pw3<SEM>(r[0]) +
+                  jm * (1.0 / 6.0 * r0_3 +
                         1.0 / 2.0 * pw2(r[0]) * (r[1] + r[2]) -
-                        1.0 / 6.0 * pw3<SEM>(r[2]) +
+                        1.0 / 6.0 * r2_3 +
                         1.0 / 2.0 * r[0] * pw2(r[2])) +
                   am * (1.0 / 2.0 * pw2(r[1]) + r[1] * r[2]);
     }
-    const double q_part2 = jm * (1.0 / 6.0 * pw3<SEM>(r[6]) +
+    const double r4_3 = pw3_tj<SEM>(r[4], P), r6_3 = r4_3;       // r[6] is r[4] (cc:186, 193)
+    const double q_part2 = jm * (1.0 / 6.0 * r6_3 +
                                  1.0 / 2.0 * pw2(r[6]) * (r[5] + r[4]) -
-                                 1.0 / 6.0 * pw3<SEM>(r[4]) +
+                                 1.0 / 6.0 * r4_3 +
                                  1.0 / 2.0 * r[6] * pw2(r[4])) +
                            am * (1.0 / 2.0 * pw2(r[5]) +
                                  r[5] * r[4]);
@@ -261,13 +287,14 @@ __device__ inline int opt_switch_times(double am, double jm, double vm, double t
             return sem_matlab(SEM) ? kOptTrue : kOptFalse;   // LTPlanner.m:222-227 returns the zeros like any other result; cc:195-200: false
         }
         const double a2 = pw2(a_0), am2 = pw2(am);
-        const double r0_2 = pw2(r[0]), r0_3 = pw3<SEM>(r[0]), r2_2 = pw2(r[2]), r2_3 = pw3<SEM>(r[2]);
-        const double r4_2 = pw2(r[4]), r4_3 = pw3<SEM>(r[4]), r6_3 = pw3<SEM>(r[6]);
+        const double r0_2 = pw2(r[0]), r2_2 = pw2(r[2]);      // mod == 0 here: r0_3, r2_3 are the cubes formed above
+        const double r4_2 = pw2(r[4]);
+        const double r4_4 = pw4_tj<SEM>(r[4], P), r6_4 = r4_4;
         double root = (jm2 * pw4<SEM>(r[0])) / 2 -
-                      (jm2 * pw4<SEM>(r[2])) / 4 +
+                      (jm2 * pw4_tj<SEM>(r[2], P)) / 4 +
                       (jm2 * r2_2 * r4_2) / 2 -
-                      (jm2 * pw4<SEM>(r[4])) / 4 +
-                      (jm2 * pw4<SEM>(r[6])) / 2 +
+                      (jm2 * r4_4) / 4 +
+                      (jm2 * r6_4) / 2 +
                       2.0 * jm * a_0 * r0_3 -
                       (2.0 * jm * am * r0_3) / 3 -
                       2.0 * jm * am * r[0] * r2_2 +
@@ -336,7 +363,7 @@ __device__ inline int opt_switch_times(double am, double jm, double vm, double t
                 const double n0_2 = pw2(r[0]);
                 r[6] = 1.0 / jm * (am / 2 + sem_sqrt<SEM>(
                            9 * am2 + 6 * sem_sqrt<SEM>(
-                               -12.0 * am * pw3<SEM>(jm) * pw3<SEM>(r[0]) +
+                               -12.0 * am * P.jm3 * pw3<SEM>(r[0]) +
                                9 * a2 * jm2 * n0_2 -
                                18 * a_0 * am * jm2 * n0_2 +
                                9 * am2 * jm2 * n0_2 +
@@ -344,7 +371,7 @@ __device__ inline int opt_switch_times(double am, double jm, double vm, double t
                                72.0 * am * dir * jm2 * q_0 +
                                72.0 * am * dir * jm2 * q_goal -
                                36 * am * jm2 * r[0] * v_0 +
-                               3 * pw4<SEM>(am) +
+                               3 * P.am4 +
                                36 * jm2 * pw2(v_0), mc), mc) / 6.0 - am);
                 r[4] = r[6] + am / jm;
                 r[1] = -(-jm * pw2(r[4]) -
@@ -423,7 +450,7 @@ __device__ inline int opt_switch_times(double am, double jm, double vm, double t
 // 485-514 (4), 526-541 (5), 553-567 (6), 579-593 (7), 606-629 (8). v_0/a_0 are already
 // mapped to the positive direction (cc:372-375); tr = t_required.
 template <int C, int SEM = kSemCpp>
-__device__ inline double v_drive_candidate(double am, double jm, double q_goal, double q_0, double v_0, double a_0,
+__device__ inline double v_drive_candidate(double am, double jm, const LimPow& P, double q_goal, double q_0, double v_0, double a_0,
                                            double dir, double tr, MatlabCtx& mc)
 {
     const double a2 = pw2(a_0), am2 = pw2(am), jm2 = pw2(jm);
@@ -435,7 +462,7 @@ __device__ inline double v_drive_candidate(double am, double jm, double q_goal, 
                 dsqrt(36 * am2 * jm2 * pw2(tr) -
                       36 * a2 * am * jm * tr +
                       72.0 * a_0 * am2 * jm * tr -
-                      72.0 * pw3<SEM>(am) * jm * tr +
+                      72.0 * P.am3 * jm * tr +
                       144 * am * dir * jm2 * q_0 -
                       144 * am * dir * jm2 * q_goal +
                       72.0 * am * jm2 * v_0 * tr
@@ -443,19 +470,19 @@ __device__ inline double v_drive_candidate(double am, double jm, double q_goal, 
                       + 12.0 * pw3<SEM>(a_0) * am
                       + 36 * a2 * am2 +
                       36 * a2 * jm * v_0 -
-                      72.0 * a_0 * pw3<SEM>(am) -
+                      72.0 * a_0 * P.am3 -
                       72.0 * a_0 * am * jm * v_0 +
-                      36 * pw4<SEM>(am) -
+                      36 * P.am4 -
                       36 * jm2 * pw2(v_0)) / 12) / jm;
     } else if constexpr (C == 2) {
-        const double jm3 = pw3<SEM>(jm);
+        const double jm3 = P.jm3;
         const double s = a_0 + am;                                       // a_0 + a_max
         const double w = (v_0 + (a_0 * (a_0 - am)) / (2.0 * jm)) / am;   // recurring quotient
         const double h = am / (2.0 * jm);
         const double g = (a_0 - am) / (2.0 * jm);
         return -(dir * (q_0 - q_goal) - jm * (
                      pw3<SEM>(s) / (6 * jm3) -
-                     pw3<SEM>(am) / (6 * jm3) +
+                     P.am3 / (6 * jm3) +
                      (am2 * s) / (2.0 * jm3) +
                      (pw2(s) *
                       (w +
@@ -511,7 +538,7 @@ __device__ inline double v_drive_candidate(double am, double jm, double q_goal, 
                 12.0 * pw3<SEM>(a_0) * am -
                 24 * a2 * jm * v_0 +
                 48 * a_0 * am * jm * v_0 +
-                4 * pw4<SEM>(am) -
+                4 * P.am4 -
                 24 * am2 * jm * v_0 +
                 12.0 * jm2 * pw2(v_0) +
                 6 * pw3<SEM>(a_0) +
@@ -524,7 +551,7 @@ __device__ inline double v_drive_candidate(double am, double jm, double q_goal, 
         const double root2 = root_squared<4, SEM>(c, 3, mc);      // LTPlanner.m:360 root(3)
         return root2 / jm;
     } else if constexpr (C == 5) {
-        const double a3 = pw3<SEM>(a_0), jm3 = pw3<SEM>(jm), jm4 = pw4<SEM>(jm), d2 = pw2(dir);
+        const double a3 = pw3<SEM>(a_0), jm3 = P.jm3, jm4 = P.jm4, d2 = pw2(dir);
         const double c[6] = {
             (144 * jm * tr + 144 * a_0),
             (-72.0 * jm2 * pw2(tr) - 144 * a_0 * jm * tr + 36 * a2 - 216 * jm * v_0),
@@ -554,7 +581,7 @@ __device__ inline double v_drive_candidate(double am, double jm, double q_goal, 
         return root2 / jm;
     } else {
         static_assert(C == 8, "case out of range");
-        const double a3 = pw3<SEM>(a_0), jm3 = pw3<SEM>(jm), jm4 = pw4<SEM>(jm), d2 = pw2(dir);
+        const double a3 = pw3<SEM>(a_0), jm3 = P.jm3, jm4 = P.jm4, d2 = pw2(dir);
         const double c[7] = {
             144.0,
             (-144 * jm * tr + 144 * a_0),
@@ -581,12 +608,12 @@ __device__ inline double v_drive_candidate(double am, double jm, double q_goal, 
 // v_0/a_0 are the direction-mapped values; the reference passes dir*v_0, dir*a_0 on.
 // Returns kOptTrue (accepted), kOptFalse (rejected) or, only with FULL == false, kOptDefer.
 template <bool FULL, int SEM = kSemCpp>
-__device__ inline int try_v_drive(double am, double jm, double vm, double t_sample, double q_goal, double q_0, double v_0, double a_0,
+__device__ inline int try_v_drive(double am, double jm, double vm, const LimPow& P, double t_sample, double q_goal, double q_0, double v_0, double a_0,
                                   double dir, double tr, double v_drive, double (&scaled_t)[7], int& mod, MatlabCtx& mc)
 {
     if (!disnan(v_drive) && v_drive > 0.0) {
         double trash;
-        const int ok = opt_switch_times<FULL, SEM>(am, jm, vm, t_sample, q_goal, q_0, dir * v_0, dir * a_0, v_drive, scaled_t, trash, mod, mc);
+        const int ok = opt_switch_times<FULL, SEM>(am, jm, vm, P, t_sample, q_goal, q_0, dir * v_0, dir * a_0, v_drive, scaled_t, trash, mod, mc);
         if (ok == kOptDefer) return kOptDefer;
         if (ok == kOptTrue && tr - scaled_t[6] < kTol && tr - scaled_t[6] > -kTol / 10) return kOptTrue;
     }
@@ -598,8 +625,8 @@ template <int C, int SEM = kSemCpp>
 LTP_DEV bool scaling_case(const JointLimits& L, double t_sample, double qg, double q0, double v0, double a0, double dir,
                           double tr, double& vd, double (&ts)[7], int& mod, MatlabCtx& mc)
 {
-    vd = v_drive_candidate<C, SEM>(L.a_max, L.j_max, qg, q0, v0, a0, dir, tr, mc);
-    return try_v_drive<true, SEM>(L.a_max, L.j_max, L.v_max, t_sample, qg, q0, v0, a0, dir, tr, vd, ts, mod, mc) == kOptTrue;
+    vd = v_drive_candidate<C, SEM>(L.a_max, L.j_max, L.pw, qg, q0, v0, a0, dir, tr, mc);
+    return try_v_drive<true, SEM>(L.a_max, L.j_max, L.v_max, L.pw, t_sample, qg, q0, v0, a0, dir, tr, vd, ts, mod, mc) == kOptTrue;
 }
 
 // cc:358-645 for one (query, joint): the eight candidates in the reference's order, then the reset

@@ -140,7 +140,7 @@ k_opt_fast(long long n, int dof, double t_sample, int goal_check, Limits lim, Qu
             double dir = 0.0;
             int mod = 0;
             MatlabCtx mc;
-            const int rc = opt_switch_times<false, SEM>(L.a_max, L.j_max, L.v_max, t_sample, qg, q0, v0, a0, L.v_max, t, dir, mod, mc);
+            const int rc = opt_switch_times<false, SEM>(L.a_max, L.j_max, L.v_max, L.pw, t_sample, qg, q0, v0, a0, L.v_max, t, dir, mod, mc);
             if (rc == kOptDefer) {
                 defer = true;
                 flags |= kLaneDeferred;
@@ -193,7 +193,7 @@ k_opt_slow(int dof, double t_sample, Limits lim, Queries in, Records out, signed
         double dir = 0.0;
         int mod = 0;
         MatlabCtx mc;
-        const int rc = opt_switch_times<true, SEM>(L.a_max, L.j_max, L.v_max, t_sample, in.q_goal[ix], in.q_0[ix], in.v_0[ix], in.a_0[ix],
+        const int rc = opt_switch_times<true, SEM>(L.a_max, L.j_max, L.v_max, L.pw, t_sample, in.q_goal[ix], in.q_0[ix], in.v_0[ix], in.a_0[ix],
                                                    L.v_max, t, dir, mod, mc);
         if constexpr (sem_matlab(SEM)) mod = 0;   // LTPlanner.m:64
         store_opt_record(out, rj, t, dir, mod);
@@ -318,8 +318,8 @@ k_reduce_scale(long long n, int dof, double t_sample, Limits lim, Queries in, Re
                     double v0 = in.v_0[ix], a0 = in.a_0[ix];
                     const double dir = out.dir[rj];
                     if (dir < 0.0) { v0 = -v0; a0 = -a0; }
-                    vd = v_drive_candidate<1, SEM>(L.a_max, L.j_max, qg, q0, v0, a0, dir, t_required, mc);
-                    acc = try_v_drive<false, SEM>(L.a_max, L.j_max, L.v_max, t_sample, qg, q0, v0, a0, dir, t_required, vd, ts, mod, mc);
+                    vd = v_drive_candidate<1, SEM>(L.a_max, L.j_max, L.pw, qg, q0, v0, a0, dir, t_required, mc);
+                    acc = try_v_drive<false, SEM>(L.a_max, L.j_max, L.v_max, L.pw, t_sample, qg, q0, v0, a0, dir, t_required, vd, ts, mod, mc);
                 }
             }
             if constexpr (sem_matlab(SEM)) {
@@ -346,8 +346,8 @@ k_reduce_scale(long long n, int dof, double t_sample, Limits lim, Queries in, Re
             double ts[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
             int mod = 0;
             MatlabCtx mc;
-            const double vd = v_drive_candidate<2, SEM>(L2.a_max, L2.j_max, qg, q0, v0, a0, dir, tr, mc);
-            const int acc = try_v_drive<false, SEM>(L2.a_max, L2.j_max, L2.v_max, t_sample, qg, q0, v0, a0, dir, tr, vd, ts, mod, mc);
+            const double vd = v_drive_candidate<2, SEM>(L2.a_max, L2.j_max, L2.pw, qg, q0, v0, a0, dir, tr, mc);
+            const int acc = try_v_drive<false, SEM>(L2.a_max, L2.j_max, L2.v_max, L2.pw, t_sample, qg, q0, v0, a0, dir, tr, vd, ts, mod, mc);
             if constexpr (sem_matlab(SEM)) {
                 if (mc.flags && acc != kOptDefer) atomicOr(&out.status[q2], matlab_status_bits(mc));
             }
@@ -400,7 +400,7 @@ k_scaling_slow(int dof, double t_sample, Limits lim, Queries in, Records out, Qu
         double vd = 0.0;
         int mod = 0, j = 0;
         long long rj = 0, q = 0;
-        JointLimits L = {0.0, 0.0, 0.0, 0.0, 0.0};
+        JointLimits L = {0.0, 0.0, 0.0, 0.0, 0.0, {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0}};
         MatlabCtx mc;
         if (live) {
             rj = (long long)queue_item(queue, cnt, it);
@@ -608,11 +608,18 @@ void launch_switch_times(hipStream_t s, long long n, int dof, double t_sample, i
     if (a_blocks > 4096) a_blocks = 4096;
     long long b_blocks = (n * dof + kQueriesPerBlock - 1) / kQueriesPerBlock;
     if (b_blocks > 1024) b_blocks = 1024;
+    // Joint slots per block. Under the libm pow rule k_reduce_scale holds 144 and k_opt_fast 108 registers per lane (3 and 4 waves per
+    // SIMD): 64 x 4 blocks fill those slots (three / four blocks per compute unit), 64 x 7 blocks leave 5 of 12 and 2 of 16 empty
+    // (profiles/r06_stage_block_shape_ab.txt: 971 -> 674 us and 375 -> 341 us per 1 M 7-DoF plans; with the exact rule's
+    // smaller kernels the one-round 64 x dof block stays ahead, 448 vs 461 us).
+    static const int exp_of = getenv("LTP_EXP_OF_JB") ? atoi(getenv("LTP_EXP_OF_JB")) : 0, exp_rs = getenv("LTP_EXP_RS_JB") ? atoi(getenv("LTP_EXP_RS_JB")) : 0;
+    const int jb_libm = (variant & kPowLibm) && jb > 4 ? 4 : jb;
+    const dim3 block_of(kQueriesPerBlock, exp_of > 0 && exp_of <= jb ? exp_of : jb_libm), block_rs(kQueriesPerBlock, exp_rs > 0 && exp_rs <= jb ? exp_rs : jb_libm);
     dispatch_variant(variant, [&](auto v) {
         constexpr int SEM = decltype(v)::value;
-        hipLaunchKernelGGL(k_opt_fast<SEM>, grid, block, 0, s, n, dof, t_sample, goal_check, lim, in, out, lane_flags, qa);
+        hipLaunchKernelGGL(k_opt_fast<SEM>, grid, block_of, 0, s, n, dof, t_sample, goal_check, lim, in, out, lane_flags, qa);
         hipLaunchKernelGGL(k_opt_slow<SEM>, dim3((unsigned)a_blocks), dim3(64), 0, s, dof, t_sample, lim, in, out, lane_flags, qa);
-        hipLaunchKernelGGL(k_reduce_scale<SEM>, grid, block, 0, s, n, dof, t_sample, lim, in, out, lane_flags, qb);
+        hipLaunchKernelGGL(k_reduce_scale<SEM>, grid, block_rs, 0, s, n, dof, t_sample, lim, in, out, lane_flags, qb);
         hipLaunchKernelGGL(k_scaling_slow<SEM>, dim3((unsigned)b_blocks), dim3(kQueriesPerBlock, 8), 0, s, dof, t_sample, lim, in, out, qb);
     });
 }
