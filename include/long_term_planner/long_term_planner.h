@@ -380,13 +380,18 @@ class LongTermPlanner {
   /** @brief NEW, default TRUE: the reference's pow(x, 3 | 4 | 6) and pow(x, 1.0 / 2) calls (cc:125-331, 378-621) are formed as glibc's
    * pow forms them, operation for operation: every switching time and every sample has the bits of the reference built with gcc +
    * glibc (>= 2.28) on a host with FMA (ltp_hip.h LTP_POW_LIBM). false: the correctly rounded powers instead (LTP_POW_EXACT: within
-   * 1 ulp of any libm, switching times within 5e-11 s of the above, stage kernels ~1/4 faster). */
+   * 1 ulp of any libm, switching times within 5e-11 s of the above). powRuleMatchingHostLibm() tells which one this host's libm is. */
+  inline void setLibmPow(bool enabled) { pow_rule_ = enabled ? LTP_POW_LIBM : LTP_POW_EXACT; markDirty(); }
+
+  /** @brief NEW: which pow rule reproduces the libm of THIS process (the one a reference built on this host calls): LTP_POW_LIBM
+   * (the default rule gives that reference's records bit for bit), LTP_POW_EXACT (setLibmPow(false) does), or -1 — a third libm:
+   * about one power in a thousand differs in its last bit from either rule, i.e. ~2 plans per million carry a jerk sample beyond
+   * 1e-9 of that reference whichever rule is set. Host only, ~20 ms, no GPU work (ltp_hip.h ltp_host_libm_pow_rule). */
+  static inline int powRuleMatchingHostLibm() { return ltp_host_libm_pow_rule(0, nullptr, nullptr); }
+
   /** @brief NEW, default false: the envelope calls evaluate only the samples at the ends of each run stretch and
    * either side of the real roots of q'(m) instead of every sample (ltp_hip.h LTP_ENVELOPE_ANALYTIC): within ulps of the exhaustive result. */
   inline void setAnalyticEnvelopes(bool enabled) { envelope_mode_ = enabled ? LTP_ENVELOPE_ANALYTIC : LTP_ENVELOPE_EXHAUSTIVE; markDirty(); }
-
-  inline void setLibmPow(bool enabled) { pow_rule_ = enabled ? LTP_POW_LIBM : LTP_POW_EXACT; markDirty(); }
-
 
   /** @brief NEW: HIP device ordinal used by this planner (default 0). */
   inline void setDevice(int device) { if (device != device_) { device_ = device; markDirty(); } }

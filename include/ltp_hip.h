@@ -162,6 +162,15 @@ int ltp_get_semantics(const ltp_planner* p);
  * points, the one-launch single call); samplers and consumers form no powers and do not depend on it. */
 int ltp_set_pow_rule(ltp_planner* p, int rule);
 int ltp_get_pow_rule(const ltp_planner* p);
+/* NEW (no counterpart in the reference): which pow rule reproduces the C library THIS process is linked against — the libm a
+ * reference built on this host calls at src/long_term_planner.cc:125-331, 378-621. Runs on the host only (no handle, no GPU):
+ * `probes` (<= 0: 2^18) planner-sized arguments through the installed pow(x, 3 | 4 | 6 | 1.0 / 2), compared bit for bit with
+ * both rules. Returns LTP_POW_LIBM when every result has the restated glibc bits (then the default rule gives the reference's
+ * records bit for bit), LTP_POW_EXACT when the installed pow is correctly rounded on all of them (then ltp_set_pow_rule(p,
+ * LTP_POW_EXACT) does), or -1: neither — the installed libm is a third one, and about one power in a thousand differs in its
+ * last bit from either rule: expect ~2 plans per million with a jerk sample beyond 1e-9 whichever rule is set.
+ * The two mismatch counts are written where the pointers are non-null. */
+int ltp_host_libm_pow_rule(long long probes, long long* mismatches_libm, long long* mismatches_exact);
 
 /* Where the run tables come from. A sampler / envelope item needs the joint's run tables (<= 20 runs of constant jerk with 10
  * closed-form coefficients each). Three ways, all with bit-identical results:

@@ -122,6 +122,7 @@ _SIGNATURES = {
     "ltp_get_envelope_mode": (C.c_int, [C.c_void_p]),
     "ltp_set_pow_rule": (C.c_int, [C.c_void_p, C.c_int]),
     "ltp_get_pow_rule": (C.c_int, [C.c_void_p]),
+    "ltp_host_libm_pow_rule": (C.c_int, [C.c_longlong, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
     "ltp_debug_libm_pow_host": (C.c_int, [C.c_void_p, C.c_longlong, _dp, _dp, _dp]),
     "ltp_debug_last_matlab_flags": (C.c_int, [C.c_void_p]),
     "ltp_debug_roots_matlab_host": (C.c_int, [C.c_void_p, C.c_longlong, C.c_int, _dp, _dp, _dp, _ip, _ip]),

@@ -521,9 +521,21 @@ class LongTermPlanner:
         self._check(self._lib.ltp_debug_math_probe_host(self._h, x.size, _ptr(x), _ptr(y), _ptr(out)))
         return out
 
+    @staticmethod
+    def powRuleMatchingHostLibm(probes=0):
+        """NEW: ("libm" | "exact" | None, mismatches vs the libm rule, mismatches vs the exact rule) — which pow rule has the bits of the
+        C library this process runs on, i.e. of a reference built on this host (ltp_hip.h ltp_host_libm_pow_rule; host only)."""
+        import ctypes as C
+        from . import _abi
+        a, b = C.c_longlong(), C.c_longlong()
+        r = _abi.lib().ltp_host_libm_pow_rule(int(probes), C.byref(a), C.byref(b))
+        return ({1: "libm", 0: "exact"}.get(r), a.value, b.value)
+
     def debugLibmPow(self, x, y):
         """pow(x, y) elementwise by the device's restated glibc pow (the arithmetic of setPowRule("libm"))."""
         x, y = _vec(x), _vec(y)
+        if y.size != x.size:
+            x, y = (np.ascontiguousarray(a, dtype=np.float64) for a in np.broadcast_arrays(x, y))     # the C call reads x.size of both
         out = np.zeros(x.size)
         self._check(self._lib.ltp_debug_libm_pow_host(self._h, x.size, _ptr(x), _ptr(y), _ptr(out)))
         return out

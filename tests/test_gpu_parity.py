@@ -289,7 +289,7 @@ def test_dense_trajectories_parity_budget(amd, oracle_mod, capsys):
 
 
 @pytest.mark.parametrize("name,n", [("panda", 300_000), ("ref", 300_000), ("ref30", 40_000)])
-def test_records_are_bit_identical_to_the_oracle_with_the_device_pow_rule(amd, oracle_mod, name, n):
+def test_records_are_bit_identical_to_the_oracle_with_the_device_pow_rule(amd, oracle_mod, name, n, restated_host_libm):
     """The cause of every last-bit difference between the device and the oracle is libm's pow: against the oracle's DIAGNOSTIC twin
     (-DLTPO_EXACT_POW: pow(x, 3 | 4 | 6) as one rounding of the exact product, pow(x, 0.5) as sqrt — csrc/ltp_math.hpp restated in C)
     every switching time, v_drive, t_required and every integer field of the device's records has the twin's BITS, and the default
@@ -327,7 +327,7 @@ def test_records_are_bit_identical_to_the_oracle_with_the_device_pow_rule(amd, o
     assert differing > 0, "libm's pow and the exact products never differed on this batch: the test would prove nothing"
 
 
-def test_device_libm_pow_is_the_host_libm_pow(amd, oracle_mod):
+def test_device_libm_pow_is_the_host_libm_pow(amd, oracle_mod, restated_host_libm):
     """The pow rule LTP_POW_LIBM is glibc's pow restated operation for operation (csrc/ltp_libm_pow.hpp): on the device it returns the
     bits of the HOST's libm for the planner's exponents on planner-like, arbitrary, negative, subnormal, huge and non-finite x, for
     arbitrary y, and where the result under- or overflows. (The same header against the same libm on the host, 1.7e10 inputs:
@@ -367,7 +367,7 @@ def test_device_libm_pow_is_the_host_libm_pow(amd, oracle_mod):
 
 
 @pytest.mark.parametrize("name,n,semantics", [("panda", 300_000, "cpp"), ("ref", 300_000, "cpp"), ("ref30", 40_000, "cpp"), ("ref", 150_000, "matlab")])
-def test_records_are_bit_identical_to_the_libm_oracle_under_the_libm_pow_rule(amd, oracle_mod, name, n, semantics):
+def test_records_are_bit_identical_to_the_libm_oracle_under_the_libm_pow_rule(amd, oracle_mod, name, n, semantics, restated_host_libm):
     """VERDICT r4 item 2, the mirror of the test above: with ltp_set_pow_rule(LTP_POW_LIBM) every switching time, v_drive, t_required
     and every integer field of the device's records has the bits of the DEFAULT oracle — the parity reference, whose powers are the
     host libm's pow — on 640 k C++-semantics plans (and 150 k in MATLAB semantics). No tolerance."""
@@ -399,7 +399,7 @@ def test_records_are_bit_identical_to_the_libm_oracle_under_the_libm_pow_rule(am
                for k in ("t_opt", "t_scaled", "v_drive")) > 0
 
 
-def test_dense_trajectories_strict_under_the_libm_pow_rule(amd, oracle_mod, capsys):
+def test_dense_trajectories_strict_under_the_libm_pow_rule(amd, oracle_mod, capsys, restated_host_libm):
     """The dense test above WITHOUT its exception clause: with ltp_set_pow_rule(LTP_POW_LIBM) every q/v/a/j sample of >= 200 k dense
     trajectories (the same sets: panda, the reference's limits, 30-DoF, 24 wide-fuzzed limit sets) is within 1e-9 of the libm
     oracle's planTrajectory, no plan excepted, and the jerk rows are bit-identical in every sampled plan."""
