@@ -86,10 +86,15 @@ static int sample_batch_any(ltp_planner* p, long long first, long long count, co
     if (!p->dbg_stamps && !(flags & (2 | 32)) && ltp::sample_walk_applies(p->dof, rows) &&
         ((flags & 64) || (!(flags & (4 | 8)) && (matlab || want_walk(p, rows.max_samples, rows.stride, f32))))) {
         if (p->walk_blocks[f32 ? 1 : 0] == 0) p->walk_blocks[f32 ? 1 : 0] = ltp::sample_walk_resident_blocks(p->device, f32);
+        if (p->walk_auto_cus == 0) {       // normally done by reserve() when the batch was planned
+            hipError_t e = hipSuccess;
+            p->walk_auto_cus = ltp::sample_walk_auto_prepare(p->device, &e);
+            LTP_HIP_TRY(p, e);
+        }
         unsigned long long* head = p->d_sample_next + (p->sample_next_slot++ & 63u);
         LTP_HIP_TRY(p, hipMemsetAsync(head, 0, sizeof(unsigned long long), s));
         const bool autonomous = ltp::launch_sample_walk(s, first, count, p->dof, p->t_sample, dev_limits(p), to_dev(in), to_dev(rec), offsets, out, f32, capacity, flags, rows, head,
-                                p->sample_blocks_override > 0 ? p->sample_blocks_override : p->walk_blocks[f32 ? 1 : 0], matlab ? ltp::kSemMatlab : ltp::kSemCpp);
+                                p->sample_blocks_override > 0 ? p->sample_blocks_override : p->walk_blocks[f32 ? 1 : 0], matlab ? ltp::kSemMatlab : ltp::kSemCpp, p->walk_auto_cus);
         LTP_HIP_TRY(p, hipGetLastError());
         const bool nv = !matlab && (flags & 16) && rows.max_samples > 0;     // flags bit 4: capped rows without the end-limit verdict
         if (nv)

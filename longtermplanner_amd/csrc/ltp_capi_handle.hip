@@ -79,6 +79,11 @@ int reserve(ltp_planner* p, long long n)
         if (p->sample_blocks[w] == 0) p->sample_blocks[w] = ltp::sample_resident_blocks(p->device, w);
     for (int w = 0; w < 2; ++w)
         if (p->sample_blocks[3 + w] == 0) p->sample_blocks[3 + w] = ltp::sample_tab_resident_blocks(p->device, w == 1);
+    if (p->walk_auto_cus == 0) {
+        hipError_t e = hipSuccess;
+        p->walk_auto_cus = ltp::sample_walk_auto_prepare(p->device, &e);
+        LTP_HIP_TRY(p, e);
+    }
     const long long queue_entries = 16 * ltp::queue_segment(n, p->dof > 0 ? p->dof : 1);
     if (queue_entries > p->ws_queue_entries) {
         if (p->d_queue) LTP_HIP_TRY(p, hipFree(p->d_queue));

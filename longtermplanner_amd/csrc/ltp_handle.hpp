@@ -44,6 +44,7 @@ struct ltp_planner {
     unsigned long long* d_tables = nullptr;   // run tables of the table pass (k_build_tables); part of the workspace
     unsigned long long tables_bytes = 0;      // allocated
     int walk_blocks[2] = {0, 0};              // resident blocks of k_sample_walk f64 / f32
+    int walk_auto_cus = 0;                    // compute units of `device`, set with the autonomous-wave kernels' LDS limit (reserve())
     unsigned long long tables_cap = 4ull << 30;   // upper bound for d_tables (ltp_create: 1/16 of the device's memory if that
                                                   // is more — 18 GiB of 288); longer ranges are processed in pieces
     double* d_small = nullptr;             // 16 doubles for the one-lane entry points

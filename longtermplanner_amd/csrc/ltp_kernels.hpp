@@ -137,7 +137,10 @@ int sample_walk_resident_blocks(int device, bool f32);
 // returns true if the autonomous-wave form took the rows (caps of at most 32 samples; flags bit 7 forbids it)
 bool launch_sample_walk(hipStream_t s, long long first, long long count, int dof, double t_sample, Limits lim, Queries in, Records rec,
                         const unsigned long long* offsets, void* out, bool f32, unsigned long long capacity, int flags, RowSpec rows,
-                        unsigned long long* next_item /* zeroed on the same stream */, int resident_blocks, int semantics = kSemCpp);
+                        unsigned long long* next_item /* zeroed on the same stream */, int resident_blocks, int semantics = kSemCpp,
+                        int auto_cus = 0 /* sample_walk_auto_prepare(device) */);
+// per device, once, outside stream capture: dynamic-LDS limit of the autonomous-wave kernels (checked) -> compute units (0: *err)
+int sample_walk_auto_prepare(int device, hipError_t* err);
 int sample_tab_resident_blocks(int device, bool f32);
 int sample_resident_blocks(int device, int which /* 0 k_sample f64, 1 k_sample f32, 2 k_envelope */);
 int envelope_resident_blocks(int device);

@@ -739,9 +739,30 @@ int sample_walk_resident_blocks(int device, bool f32)
     return cus * per_cu;
 }
 
+// Once per device and handle (reserve(); never inside a stream capture): the autonomous-wave kernels keep kWalkAutoWaves WalkBatch
+// records (154 KB) in dynamic LDS, above the default limit — raise it for every variant, checked — and launch one block per
+// compute unit. Returns the compute-unit count, or 0 with *err set.
+int sample_walk_auto_prepare(int device, hipError_t* err)
+{
+    const int lds = (int)(kWalkAutoWaves * sizeof(WalkBatch));
+    hipError_t e = hipSuccess;
+#define LTP_WALK_AUTO_ATTR(K) if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(K), hipFuncAttributeMaxDynamicSharedMemorySize, lds)
+    LTP_WALK_AUTO_ATTR(k_sample_walk_auto_f64_nv); LTP_WALK_AUTO_ATTR(k_sample_walk_auto_f64_nt_nv);
+    LTP_WALK_AUTO_ATTR(k_sample_walk_auto_f32_nv); LTP_WALK_AUTO_ATTR(k_sample_walk_auto_f32_nt_nv);
+    LTP_WALK_AUTO_ATTR(k_sample_walk_auto_f64); LTP_WALK_AUTO_ATTR(k_sample_walk_auto_f64_nt);
+    LTP_WALK_AUTO_ATTR(k_sample_walk_auto_f32); LTP_WALK_AUTO_ATTR(k_sample_walk_auto_f32_nt);
+    LTP_WALK_AUTO_ATTR(k_sample_walk_matlab_auto_f64); LTP_WALK_AUTO_ATTR(k_sample_walk_matlab_auto_f64_nt);
+    LTP_WALK_AUTO_ATTR(k_sample_walk_matlab_auto_f32); LTP_WALK_AUTO_ATTR(k_sample_walk_matlab_auto_f32_nt);
+#undef LTP_WALK_AUTO_ATTR
+    int cus = 0;
+    if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
+    if (err) *err = e;
+    return e == hipSuccess && cus > 0 ? cus : 0;
+}
+
 bool launch_sample_walk(hipStream_t s, long long first, long long count, int dof, double t_sample, Limits lim, Queries in, Records rec,
                         const unsigned long long* offsets, void* out, bool f32, unsigned long long capacity, int flags, RowSpec rows,
-                        unsigned long long* next_item, int resident_blocks, int semantics)
+                        unsigned long long* next_item, int resident_blocks, int semantics, int auto_cus)
 {
     if (count <= 0) return false;
     // flags bit 4: capped rows without the end-limit verdict — the walk stops at the cap (uncapped rows reach the last sample anyway)
@@ -752,19 +773,15 @@ bool launch_sample_walk(hipStream_t s, long long first, long long count, int dof
     if ((long long)spread > nbatches) spread = (int)nbatches;
     if (walk_auto_rows(rows) && !(flags & 128)) {
         // autonomous waves (one block per compute unit); flags bit 7 keeps the builder / streaming-wave form (A/B runs)
-        static int cus = 0;
+        // (the compute-unit count and the kernels' dynamic-LDS limit are per DEVICE and set up once per handle, outside any capture:
+        // sample_walk_auto_prepare, called from reserve())
         const unsigned lds = (unsigned)(kWalkAutoWaves * sizeof(WalkBatch));
-        if (cus == 0) {
-            int dev = 0;
-            (void)hipGetDevice(&dev);
-            if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-        }
+        const int cus = auto_cus > 0 ? auto_cus : 256;
         long long ablocks = cus;
         if (ablocks * kWalkAutoWaves > nbatches) ablocks = (nbatches + kWalkAutoWaves - 1) / kWalkAutoWaves;
         const dim3 agrid((unsigned)ablocks), ablock(kWalkAutoThreads);
 #define LTP_WALK_AUTO_CASE(K, TY)                                                                                                    \
     do {                                                                                                                              \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(K), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                \
         hipLaunchKernelGGL(K, agrid, ablock, lds, s, first, count, dof, t_sample, lim, in, rec, offsets, (TY*)out, capacity, spread, rows, next_item); \
     } while (0)
         switch ((flags & 1) | (f32 ? 2 : 0) | (semantics == kSemMatlab ? 4 : (no_verdict ? 8 : 0))) {
