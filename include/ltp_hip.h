@@ -227,24 +227,45 @@ int ltp_end_limit_batch(ltp_planner* p, long long first, long long count, const 
 
 /* getTrajectory (cc:706-841) + the end-limit check (cc:59-61) for plans [first, first+count):
  * plan p is written at out + (offsets[p] - offsets[first]); plans that would end beyond
- * `capacity` doubles get LTP_STATUS_OVERFLOW and are skipped.
- * flags: bit 0 = non-temporal stores (recommended); bit 1 = diagnostic dry run (stores without arithmetic);
- * bit 2 = force the table pass (k_build_tables + k_sample_tab_*: kept as the sampler that reads the packed run tables of
- * include/ltp_run_tables.hpp; the library takes it by itself only where bit 5 has forbidden the walk kernel for capped rows of at most
- * 8 KB / 16 KB per joint, and in MATLAB semantics with the walk kernel forbidden), bit 3 = force the fused table build; bit 4 = the caller does
- * not need the end-limit verdict (cc:59-61) from THIS call: for capped rows (ltp_set_max_samples) the walk kernels then stop at the cap
- * instead of walking every joint to its last sample, and LTP_STATUS_END_LIMIT is left unspecified by the call (it is formed by
- * ltp_plan_switch_times_batch with end_limit = 1 / ltp_end_limit_batch, or by a call without this bit; rows are the same);
- * bit 5 = never k_sample_walk_* (rows under a cap of <= 768 samples, float32 rows, rows of every 3rd sample or sparser, and every
- * row format in MATLAB semantics take it by themselves: the run tables then stay in the compute unit, no table pass at all; same
- * rows), bit 6 = force it (any row format); bit 7 = keep its builder / streaming-wave form also for caps of at most 32 samples, which
- * otherwise take the autonomous-wave form of the same kernel (k_sample_walk_auto_*: every wave builds and writes its own batches);
- * bits 8..23 = block interleave factor (0 = default 64, 1 = blocks in plan order). Large tiles (>= 64 GiB)
- * written with the default interleave reach the HBM fill ceiling; see DESIGN.md. */
+ * `capacity` ELEMENTS get LTP_STATUS_OVERFLOW and are skipped. offsets, row strides and capacity are in elements and identical
+ * for both row formats (rows are padded to 32 elements). `out`: device, 16-byte aligned.
+ *
+ * ltp_sample_batch_ex is the entry point; its policy is a struct of named fields. Zero-initialise it, set .size =
+ * sizeof(ltp_sample_opts) and only the fields you mean (opts == NULL: all defaults). Every choice writes THE SAME ROWS; the
+ * fields only pick which kernel does it (DESIGN.md §4 has the measurements behind the defaults). */
+#define LTP_ROWS_F64 0               /* binary64 rows (the reference's) */
+#define LTP_ROWS_F32 1               /* the same binary64 results, rounded once to float when stored */
+#define LTP_STORES_NONTEMPORAL 0     /* default: rows bypass the caches (they are written once and read by someone else) */
+#define LTP_STORES_PLAIN 1
+#define LTP_SAMPLER_AUTO 0           /* default: the library picks by row format (below) */
+#define LTP_SAMPLER_FUSED 1          /* k_sample_*: a block builds a plan's run tables in LDS and streams its rows (whole f64 rows take it) */
+#define LTP_SAMPLER_WALK 2           /* k_sample_walk_*: builder wave + streaming waves, tables never leave the compute unit (capped rows of
+                                      * <= 768 samples, float32 rows, rows of every 3rd sample or sparser, MATLAB semantics take it);
+                                      * caps of <= 32 samples use its autonomous-wave form (every wave builds and writes its own batches) */
+#define LTP_SAMPLER_WALK_STREAMING 3 /* ... and keep the builder / streaming-wave form for caps of <= 32 samples too (A/B runs) */
+#define LTP_SAMPLER_TABLE 4          /* k_build_tables + k_sample_tab_*: through the packed run tables of include/ltp_run_tables.hpp in HBM */
+#define LTP_VERDICT_KEEP 0           /* default: the call also forms planTrajectory's end-limit verdict (cc:59-61, LTP_STATUS_END_LIMIT) */
+#define LTP_VERDICT_SKIP 1           /* capped rows: stop at the cap instead of walking every joint to its last sample; LTP_STATUS_END_LIMIT
+                                      * is then left unspecified by this call (ltp_end_limit_batch / end_limit = 1 form it); same rows */
+typedef struct {
+    unsigned size;       /* sizeof(ltp_sample_opts) in the caller's build: fields beyond it keep their defaults */
+    int format;          /* LTP_ROWS_* : the element type `out` points to */
+    int stores;          /* LTP_STORES_* */
+    int sampler;         /* LTP_SAMPLER_* */
+    int verdict;         /* LTP_VERDICT_* */
+    int interleave;      /* block interleave factor of the work queue: 0 = default (64), 1 = blocks in plan order, <= 65535. Large
+                          * tiles (>= 64 GiB) written with the default reach the HBM fill ceiling */
+    int dry_run;         /* DIAGNOSTIC, 0 | 1: the store pattern without the arithmetic (not results) */
+} ltp_sample_opts;
+int ltp_sample_batch_ex(ltp_planner* p, long long first, long long count, const ltp_queries* in, const ltp_records* rec,
+                        const unsigned long long* offsets, void* out, unsigned long long capacity, const ltp_sample_opts* opts,
+                        void* stream);
+/* The same call with the policy packed into an int (rounds 1-5; kept for its callers, a thin wrapper over the same launcher):
+ * bit 0 = LTP_STORES_NONTEMPORAL (NOTE: 0 here means plain stores), bit 1 = dry_run, bit 2 = LTP_SAMPLER_TABLE, bit 3 =
+ * LTP_SAMPLER_FUSED, bit 4 = LTP_VERDICT_SKIP, bit 5 = never the walk kernels, bit 6 = LTP_SAMPLER_WALK, bit 6 | bit 7 =
+ * LTP_SAMPLER_WALK_STREAMING, bits 8..23 = interleave. New code: ltp_sample_batch_ex. */
 int ltp_sample_batch(ltp_planner* p, long long first, long long count, const ltp_queries* in, const ltp_records* rec,
                      const unsigned long long* offsets, double* out, unsigned long long capacity, int flags, void* stream);
-/* SURVEY.md §8(f).2 float32 rows: the same binary64 results, rounded once to float when stored. offsets, row strides
- * and capacity are in ELEMENTS and identical for both formats (rows are padded to 32 elements). */
 int ltp_sample_batch_f32(ltp_planner* p, long long first, long long count, const ltp_queries* in, const ltp_records* rec,
                          const unsigned long long* offsets, float* out, unsigned long long capacity, int flags, void* stream);
 

@@ -41,6 +41,12 @@ class LtpError(RuntimeError):
         self.code = code
 
 
+class SampleOpts(C.Structure):
+    """ltp_sample_opts (include/ltp_hip.h): the sampler's policy as named fields, size-versioned."""
+    _fields_ = [("size", C.c_uint), ("format", C.c_int), ("stores", C.c_int), ("sampler", C.c_int), ("verdict", C.c_int),
+                ("interleave", C.c_int), ("dry_run", C.c_int)]
+
+
 class Queries(C.Structure):
     _fields_ = [("q_goal", C.c_void_p), ("q_0", C.c_void_p), ("v_0", C.c_void_p), ("a_0", C.c_void_p),
                 ("query_stride", C.c_longlong), ("joint_stride", C.c_longlong)]
@@ -137,6 +143,8 @@ _SIGNATURES = {
     "ltp_plan_switch_times_batch": (C.c_int, [C.c_void_p, C.c_longlong, C.POINTER(Queries), C.POINTER(Records), C.c_void_p, C.c_void_p]),
     "ltp_sample_batch": (C.c_int, [C.c_void_p, C.c_longlong, C.c_longlong, C.POINTER(Queries), C.POINTER(Records), C.c_void_p,
                                    C.c_void_p, C.c_ulonglong, C.c_int, C.c_void_p]),
+    "ltp_sample_batch_ex": (C.c_int, [C.c_void_p, C.c_longlong, C.c_longlong, C.POINTER(Queries), C.POINTER(Records), C.c_void_p,
+                                      C.c_void_p, C.c_ulonglong, C.c_void_p, C.c_void_p]),
     "ltp_sample_batch_f32": (C.c_int, [C.c_void_p, C.c_longlong, C.c_longlong, C.POINTER(Queries), C.POINTER(Records), C.c_void_p,
                                        C.c_void_p, C.c_ulonglong, C.c_int, C.c_void_p]),
     "ltp_replan_states_f32_batch": (C.c_int, [C.c_void_p, C.c_longlong, C.c_longlong, C.POINTER(Queries), C.POINTER(Records), C.c_void_p,

@@ -148,6 +148,32 @@ int ltp_sample_batch_f32(ltp_planner* p, long long first, long long count, const
     return sample_batch_any(p, first, count, in, rec, offsets, out, true, capacity, flags, stream);
 }
 
+// the named form of the sampler's policy (include/ltp_hip.h ltp_sample_opts) -> the flag word the kernels' launcher reads
+int ltp_sample_batch_ex(ltp_planner* p, long long first, long long count, const ltp_queries* in, const ltp_records* rec,
+                        const unsigned long long* offsets, void* out, unsigned long long capacity, const ltp_sample_opts* opts, void* stream)
+{
+    ltp_sample_opts o;
+    memset(&o, 0, sizeof o);
+    if (opts) {
+        // size-versioned: a caller built against an older (shorter) struct leaves the newer fields at their defaults (0)
+        if (opts->size < sizeof(unsigned) + sizeof(int)) return fail(p, LTP_ERR_INVALID_ARGUMENT, "ltp_sample_opts.size is not set");
+        memcpy(&o, opts, opts->size < sizeof o ? opts->size : sizeof o);
+    }
+    if ((o.format != LTP_ROWS_F64 && o.format != LTP_ROWS_F32) || (o.stores != LTP_STORES_NONTEMPORAL && o.stores != LTP_STORES_PLAIN) ||
+        o.sampler < LTP_SAMPLER_AUTO || o.sampler > LTP_SAMPLER_TABLE || (o.verdict != LTP_VERDICT_KEEP && o.verdict != LTP_VERDICT_SKIP) ||
+        o.interleave < 0 || o.interleave > 0xFFFF || (o.dry_run != 0 && o.dry_run != 1))
+        return fail(p, LTP_ERR_INVALID_ARGUMENT, "ltp_sample_opts: a field is out of range");
+    int flags = (o.stores == LTP_STORES_NONTEMPORAL ? 1 : 0) | (o.dry_run ? 2 : 0) | (o.verdict == LTP_VERDICT_SKIP ? 16 : 0) | (o.interleave << 8);
+    switch (o.sampler) {
+    case LTP_SAMPLER_FUSED: flags |= 8 | 32; break;
+    case LTP_SAMPLER_WALK: flags |= 64; break;
+    case LTP_SAMPLER_WALK_STREAMING: flags |= 64 | 128; break;
+    case LTP_SAMPLER_TABLE: flags |= 4 | 32; break;
+    default: break;
+    }
+    return sample_batch_any(p, first, count, in, rec, offsets, out, o.format == LTP_ROWS_F32, capacity, flags, stream);
+}
+
 int ltp_envelope_batch(ltp_planner* p, long long first, long long count, const ltp_queries* in, const ltp_records* rec,
                        int window, int n_windows, double* env, void* stream)
 {

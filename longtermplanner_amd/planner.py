@@ -443,6 +443,20 @@ class LongTermPlanner:
                        out.data_ptr(), out.numel(), (1 if streaming else 0) | (2 if dry else 0) | (int(spread) << 8)
                        | (0 if tables is None else (4 if tables else 8)) | (0 if walk is None else (64 if walk else 32)) | (128 if auto_waves is False else 0) | (0 if verdict else 16), self._stream()))
 
+    SAMPLERS = {"auto": 0, "fused": 1, "walk": 2, "walk_streaming": 3, "table": 4}
+
+    def sampleBatchEx(self, batch: DeviceBatch, first, count, out, sampler="auto", nontemporal=True, verdict=True, interleave=0, dry=False):
+        """getTrajectory for plans [first, first+count) through ltp_sample_batch_ex: the policy as the named fields of ltp_sample_opts
+        (sampler: "auto" | "fused" | "walk" | "walk_streaming" | "table"). The same rows whatever the fields say."""
+        import torch
+        from ._abi import SampleOpts
+        assert out.dtype in (torch.float32, torch.float64)
+        o = SampleOpts(C.sizeof(SampleOpts), 1 if out.dtype == torch.float32 else 0, 0 if nontemporal else 1, self.SAMPLERS[sampler],
+                       0 if verdict else 1, int(interleave), 1 if dry else 0)
+        rec = batch.c_records()
+        self._check(self._lib.ltp_sample_batch_ex(self._h, first, count, C.byref(batch.queries), C.byref(rec), batch.offsets.data_ptr(),
+                                                  out.data_ptr(), out.numel(), C.addressof(o), self._stream()))
+
     def envelopeBatch(self, batch: DeviceBatch, first, count, window, n_windows, out=None):
         """NEW (on-device consumer): [count, dof, n_windows, 2] = min / max of q over windows of `window`
         samples of plans [first, first+count), without storing the trajectories (ltp_envelope_batch)."""

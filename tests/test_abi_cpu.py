@@ -40,6 +40,26 @@ def test_row_stride(abi):
     assert lib.ltp_row_stride(1718) == 1728
 
 
+def test_sample_opts_are_validated_before_anything_runs(abi):
+    """ltp_sample_batch_ex: the policy is a size-versioned struct of named fields; an unset size or a field out of
+    range is LTP_ERR_INVALID_ARGUMENT before any device work (checked here without a device and without a handle)."""
+    lib = abi.lib()
+    O = abi.SampleOpts
+    assert C.sizeof(O) == 28
+    text = open(os.path.join(ROOT, "include", "ltp_hip.h")).read()
+    fields = re.search(r"typedef struct \{([^}]*)\} ltp_sample_opts;", text, flags=re.S).group(1)
+    assert re.findall(r"^\s*(?:unsigned|int) (\w+);", fields, flags=re.M) == [f[0] for f in O._fields_]
+
+    def call(o):
+        return lib.ltp_sample_batch_ex(None, 0, 0, None, None, None, None, 0, C.addressof(o) if o is not None else None, None)
+    INVALID = 1
+    assert call(O(0, 0, 0, 0, 0, 0, 0)) == INVALID                      # size not set
+    for bad in (dict(format=2), dict(stores=-1), dict(sampler=5), dict(verdict=2), dict(interleave=70000), dict(dry_run=3)):
+        assert call(O(**dict(dict(size=C.sizeof(O)), **bad))) == INVALID, bad
+    # a well-formed struct gets past the field checks and is refused for the null handle / arguments instead (same code, later check)
+    assert call(O(size=C.sizeof(O), sampler=2, verdict=1)) == INVALID and call(None) == INVALID
+
+
 def _has_gpu():
     try:
         import torch

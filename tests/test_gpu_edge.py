@@ -1407,3 +1407,43 @@ def test_capped_rows_without_the_end_limit_verdict(amd, ref7):
         b3 = ltp.planSwitchTimesBatch(qg, q0, v0, a0, end_limit=True)
         torch.cuda.synchronize()
         assert torch.equal(b3.status, st)
+
+
+@pytest.mark.gpu
+def test_sample_opts_struct_selects_the_same_kernels_as_the_flag_word(amd, ref7):
+    """ltp_sample_batch_ex takes its policy as the named fields of ltp_sample_opts; each field value launches the
+    kernel the packed flag word of ltp_sample_batch launched (ltp_debug last kernel name), and every choice writes the same bytes."""
+    import torch
+    D, lim, _, _ = ref7
+    ltp = amd.LongTermPlanner(D, 0.004, device=0, **lim)
+    n = 6000
+    qg, q0, v0, a0 = ltp.generateQueries(n, seed=91)
+    for cap, dt in ((0, torch.float64), (24, torch.float64), (128, torch.float32)):
+        ltp.setMaxSamples(cap)
+        b = ltp.planSwitchTimesBatch(qg, q0, v0, a0)
+        ref = torch.full((int(b.offsets[-1].item()) + 8,), 3.0, dtype=dt, device="cuda")
+        ltp.sampleBatch(b, 0, n, ref)                      # flags = 1: non-temporal stores, everything else automatic
+        auto_kernel = ltp.lastSamplerKernel()
+        st = b.status.clone()
+        pairs = [("auto", {}), ("fused", dict(tables=False, walk=False)), ("walk", dict(walk=True)),
+                 ("walk_streaming", dict(walk=True, auto_waves=False)), ("table", dict(tables=True, walk=False))]
+        for sampler, kw in pairs:
+            a = torch.full_like(ref, 3.0)
+            b1 = ltp.planSwitchTimesBatch(qg, q0, v0, a0)
+            ltp.sampleBatch(b1, 0, n, a, **kw)
+            k_flags = ltp.lastSamplerKernel()
+            e = torch.full_like(ref, 3.0)
+            b2 = ltp.planSwitchTimesBatch(qg, q0, v0, a0)
+            ltp.sampleBatchEx(b2, 0, n, e, sampler=sampler)
+            torch.cuda.synchronize()
+            assert ltp.lastSamplerKernel() == k_flags, (cap, sampler, ltp.lastSamplerKernel(), k_flags)
+            if sampler == "auto":
+                assert k_flags == auto_kernel
+            assert torch.equal(e, ref) and torch.equal(a, ref), (cap, sampler)
+            assert torch.equal(b2.status, st) and torch.equal(b2.traj_len, b.traj_len)
+        # plain stores, an interleave factor and "no verdict" are fields too
+        e = torch.full_like(ref, 3.0)
+        b3 = ltp.planSwitchTimesBatch(qg, q0, v0, a0)
+        ltp.sampleBatchEx(b3, 0, n, e, nontemporal=False, interleave=7, verdict=False)
+        torch.cuda.synchronize()
+        assert torch.equal(e, ref) and "_nt" not in ltp.lastSamplerKernel().replace("k_sample_walk", "")
