@@ -319,8 +319,7 @@ def run_workload(wl, ctx):
     if wl.semantics != "cpp":
         ltp.setSemantics(wl.semantics)
     ltp.setPowRule(wl.pow_rule)
-    if wl.envelope_analytic:
-        ltp.setEnvelopeMode("analytic")
+    ltp.setEnvelopeMode("analytic" if wl.envelope_analytic else "exhaustive")      # explicit: the library's default is analytic since round 6
     if wl.global_batch:
         first_query, n = shard_range(wl.global_batch, rank, world)
         total_queries = wl.global_batch

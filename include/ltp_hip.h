@@ -279,14 +279,17 @@ int ltp_sample_batch_f32(ltp_planner* p, long long first, long long count, const
 int ltp_envelope_batch(ltp_planner* p, long long first, long long count, const ltp_queries* in, const ltp_records* rec,
                        int window, int n_windows, double* env, void* stream);
 /* How the envelope calls (ltp_envelope_batch, ltp_envelope_multi, ltp_plan_envelope*_host) find a window's extreme samples.
- * LTP_ENVELOPE_EXHAUSTIVE (default)  every sample of the window is evaluated: min / max have the BITS of the same reduction of the rows.
- * LTP_ENVELOPE_ANALYTIC              inside a run q is one cubic in the sample index, so only the samples at the ends of each (run,
+ * LTP_ENVELOPE_ANALYTIC (default)    inside a run q is one cubic in the sample index, so only the samples at the ends of each (run,
  *                                    window) stretch and either side of the real roots of its derivative are evaluated (they ARE samples
  *                                    of the row): a few evaluations per run instead of `window`, by a lane-per-(plan, joint) walk without
- *                                    run tables or workspace (k_envelope_walk: 3x the plans/s); the result can differ from the exhaustive
- *                                    one where a neighbouring sample undercuts by rounding alone, i.e. by a few ulps of q (tested: <= 1e-12;
- *                                    identical in all 8e7 values of the test). With ltp_set_table_pass(p, 1 | -1) the block-cooperative
- *                                    kernel's analytic form runs instead (same values). */
+ *                                    run tables or workspace (k_envelope_walk: 3x the plans/s). By construction within a few ulps of q
+ *                                    (<= 1e-12) of the exhaustive result — it could differ only where a neighbouring sample undercuts by
+ *                                    rounding alone; MEASURED identical in all 8.8e9 window values of profiles/r06_envelope_mode_soak.json
+ *                                    (panda, the reference's limits, 30-DoF, 36 wide-fuzzed limit sets, six window geometries), which is
+ *                                    why it is the default since round 6. With ltp_set_table_pass(p, 1 | -1) the block-cooperative
+ *                                    kernel's analytic form runs instead (same values).
+ * LTP_ENVELOPE_EXHAUSTIVE            every sample of the window is evaluated: min / max have the BITS of the same reduction of the rows,
+ *                                    by construction. The opt-in for callers who need that guarantee rather than the measurement. */
 #define LTP_ENVELOPE_EXHAUSTIVE 0
 #define LTP_ENVELOPE_ANALYTIC 1
 int ltp_set_envelope_mode(ltp_planner* p, int mode);

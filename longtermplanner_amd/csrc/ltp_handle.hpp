@@ -51,7 +51,7 @@ struct ltp_planner {
     bool small_dirty = false;              // a fused small-batch call failed: k_plan_small's arrival word may be non-zero
     const char* last_kernel = "";          // row / envelope kernel of the latest ltp_sample_batch* / ltp_envelope_batch
     int semantics = 0;                     // LTP_SEMANTICS_CPP (the reference's C++, default) or LTP_SEMANTICS_MATLAB
-    int envelope_mode = 0;                 // LTP_ENVELOPE_EXHAUSTIVE (default, bit-identical to the reduced rows) or LTP_ENVELOPE_ANALYTIC
+    int envelope_mode = LTP_ENVELOPE_ANALYTIC;   // the default since round 6 (8.8e9 window values identical to the exhaustive form, profiles/r06_envelope_mode_soak.json); LTP_ENVELOPE_EXHAUSTIVE: bit-identical to the reduced rows by construction
     int pow_rule = LTP_POW_LIBM;           // LTP_POW_LIBM (default) or LTP_POW_EXACT: how pow(x, 3 | 4 | 6 | 1/2) is formed (ltp_math.hpp)
     int last_matlab_flags = 0;             // MATLAB semantics: flags of the latest one-lane call (1 = complex intermediate, 2 = error)
     unsigned long long* dbg_stamps = nullptr; // diagnostic: per-block start/end stamps of k_sample (caller-owned)

@@ -125,8 +125,9 @@ class LongTermPlanner:
         self._check(self._lib.ltp_set_semantics(self._h, int(code)))
 
     def setEnvelopeMode(self, mode):
-        """NEW: "exhaustive" (default: every sample of a window, bit-identical to the reduced rows) or "analytic" (the
-        samples at the ends of each run stretch and either side of the roots of q'(m): a few evaluations per run; within ulps of q)."""
+        """NEW: "analytic" (default since round 6: the samples at the ends of each run stretch and either side of the
+        roots of q'(m), a few evaluations per run; identical to the exhaustive form in 8.8e9 soaked values, <= 1e-12 by construction) or
+        "exhaustive" (every sample of a window: the bits of the reduced rows by construction)."""
         code = {"exhaustive": 0, "analytic": 1}.get(mode, mode)
         self._check(self._lib.ltp_set_envelope_mode(self._h, int(code)))
 

@@ -1447,3 +1447,22 @@ def test_sample_opts_struct_selects_the_same_kernels_as_the_flag_word(amd, ref7)
         ltp.sampleBatchEx(b3, 0, n, e, nontemporal=False, interleave=7, verdict=False)
         torch.cuda.synchronize()
         assert torch.equal(e, ref) and "_nt" not in ltp.lastSamplerKernel().replace("k_sample_walk", "")
+
+
+@pytest.mark.gpu
+def test_envelope_default_is_the_analytic_form_and_has_the_exhaustive_bits(amd):
+    """the default envelope mode is LTP_ENVELOPE_ANALYTIC since round 6 (profiles/r06_envelope_mode_soak.json: 8.8e9
+    window values, none different from the exhaustive form); the exhaustive form stays available and, here too, has the same bits."""
+    import torch
+    D, lim = amd.limit_set("panda")
+    ltp = amd.LongTermPlanner(D, 0.001, device=0, **lim)
+    q = ltp.generateQueries(30000, seed=5)
+    b = ltp.planSwitchTimesBatch(*q)
+    dflt = ltp.envelopeBatch(b, 0, 30000, 48, 40).clone()
+    assert ltp.lastSamplerKernel() == "k_envelope_walk analytic"
+    ltp.setEnvelopeMode("exhaustive")
+    b2 = ltp.planSwitchTimesBatch(*q)
+    ex = ltp.envelopeBatch(b2, 0, 30000, 48, 40)
+    torch.cuda.synchronize()
+    assert "analytic" not in ltp.lastSamplerKernel()
+    assert torch.equal(torch.nan_to_num(dflt, nan=7.0), torch.nan_to_num(ex, nan=7.0)) and torch.equal(b.status, b2.status)
