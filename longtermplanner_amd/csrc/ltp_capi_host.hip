@@ -252,7 +252,7 @@ int plan_batch_host_fused(ltp_planner* p, long long n, const double* const (&h_i
         capture_geometry(p);
         ltp::launch_plan_small(nullptr, (int)n, dof, p->t_sample, p->goal_check, ltp::RowSpec{p->max_samples, p->sample_stride}, dev_limits(p), in,
                                to_dev(&hr), (unsigned long long*)(p->h_arena + L.offsets), rows, kFusedRowsBytes / sizeof(double),
-                               (int*)(p->h_arena + ends_at), (unsigned int*)p->d_small, done, given != nullptr, p->pow_rule == LTP_POW_LIBM);
+                               (int*)(p->h_arena + ends_at), (unsigned int*)p->d_small, done, given != nullptr, p->pow_rule == LTP_POW_LIBM, true);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) { if (rows) g_pinned.release(rows); return hip_fail(p, e, "k_plan_small"); }   // nothing was launched
     }

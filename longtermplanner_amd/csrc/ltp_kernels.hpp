@@ -172,7 +172,8 @@ void launch_plan_small(hipStream_t s, int n, int dof, double t_sample, int goal_
                        Records rec, unsigned long long* offsets, double* out_rows, unsigned long long capacity, int* end_flags,
                        unsigned int* arrivals, volatile int* done,
                        bool records_given = false /* getTrajectory: t_scaled, dir, mod, v_drive of `rec` are inputs */,
-                       bool libm_pow = false /* the pow rule LTP_POW_LIBM */);
+                       bool libm_pow = false /* the pow rule LTP_POW_LIBM */,
+                       bool host_inputs = false /* in[] is host memory this thread may read now: a few queries then ride in the kernel arguments */);
 void launch_generate(hipStream_t s, long long n, int dof, Limits lim, unsigned long long seed, long long first_query,
                      double* q_goal, double* q_0, double* v_0, double* a_0, long long sq, long long sj);
 

@@ -30,7 +30,12 @@ struct SmallHost {               // device-addressable host memory (or device me
     int* end_flags;              // [gridDim.x][n]: LTP_STATUS_END_LIMIT bits found by each block for the joints it sampled
     unsigned int* arrivals;      // device memory, zero between launches: blocks that have finished
     volatile int* done;          // set to 1 (2: rows did not fit `capacity`, nothing sampled) when everything above is visible
+    // A call of at most kSmallInline pairs carries its queries IN the kernel arguments: in[] points to host memory, so reading it is
+    // a PCIe round trip (~2 us) that can only start once the pointer itself has arrived with the kernel arguments — a second one.
+    int n_inline;                // pairs held in inl (0: read in[])
+    double inl[4][16];           // q_goal, q_0, v_0, a_0 of pair i at inl[k][i]
 };
+constexpr int kSmallInline = 16;
 
 struct SmallShared {             // LDS of one small-batch block
     SegTable tab;
@@ -40,6 +45,10 @@ struct SmallShared {             // LDS of one small-batch block
     int flags[kSmallPairs], slowest[kSmallPairs], len[kSmallPairs], status[kSmallPairs];
     unsigned long long off[kSmallPairs + 1];
     int fit;
+    // candidate 2 of timeScaling as the second wave evaluated it beside the first wave's candidate 1 (at most 64 pairs)
+    double c2_ts[64][7], c2_vd[64];
+    int c2_mod[64], c2_acc[64];
+    double in0[3][kSmallPairs];     // q_0, v_0, a_0 of every pair, for the table build (not read from host memory a second time)
     unsigned long long tick[8];     // diagnostic: wall clock of thread 0 at the phase boundaries
 };
 
@@ -72,9 +81,15 @@ LTP_DEV void plan_small_body(int n, int dof, double t_sample, int goal_check, Ro
     // (so that joints in different branches of optSwitchTimes / timeScaling run side by side) was measured and is SLOWER by 1.8x:
     // the kernel is ~530 KB of straight-line code behind a 64 KB instruction cache, and four waves in four places of it wait for
     // instruction fetches more than one wave walking through it (single call)
-    const int pid = t;
-    const bool pair = pid < pairs;
-    const int q = pair ? pid / dof : 0, j = pair ? pid - q * dof : 0;
+    // With at most 64 pairs (the single call: 7) wave 1 shadows wave 0's lanes: it loads the same inputs and, while wave 0 evaluates
+    // timeScaling's first candidate, evaluates the second (cc:408-446) for the same (query, joint) — the two are independent
+    // computations, the reference merely tries them in order, and three of ten joints need the second (one wave would run both, one
+    // after the other: 5.6 us of a 27 us call). "First accepted in order" is then a lookup, as in k_scaling_slow.
+    const bool dual = !GIVEN && pairs <= 64;
+    const bool shadow = dual && t >= 64 && t < 64 + pairs;
+    const int pid = shadow ? t - 64 : t;
+    const bool pair = t < pairs;
+    const int q = (pair || shadow) ? pid / dof : 0, j = (pair || shadow) ? pid - q * dof : 0;
     JointLimits L = {0.0, 0.0, 0.0, 0.0, 0.0, {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0}};
     double qg = 0.0, q0 = 0.0, v0 = 0.0, a0 = 0.0;
     if constexpr (GIVEN) {
@@ -83,6 +98,7 @@ LTP_DEV void plan_small_body(int n, int dof, double t_sample, int goal_check, Ro
         if (pair) {
             L = load_limits(lim, j);
             q0 = io.in[1][pid]; v0 = io.in[2][pid]; a0 = io.in[3][pid];
+            sh.in0[0][pid] = q0; sh.in0[1][pid] = v0; sh.in0[2][pid] = a0;
             double ts[7];
 #pragma unroll
             for (int k = 0; k < 7; ++k) { ts[k] = io.rec.t_scaled[pid * 7 + k]; s_t_scaled[pid][k] = ts[k]; s_t_opt[pid][k] = 0.0; }
@@ -97,9 +113,13 @@ LTP_DEV void plan_small_body(int n, int dof, double t_sample, int goal_check, Ro
     } else {
     if (t == 0) sh.tick[0] = (unsigned long long)wall_clock64();
     // ---- stage 1 ----
-    if (pair) {
+    if (pair || shadow) {
         L = load_limits(lim, j);
-        qg = io.in[0][pid]; q0 = io.in[1][pid]; v0 = io.in[2][pid]; a0 = io.in[3][pid];
+        if (io.n_inline >= pairs) { const int e = pid & (kSmallInline - 1); qg = io.inl[0][e]; q0 = io.inl[1][e]; v0 = io.inl[2][e]; a0 = io.inl[3][e]; }
+        else { qg = io.in[0][pid]; q0 = io.in[1][pid]; v0 = io.in[2][pid]; a0 = io.in[3][pid]; }
+    }
+    if (pair) {
+        sh.in0[0][pid] = q0; sh.in0[1][pid] = v0; sh.in0[2][pid] = a0;
         int flags = check_inputs_joint<SEM>(L, q0, v0, a0) ? 0 : kStatusInvalidInput;
         if (goal_check && !(qg >= L.q_min && qg <= L.q_max)) flags |= kStatusGoalOutside;
         double tt[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
@@ -132,17 +152,59 @@ LTP_DEV void plan_small_body(int n, int dof, double t_sample, int goal_check, Ro
     }
     __syncthreads();
     // ---- time scaling + fallback (cc:43-55) ----
+    if (shadow) {
+        // wave 1: candidate 2 for the lanes wave 0 evaluates candidate 1 for
+        int acc = 0, mod = 0;
+        double ts[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        double vd = 0.0;
+        if (s_status[q] == 0 && j != s_slowest[q]) {
+            const double dir = s_dir[pid];
+            double v0m = v0, a0m = a0;
+            if (dir < 0.0) { v0m = -v0m; a0m = -a0m; }   // cc:372-375
+            MatlabCtx mc;
+            acc = scaling_case<2, SEM>(L, t_sample, qg, q0, v0m, a0m, dir, s_treq[q], vd, ts, mod, mc) ? 1 : 0;
+        }
+#pragma unroll
+        for (int k = 0; k < 7; ++k) sh.c2_ts[pid][k] = ts[k];
+        sh.c2_vd[pid] = vd;
+        sh.c2_mod[pid] = mod;
+        sh.c2_acc[pid] = acc;
+    }
+    bool c1_rejected = false;
+    double ts[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    double vd = L.v_max;
+    int mod = 0;                                       // failed query: zero record, never sampled
+    if (pair && dual && s_status[q] == 0 && j != s_slowest[q]) {
+        const double dir = s_dir[pid];
+        double v0m = v0, a0m = a0;
+        if (dir < 0.0) { v0m = -v0m; a0m = -a0m; }
+        MatlabCtx mc;
+        c1_rejected = !scaling_case<1, SEM>(L, t_sample, qg, q0, v0m, a0m, dir, s_treq[q], vd, ts, mod, mc);
+    }
+    if (dual) __syncthreads();
     if (pair) {
         const int flags = s_status[q];
-        double ts[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-        double vd = L.v_max;
-        int mod = 0;                                   // failed query: zero record, never sampled
         if (flags == 0) {
-            mod = s_mod[pid];
+            if (!dual) mod = s_mod[pid];
+            else if (j == s_slowest[q]) mod = s_mod[pid];
             if (j != s_slowest[q]) {
                 int which = 0;
                 MatlabCtx mc;
-                time_scaling_full<SEM>(L, t_sample, qg, q0, v0, a0, s_dir[pid], s_treq[q], vd, ts, mod, which, mc);
+                if (!dual) {
+                    time_scaling_full<SEM>(L, t_sample, qg, q0, v0, a0, s_dir[pid], s_treq[q], vd, ts, mod, which, mc);
+                } else if (c1_rejected) {
+                    if (sh.c2_acc[pid]) {
+#pragma unroll
+                        for (int k = 0; k < 7; ++k) ts[k] = sh.c2_ts[pid][k];
+                        vd = sh.c2_vd[pid];
+                        mod = sh.c2_mod[pid];
+                    } else {
+                        const double dir = s_dir[pid];
+                        double v0m = v0, a0m = a0;
+                        if (dir < 0.0) { v0m = -v0m; a0m = -a0m; }
+                        time_scaling_tail<SEM>(L, t_sample, qg, q0, v0m, a0m, dir, s_treq[q], vd, ts, mod, which, mc);
+                    }
+                }
             }
             double mx = ts[0];
 #pragma unroll
@@ -198,9 +260,9 @@ LTP_DEV void plan_small_body(int n, int dof, double t_sample, int goal_check, Ro
                     if (k < 7) pa = s_t_scaled[rj][k];
                     else if (k == 7) { pa = s_dir[rj]; pb = lim.j_max[jj]; }
                     else if (k == 8) { pa = s_vd[rj]; pb = s_dir[rj]; }
-                    else if (k == 9) pa = io.in[1][rj];
-                    else if (k == 10) pa = io.in[2][rj];
-                    else if (k == 11) pa = io.in[3][rj];
+                    else if (k == 9) pa = sh.in0[0][rj];
+                    else if (k == 10) pa = sh.in0[1][rj];
+                    else if (k == 11) pa = sh.in0[2][rj];
                     else if (k == 12) pa = (double)s_mod[rj];
                 }
                 build_run_tables(tab, p, jj, 1, len, t_sample, lim, lrec, pa, pb);
@@ -270,12 +332,19 @@ int small_batch_blocks(int dof, bool with_rows) { return !with_rows ? 1 : (dof <
 
 void launch_plan_small(hipStream_t s, int n, int dof, double t_sample, int goal_check, RowSpec rows, Limits lim, const double* const in[4],
                        Records rec, unsigned long long* offsets, double* out_rows, unsigned long long capacity, int* end_flags,
-                       unsigned int* arrivals, volatile int* done, bool records_given, bool libm_pow)
+                       unsigned int* arrivals, volatile int* done, bool records_given, bool libm_pow, bool host_inputs)
 {
     SmallHost io;
     for (int k = 0; k < 4; ++k) io.in[k] = in[k];
     io.rec = rec; io.offsets = offsets; io.rows = out_rows; io.capacity = capacity; io.end_flags = end_flags; io.arrivals = arrivals;
     io.done = done;
+    // the queries ride in the kernel arguments when they are few (`in` is then host memory the caller has just filled)
+    io.n_inline = 0;
+    if (!records_given && host_inputs && n * dof <= kSmallInline) {
+        io.n_inline = n * dof;
+        for (int k = 0; k < 4; ++k)
+            for (int i = 0; i < n * dof; ++i) io.inl[k][i] = in[k][i];
+    }
     const dim3 grid((unsigned)small_batch_blocks(dof, out_rows != nullptr));
     // (with the records given there are no powers left to form: one instantiation)
     if (records_given) hipLaunchKernelGGL((k_plan_small<true, kSemCpp>), grid, dim3(kSampleThreads), 0, s, n, dof, t_sample, goal_check, rows, lim, io);

@@ -658,4 +658,29 @@ LTP_DEV bool time_scaling_full(const JointLimits& L, double t_sample, double qg,
     return false;
 }
 
+// cc:449-645 for one (query, joint): candidates 3..8 in the reference's order and the reset, for a caller that has already
+// evaluated (and seen rejected) candidates 1 and 2. v0 / a0 already mapped to the positive direction (cc:372-375).
+template <int SEM = kSemCpp>
+LTP_DEV bool time_scaling_tail(const JointLimits& L, double t_sample, double qg, double q0, double v0, double a0, double dir,
+                               double tr, double& vd, double (&ts)[7], int& mod, int& which, MatlabCtx& mc)
+{
+    which = 3;
+    if (scaling_case<3, SEM>(L, t_sample, qg, q0, v0, a0, dir, tr, vd, ts, mod, mc)) return true;
+    which = 4;
+    if (scaling_case<4, SEM>(L, t_sample, qg, q0, v0, a0, dir, tr, vd, ts, mod, mc)) return true;
+    which = 5;
+    if (scaling_case<5, SEM>(L, t_sample, qg, q0, v0, a0, dir, tr, vd, ts, mod, mc)) return true;
+    which = 6;
+    if (scaling_case<6, SEM>(L, t_sample, qg, q0, v0, a0, dir, tr, vd, ts, mod, mc)) return true;
+    which = 7;
+    if (scaling_case<7, SEM>(L, t_sample, qg, q0, v0, a0, dir, tr, vd, ts, mod, mc)) return true;
+    which = 8;
+    if (scaling_case<8, SEM>(L, t_sample, qg, q0, v0, a0, dir, tr, vd, ts, mod, mc)) return true;
+    which = 0;   // cc:640-644
+    mod = 0;
+    zero7(ts);
+    vd = L.v_max;
+    return false;
+}
+
 }  // namespace ltp

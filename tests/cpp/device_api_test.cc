@@ -239,6 +239,10 @@ int main()
         // (a) cold handle: the table workspace does not exist yet and must not be allocated inside the capture
         HIP(hipStreamBeginCapture(s, hipStreamCaptureModeGlobal));
         const int ra = ltp_plan_switch_times_batch(h, n, &q, &rec, offsets2, s);
+        // the default envelope form (analytic, k_envelope_walk: round 6) needs no workspace; the exhaustive form takes the table pass
+        const int rb0 = ltp_envelope_batch(h, 0, n, &q, &rec, W, K, env2, s);
+        CHECK(ltp_get_envelope_mode(h) == LTP_ENVELOPE_ANALYTIC && rb0 == LTP_OK);
+        LTP(ltp_set_envelope_mode(h, LTP_ENVELOPE_EXHAUSTIVE));
         const int rb = ltp_envelope_batch(h, 0, n, &q, &rec, W, K, env2, s);
         const int rc4 = ltp_sample_batch(h, 0, n, &q, &rec, offsets2, tile3, cap3, 1 | 4, s);      // the table-pass kernels: need the workspace
         const int rc5 = ltp_sample_batch(h, 0, n, &q, &rec, offsets2, tile5, cap3, 1, s);          // default for these rows: no workspace needed

@@ -345,6 +345,7 @@ static void testRound5Options()
   std::printf("pow rules, %d plans: switching times differ by at most %.3e s, %zu of %zu entries in their bits\n", n, worst, other_bits, a.t_scaled.size());
   EXPECT_TRUE(worst < 1e-9);
   std::vector<double> e_all, e_ana;
+  libm.setAnalyticEnvelopes(false);                         // the exhaustive form (the default is the analytic one since round 6)
   const long long e1 = libm.planEnvelopeBatch(n, qg.data(), q0.data(), v0.data(), a0.data(), 20, 12, e_all);
   libm.setAnalyticEnvelopes(true);
   const long long e2 = libm.planEnvelopeBatch(n, qg.data(), q0.data(), v0.data(), a0.data(), 20, 12, e_ana);
