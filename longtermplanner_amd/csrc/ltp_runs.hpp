@@ -105,6 +105,78 @@ LTP_DEV void for_each_run_loaded(const JointRecord& R, double j_max, int len, do
     const double d20 = (fr[2] - fr[0]) / Ts;
     const double corr[9] = {frts[0] * J0, (1 - frts[1]) * J2, frts[2] * J2, d20 * J2, (1 - frts[3]) * J4,
                             frts[4] * J4, 0.0, (1 - frts[5]) * J6, frts[6] * J6};
+    if constexpr (SEM != kSemMatlab) {
+        // ---- C++ semantics: the walk below, written without lane branches (round 6) ----
+        // One lane's stream is what a builder wave of k_sample_walk_* or a single call waits for, and the general form further down
+        // spends ~250 instructions per run on ~45 of arithmetic: compare masks combined on the scalar unit, exec-mask branches around
+        // every conditional assignment of jerk_at and around run_coef's modes. Same values, same order of every floating-point
+        // operation: the seven range fills become seven unsigned interval tests that select the FACTOR of Jp[k] = dj * {+-1.0, 0.0}
+        // (one dword; later ranges override earlier ones as cc:759-766 does), the corrections become ten unconditional additions of
+        // either the term or -0.0 (x + -0.0 == x for every x, also for -0.0 and NaN) in the reference's order (cc:768-807), the
+        // cut search is a max / select / min per group, and the modes are interval tests.
+        int st[7];
+        unsigned wid[7];
+        st[0] = 0;
+        wid[0] = sw[0] > 0 ? (unsigned)sw[0] : 0u;
+#pragma unroll
+        for (int k = 1; k < 7; ++k) {
+            st[k] = sw[k - 1];
+            const int d = sw[k] - sw[k - 1];
+            wid[k] = d > 0 ? (unsigned)d : 0u;
+        }
+        constexpr unsigned kOneHi = 0x3ff00000u, kMinusOneHi = 0xbff00000u, kNoneHi = 0x7ff80000u;   // high words of 1.0, -1.0, a NaN
+        const unsigned fac[7] = {modp ? kMinusOneHi : kOneHi, 0u, modp ? kOneHi : kMinusOneHi, 0u, kMinusOneHi, 0u, kOneHi};
+        // where each correction lands (-1: nowhere, a run never starts below 0) and what is added there, cc:768-807
+        const bool o1 = sw[2] >= sw[1], o2 = sw[2] - sw[0] > 0;
+        const int p_a = o1 ? sw[0] + 1 : -1;                              // + corr0                                   (cc:771)
+        const int p_b = sw[1] > 0 ? sw[1] : -1;                           // + corr1 (cc:774) | + corr0 + corr3        (cc:781)
+        const double b1 = o1 ? corr[1] : corr[0], b2 = o1 ? -0.0 : corr[3];
+        const int p_c = o1 ? sw[2] + 1 : -1;                              // + corr2                                   (cc:776)
+        const int p_d = sw[3] > 0 ? sw[3] : -1;                           // + corr4                                   (cc:787)
+        const int p_e = o2 ? sw[4] + 1 : (sw[4] > 0 ? sw[4] : -1);        // + corr5 (cc:793) | + corr5 + corr0 + corr3 (cc:798)
+        const double e2 = o2 ? -0.0 : corr[0], e3 = o2 ? -0.0 : corr[3];
+        const int p_f = sw[5] > 0 ? sw[5] : -1;                           // + corr7                                   (cc:804)
+        const int p_g = sw[6] + 1;                                        // + corr8                                   (cc:807)
+        constexpr int cut_lo[7] = {0, 0, 0, -1, 0, 0, 0}, cut_hi[7] = {2, 1, 2, 1, 2, 1, 2};
+        int glo[7], ghi[7];
+#pragma unroll
+        for (int g = 0; g < 7; ++g) { glo[g] = sw[g] + cut_lo[g]; ghi[g] = sw[g] + cut_hi[g]; }
+        // cc:813, 822: the constant-velocity samples are s2 + 1 .. s3 - 2 when s3 - s2 > 2
+        const int vs0 = sw[2] + 1;
+        const unsigned vsw = sw[3] - sw[2] > 2 ? (unsigned)(sw[3] - 1 - vs0) : 0u;
+        int b = 0;
+        for (int run = 0; run < kMaxSegments && b < len; ++run) {
+            int e = len;
+#pragma unroll
+            for (int g = 0; g < 7; ++g) {
+                const int c = glo[g] > b ? glo[g] : b + 1;
+                const int cc = c <= ghi[g] ? c : 0x7fffffff;
+                e = cc < e ? cc : e;
+            }
+            const int mode = (b > sw[6] ? kModeTail : 0) | ((unsigned)(b - vs0) < vsw ? kModeVSnap : 0);
+            unsigned fh = kNoneHi;
+#pragma unroll
+            for (int k = 0; k < 7; ++k) fh = (unsigned)(b - st[k]) < wid[k] ? fac[k] : fh;
+            double J = dj * __builtin_bit_cast(double, (unsigned long long)fh << 32);
+            J = fh == kNoneHi ? 0.0 : J;
+            J = J + (b == p_a ? corr[0] : -0.0);
+            J = J + (b == p_b ? b1 : -0.0);
+            J = J + (b == p_b ? b2 : -0.0);
+            J = J + (b == p_c ? corr[2] : -0.0);
+            J = J + (b == p_d ? corr[4] : -0.0);
+            J = J + (b == p_e ? corr[5] : -0.0);
+            J = J + (b == p_e ? e2 : -0.0);
+            J = J + (b == p_e ? e3 : -0.0);
+            J = J + (b == p_f ? corr[7] : -0.0);
+            J = J + (b == p_g ? corr[8] : -0.0);
+            const RunCoef rc = run_coef<SEM>(mode, J, a, v, q, vsnap, Ts);
+            if (visit(b, e, rc)) return;
+            double jj;
+            run_eval(rc.c, e - b, q, v, a, jj);
+            b = e;
+        }
+        return;
+    }
     // Candidate cut points: every index where the jerk array or a snap rule (cc:815-829) can change — the same set as kCutBase /
     // kCutDelta of the cooperative build: per sampled switch index s_g a few CONSECUTIVE integers s_g + lo_g .. s_g + hi_g. The next
     // cut after b inside group g is therefore max(s_g + lo_g, b + 1) if that is <= s_g + hi_g: three operations per group instead of
