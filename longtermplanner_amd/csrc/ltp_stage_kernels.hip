@@ -208,6 +208,7 @@ k_opt_slow(int dof, double t_sample, Limits lim, Queries in, Records out, signed
 // 2 % slower on the same box: left alone. Same for k_opt_fast at 80 registers, -15 %.)
 template <int SEM>
 __global__ void __launch_bounds__(kQueriesPerBlock* kMaxJointSlots)
+__attribute__((amdgpu_waves_per_eu(4, 4)))      // 128 registers (libm rule: 144 -> 128 with 32 bytes of scratch): four 4-wave blocks per compute unit, 568 -> 534 us per 1 M
 k_reduce_scale(long long n, int dof, double t_sample, Limits lim, Queries in, Records out,
                const signed char* __restrict__ lane_flags, Queue queue)
 {
@@ -385,6 +386,9 @@ k_scaling_slow(int dof, double t_sample, Limits lim, Queries in, Records out, Qu
     __shared__ int s_acc[8][kQueriesPerBlock];
     const int x = threadIdx.x;
     const int c = __builtin_amdgcn_readfirstlane(threadIdx.y);
+    // the degree-6 and degree-5 candidates are the kernel's latency: their waves go first on the SIMD they share with a quartic
+    // candidate (profiles/r06_stage_small_ab.txt: 253 -> 242 us per 1 M queries, 154 -> 152 us per 100 k)
+    if (c == 7 || c == 4) __builtin_amdgcn_s_setprio(3);
     unsigned long long cnt[kQueueShards];
     const unsigned long long count = queue_total(queue, cnt);
     // MATLAB semantics: the queued items spread over the blocks that run at once (one 8-wave block per compute unit),
