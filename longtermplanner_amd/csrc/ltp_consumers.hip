@@ -375,7 +375,9 @@ k_end_limit(long long first, long long count, int dof, double t_sample, Limits l
     if (len <= 0) return;                                     // failed before sampling: the reference never gets to cc:59
     const long long ix = p * in.sq + (long long)j * in.sj;
     double q = in.q_0[ix], v = in.v_0[ix], a = in.a_0[ix];
-    for_each_run(lim, rec, p * dof + j, j, len, t_sample, q, v, a, [](int, int, const RunCoef&) { return false; });
+    // (a tail run, i > s6, has a = v = 0: q no longer moves, so the state before the first of them IS the last sample's position — the
+    // two or three one-sample runs behind s6 need not be walked)
+    for_each_run(lim, rec, p * dof + j, j, len, t_sample, q, v, a, [](int, int, const RunCoef& rc) { return (rc.mode & kModeTail) != 0; });
     if (q < lim.q_min[j] || q > lim.q_max[j]) atomicOr(&rec.status[p], kStatusEndLimit);
 }
 

@@ -13,6 +13,12 @@ template <typename T> struct OutVec;
 template <> struct OutVec<double> { typedef double2_t type; static constexpr int N = 2; };
 template <> struct OutVec<float> { typedef float4_t type; static constexpr int N = 4; };
 
+LTP_DEV LimPow load_limit_powers(const Limits& lim, int j)
+{
+    const double* w = lim.pw + (long long)j * kLimPowN;
+    return LimPow{w[0], w[1], w[2], w[3], w[4], w[5], w[6]};
+}
+
 LTP_DEV JointLimits load_limits(const Limits& lim, int j)
 {
     JointLimits L;
@@ -21,8 +27,7 @@ LTP_DEV JointLimits load_limits(const Limits& lim, int j)
     L.v_max = lim.v_max[j];
     L.a_max = lim.a_max[j];
     L.j_max = lim.j_max[j];
-    const double* w = lim.pw + (long long)j * kLimPowN;
-    L.pw = LimPow{w[0], w[1], w[2], w[3], w[4], w[5], w[6]};
+    L.pw = load_limit_powers(lim, j);
     return L;
 }
 

@@ -126,7 +126,7 @@ LTP_DEV void plan_small_body(int n, int dof, double t_sample, int goal_check, Ro
         double dir = 0.0;
         int mod = 0;
         MatlabCtx mc;
-        if (opt_switch_times<true, SEM>(L.a_max, L.j_max, L.v_max, L.pw, t_sample, qg, q0, v0, a0, L.v_max, tt, dir, mod, mc) == kOptFalse) flags |= kStatusOptFailed;
+        if (opt_switch_times<true, SEM, true>(L.a_max, L.j_max, L.v_max, L.pw, t_sample, qg, q0, v0, a0, L.v_max, tt, dir, mod, mc) == kOptFalse) flags |= kStatusOptFailed;
 #pragma unroll
         for (int k = 0; k < 7; ++k) s_t_opt[pid][k] = tt[k];
         s_dir[pid] = dir;
@@ -279,7 +279,7 @@ LTP_DEV void plan_small_body(int n, int dof, double t_sample, int goal_check, Ro
         // no rows wanted: the end-limit check alone (k_end_limit). (For a single call the cooperative table build — 32 lanes per
         // joint, the verdict from its step (5) — was measured in this place: 9.9 us against 10.7 us for this walk; not kept.)
         double qq = q0, vv = v0, aa = a0;
-        for_each_run(lim, lrec, pid, j, s_len[q], t_sample, qq, vv, aa, [](int, int, const RunCoef&) { return false; });
+        for_each_run(lim, lrec, pid, j, s_len[q], t_sample, qq, vv, aa, [](int, int, const RunCoef& rc) { return (rc.mode & kModeTail) != 0; });   // q rests in the tail
         if (qq < L.q_min || qq > L.q_max) atomicOr(&s_status[q], kStatusEndLimit);
     }
     __syncthreads();

@@ -68,15 +68,17 @@ struct JointLimits {
 
 // pw3 / pw4 of a value that is USUALLY the joint's tj: when every active lane of the wave holds exactly tj's bits, the stored power
 // (the same function of the same bits) is the result and the wave skips the evaluation; otherwise all lanes evaluate.
-template <int SEM> LTP_DEV double pw3_tj(double x, const LimPow& P)
+// (MEMO false: the kernels of the compaction queues, whose lanes hold different joints in per-lane registers — there the stored powers
+// would cost six registers per lane in kernels at their register cap and the wave-wide match is rare.)
+template <int SEM, bool MEMO = true> LTP_DEV double pw3_tj(double x, const LimPow& P)
 {
-    if constexpr (!sem_libm(SEM)) return pw3<SEM>(x);        // the exact rule's cube is six operations: nothing to skip
+    if constexpr (!sem_libm(SEM) || !MEMO) return pw3<SEM>(x);        // the exact rule's cube is six operations: nothing to skip
     else if (__builtin_amdgcn_ballot_w64(__builtin_bit_cast(unsigned long long, x) != __builtin_bit_cast(unsigned long long, P.tj)) == 0ull) return P.tj3;
     return pw3<SEM>(x);
 }
-template <int SEM> LTP_DEV double pw4_tj(double x, const LimPow& P)
+template <int SEM, bool MEMO = true> LTP_DEV double pw4_tj(double x, const LimPow& P)
 {
-    if constexpr (!sem_libm(SEM)) return pw4<SEM>(x);
+    if constexpr (!sem_libm(SEM) || !MEMO) return pw4<SEM>(x);
     else if (__builtin_amdgcn_ballot_w64(__builtin_bit_cast(unsigned long long, x) != __builtin_bit_cast(unsigned long long, P.tj)) == 0ull) return P.tj4;
     return pw4<SEM>(x);
 }
@@ -94,7 +96,7 @@ LTP_DEV bool check_inputs_joint(const JointLimits& L, double q_0, double v_0, do
 }
 
 // cc:650-701 (LTPlanner.m:435-484). Writes r[0..2] only.
-template <int SEM = kSemCpp>
+template <int SEM = kSemCpp, bool MEMO = true>
 LTP_DEV void opt_braking(double am, double jm, const LimPow& P, double t_sample, double v_0, double a_0,
                          double& q, double (&r)[7], double& dir, MatlabCtx& mc)
 {
@@ -119,7 +121,7 @@ LTP_DEV void opt_braking(double am, double jm, const LimPow& P, double t_sample,
     q = v_0 * (r[0] + r[1] + r[2]) +
         a_0 * (1.0 / 2.0 * pw2(r[0]) + r[0] * (r[1] + r[2]) + 1.0 / 2.0 * pw2(r[2])) +
         jm * (1.0 / 6.0 * pw3<SEM>(r[0]) + 1.0 / 2.0 * pw2(r[0]) * (r[1] + r[2]) -
-              1.0 / 6.0 * pw3_tj<SEM>(r[2], P) + 1.0 / 2.0 * r[0] * pw2(r[2])) +
+              1.0 / 6.0 * pw3_tj<SEM, MEMO>(r[2], P) + 1.0 / 2.0 * r[0] * pw2(r[2])) +
         am * (1.0 / 2.0 * pw2(r[1]) + r[1] * r[2]);
     q = dir * q;
 }
@@ -189,7 +191,7 @@ LTP_DEV void zero7(double (&t)[7])
 // kernels every lane runs.
 constexpr int kOptFalse = 0, kOptTrue = 1, kOptDefer = 2;
 
-template <bool FULL, int SEM = kSemCpp>
+template <bool FULL, int SEM = kSemCpp, bool MEMO = !FULL>
 __device__ inline int opt_switch_times(double am, double jm, double vm, const LimPow& P, double t_sample,
                                        double q_goal, double q_0, double v_0, double a_0, double v_drive,
                                        double (&t)[7], double& dir, int& mod, MatlabCtx& mc)
@@ -206,7 +208,7 @@ __device__ inline int opt_switch_times(double am, double jm, double vm, const Li
         }
     }
     double q_stop = 0.0;
-    opt_braking<SEM>(am, jm, P, t_sample, v_0, a_0, q_stop, r, dir, mc);
+    opt_braking<SEM, MEMO>(am, jm, P, t_sample, v_0, a_0, q_stop, r, dir, mc);
     const double q_diff = q_goal - (q_0 + q_stop);
     if (dabs(q_diff) < kEps) {
         cumsum7(r, t);
@@ -222,7 +224,7 @@ __device__ inline int opt_switch_times(double am, double jm, double vm, const Li
     if (v_0 + 0.5 * a_0 * dabs(a_0) / jm > v_drive) {
         mod = 1;
         double emp;
-        opt_braking<SEM>(am, jm, P, t_sample, v_0 - v_drive, a_0, q_brake, r, emp, mc);
+        opt_braking<SEM, MEMO>(am, jm, P, t_sample, v_0 - v_drive, a_0, q_brake, r, emp, mc);
     } else {
         r[0] = (am - a_0) / jm;
         r[2] = am / jm;
@@ -261,7 +263,7 @@ __device__ inline int opt_switch_times(double am, double jm, double vm, const Li
         q_part1 = q_brake + v_drive * (r[0] + r[1] + r[2]);
     } else {
         r0_3 = pw3<SEM>(r[0]);
-        r2_3 = pw3_tj<SEM>(r[2], P);
+        r2_3 = pw3_tj<SEM, MEMO>(r[2], P);
         q_part1 = v_0 * (r[0] + r[1] + r[2]) +
                   a_0 * (1.0 / 2.0 * pw2(r[0]) +
                          r[0] * (r[1] + r[2]) +
@@ -272,7 +274,7 @@ __device__ inline int opt_switch_times(double am, double jm, double vm, const Li
                         1.0 / 2.0 * r[0] * pw2(r[2])) +
                   am * (1.0 / 2.0 * pw2(r[1]) + r[1] * r[2]);
     }
-    const double r4_3 = pw3_tj<SEM>(r[4], P), r6_3 = r4_3;       // r[6] is r[4] (cc:186, 193)
+    const double r4_3 = pw3_tj<SEM, MEMO>(r[4], P), r6_3 = r4_3;       // r[6] is r[4] (cc:186, 193)
     const double q_part2 = jm * (1.0 / 6.0 * r6_3 +
                                  1.0 / 2.0 * pw2(r[6]) * (r[5] + r[4]) -
                                  1.0 / 6.0 * r4_3 +
@@ -289,9 +291,9 @@ __device__ inline int opt_switch_times(double am, double jm, double vm, const Li
         const double a2 = pw2(a_0), am2 = pw2(am);
         const double r0_2 = pw2(r[0]), r2_2 = pw2(r[2]);      // mod == 0 here: r0_3, r2_3 are the cubes formed above
         const double r4_2 = pw2(r[4]);
-        const double r4_4 = pw4_tj<SEM>(r[4], P), r6_4 = r4_4;
+        const double r4_4 = pw4_tj<SEM, MEMO>(r[4], P), r6_4 = r4_4;
         double root = (jm2 * pw4<SEM>(r[0])) / 2 -
-                      (jm2 * pw4_tj<SEM>(r[2], P)) / 4 +
+                      (jm2 * pw4_tj<SEM, MEMO>(r[2], P)) / 4 +
                       (jm2 * r2_2 * r4_2) / 2 -
                       (jm2 * r4_4) / 4 +
                       (jm2 * r6_4) / 2 +

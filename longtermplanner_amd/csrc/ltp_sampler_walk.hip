@@ -360,7 +360,8 @@ LTP_DEV bool walk_lane(Slot& W, const WalkLaneIn& L, long long needed_end, bool 
         } else if (last_b == L.len) {
             last_b = b;                                                          // first run that is not needed: it ends the last stored one
         }
-        return stop_at_cap && (long long)b >= needed_end;                        // otherwise the walk goes to the last sample: end-limit check
+        // otherwise the walk goes on for the end-limit check — to the first tail run (C++ semantics: a = v = 0 there, q rests)
+        return (long long)b >= needed_end && (stop_at_cap || (SEM != kSemMatlab && (rc.mode & kModeTail) != 0));
     }, last_joint);
     W.close(runs, last_b);
     W.vsnap = L.R.v_drive * L.R.dir;                                             // as the walk forms it (cc:823)

@@ -410,21 +410,24 @@ k_scaling_slow(int dof, double t_sample, Limits lim, Queries in, Records out, Qu
             rj = (long long)queue_item(queue, cnt, it);
             q = rj / dof;
             j = (int)(rj - q * dof);
-            L = load_limits(lim, j);
+            // (the joint's five limits here; its power table inside each candidate's case: per lane in this kernel, and held across
+            // the switch it costs every candidate the registers of all seven entries — the MATLAB-semantics solver then spills)
+            L.q_min = lim.q_min[j]; L.q_max = lim.q_max[j]; L.v_max = lim.v_max[j]; L.a_max = lim.a_max[j]; L.j_max = lim.j_max[j];
             const long long ix = q * in.sq + (long long)j * in.sj;
             const double qg = in.q_goal[ix], q0 = in.q_0[ix];
             double v0 = in.v_0[ix], a0 = in.a_0[ix];
             const double dir = out.dir[rj], tr = out.t_required[q];
             if (dir < 0.0) { v0 = -v0; a0 = -a0; }   // cc:372-375
+            JointLimits Lc = L;
             switch (c) {
-            case 0: acc = scaling_case<1, SEM>(L, t_sample, qg, q0, v0, a0, dir, tr, vd, ts, mod, mc); break;
-            case 1: acc = scaling_case<2, SEM>(L, t_sample, qg, q0, v0, a0, dir, tr, vd, ts, mod, mc); break;
-            case 2: acc = scaling_case<3, SEM>(L, t_sample, qg, q0, v0, a0, dir, tr, vd, ts, mod, mc); break;
-            case 3: acc = scaling_case<4, SEM>(L, t_sample, qg, q0, v0, a0, dir, tr, vd, ts, mod, mc); break;
-            case 4: acc = scaling_case<5, SEM>(L, t_sample, qg, q0, v0, a0, dir, tr, vd, ts, mod, mc); break;
-            case 5: acc = scaling_case<6, SEM>(L, t_sample, qg, q0, v0, a0, dir, tr, vd, ts, mod, mc); break;
-            case 6: acc = scaling_case<7, SEM>(L, t_sample, qg, q0, v0, a0, dir, tr, vd, ts, mod, mc); break;
-            default: acc = scaling_case<8, SEM>(L, t_sample, qg, q0, v0, a0, dir, tr, vd, ts, mod, mc); break;
+            case 0: Lc.pw = load_limit_powers(lim, j); acc = scaling_case<1, SEM>(Lc, t_sample, qg, q0, v0, a0, dir, tr, vd, ts, mod, mc); break;
+            case 1: Lc.pw = load_limit_powers(lim, j); acc = scaling_case<2, SEM>(Lc, t_sample, qg, q0, v0, a0, dir, tr, vd, ts, mod, mc); break;
+            case 2: Lc.pw = load_limit_powers(lim, j); acc = scaling_case<3, SEM>(Lc, t_sample, qg, q0, v0, a0, dir, tr, vd, ts, mod, mc); break;
+            case 3: Lc.pw = load_limit_powers(lim, j); acc = scaling_case<4, SEM>(Lc, t_sample, qg, q0, v0, a0, dir, tr, vd, ts, mod, mc); break;
+            case 4: Lc.pw = load_limit_powers(lim, j); acc = scaling_case<5, SEM>(Lc, t_sample, qg, q0, v0, a0, dir, tr, vd, ts, mod, mc); break;
+            case 5: Lc.pw = load_limit_powers(lim, j); acc = scaling_case<6, SEM>(Lc, t_sample, qg, q0, v0, a0, dir, tr, vd, ts, mod, mc); break;
+            case 6: Lc.pw = load_limit_powers(lim, j); acc = scaling_case<7, SEM>(Lc, t_sample, qg, q0, v0, a0, dir, tr, vd, ts, mod, mc); break;
+            default: Lc.pw = load_limit_powers(lim, j); acc = scaling_case<8, SEM>(Lc, t_sample, qg, q0, v0, a0, dir, tr, vd, ts, mod, mc); break;
             }
         }
         s_acc[c][x] = acc ? 1 : 0;
