@@ -74,7 +74,7 @@ def counters(d, want):
 def stats(d, want):
     f = latest(f"{G}/{d}/**/*_kernel_stats.csv")
     return {r["Name"].split("(")[0].replace("void ", ""): float(r["AverageNs"]) / 1e3 for r in csv.DictReader(open(f)) if want(r["Name"])} if f else {}
-out = {"collected": "round 5, tools/refresh_profiles.sh ${TAG} + tools/collect_profiles.sh ${TAG}",
+out = {"collected": "round ${TAG#r0}, tools/refresh_profiles.sh ${TAG} + tools/collect_profiles.sh ${TAG}",
        "how": "separate rocprofv3 passes of `python3 bench.py --no-secondary --no-cpu-baseline <workload>`: --pmc WRITE_SIZE (KiB, exact for 16-byte-per-lane stores per "
               "MI355X_MICROARCH.md) for the row writers; --pmc SQ_INSTS_VALU ... and --kernel-trace --stats for the stage / envelope kernels. valu_issue_frac = "
               "SQ_INSTS_VALU (wave instructions) x 4 issue cycles / (1024 SIMDs x 2.4 GHz x kernel time): the share of the chip's vector issue slots the kernel used",

@@ -26,12 +26,12 @@ for a in "--limits ref" "--limits ref30 --batch 200000" "--switch-only --batch 1
          "--sample-stride 2" "--max-samples 512" "--max-samples 512 --no-walk" "--f32" "--f32 --no-walk" "--f32 --sample-stride 4" "--f32 --sample-stride 4 --no-walk" "--f32 --limits ref" \
          "--f32 --max-samples 256" "--f32 --max-samples 256 --table-pass off" "--f32 --max-samples 1024" "--f32 --max-samples 1024 --no-walk" "--envelope 64:32" \
          "--envelope 64:32 --table-pass off" "--envelope 64:32 --limits ref" "--receding 10:100" "--receding 10:100 --end-limit" \
-         "--receding 10:100 --max-samples 128" "--receding 10:100 --max-samples 128 --no-walk" "--receding 10:100 --max-samples 128 --table-pass off" "--tile-gib 64" "--layout joint_major" \
+         "--receding 10:100 --max-samples 128" "--receding 10:100 --max-samples 128 --no-walk" "--receding 10:100 --max-samples 128 --table-pass off" "--tile-gib 64" "--layout joint_major" "--switch-only --layout joint_major" "--switch-only --batch 100000 --layout joint_major" \
          "--semantics matlab --steps 3" "--semantics matlab --limits ref --steps 2" "--semantics matlab --switch-only --batch 100000 --steps 30 --warmup 3" \
          "--semantics matlab --switch-only --batch 100000 --limits ref --steps 30 --warmup 3" "--semantics matlab --envelope 64:32" \
          "--switch-only --batch 100000 --pow-rule exact" "--switch-only --pow-rule exact" "--switch-only --limits ref --pow-rule exact" "--pow-rule exact" \
          "--max-samples 64 --pow-rule exact" "--receding 10:100 --max-samples 128 --pow-rule exact" "--envelope 64:32 --envelope-analytic" "--envelope 64:32 --limits ref --envelope-analytic" \
-         "--envelope 256:8" "--envelope 256:8 --envelope-analytic" "--semantics matlab --envelope 64:32 --envelope-analytic" \
+         "--envelope 256:8" "--envelope 256:8 --envelope-analytic" "--switch-only --batch 100000 --limits ref --pow-rule exact" "--switch-only --limits ref30 --batch 200000" "--semantics matlab --envelope 64:32 --envelope-analytic" \
          "--gpus 1 --force-dist --gather --checksum --steps 5" \
          "--gpus 8 --one-process --device 0 --global-batch 10000000 --switch-only --end-limit --checksum --steps 5" \
          "--gpus 8 --one-process --device 0 --global-batch 10000000 --envelope 64:32 --steps 2" \
