@@ -74,10 +74,36 @@ LTP_DEV RunCoef run_coef(int mode, double J, double a_s, double v_s, double q_s,
     // The products and sums below are separate roundings in the library (it is built with -ffp-contract=off); pinned here so that
     // a consumer compiled with hipcc's default (-ffp-contract=fast) gets the same coefficients, i.e. the library's bits.
 #pragma clang fp contract(off)
-    // Written as selects of the INPUTS, not as branches around the coefficient blocks (round 6): a lane of a run walk meets all three
-    // kinds of run, and a wave whose lanes sit in different kinds would execute every branch in turn. The values are those of the
-    // obvious branch form, to the bit: a constant-velocity run is an ordinary run whose velocity is vsnap and whose acceleration
-    // and jerk contribute +0.0 to v and q (x + 0.0 == x: v_drive is never zero), a tail run one whose state is all zero.
+    RunCoef r;
+#pragma unroll
+    for (int x = 0; x < kRunCoefs; ++x) r.c[x] = 0.0;
+    const double tj = Ts * J;
+    r.mode = mode;
+    r.c[9] = J;
+    if (!(mode & kModeTail) || (SEM == kSemMatlab && (mode & kModeKeepA))) { r.c[7] = a_s; r.c[8] = tj; }
+    r.c[0] = q_s;
+    if (mode & kModeVSnap) {
+        r.c[4] = vsnap;
+        r.c[1] = Ts * vsnap;
+    } else if (!(mode & kModeTail)) {
+        // binomial-sum form -> monomial basis: m(m+1)/2 = (m^2 + m)/2, m(m+1)(m+2)/6 = (m^3 + 3 m^2 + 2 m)/6
+        const double v1 = Ts * a_s, v2 = 0.5 * (Ts * tj);
+        const double q1 = Ts * v_s, q2 = 0.5 * (Ts * (Ts * a_s)), q3 = (Ts * (Ts * tj)) * (1.0 / 6.0);
+        r.c[4] = v_s; r.c[5] = v1 + v2; r.c[6] = v2;
+        r.c[1] = q1 + (q2 + 2.0 * q3); r.c[2] = q2 + 3.0 * q3; r.c[3] = q3;
+    }
+    return r;
+}
+
+// run_coef for callers whose lanes hold runs of DIFFERENT kinds (a lane-per-joint walk, ltp_runs.hpp): the same coefficients, to the
+// bit, from selects of the inputs instead of branches around the coefficient blocks — a wave whose lanes sit in all three kinds of
+// run would execute every branch in turn. A constant-velocity run is an ordinary run whose velocity is vsnap and whose acceleration
+// and jerk contribute +0.0 to v and q (x + 0.0 == x; v_drive is never zero), a tail run one whose state is all zero. Callers
+// whose waves hold ONE run at a time (the streaming loops: the mode is wave-uniform, the untaken branches are skipped) use run_coef.
+template <int SEM = kSemCpp>
+LTP_DEV RunCoef run_coef_sel(int mode, double J, double a_s, double v_s, double q_s, double vsnap, double Ts)
+{
+#pragma clang fp contract(off)
     RunCoef r;
     const bool tail = (mode & kModeTail) != 0, vsn = (mode & kModeVSnap) != 0;
     const bool keep_a = !tail || (SEM == kSemMatlab && (mode & kModeKeepA));

@@ -82,7 +82,10 @@ LTP_DEV JointRecord load_joint_record(const Records& rec, long long rj)
     return R;
 }
 
-template <int SEM = kSemCpp, class Visit>
+// LEAN (C++ semantics only): the branch-free form of the walk below (round 6). false: the general form, whose compare masks and
+// branches live on the scalar unit — the builder wave of k_sample_walk_* shares its SIMD with five streaming waves, and there the
+// scalar work was free while every vector instruction is not (profiles/r06_walk_forms_ab.txt).
+template <int SEM = kSemCpp, bool LEAN = true, class Visit>
 LTP_DEV void for_each_run_loaded(const JointRecord& R, double j_max, int len, double Ts, double& q, double& v, double& a, Visit&& visit,
                                  bool last_joint = true)
 {
@@ -105,7 +108,7 @@ LTP_DEV void for_each_run_loaded(const JointRecord& R, double j_max, int len, do
     const double d20 = (fr[2] - fr[0]) / Ts;
     const double corr[9] = {frts[0] * J0, (1 - frts[1]) * J2, frts[2] * J2, d20 * J2, (1 - frts[3]) * J4,
                             frts[4] * J4, 0.0, (1 - frts[5]) * J6, frts[6] * J6};
-    if constexpr (SEM != kSemMatlab) {
+    if constexpr (SEM != kSemMatlab && LEAN) {
         // ---- C++ semantics: the walk below, written without lane branches (round 6) ----
         // One lane's stream is what a builder wave of k_sample_walk_* or a single call waits for, and the general form further down
         // spends ~250 instructions per run on ~45 of arithmetic: compare masks combined on the scalar unit, exec-mask branches around
@@ -169,7 +172,7 @@ LTP_DEV void for_each_run_loaded(const JointRecord& R, double j_max, int len, do
             J = J + (b == p_e ? e3 : -0.0);
             J = J + (b == p_f ? corr[7] : -0.0);
             J = J + (b == p_g ? corr[8] : -0.0);
-            const RunCoef rc = run_coef<SEM>(mode, J, a, v, q, vsnap, Ts);
+            const RunCoef rc = run_coef_sel<SEM>(mode, J, a, v, q, vsnap, Ts);
             if (visit(b, e, rc)) return;
             double jj;
             run_eval(rc.c, e - b, q, v, a, jj);
@@ -233,7 +236,7 @@ template <int SEM = kSemCpp, class Visit>
 LTP_DEV void for_each_run(const Limits& lim, const Records& rec, long long rj, int j, int len, double Ts, double& q, double& v,
                           double& a, Visit&& visit, bool last_joint = true)
 {
-    for_each_run_loaded<SEM>(load_joint_record(rec, rj), lim.j_max[j], len, Ts, q, v, a, visit, last_joint);
+    for_each_run_loaded<SEM, true>(load_joint_record(rec, rj), lim.j_max[j], len, Ts, q, v, a, visit, last_joint);
 }
 
 }  // namespace ltp

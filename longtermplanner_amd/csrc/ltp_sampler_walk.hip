@@ -341,14 +341,14 @@ struct WalkLaneIn {
 // the slot holds (compact batches only: the batch is then rebuilt wide). q_end receives the last trajectory sample (cc:59-61) —
 // unless stop_at_cap: the walk then ends at the first run that is not needed (no end-limit verdict: LTPlanner.m has none, and a
 // caller of the C++ semantics may ask for rows without it, ltp_sample_batch flags bit 4).
-template <int SEM, class Slot>
+template <int SEM, bool LEAN, class Slot>
 LTP_DEV bool walk_lane(Slot& W, const WalkLaneIn& L, long long needed_end, bool stop_at_cap, double Ts, double& q_end, bool last_joint)
 {
     constexpr int RUNS = Slot::kRuns;
     double q = L.q0, v = L.v0, a = L.a0;
     int runs = 0, last_b = L.len;
     bool too_many = false;
-    for_each_run_loaded<SEM>(L.R, L.j_max, L.len, Ts, q, v, a, [&](int b, int, const RunCoef& rc) {
+    for_each_run_loaded<SEM, LEAN>(L.R, L.j_max, L.len, Ts, q, v, a, [&](int b, int, const RunCoef& rc) {
         if ((long long)b < needed_end) {
             if (runs < RUNS) {
                 // q, v, a still hold the state before this run: the walk advances them after the visit
@@ -408,7 +408,11 @@ LTP_DEV int walk_item_plans(const WalkCtx& c, int len, int np_item, int& nlive)
 // (compact: the first kWalkRuns runs inside the cap; WIDE: every run), the end-limit verdict (cc:59-61) and the tile-capacity rule, the
 // plan-level header. The calling wave owns B. Returns false without a valid header if a compact batch does not do: a lane has more
 // runs inside the cap than a slot holds, or a plan lies wholly inside the cap (nearly always more than kWalkRuns runs: wide at once).
-template <int SEM, bool WIDE, bool STOP>
+#ifndef LTP_WALK_BUILDER_LEAN
+#define LTP_WALK_BUILDER_LEAN 0
+#endif
+constexpr bool kWalkBuilderLean = LTP_WALK_BUILDER_LEAN != 0;   // the builder wave of the builder / streaming-wave form: see for_each_run_loaded
+template <int SEM, bool WIDE, bool STOP, bool LEAN>
 LTP_DEV bool walk_build(const WalkCtx& c, WalkBatch& B, long long pb, int plist, int base, int np, int j0, int nj)
 {
     const int lane = c.lane;
@@ -442,8 +446,8 @@ LTP_DEV bool walk_build(const WalkCtx& c, WalkBatch& B, long long pb, int plist,
     bool too_many = false;
     if (slen > 0) {
         double q_end;
-        if constexpr (WIDE) too_many = walk_lane<SEM>(B.wslot[lane], L, c.needed_end, STOP, c.t_sample, q_end, j0 + jl == c.dof - 1);
-        else too_many = walk_lane<SEM>(B.slot[lane], L, c.needed_end, STOP, c.t_sample, q_end, j0 + jl == c.dof - 1);
+        if constexpr (WIDE) too_many = walk_lane<SEM, LEAN>(B.wslot[lane], L, c.needed_end, STOP, c.t_sample, q_end, j0 + jl == c.dof - 1);
+        else too_many = walk_lane<SEM, LEAN>(B.slot[lane], L, c.needed_end, STOP, c.t_sample, q_end, j0 + jl == c.dof - 1);
         if constexpr (SEM == kSemCpp && !STOP) {                                             // (LTPlanner.m has no position limits)
             if (q_end < L.q_min || q_end > L.q_max) atomicOr(&c.rec.status[p], kStatusEndLimit);   // cc:59-61: the last sample
         }
@@ -551,7 +555,7 @@ LTP_DEV void sample_walk_body(long long first, long long count, int dof, double 
     auto build = [&](long long pb, int plist, int base, int np, int j0, int nj, auto wide_tag) -> bool {
         constexpr bool WIDE = decltype(wide_tag)::value;
         wait_buffer_free();
-        if (!walk_build<SEM, WIDE, STOP>(ctx, buf[seq % kWalkBuffers], pb, plist, base, np, j0, nj)) return false;
+        if (!walk_build<SEM, WIDE, STOP, kWalkBuilderLean>(ctx, buf[seq % kWalkBuffers], pb, plist, base, np, j0, nj)) return false;
         // publish: everything above is LDS traffic of this one wave, in order
         __hip_atomic_store(&s_ready[seq % kWalkBuffers], seq + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         ++seq;
@@ -674,11 +678,11 @@ LTP_DEV void sample_walk_auto_body(long long first, long long count, int dof, do
             const int np = nlive - base < ppb ? nlive - base : ppb;
             for (int jc = 0; jc < dof; jc += kWalkLanes) {
                 const int jc_end = dof - jc < kWalkLanes ? dof : jc + kWalkLanes;
-                if (walk_build<SEM, false, STOP>(ctx, B, pb_now, plist, base, np, jc, jc_end - jc)) { stream(false); continue; }
+                if (walk_build<SEM, false, STOP, true>(ctx, B, pb_now, plist, base, np, jc, jc_end - jc)) { stream(false); continue; }
                 for (int sub = 0; sub < np; sub += wpb)
                     for (int j0 = jc; j0 < jc_end; j0 += wide_nj) {
                         const int npw = np - sub < wpb ? np - sub : wpb, njw = jc_end - j0 < wide_nj ? jc_end - j0 : wide_nj;
-                        (void)walk_build<SEM, true, STOP>(ctx, B, pb_now, plist, base + sub, npw, j0, njw);
+                        (void)walk_build<SEM, true, STOP, true>(ctx, B, pb_now, plist, base + sub, npw, j0, njw);
                         stream(true);
                     }
             }
