@@ -411,7 +411,11 @@ LTP_DEV int walk_item_plans(const WalkCtx& c, int len, int np_item, int& nlive)
 #ifndef LTP_WALK_BUILDER_LEAN
 #define LTP_WALK_BUILDER_LEAN 0
 #endif
-constexpr bool kWalkBuilderLean = LTP_WALK_BUILDER_LEAN != 0;   // the builder wave of the builder / streaming-wave form: see for_each_run_loaded
+constexpr bool kWalkBuilderLean = LTP_WALK_BUILDER_LEAN != 0;
+#ifndef LTP_WALK_AUTO_LEAN
+#define LTP_WALK_AUTO_LEAN 1
+#endif
+constexpr bool kWalkAutoLean = LTP_WALK_AUTO_LEAN != 0;         // the autonomous waves (every wave walks AND streams): the branch-free form   // the builder wave of the builder / streaming-wave form: see for_each_run_loaded
 template <int SEM, bool WIDE, bool STOP, bool LEAN>
 LTP_DEV bool walk_build(const WalkCtx& c, WalkBatch& B, long long pb, int plist, int base, int np, int j0, int nj)
 {
@@ -678,11 +682,11 @@ LTP_DEV void sample_walk_auto_body(long long first, long long count, int dof, do
             const int np = nlive - base < ppb ? nlive - base : ppb;
             for (int jc = 0; jc < dof; jc += kWalkLanes) {
                 const int jc_end = dof - jc < kWalkLanes ? dof : jc + kWalkLanes;
-                if (walk_build<SEM, false, STOP, true>(ctx, B, pb_now, plist, base, np, jc, jc_end - jc)) { stream(false); continue; }
+                if (walk_build<SEM, false, STOP, kWalkAutoLean>(ctx, B, pb_now, plist, base, np, jc, jc_end - jc)) { stream(false); continue; }
                 for (int sub = 0; sub < np; sub += wpb)
                     for (int j0 = jc; j0 < jc_end; j0 += wide_nj) {
                         const int npw = np - sub < wpb ? np - sub : wpb, njw = jc_end - j0 < wide_nj ? jc_end - j0 : wide_nj;
-                        (void)walk_build<SEM, true, STOP, true>(ctx, B, pb_now, plist, base + sub, npw, j0, njw);
+                        (void)walk_build<SEM, true, STOP, kWalkAutoLean>(ctx, B, pb_now, plist, base + sub, npw, j0, njw);
                         stream(true);
                     }
             }
