@@ -1466,3 +1466,38 @@ def test_envelope_default_is_the_analytic_form_and_has_the_exhaustive_bits(amd):
     torch.cuda.synchronize()
     assert "analytic" not in ltp.lastSamplerKernel()
     assert torch.equal(torch.nan_to_num(dflt, nan=7.0), torch.nan_to_num(ex, nan=7.0)) and torch.equal(b.status, b2.status)
+
+
+@pytest.mark.gpu
+def test_limit_power_tables_follow_set_limits_and_the_pow_rule(amd):
+    """Round 6: the powers of a joint's limits (LimPow: a_max / j_max, its cube and fourth power, a_max^3, a_max^4, j_max^3, j_max^4) are
+    formed once per ltp_create / ltp_set_limits under BOTH pow rules and picked by the handle's rule at launch. A handle that has had
+    other limits and the other rule before must give the bits of a fresh one: batched switching times (the tj memo and the stored
+    powers in k_opt_fast / k_reduce_scale / the queue kernels), the single call, and the one-joint entry points."""
+    import torch
+    D, lim_a = amd.limit_set("panda")
+    _, lim_b = amd.limit_set("ref")
+    n = 40000
+    used = amd.LongTermPlanner(D, 0.001, device=0, **lim_b)
+    q_b = used.generateQueries(n, seed=3)
+    used.setPowRule("exact")
+    used.planSwitchTimesBatch(*q_b)                                # the handle has run with other limits and the other rule
+    used.setLimits(**lim_a)
+    for rule in ("libm", "exact", "libm"):
+        used.setPowRule(rule)
+        fresh = amd.LongTermPlanner(D, 0.001, device=0, **lim_a)
+        fresh.setPowRule(rule)
+        q = fresh.generateQueries(n, seed=12)
+        bu, bf = used.planSwitchTimesBatch(*q), fresh.planSwitchTimesBatch(*q)
+        torch.cuda.synchronize()
+        for name in ("t_opt", "t_scaled", "dir", "v_drive", "mod", "t_required", "slowest", "traj_len", "status"):
+            x, y = getattr(bu, name), getattr(bf, name)
+            assert torch.equal(x.view(torch.uint8), y.view(torch.uint8)), (rule, name)
+        qh = [t[:3].cpu().numpy() for t in q]
+        su, sf = used.planBatchHost(*qh, sample=False), fresh.planBatchHost(*qh, sample=False)       # k_plan_small
+        assert su["t_scaled"].tobytes() == sf["t_scaled"].tobytes() and su["t_opt"].tobytes() == sf["t_opt"].tobytes()
+        # and they are the bits of the batched path (same device functions, with and without the memo)
+        assert su["t_scaled"].tobytes() == bf.t_scaled[:3].cpu().numpy().tobytes()
+        ou = used.optSwitchTimes(2, float(qh[0][0, 2]), float(qh[1][0, 2]), float(qh[2][0, 2]), float(qh[3][0, 2]), lim_a["v_max"][2])
+        of = fresh.optSwitchTimes(2, float(qh[0][0, 2]), float(qh[1][0, 2]), float(qh[2][0, 2]), float(qh[3][0, 2]), lim_a["v_max"][2])
+        assert np.asarray(ou[1]).tobytes() == np.asarray(of[1]).tobytes()
