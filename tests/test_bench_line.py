@@ -66,3 +66,22 @@ def test_plain_variant_line_is_unchanged():
     out, _, _ = _canned()
     line, side, notes = bench.assemble_lines(out, [], None, "f.jsonl")
     assert side == [] and notes == [] and json.loads(line) == out
+
+
+def test_multi_gpu_line_keeps_the_same_contract(tmp_path):
+    """The N > 1 path (rank 0 of a launcher's ranks): one secondary workload (configs[3], 10 M queries sharded), no rccl_world1 child —
+    the same single short line, the same file."""
+    out, secondary, _ = _canned()
+    out.update(n_gpus=8, value=8 * out["value"], scaling="weak")
+    out["config"].update(global_batch=8_000_000, backend="nccl (RCCL over xGMI)", rank_devices=list(range(8)))
+    out["cpu_baseline"]["measured_on"] = "rank 0 of 8, after the timed steps, while the other ranks wait in the final barrier"
+    sec = [dict(secondary[0], name="configs[3]: 10 M x 7-DoF queries sharded over 8 GPUs, full sampling")]
+    f = str(tmp_path / "bench_secondary.jsonl")
+    so, se = io.StringIO(), io.StringIO()
+    with redirect_stdout(so), redirect_stderr(se):
+        bench.emit_result(out, sec, None, f)
+    lines = so.getvalue().splitlines()
+    assert len(lines) == 1 and len(lines[0]) < bench.HEADLINE_BUDGET
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["secondary"]["count"] == 1 and "rccl_world1" not in d and d["roofline"]["frac"] and d["cpu_baseline"]["cores"]
+    assert [json.loads(x)["kind"] for x in open(f).read().splitlines()] == ["secondary"]
