@@ -380,7 +380,7 @@ k_reduce_scale(long long n, int dof, double t_sample, Limits lim, Queries in, Re
 // lookup over eight flags in LDS.
 template <int SEM>
 __global__ void __launch_bounds__(kQueriesPerBlock * 8)
-k_scaling_slow(int dof, double t_sample, Limits lim, Queries in, Records out, Queue queue)
+k_scaling_slow(int dof, double t_sample, Limits lim, Queries in, Records out, Queue queue, int exp_per)
 {
     if constexpr (sem_libm(SEM)) libm::stage_tables();        // the block's LDS copy of glibc's pow tables (ltp_libm_pow.hpp)
     __shared__ int s_acc[8][kQueriesPerBlock];
@@ -395,7 +395,10 @@ k_scaling_slow(int dof, double t_sample, Limits lim, Queries in, Records out, Qu
     // 1 .. 64 per block — LAPACK's iteration takes 16-30 sweeps on nearly every degree-6 polynomial, so a wave of 64 pays the union of
     // 64 lanes' branches in every one of them (100 k queries: 0.476 -> 0.457 ms). C++ semantics keeps 64 per block: there ONE lane's 76
     // Francis steps decide the kernel whatever its company, and 256 blocks instead of 20 were 3 % slower (155.7 -> 160.6 us, one box).
-    const unsigned long long per = sem_matlab(SEM) ? slow_lanes_per_block(count, gridDim.x, kSlowWavesAtOnce / 8) : (unsigned long long)kQueriesPerBlock;
+    const unsigned long long per = sem_matlab(SEM) ? slow_lanes_per_block(count, gridDim.x, kSlowWavesAtOnce / 8) : (exp_per > 0 ? (unsigned long long)exp_per
+                                     // a queue of up to 64 blocks' worth is dealt 32 to a block: the waves' company halves and the chip has the room
+                                     // (S-ref 100 k: 323 -> 294 us; beyond that more instruction streams cost more than they free, r06_stage_small_ab.txt)
+                                     : (count <= 4096ull ? 32ull : (unsigned long long)kQueriesPerBlock));
     for (unsigned long long base = (unsigned long long)blockIdx.x * per; base < count; base += (unsigned long long)gridDim.x * per) {
         const unsigned long long it = base + x;
         const bool live = (unsigned long long)x < per && it < count;
@@ -620,6 +623,7 @@ void launch_switch_times(hipStream_t s, long long n, int dof, double t_sample, i
     // (profiles/r06_stage_block_shape_ab.txt: 971 -> 674 us and 375 -> 341 us per 1 M 7-DoF plans; with the exact rule's
     // smaller kernels the one-round 64 x dof block stays ahead, 448 vs 461 us).
     static const int exp_of = getenv("LTP_EXP_OF_JB") ? atoi(getenv("LTP_EXP_OF_JB")) : 0, exp_rs = getenv("LTP_EXP_RS_JB") ? atoi(getenv("LTP_EXP_RS_JB")) : 0;
+    static const int exp_ss = getenv("LTP_EXP_SS_PER") ? atoi(getenv("LTP_EXP_SS_PER")) : 0;
     const int jb_libm = (variant & kPowLibm) && jb > 4 ? 4 : jb;
     const dim3 block_of(kQueriesPerBlock, exp_of > 0 && exp_of <= jb ? exp_of : jb_libm), block_rs(kQueriesPerBlock, exp_rs > 0 && exp_rs <= jb ? exp_rs : jb_libm);
     dispatch_variant(variant, [&](auto v) {
@@ -627,7 +631,7 @@ void launch_switch_times(hipStream_t s, long long n, int dof, double t_sample, i
         hipLaunchKernelGGL(k_opt_fast<SEM>, grid, block_of, 0, s, n, dof, t_sample, goal_check, lim, in, out, lane_flags, qa);
         hipLaunchKernelGGL(k_opt_slow<SEM>, dim3((unsigned)a_blocks), dim3(64), 0, s, dof, t_sample, lim, in, out, lane_flags, qa);
         hipLaunchKernelGGL(k_reduce_scale<SEM>, grid, block_rs, 0, s, n, dof, t_sample, lim, in, out, lane_flags, qb);
-        hipLaunchKernelGGL(k_scaling_slow<SEM>, dim3((unsigned)b_blocks), dim3(kQueriesPerBlock, 8), 0, s, dof, t_sample, lim, in, out, qb);
+        hipLaunchKernelGGL(k_scaling_slow<SEM>, dim3((unsigned)b_blocks), dim3(kQueriesPerBlock, 8), 0, s, dof, t_sample, lim, in, out, qb, exp_ss);
     });
 }
 
