@@ -124,7 +124,112 @@ __device__ __forceinline__ void step_variant(double (&T)[6][6], double sh0, doub
     T[3][1] = 0.0;
 }
 
-// mode 0: the product's step; 1: no_setup; 2: no_updates; 3: shifts_only; 4: the pull-back loop alone
+
+// a TUNED single-lane step (same operations on the same elements): the two possible start-row quotients are formed side by side
+// (their division chains overlap), and the "reflector is degenerate" guards are decided for the whole wave (one ballot, a scalar
+// branch) instead of as lane masks around the updates
+__device__ __forceinline__ void step_tuned(double (&T)[6][6], double sh0, double sh1, double sh2)
+{
+    int im;
+    double v0, v1, v2;
+    {
+        const double Tmm = T[1][1], T00 = T[0][0];
+        const double r = sh0 - Tmm, s = sh1 - Tmm, r0 = sh0 - T00, s0 = sh1 - T00;
+        const double qa = (r * s - sh2) / T[2][1], qb_ = (r0 * s0 - sh2) / T[1][0];
+        v0 = qa + T[1][2];
+        v1 = T[2][2] - Tmm - r - s;
+        v2 = T[3][2];
+        const double lhs = T[1][0] * (rabs(v1) + rabs(v2));
+        const double rhs = v0 * (rabs(T00) + rabs(Tmm) + rabs(T[2][2]));
+        const bool start1 = rabs(lhs) < kDblEps * rhs;
+        im = start1 ? 1 : 0;
+        v0 = start1 ? v0 : qb_ + T[0][1];
+        v1 = start1 ? v1 : T[1][1] - T00 - r0 - s0;
+        v2 = start1 ? v2 : T[2][1];
+    }
+    const bool uniform0 = __builtin_amdgcn_ballot_w64(im != 0) == 0ull;
+    if (im == 0) {
+        double e0, e1, tau, beta;
+        householder3(v0, v1, v2, e0, e1, tau, beta);
+        const bool ok = beta != 0.0 && tau != 0.0;
+        if (uniform0 && __builtin_amdgcn_ballot_w64(!ok) == 0ull) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                double tmp = e0 * T[1][j] + e1 * T[2][j];
+                tmp += T[0][j];
+                T[0][j] -= tau * tmp; T[1][j] -= (tau * e0) * tmp; T[2][j] -= (tau * e1) * tmp;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                double tmp = T[i][1] * e0 + T[i][2] * e1;
+                tmp += T[i][0];
+                T[i][0] -= tau * tmp; T[i][1] -= (tau * tmp) * e0; T[i][2] -= (tau * tmp) * e1;
+            }
+        } else if (ok) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                double tmp = e0 * T[1][j] + e1 * T[2][j];
+                tmp += T[0][j];
+                T[0][j] -= tau * tmp; T[1][j] -= (tau * e0) * tmp; T[2][j] -= (tau * e1) * tmp;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                double tmp = T[i][1] * e0 + T[i][2] * e1;
+                tmp += T[i][0];
+                T[i][0] -= tau * tmp; T[i][1] -= (tau * tmp) * e0; T[i][2] -= (tau * tmp) * e1;
+            }
+        }
+    }
+    {
+        const bool first = im == 1;
+        double w0, w1, w2;
+        if (first) { w0 = v0; w1 = v1; w2 = v2; } else { w0 = T[1][0]; w1 = T[2][0]; w2 = T[3][0]; }
+        double e0, e1, tau, beta;
+        householder3(w0, w1, w2, e0, e1, tau, beta);
+        if (beta != 0.0) {
+            if (first) T[1][0] = -T[1][0]; else T[1][0] = beta;
+            if (tau != 0.0) {
+#pragma unroll
+                for (int j = 1; j < 4; ++j) {
+                    double tmp = e0 * T[2][j] + e1 * T[3][j];
+                    tmp += T[1][j];
+                    T[1][j] -= tau * tmp; T[2][j] -= (tau * e0) * tmp; T[3][j] -= (tau * e1) * tmp;
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    double tmp = T[i][2] * e0 + T[i][3] * e1;
+                    tmp += T[i][1];
+                    T[i][1] -= tau * tmp; T[i][2] -= (tau * tmp) * e0; T[i][3] -= (tau * tmp) * e1;
+                }
+            }
+        }
+    }
+    {
+        double e0, tau, beta;
+        householder2(T[2][1], T[3][1], e0, tau, beta);
+        if (beta != 0.0) {
+            T[2][1] = beta;
+            if (tau != 0.0) {
+#pragma unroll
+                for (int j = 2; j < 4; ++j) {
+                    double tmp = e0 * T[3][j];
+                    tmp += T[2][j];
+                    T[2][j] -= tau * tmp; T[3][j] -= (tau * e0) * tmp;
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    double tmp = T[i][3] * e0;
+                    tmp += T[i][2];
+                    T[i][2] -= tau * tmp; T[i][3] -= (tau * tmp) * e0;
+                }
+            }
+        }
+    }
+    if (im == 0) { T[2][0] = 0.0; T[3][0] = 0.0; }
+    T[3][1] = 0.0;
+}
+
+// mode 5: step_tuned. mode 0: the product's step; 1: no_setup; 2: no_updates; 3: shifts_only; 4: the pull-back loop alone
 __global__ void __launch_bounds__(64) probe(const double* t0, int steps, int mode, int lanes, double* out, unsigned long long* ticks)
 {
     double T0[6][6], T[6][6];
@@ -138,6 +243,7 @@ __global__ void __launch_bounds__(64) probe(const double* t0, int steps, int mod
             else if (mode == 1) step_variant<false, true>(T, sh0, sh1, sh2);
             else if (mode == 2) step_variant<true, false>(T, sh0, sh1, sh2);
             else if (mode == 3) step_variant<false, false>(T, sh0, sh1, sh2);
+            else if (mode == 5) step_tuned(T, sh0, sh1, sh2);
             // pull the window back towards its start: bounded values, the same 16 operations in every variant
 #pragma unroll
             for (int i = 0; i < 4; ++i)
@@ -175,6 +281,16 @@ int main()
             }
             ns[mode][lanes == 64] = best * 10.0 / steps;
         }
+    }
+    for (int lanes : {1, 64}) {
+        unsigned long long best = ~0ull, t;
+        for (int rep = 0; rep < 5; ++rep) {
+            hipLaunchKernelGGL(probe, dim3(1), dim3(64), 0, nullptr, dt, steps, 5, lanes, dout, dticks);
+            CK(hipDeviceSynchronize());
+            CK(hipMemcpy(&t, dticks, 8, hipMemcpyDeviceToHost));
+            best = t < best ? t : best;
+        }
+        printf("tuned single-lane step (both start-row quotients at once, wave-level guards), %d lane(s): %.1f ns per step\n", lanes, best * 10.0 / steps);
     }
     for (int col = 0; col < 2; ++col) {
         printf("%s active lane(s) of one wave, %d steps:\n", col ? "64" : "1", steps);
