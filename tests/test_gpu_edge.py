@@ -1501,3 +1501,31 @@ def test_limit_power_tables_follow_set_limits_and_the_pow_rule(amd):
         ou = used.optSwitchTimes(2, float(qh[0][0, 2]), float(qh[1][0, 2]), float(qh[2][0, 2]), float(qh[3][0, 2]), lim_a["v_max"][2])
         of = fresh.optSwitchTimes(2, float(qh[0][0, 2]), float(qh[1][0, 2]), float(qh[2][0, 2]), float(qh[3][0, 2]), lim_a["v_max"][2])
         assert np.asarray(ou[1]).tobytes() == np.asarray(of[1]).tobytes()
+
+
+@pytest.mark.gpu
+def test_sample_opts_from_an_older_header_keep_the_newer_fields_at_their_defaults(amd, ref7):
+    """ltp_sample_opts is size-versioned: a caller built against a SHORTER struct (here: size, format, stores, sampler = 16 bytes) is
+    served as if the fields it does not know were zero, whatever bytes follow its struct in memory."""
+    import ctypes as C
+    import torch
+    D, lim, _, _ = ref7
+    ltp = amd.LongTermPlanner(D, 0.004, device=0, **lim)
+    ltp.setMaxSamples(48)
+    n = 3000
+    q = ltp.generateQueries(n, seed=17)
+    b = ltp.planSwitchTimesBatch(*q)
+    ref = torch.full((int(b.offsets[-1].item()) + 8,), 3.0, dtype=torch.float64, device="cuda")
+    ltp.sampleBatchEx(b, 0, n, ref, sampler="walk")
+    st = b.status.clone()
+    raw = (C.c_int * 7)(16, 0, 0, 2, 0x7fffffff, -5, 99)          # size 16: [verdict, interleave, dry_run] are not the caller's
+    b2 = ltp.planSwitchTimesBatch(*q)
+    got = torch.full_like(ref, 3.0)
+    rec = b2.c_records()
+    rc = ltp._lib.ltp_sample_batch_ex(ltp._h, 0, n, C.byref(b2.queries), C.byref(rec), b2.offsets.data_ptr(), got.data_ptr(), got.numel(),
+                                      C.addressof(raw), None)
+    torch.cuda.synchronize()
+    assert rc == 0 and torch.equal(got, ref) and torch.equal(b2.status, st)
+    raw[0] = 28                                                    # the full struct: now the garbage IS the caller's, and is refused
+    assert ltp._lib.ltp_sample_batch_ex(ltp._h, 0, n, C.byref(b2.queries), C.byref(rec), b2.offsets.data_ptr(), got.data_ptr(), got.numel(),
+                                        C.addressof(raw), None) == 1
