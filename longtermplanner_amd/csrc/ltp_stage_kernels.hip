@@ -622,8 +622,14 @@ void launch_switch_times(hipStream_t s, long long n, int dof, double t_sample, i
     // SIMD): 64 x 4 blocks fill those slots (three / four blocks per compute unit), 64 x 7 blocks leave 5 of 12 and 2 of 16 empty
     // (profiles/r06_stage_block_shape_ab.txt: 971 -> 674 us and 375 -> 341 us per 1 M 7-DoF plans; with the exact rule's
     // smaller kernels the one-round 64 x dof block stays ahead, 448 vs 461 us).
+    // (the A/B runs of profiles/r06_stage_block_shape_ab.txt / r06_stage_small_ab.txt set these shapes from the environment: a build with
+    // -DLTP_EXP_KNOBS reads LTP_EXP_OF_JB, LTP_EXP_RS_JB, LTP_EXP_SS_PER; the product reads no environment)
+#ifdef LTP_EXP_KNOBS
     static const int exp_of = getenv("LTP_EXP_OF_JB") ? atoi(getenv("LTP_EXP_OF_JB")) : 0, exp_rs = getenv("LTP_EXP_RS_JB") ? atoi(getenv("LTP_EXP_RS_JB")) : 0;
     static const int exp_ss = getenv("LTP_EXP_SS_PER") ? atoi(getenv("LTP_EXP_SS_PER")) : 0;
+#else
+    constexpr int exp_of = 0, exp_rs = 0, exp_ss = 0;
+#endif
     const int jb_libm = (variant & kPowLibm) && jb > 4 ? 4 : jb;
     const dim3 block_of(kQueriesPerBlock, exp_of > 0 && exp_of <= jb ? exp_of : jb_libm), block_rs(kQueriesPerBlock, exp_rs > 0 && exp_rs <= jb ? exp_rs : jb_libm);
     dispatch_variant(variant, [&](auto v) {

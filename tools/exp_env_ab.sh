@@ -1,5 +1,6 @@
 #!/bin/bash
 # per-kernel times (rocprofv3 --kernel-trace --stats) of one bench line under a list of environment settings, on one box
+# (the LTP_EXP_* shapes of the stage kernels are read by a library built with -DLTP_EXP_KNOBS only: make -C longtermplanner_amd/csrc clean all EXTRA=-DLTP_EXP_KNOBS)
 # usage: bash tools/exp_env_ab.sh "<bench args>" "VAR=a VAR2=b" "VAR=c" ...   -> gpurun_out/env_ab.txt (appended)
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
