@@ -81,7 +81,8 @@ typedef enum {
  *                operation (csrc/ltp_libm_pow.hpp, bit-identical to the installed libm on 1.7e10 inputs): every record has the
  *                bits a reference built with gcc + glibc computes on such a host and every sample is within 1e-9 of it, no plan
  *                excepted (tests/test_gpu_parity.py; 34.1 M dense trajectories in profiles/r05_parity_report.json). Costs ~45 fp64
- *                operations and 3 table reads per power: +1.4 % on a full-sampling batch, +35 % on switching times only.
+ *                operations and 3 table reads per power: +1 % on a full-sampling batch, +10 % on switching times only (round 6: the
+ *                powers of the limits are formed once per ltp_set_limits; +35 % before).
  * LTP_POW_EXACT  one rounding of the exact product, sqrt for the power 1/2: what a correctly rounded pow returns; within
  *                1 ulp of ANY libm (so within the differences between two libm builds of the reference); the faster rule. */
 #define LTP_POW_EXACT 0
